@@ -1,0 +1,184 @@
+/* tcdiff_hip.h -- C ABI of libtcdiff_gfx950.so: the MI355X (gfx950) kernels behind TCDiff's denoising hot path.
+ *
+ * The reference (Da1yuqin/TCDiff) has no FFI: its boundary for this path is the Python class surface
+ * `model.model.DanceDecoder` / `model.diffusion.GaussianDiffusion` (TCDiff.py:18-19,76-102).  The host side
+ * that mirrors that surface is `tcdiff_amd/{model,diffusion}.py`; every device operation it performs goes
+ * through the entry points below (ctypes binding: tcdiff_amd/_lib.py).
+ *
+ * Conventions
+ *   - every function returns 0 (TCDIFF_OK) or a negative error code; nothing is allocated, nothing
+ *     synchronises the host; all pointers are caller-owned DEVICE pointers; work is enqueued on `stream`.
+ *   - `dtype` selects the arithmetic of GEMM/attention operands: TC_DTYPE_BF16 (bf16 operands,
+ *     v_mfma_f32_32x32x16_bf16, fp32 accumulate) or TC_DTYPE_F32 (fp32 operands, v_mfma_f32_32x32x2_f32:
+ *     an exact fp32 fma chain -- the parity mode).  "T" below means that element type.
+ *   - the residual stream, LayerNorm statistics, softmax, FiLM and the diffusion update are always fp32.
+ *   - matrices are row-major; `ld*` are leading dimensions in ELEMENTS; operand rows must be 16-byte
+ *     aligned and K must be a multiple of 64 (bf16) / 32 (f32) elements (pad with zeros).
+ */
+#ifndef TCDIFF_HIP_H
+#define TCDIFF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef __HIP__
+typedef struct ihipStream_t* hipStream_t;
+#endif
+
+#define TCDIFF_OK 0
+#define TCDIFF_ERR_ARG (-1)
+#define TCDIFF_ERR_ALIGN (-2)
+#define TCDIFF_ERR_LAUNCH (-3)
+#define TCDIFF_ERR_UNSUPPORTED (-4)
+
+#define TC_DTYPE_F32 0
+#define TC_DTYPE_BF16 1
+
+/* activations (fused into GEMM epilogues and elementwise helpers) */
+#define TC_ACT_NONE 0
+#define TC_ACT_RELU 1
+#define TC_ACT_GELU 2 /* exact erf form: F.gelu, TCDiff.py:85 */
+#define TC_ACT_MISH 3 /* nn.Mish, model/model.py:157,457 */
+#define TC_ACT_SILU 4 /* nn.SiLU, model/model.py:499 */
+
+/* ---- gemm_tile epilogues ------------------------------------------------------------------------ */
+#define TC_EPI_STORE_T 0   /* out[m][n] = T(act(acc + bias[n]))                                       */
+#define TC_EPI_STORE_F32 1 /* out[m][n] = act(acc + bias[n]) as fp32                                  */
+#define TC_EPI_QKV_HEADS 2 /* scatter to the head-major Q / K / V^T images read by tcdiff_attention   */
+
+typedef struct {
+    int mode;          /* TC_EPI_* */
+    int act;           /* TC_ACT_* */
+    float scale_q;     /* QKV: multiplies the Q columns (1/8 = 1/sqrt(d_k), model/model.py:97) */
+    const float* bias; /* [N] or NULL */
+    void* out;         /* STORE_T: T[M][ldc]; STORE_F32: float[M][ldc]; QKV: Q image */
+    void* out_k;       /* QKV: K image    T[n_seq][H][Lp][64]                       */
+    void* out_vt;      /* QKV: V^T image  T[n_seq][H][64][Lp] (key order: see tcdiff_attention) */
+    int ldc;
+    int L, Lp, H;      /* QKV: tokens per sequence (row m -> sequence m / L, token m % L), padded length, heads */
+    int n_q, n_k;      /* QKV: columns [0,n_q) are Q, [n_q,n_q+n_k) are K, the rest V */
+    int tok_off;       /* QKV: added to the token index  */
+    int seq_off;       /* QKV: added to the sequence index */
+} tcdiff_tile_epi;
+
+/* C[M,N] = A[M,K] * W[N,K]^T with epilogue.  If A2 != NULL, output columns >= split_n (a multiple of 128)
+ * take their A operand from A2 (same shape/ld as A): one launch computes Q,K from rot(h) and V from h
+ * (model/model.py:374-383).  a_mod > 0: A row = m % a_mod.
+ * Replaces: nn.Linear calls model/model.py:78-80,399,454-465,490-494,522-528,560,623,164-166. */
+int tcdiff_gemm_tile(int dtype, const void* A, const void* A2, int split_n, const void* W, int M, int N, int K,
+                     int lda, int ldw, int a_mod, const tcdiff_tile_epi* epi, hipStream_t stream);
+
+/* ---- gemm_rowln: N = 512, row-complete epilogue ------------------------------------------------- */
+#define TC_ROW_BIAS 1       /* v = acc + bias[n]                                                       */
+#define TC_ROW_LN_POST 2    /* v = LayerNorm_{ln_eps}(v) * ln_g + ln_b      (SBI_MSA.layer_norm, model/model.py:106) */
+#define TC_ROW_FILM 4       /* v = (film[seq][n] + 1) * v + film[seq][512+n] (featurewise_affine, model/model.py:171) */
+#define TC_ROW_RES 8        /* v = xres[m][n] + v  (implied by FILM as well)                           */
+#define TC_ROW_STORE_X 16   /* xout[m'][n] = v (fp32)                                                  */
+#define TC_ROW_NEXT_LN 32   /* u = LayerNorm_{nln_eps}(v) * nln_g + nln_b  (the next block's norm, model/model.py:326,332,338,344) */
+#define TC_ROW_STORE_H 64   /* hout[m'][n] = T(u)                                                      */
+#define TC_ROW_STORE_ROT 128 /* rout[m'][n] = T(rotary(u, pos = m' % L))   (model/model.py:375,387)    */
+
+typedef struct {
+    int flags;
+    const float* bias;
+    const float* ln_g;
+    const float* ln_b;
+    float ln_eps;
+    const float* film; /* base of this block's FiLM rows: film[seq * film_ld + n] scale, +512 shift */
+    int film_ld;
+    const float* xres; /* fp32 [*,512] */
+    int xres_mod;      /* > 0: residual row = m % xres_mod */
+    float* xout;
+    int L;             /* tokens per sequence */
+    const float* nln_g;
+    const float* nln_b;
+    float nln_eps;
+    void* hout;
+    void* rout;
+    const float* rope; /* [Lmax][512]: rope[p][2j] = cos(p*freq_j), rope[p][2j+1] = sin(p*freq_j) */
+    int out_mul, out_add; /* output row m' = m * out_mul + out_add (0 -> 1) */
+} tcdiff_row_epi;
+
+/* out rows[M,512] = epilogue(A[M,K] * W[512,K]^T).  Replaces fc+layer_norm+FiLM+residual
+ * (model/model.py:103-106,327,334), linear2+FiLM+residual (:339,399-401), linear3(norm4(x)) (:344) and the
+ * last fusion-projection linear (:527), each fused with the LayerNorm(+rotary) that consumes its result. */
+int tcdiff_gemm_rowln(int dtype, const void* A, const void* W, int M, int K, int lda, int ldw, int a_mod,
+                      const tcdiff_row_epi* epi, hipStream_t stream);
+
+/* ---- fused attention ------------------------------------------------------------------------------
+ * O[(seq*Lq + q)*ldo + head*64 + d] = softmax_k(Q[seq][head][q] . K[kv][head][k]) V[kv][head][k][d]
+ * Q  : T[n_seq][H][Lp_q][64]   (already scaled by 1/sqrt(64))
+ * K  : T[n_kv ][H][Lp_k][64]
+ * Vt : T[n_kv ][H][64][Lp_k]   key axis in "vt order": f32 natural; bf16: inside every group of 16 keys,
+ *                               index bits 2 and 3 are swapped (written by TC_EPI_QKV_HEADS / tcdiff_scatter_time_kv)
+ * kv = seq < n_shared ? 0 : seq - n_shared + (n_shared > 0)   (the unconditional CFG branch shares one K/V)
+ * Lp_q % 128 == 0, Lp_k % 64 == 0, pad rows of Q/K/Vt must be finite (zero).  Keys >= Lk are masked.
+ * Replaces model/model.py:97-102 (SBI_MSA core) and nn.MultiheadAttention's core (model/model.py:228-236). */
+int tcdiff_attention(int dtype, const void* Q, const void* K, const void* Vt, void* O, int n_seq, int H, int Lq,
+                     int Lk, int Lp_q, int Lp_k, int ldo, int n_shared, hipStream_t stream);
+
+/* ---- LayerNorm (+ rotary) prologue: one wave per 512-wide row ---------------------------------------
+ * u = LayerNorm_eps(x[row]) * g + b; optional outputs: h = T(u); rot = T(rotary(u, pos)); y32 = u (fp32).
+ * pos = pos_base + (row % pos_mod).  Replaces model/model.py:326 etc. where no producing GEMM can fuse it,
+ * norm_cond (:616) and the music encoder's norms (:220-221). */
+int tcdiff_ln_rot(int dtype, const float* x, int rows, const float* g, const float* b, float eps, void* h,
+                  void* rot, float* y32, const float* rope, int pos_mod, int pos_base, hipStream_t stream);
+
+/* rope[p][2j] = cos(p * freqs[j]), rope[p][2j+1] = sin(p * freqs[j]), p < n_pos, j < 256
+ * (model/rotary_embedding_torch.py:115-130 + :58: the table the reference recomputes on every call). */
+int tcdiff_rope_table(const float* freqs, float* rope, int n_pos, hipStream_t stream);
+
+/* ---- small elementwise helpers of the step-invariant / per-step conditioning path ----------------- */
+/* dst[r][c] = T(src row r)[c] for c < cols, 0 for cols <= c < ld_dst.  Source row r lives at
+ * src + (r / rows_per_batch) * batch_stride + (r % rows_per_batch) * row_stride  (strides in floats). */
+int tcdiff_convert_pad(int dtype, const float* src, void* dst, int rows, int cols, int ld_dst, int rows_per_batch,
+                       long batch_stride, long row_stride, hipStream_t stream);
+/* emb[i] = T([sin(t_i * f_k), cos(t_i * f_k)]), k < 256 (SinusoidalPosEmb, model/utils.py:36-48); times int32 */
+int tcdiff_sinusoidal(int dtype, const int* times, int n, const float* freq, void* emb, hipStream_t stream);
+/* out[b][c] = mean_s x[b][s][c]   (model/model.py:593) */
+int tcdiff_mean_pool(const float* x, float* out, int B, int S, int C, hipStream_t stream);
+/* out[i][c] = T(act(a[ia[i]][c] + (b ? b[i][c] : 0))), c < 512; ia == NULL -> identity
+ * (t = to_time_cond(t_hidden) + cond_hidden; Mish(t): model/model.py:612,157) */
+int tcdiff_add_act(int dtype, const float* a, const int* ia, const float* b, int n, int act, void* out,
+                   float* out32, hipStream_t stream);
+/* per-step: copy the two time-token K/V rows of every layer into the cross-attention caches.
+ * tab: T[NL][n_t][2][1024] (K cols 0..511, V cols 512..1023); tidx[seq] selects the row set.
+ * Kc: T[NL][n_kv][H][Lp][64], Vtc: T[NL][n_kv][H][64][Lp]; rows tok0, tok0+1.  */
+int tcdiff_scatter_time_kv(int dtype, const void* tab, int n_t, const int* tidx, void* Kc, void* Vtc, int NL,
+                           int n_kv, int H, int Lp, int tok0, hipStream_t stream);
+
+/* ---- sampler steps --------------------------------------------------------------------------------
+ * step scalars live in DEVICE memory so that one captured hipGraph serves every step:
+ *   counter[0] = index of the current step; params[step][8] floats, tseq[step] = timestep index.
+ * tcdiff_step_begin: tidx[i] = tseq[counter[0]] for i < n.   tcdiff_step_end: counter[0] += 1.          */
+int tcdiff_step_begin(const int* counter, const int* tseq, int* tidx, int n, hipStream_t stream);
+int tcdiff_step_end(int* counter, hipStream_t stream);
+
+/* DDPM: params = {w, coef1, coef2, sigma}  (model/diffusion.py:217-252, model/model.py:546)
+ *   x0 = clamp(unc + (cond - unc) * w, -1, 1);  x <- coef1*x0 + coef2*x + sigma*eps
+ * DDIM: params = {w, sqrt_recip_ac, sqrt_recipm1_ac, sqrt_ac_next, c, sigma, last}  (model/diffusion.py:195-204,407-431)
+ *   x0 = clamp(...); pn = (sqrt_recip_ac*x - x0)/sqrt_recipm1_ac; x <- last ? x0 : sqrt_ac_next*x0 + c*pn + sigma*eps
+ * out_unc / out_cond: fp32 [n_rows][ldo] network outputs (out_unc may be NULL when w == 1 is known: x0 = clamp(cond)).
+ * eps: fp32 [n_rows][nfeat] or NULL -> Philox4x32-10 normal keyed by (seed, clip0 + row / L, timestep, element).
+ * traj: optional fp32 [n_rows][3]: channels 4,5 of x are overwritten with traj[...,0:2] after the update
+ * (model/diffusion.py:427-431).  x is updated in place; x0_out (optional) receives x0. */
+#define TC_SAMPLER_DDPM 0
+#define TC_SAMPLER_DDIM 1
+int tcdiff_sampler_update(int mode, const float* out_unc, const float* out_cond, int ldo, float* x,
+                          const float* eps, const float* traj, float* x0_out, int n_rows, int nfeat, int L,
+                          const int* counter, const float* params, const int* tseq, uint64_t seed, int clip0,
+                          hipStream_t stream);
+
+/* x[1:, :half] = x[:-1, half:] on the (b, seq_len, dn*nfeat) view (model/diffusion.py:502-506,599-601) */
+int tcdiff_window_couple(float* x, int b, int seq_len, int row_elems, hipStream_t stream);
+
+/* library identification */
+const char* tcdiff_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TCDIFF_HIP_H */

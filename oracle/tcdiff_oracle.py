@@ -1,0 +1,534 @@
+"""CPU oracle for the TCDiff denoising hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a from-scratch functional restatement (torch CPU, fp32) of the
+reference algorithm for the path named by BASELINE.json: the ``DanceDecoder``
+denoiser and the ``GaussianDiffusion`` samplers.  Nothing here is shipped or
+measured as the product: only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import it (as the checker / the
+reported CPU baseline).  The product path (``tcdiff_amd``) never imports it.
+
+Parity status: PINNED.  ``oracle/validate_against_reference.py`` imports the real
+reference from /root/reference (in the build container only) and checks every
+function below against it; ``tests/golden/*.npz`` (made by
+``tests/golden/make_golden.py`` from the real reference) are checked in
+``tests/test_oracle_golden.py`` on any box.
+
+All citations are file:line in the reference repo (Da1yuqin/TCDiff @ 2025-10-17).
+Weights are passed as a flat ``state_dict`` (name -> tensor) with the reference's
+own key names, so a reference checkpoint feeds the oracle unchanged.
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+SD = Dict[str, torch.Tensor]
+
+DK = 64  # SBI_MSA hard-codes d_k = 64 (model/model.py:55)
+
+
+# ----------------------------------------------------------------------------------------------
+# schedule tables  (model/utils.py:67-99, model/diffusion.py:109-169)
+# ----------------------------------------------------------------------------------------------
+def cosine_betas(n_timestep: int, s: float = 8e-3) -> np.ndarray:
+    """model/utils.py:78-86 -- fp64 cosine schedule, clipped to [0, 0.999]."""
+    ts = torch.arange(n_timestep + 1, dtype=torch.float64) / n_timestep + s
+    ac = torch.cos(ts / (1 + s) * np.pi / 2).pow(2)
+    ac = ac / ac[0]
+    betas = 1 - ac[1:] / ac[:-1]
+    return np.clip(betas.numpy(), 0, 0.999)
+
+
+def linear_betas(n_timestep: int, start: float = 1e-4, end: float = 2e-2) -> np.ndarray:
+    """model/utils.py:70-76."""
+    return (torch.linspace(start ** 0.5, end ** 0.5, n_timestep, dtype=torch.float64) ** 2).numpy()
+
+
+def make_tables(n_timestep: int = 1000, schedule: str = "cosine") -> Dict[str, torch.Tensor]:
+    """The 13 fp32 [T] buffers of GaussianDiffusion.__init__ (model/diffusion.py:109-169).
+
+    betas are cast to fp32 FIRST (``torch.Tensor(np_f64)``), every derived table is then
+    computed in fp32 (``np.sqrt`` on a torch tensor dispatches to torch.sqrt)."""
+    b64 = cosine_betas(n_timestep) if schedule == "cosine" else linear_betas(n_timestep)
+    betas = torch.tensor(b64, dtype=torch.float64).to(torch.float32)
+    alphas = 1.0 - betas
+    ac = torch.cumprod(alphas, dim=0)
+    ac_prev = torch.cat([torch.ones(1), ac[:-1]])
+    post_var = betas * (1.0 - ac_prev) / (1.0 - ac)
+    t = {
+        "betas": betas,
+        "alphas_cumprod": ac,
+        "alphas_cumprod_prev": ac_prev,
+        "sqrt_alphas_cumprod": torch.sqrt(ac),
+        "sqrt_one_minus_alphas_cumprod": torch.sqrt(1.0 - ac),
+        "log_one_minus_alphas_cumprod": torch.log(1.0 - ac),
+        "sqrt_recip_alphas_cumprod": torch.sqrt(1.0 / ac),
+        "sqrt_recipm1_alphas_cumprod": torch.sqrt(1.0 / ac - 1),
+        "posterior_variance": post_var,
+        "posterior_log_variance_clipped": torch.log(torch.clamp(post_var, min=1e-20)),
+        # the reference applies numpy's sqrt to torch tensors here (model/diffusion.py:155,159); numpy's
+        # fp32 sqrt and torch's differ in the last bit for some inputs, so the same call is used
+        "posterior_mean_coef1": betas * torch.from_numpy(np.sqrt(ac_prev.numpy())) / (1.0 - ac),
+        "posterior_mean_coef2": (1.0 - ac_prev) * torch.from_numpy(np.sqrt(alphas.numpy())) / (1.0 - ac),
+        "p2_loss_weight": (1 + ac / (1 - ac)) ** -0.0,
+    }
+    return t
+
+
+# ----------------------------------------------------------------------------------------------
+# building blocks
+# ----------------------------------------------------------------------------------------------
+def rotary(x: torch.Tensor, freqs: torch.Tensor) -> torch.Tensor:
+    """RotaryEmbedding.rotate_queries_or_keys (model/rotary_embedding_torch.py:107-113,46-59,39-43).
+
+    Position = index along dim -2; pair j=(2j,2j+1) rotates by angle pos*freqs[j]:
+    (y0, y1) = (x0 cos - x1 sin, x1 cos + x0 sin)."""
+    n = x.shape[-2]
+    ang = torch.arange(n, dtype=freqs.dtype)[:, None] * freqs[None, :]  # (n, D/2)
+    ang = ang.repeat_interleave(2, dim=-1)  # (n, D): [a0,a0,a1,a1,...]
+    xp = x.reshape(*x.shape[:-1], -1, 2)
+    rh = torch.stack((-xp[..., 1], xp[..., 0]), dim=-1).reshape(x.shape)
+    return x * ang.cos() + rh * ang.sin()
+
+
+def sinusoidal_emb(times: torch.Tensor, dim: int) -> torch.Tensor:
+    """SinusoidalPosEmb (model/utils.py:36-48)."""
+    half = dim // 2
+    f = torch.exp(torch.arange(half) * -(math.log(10000) / (half - 1)))
+    e = times[:, None] * f[None, :]
+    return torch.cat((e.sin(), e.cos()), dim=-1)
+
+
+def mish(x: torch.Tensor) -> torch.Tensor:
+    return x * torch.tanh(F.softplus(x))
+
+
+def layer_norm(x, sd: SD, prefix: str, eps: float) -> torch.Tensor:
+    return F.layer_norm(x, (x.shape[-1],), sd[prefix + ".weight"], sd[prefix + ".bias"], eps)
+
+
+def linear(x, sd: SD, prefix: str, bias: bool = True) -> torch.Tensor:
+    return F.linear(x, sd[prefix + ".weight"], sd[prefix + ".bias"] if bias else None)
+
+
+def _heads(x: torch.Tensor, n_head: int) -> torch.Tensor:
+    b, n, _ = x.shape
+    return x.view(b, n, n_head, -1).transpose(1, 2)  # (b,h,n,dk)
+
+
+def sbi_msa(q_in, k_in, v_in, sd: SD, prefix: str, n_head: int) -> torch.Tensor:
+    """SBI_MSA.forward with trj_dist=None, eval mode (model/model.py:71-107).
+
+    softmax((Q/8) K^T) V, bias-free projections, bias-free fc, LayerNorm(eps=1e-6).
+    The ``indexed_matrix`` product (:82-83) does not reach the output and is omitted."""
+    q = _heads(F.linear(q_in, sd[prefix + ".w_qs.weight"]), n_head)
+    k = _heads(F.linear(k_in, sd[prefix + ".w_ks.weight"]), n_head)
+    v = _heads(F.linear(v_in, sd[prefix + ".w_vs.weight"]), n_head)
+    att = torch.softmax(torch.matmul(q / (DK ** 0.5), k.transpose(2, 3)), dim=-1)
+    o = torch.matmul(att, v).transpose(1, 2).reshape(q_in.shape[0], q_in.shape[1], -1)
+    o = F.linear(o, sd[prefix + ".fc.weight"])
+    return layer_norm(o, sd, prefix + ".layer_norm", 1e-6)
+
+
+def film(t: torch.Tensor, sd: SD, prefix: str):
+    """DenseFiLM (model/model.py:154-168): Linear(Mish(t)) -> (scale, shift), each (B,1,D)."""
+    p = linear(mish(t), sd, prefix + ".block.1")[:, None, :]
+    return p.chunk(2, dim=-1)
+
+
+def affine(x, scale_shift):
+    """featurewise_affine (model/model.py:171-173)."""
+    scale, shift = scale_shift
+    return (scale + 1) * x + shift
+
+
+def gelu(x):
+    return F.gelu(x)  # exact erf form: TCDiff.py:85 passes F.gelu
+
+
+def encoder_layer(x, sd: SD, prefix: str, freqs, n_head: int) -> torch.Tensor:
+    """TransformerEncoderLayer, norm_first, eval (model/model.py:211-245).
+
+    nn.MultiheadAttention with packed in_proj (+bias), q=k=rot(LN1 x), v=LN1 x, out_proj with bias."""
+    d = x.shape[-1]
+    h = layer_norm(x, sd, prefix + ".norm1", 1e-5)
+    qk = rotary(h, freqs)
+    w, b = sd[prefix + ".self_attn.in_proj_weight"], sd[prefix + ".self_attn.in_proj_bias"]
+    q = _heads(F.linear(qk, w[:d], b[:d]), n_head)
+    k = _heads(F.linear(qk, w[d:2 * d], b[d:2 * d]), n_head)
+    v = _heads(F.linear(h, w[2 * d:], b[2 * d:]), n_head)
+    att = torch.softmax(torch.matmul(q, k.transpose(2, 3)) / math.sqrt(d // n_head), dim=-1)
+    o = torch.matmul(att, v).transpose(1, 2).reshape(x.shape)
+    x = x + linear(o, sd, prefix + ".self_attn.out_proj")
+    h = layer_norm(x, sd, prefix + ".norm2", 1e-5)
+    return x + linear(gelu(linear(h, sd, prefix + ".linear1")), sd, prefix + ".linear2")
+
+
+def decoder_layer(x, mem, t, sd: SD, prefix: str, freqs, n_head: int) -> torch.Tensor:
+    """FiLMTransformerDecoderLayer.forward, norm_first, eval (model/model.py:323-344,371).
+
+    The traj_Modulation result (:346-355) is discarded by ``return x`` (:371): not computed."""
+    h = layer_norm(x, sd, prefix + ".norm1", 1e-5)
+    qk = rotary(h, freqs)
+    x = x + affine(sbi_msa(qk, qk, h, sd, prefix + ".self_attn", n_head), film(t, sd, prefix + ".film1"))
+    h = layer_norm(x, sd, prefix + ".norm2", 1e-5)
+    c = sbi_msa(rotary(h, freqs), rotary(mem, freqs), mem, sd, prefix + ".multihead_attn", n_head)
+    x = x + affine(c, film(t, sd, prefix + ".film2"))
+    h = layer_norm(x, sd, prefix + ".norm3", 1e-5)
+    f = linear(gelu(linear(h, sd, prefix + ".linear1")), sd, prefix + ".linear2")
+    x = x + affine(f, film(t, sd, prefix + ".film3"))
+    return linear(layer_norm(x, sd, prefix + ".norm4", 1e-5), sd, prefix + ".linear3")  # NO residual (:344)
+
+
+# ----------------------------------------------------------------------------------------------
+# DanceDecoder
+# ----------------------------------------------------------------------------------------------
+def infer_config(sd: SD) -> dict:
+    latent = sd["input_projection.weight"].shape[0]
+    nfeats = sd["input_projection.weight"].shape[1]
+    dn = sd["relative_projection_layer.0.weight"].shape[1] // latent
+    seq_len = sd["null_cond_embed"].shape[1]
+    n_layers = 1 + max(int(k.split(".")[2]) for k in sd if k.startswith("seqTransDecoder.stack."))
+    n_head = sd["seqTransDecoder.stack.0.self_attn.w_qs.weight"].shape[0] // DK
+    return dict(latent=latent, nfeats=nfeats, dn=dn, seq_len=seq_len, n_layers=n_layers, n_head=n_head)
+
+
+def music_branch(sd: SD, cond_embed: torch.Tensor, cfg: dict):
+    """Step-invariant part of DanceDecoder.forward (model/model.py:572-583,593-597):
+    returns (cond_tokens (B,S,D) before the keep-mask select, cond_hidden (B,D) for kept clips)."""
+    b, clen, _ = cond_embed.shape
+    if clen % 2 == 1:
+        cond_embed = cond_embed[:, :-1, :]
+    c = cond_embed.reshape(b, clen // 2, -1).float()
+    tok = linear(F.relu(linear(c, sd, "cond_projection.0")), sd, "cond_projection.2")
+    for i in range(2):
+        tok = encoder_layer(tok, sd, f"cond_encoder.{i}", sd["rotary.freqs"], cfg["n_head"])
+    return tok
+
+
+def cond_hidden_of(sd: SD, tokens: torch.Tensor) -> torch.Tensor:
+    """non_attn_cond_projection on mean-pooled tokens (model/model.py:593-597,496-501)."""
+    p = tokens.mean(dim=-2)
+    p = layer_norm(p, sd, "non_attn_cond_projection.0", 1e-5)
+    return linear(F.silu(linear(p, sd, "non_attn_cond_projection.1")), sd, "non_attn_cond_projection.3")
+
+
+def decoder_forward(sd: SD, x, cond_embed, times, cond_drop_prob: float = 0.0,
+                    keep_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """DanceDecoder.forward, eval, trj_dist=None (model/model.py:548-624).
+
+    keep_mask: optional explicit bool (B,) (else prob_mask_like semantics, model/utils.py:52-58)."""
+    cfg = infer_config(sd)
+    D, S, dn, nf = cfg["latent"], cfg["seq_len"], cfg["dn"], cfg["nfeats"]
+    B = x.shape[0]
+    x = x.reshape(B, -1, nf)
+    # :560-561 input projection + fusion projection over per-frame concatenated dancers
+    x = linear(x, sd, "input_projection")
+    f = x.reshape(B, S, D * dn)
+    f = F.relu(linear(f, sd, "relative_projection_layer.0"))
+    f = F.relu(linear(f, sd, "relative_projection_layer.2"))
+    x = linear(f, sd, "relative_projection_layer.4").reshape(B, dn * S, D)
+    # :567-569 keep mask
+    if keep_mask is None:
+        p = 1 - cond_drop_prob
+        if p == 1:
+            keep_mask = torch.ones(B, dtype=torch.bool)
+        elif p == 0:
+            keep_mask = torch.zeros(B, dtype=torch.bool)
+        else:
+            keep_mask = torch.zeros(B).float().uniform_(0, 1) < p
+    # :572-589 music tokens, null select
+    tok = music_branch(sd, cond_embed, cfg)
+    tok = torch.where(keep_mask[:, None, None], tok, sd["null_cond_embed"].to(tok.dtype))
+    # :593-610 pooled hidden, null select
+    ch = cond_hidden_of(sd, tok)
+    ch = torch.where(keep_mask[:, None], ch, sd["null_cond_hidden"].to(ch.dtype))
+    # :601-612 time path
+    th = mish(linear(sinusoidal_emb(times, D), sd, "time_mlp.1"))
+    t = linear(th, sd, "to_time_cond.0") + ch
+    ttok = linear(th, sd, "to_time_tokens.0").reshape(B, 2, D)
+    # :615-616 memory
+    mem = layer_norm(torch.cat((tok, ttok), dim=-2), sd, "norm_cond", 1e-5)
+    # :621 decoder stack, :623 final layer
+    for i in range(cfg["n_layers"]):
+        x = decoder_layer(x, mem, t, sd, f"seqTransDecoder.stack.{i}", sd["rotary.freqs"], cfg["n_head"])
+    return linear(x, sd, "final_layer")
+
+
+def guided_forward(sd: SD, x, cond_embed, times, guidance_weight) -> torch.Tensor:
+    """DanceDecoder.guided_forward (model/model.py:542-546)."""
+    unc = decoder_forward(sd, x, cond_embed, times, cond_drop_prob=1)
+    con = decoder_forward(sd, x, cond_embed, times, cond_drop_prob=0)
+    return unc + (con - unc) * guidance_weight
+
+
+# ----------------------------------------------------------------------------------------------
+# GaussianDiffusion samplers
+# ----------------------------------------------------------------------------------------------
+NoiseFn = Callable[[int, torch.Size], torch.Tensor]  # (call index, shape) -> N(0,1) tensor
+
+
+def _default_noise(_i, shape):
+    return torch.randn(shape)
+
+
+def ddpm_guidance_weight(i: int, n_timestep: int, w: float) -> float:
+    """Guidance clipping of p_mean_variance (model/diffusion.py:219-224)."""
+    if i > 1.0 * n_timestep:
+        return min(w, 0)
+    if i < 0.1 * n_timestep:
+        return min(w, 1)
+    return w
+
+
+def p_sample(sd: SD, tab, x, cond, i: int, n_timestep: int, w: float, eps: torch.Tensor):
+    """p_sample + p_mean_variance + q_posterior, predict_epsilon=False, clip_denoised=True
+    (model/diffusion.py:206-252)."""
+    B = x.shape[0]
+    t = torch.full((B,), i, dtype=torch.long)
+    x0 = guided_forward(sd, x, cond, t, ddpm_guidance_weight(i, n_timestep, w)).clamp(-1.0, 1.0)
+    mean = tab["posterior_mean_coef1"][i] * x0 + tab["posterior_mean_coef2"][i] * x
+    logvar = tab["posterior_log_variance_clipped"][i]
+    nonzero = 0.0 if i == 0 else 1.0
+    return mean + nonzero * (0.5 * logvar).exp() * eps, x0
+
+
+def p_sample_loop(sd: SD, shape, cond, noise: Optional[torch.Tensor] = None, n_timestep: int = 1000,
+                  guidance_weight: float = 2, schedule: str = "cosine", start_point: Optional[int] = None,
+                  step_noise: NoiseFn = _default_noise, return_diffusion: bool = False):
+    """GaussianDiffusion.p_sample_loop (model/diffusion.py:255-286).
+
+    ``step_noise(i, shape)`` supplies the randn_like draw of step i (drawn at i == 0 too, :246)."""
+    tab = make_tables(n_timestep, schedule)
+    start = n_timestep if start_point is None else start_point
+    x = torch.randn(shape) if noise is None else noise.clone()
+    diff = [x]
+    for i in reversed(range(0, start)):
+        x, _ = p_sample(sd, tab, x, cond, i, n_timestep, guidance_weight, step_noise(i, x.shape))
+        if return_diffusion:
+            diff.append(x)
+    return (x, diff) if return_diffusion else x
+
+
+def ddim_time_pairs(n_timestep: int, sampling_timesteps: int = 50):
+    """model/diffusion.py:389-391: linspace(-1, T-1, 51).int() reversed, consecutive pairs."""
+    times = torch.linspace(-1, n_timestep - 1, steps=sampling_timesteps + 1)
+    times = list(reversed(times.int().tolist()))
+    return list(zip(times[:-1], times[1:]))
+
+
+def model_predictions(sd: SD, tab, x, cond, time: int, w: float):
+    """model/diffusion.py:195-204 with clip_x_start=True."""
+    t = torch.full((x.shape[0],), time, dtype=torch.long)
+    x0 = guided_forward(sd, x, cond, t, w).clamp(-1.0, 1.0)
+    pred_noise = (tab["sqrt_recip_alphas_cumprod"][time] * x - x0) / tab["sqrt_recipm1_alphas_cumprod"][time]
+    return pred_noise, x0
+
+
+def _overwrite_traj(x, x0_traj, frames: int, nf: int):
+    """x[:,:,:,[4,5]] = x_0[:,:,:,[0,1]] on the (b, frames, dn, nf) view (model/diffusion.py:396-403)."""
+    b, seq, _ = x.shape
+    xv = x.reshape(b, frames, seq // frames, nf)
+    xv[:, :, :, [4, 5]] = x0_traj.reshape(b, frames, seq // frames, -1)[:, :, :, [0, 1]]
+    return xv.reshape(b, seq, nf)
+
+
+def ddim_sample(sd: SD, shape, cond, x_0: Optional[torch.Tensor] = None, n_timestep: int = 1000,
+                guidance_weight: float = 2, schedule: str = "cosine", init_noise: Optional[torch.Tensor] = None,
+                step_noise: NoiseFn = _default_noise, frames: int = 150):
+    """GaussianDiffusion.ddim_sample, 50 steps, eta=1 (model/diffusion.py:386-442).
+
+    ``frames`` is the reference's hard-coded 150 (:399-400)."""
+    tab = make_tables(n_timestep, schedule)
+    ac = tab["alphas_cumprod"]
+    nf = shape[-1]
+    x = torch.randn(shape) if init_noise is None else init_noise.clone()
+    if x_0 is not None:
+        x = _overwrite_traj(x, x_0, frames, nf)
+    for time, time_next in ddim_time_pairs(n_timestep):
+        pred_noise, x_start = model_predictions(sd, tab, x, cond, time, guidance_weight)
+        if time_next < 0:
+            x = x_start
+            continue
+        alpha, alpha_next = ac[time], ac[time_next]
+        sigma = 1 * ((1 - alpha / alpha_next) * (1 - alpha_next) / (1 - alpha)).sqrt()
+        c = (1 - alpha_next - sigma ** 2).sqrt()
+        x = x_start * alpha_next.sqrt() + c * pred_noise + sigma * step_noise(time, x.shape)
+        if x_0 is not None:
+            x = _overwrite_traj(x, x_0, frames, nf)
+    if x_0 is not None:
+        x = _overwrite_traj(x, x_0, frames, nf)
+    return x
+
+
+def long_ddim_sample(sd: SD, shape, cond, x_0, seq_len: int, n_timestep: int = 1000,
+                     guidance_weight: float = 2, schedule: str = "cosine",
+                     init_noise: Optional[torch.Tensor] = None, step_noise: NoiseFn = _default_noise):
+    """GaussianDiffusion.long_ddim_sample (model/diffusion.py:446-515): weight ramp (:454) and
+    window coupling x[1:, :half] = x[:-1, half:] on the (b, seq_len, dn, nf) view (:502-506).
+    x_0 is (b, seq, dn, 3) here (:461-462)."""
+    if shape[0] == 1:
+        return ddim_sample(sd, shape, cond, None, n_timestep, guidance_weight, schedule, init_noise, step_noise)
+    tab = make_tables(n_timestep, schedule)
+    ac = tab["alphas_cumprod"]
+    nf = shape[-1]
+    weights = np.clip(np.linspace(0, guidance_weight * 2, 50), None, guidance_weight)
+    x = torch.randn(shape) if init_noise is None else init_noise.clone()
+    if x_0 is not None:
+        x = _overwrite_traj(x, x_0.reshape(shape[0], -1, 3), x_0.shape[1], nf)
+    half = seq_len // 2
+    for (time, time_next), w in zip(ddim_time_pairs(n_timestep), weights):
+        pred_noise, x_start = model_predictions(sd, tab, x, cond, time, float(w))
+        if time_next < 0:
+            x = x_start
+            continue
+        alpha, alpha_next = ac[time], ac[time_next]
+        sigma = 1 * ((1 - alpha / alpha_next) * (1 - alpha_next) / (1 - alpha)).sqrt()
+        c = (1 - alpha_next - sigma ** 2).sqrt()
+        x = x_start * alpha_next.sqrt() + c * pred_noise + sigma * step_noise(time, x.shape)
+        if x_0 is not None:
+            x = _overwrite_traj(x, x_0.reshape(shape[0], -1, 3), x_0.shape[1], nf)
+        if time > 0:
+            xv = x.reshape(shape[0], seq_len, shape[1] // seq_len, nf)
+            xv[1:, :half] = xv[:-1, half:].clone()
+            x = xv.reshape(shape[0], -1, nf)
+    if x_0 is not None:
+        x = _overwrite_traj(x, x_0.reshape(shape[0], -1, 3), x_0.shape[1], nf)
+    return x
+
+
+def q_sample(tab, x_start, t: torch.Tensor, noise: torch.Tensor):
+    """model/diffusion.py:625-634."""
+    sh = (-1,) + (1,) * (x_start.dim() - 1)
+    return tab["sqrt_alphas_cumprod"][t].reshape(sh) * x_start + \
+        tab["sqrt_one_minus_alphas_cumprod"][t].reshape(sh) * noise
+
+
+# ----------------------------------------------------------------------------------------------
+# synthetic, name-keyed weights: identical on every box, independent of
+# module construction order.
+# ----------------------------------------------------------------------------------------------
+def reference_param_shapes(nfeats=151, seq_len=150, latent=512, ff=1024, n_layers=8, n_head=8,
+                           cond_dim=438, dn=3) -> Dict[str, tuple]:
+    """Every state_dict entry of the reference DanceDecoder (attribute names model/model.py:440-540)."""
+    D = latent
+    s: Dict[str, tuple] = {}
+
+    def lin(p, o, i, bias=True):
+        s[p + ".weight"] = (o, i)
+        if bias:
+            s[p + ".bias"] = (o,)
+
+    def ln(p):
+        s[p + ".weight"] = (D,)
+        s[p + ".bias"] = (D,)
+
+    # the single RotaryEmbedding module is registered under every layer that holds it, so its
+    # buffer appears once per holder in state_dict() (model/model.py:444,483,514)
+    s["rotary.freqs"] = (D // 2,)
+    for i in range(2):
+        s[f"cond_encoder.{i}.rotary.freqs"] = (D // 2,)
+    for i in range(n_layers):
+        s[f"seqTransDecoder.stack.{i}.rotary.freqs"] = (D // 2,)
+    lin("time_mlp.1", 4 * D, D)
+    lin("to_time_cond.0", D, 4 * D)
+    lin("to_time_tokens.0", 2 * D, 4 * D)
+    s["null_cond_embed"] = (1, seq_len, D)
+    s["null_cond_hidden"] = (1, D)
+    ln("norm_cond")
+    lin("input_projection", D, nfeats)
+    for i in range(2):
+        p = f"cond_encoder.{i}"
+        s[p + ".self_attn.in_proj_weight"] = (3 * D, D)
+        s[p + ".self_attn.in_proj_bias"] = (3 * D,)
+        lin(p + ".self_attn.out_proj", D, D)
+        lin(p + ".linear1", ff, D)
+        lin(p + ".linear2", D, ff)
+        ln(p + ".norm1")
+        ln(p + ".norm2")
+    lin("cond_projection.0", cond_dim, 2 * cond_dim)
+    lin("cond_projection.2", D, cond_dim)
+    ln("non_attn_cond_projection.0")
+    lin("non_attn_cond_projection.1", D, D)
+    lin("non_attn_cond_projection.3", D, D)
+    for i in range(n_layers):
+        p = f"seqTransDecoder.stack.{i}"
+        for a in ("self_attn", "multihead_attn"):
+            for w in ("w_qs", "w_ks", "w_vs"):
+                lin(f"{p}.{a}.{w}", n_head * DK, D, bias=False)
+            lin(f"{p}.{a}.fc", D, n_head * DK, bias=False)
+            ln(f"{p}.{a}.layer_norm")
+        lin(p + ".linear1", ff, D)
+        lin(p + ".linear2", D, ff)
+        for n in ("norm1", "norm2", "norm3", "norm4"):
+            ln(f"{p}.{n}")
+        for fl in ("film1", "film2", "film3"):
+            lin(f"{p}.{fl}.block.1", 2 * D, D)
+        lin(p + ".linear3", D, D)
+        dims = [(D, 128), (128, 128), (128, D)]
+        for j, (di, do) in enumerate(dims):  # dead w.r.t. the output, kept for checkpoint parity
+            lin(f"{p}.traj_Modulation.{j}._layer", do, di)
+            lin(f"{p}.traj_Modulation.{j}._hyper_bias", do, 512, bias=False)
+            lin(f"{p}.traj_Modulation.{j}._hyper_gate", do, 512)
+    lin("final_layer", nfeats, D)
+    lin("relative_projection_layer.0", 2 * D, D * dn)
+    lin("relative_projection_layer.2", 2 * D, 2 * D)
+    lin("relative_projection_layer.4", D * dn, 2 * D)
+    s["embeddings_table.weight"] = (10, DK * n_head)
+    lin("traj_embedding.0", 64, 2)
+    lin("traj_embedding.2", D, 64)
+    return s
+
+
+def synth_tensor(name: str, shape: tuple) -> torch.Tensor:
+    """Name-seeded synthetic parameter."""
+    import zlib
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()))
+    if name.endswith("rotary.freqs"):
+        d = shape[0] * 2
+        return 1.0 / (10000 ** (torch.arange(0, d, 2)[: d // 2].float() / d))
+    is_norm = ".norm" in name or "layer_norm" in name or name.startswith("norm_cond") \
+        or name.startswith("non_attn_cond_projection.0")
+    if is_norm and name.endswith(".weight"):
+        return 1.0 + 0.1 * (torch.rand(shape, generator=g) * 2 - 1)
+    if (is_norm and name.endswith(".bias")) or name.startswith("null_cond"):
+        return 0.1 * torch.randn(shape, generator=g)
+    if name.endswith(".bias") or name.endswith("in_proj_bias"):
+        # bias ~ U(-1/sqrt(fan_in), ..) needs fan_in of the matching weight: use shape-independent 1/sqrt(512)
+        return (torch.rand(shape, generator=g) * 2 - 1) / math.sqrt(512.0)
+    fan_in = shape[-1]
+    return (torch.rand(shape, generator=g) * 2 - 1) / math.sqrt(fan_in)
+
+
+def synth_state_dict(**cfg) -> SD:
+    return {k: synth_tensor(k, v) for k, v in sorted(reference_param_shapes(**cfg).items())}
+
+
+def synth_cond(clip_idx: int, seq_len: int = 150, cond_dim: int = 438) -> torch.Tensor:
+    g = torch.Generator().manual_seed(1000 + clip_idx)
+    return torch.randn(2 * seq_len + 1, cond_dim, generator=g)
+
+
+def synth_xT(clip_idx: int, L: int, nfeats: int = 151) -> torch.Tensor:
+    g = torch.Generator().manual_seed(2000 + clip_idx)
+    return torch.randn(L, nfeats, generator=g)
+
+
+def synth_step_eps(clip_idx: int, step: int, L: int, nfeats: int = 151) -> torch.Tensor:
+    g = torch.Generator().manual_seed((3000 + clip_idx) * 100003 + step)
+    return torch.randn(L, nfeats, generator=g)
+
+
+def synth_traj(clip_idx: int, L: int) -> torch.Tensor:
+    g = torch.Generator().manual_seed(4000 + clip_idx)
+    return torch.rand(L, 3, generator=g) * 2 - 1
+
+
+def batch_step_noise(clip_ids, L: int, nfeats: int = 151) -> NoiseFn:
+    def fn(i, shape):
+        return torch.stack([synth_step_eps(c, i, L, nfeats) for c in clip_ids])
+    return fn

@@ -1,0 +1,222 @@
+// Fused softmax(Q K^T) V for the TCDiff denoiser (d_k = 64 per head), gfx950.
+//
+// Replaces the materialised-score attention of SBI_MSA (model/model.py:97-102: matmul, softmax over the
+// flattened frame x dancer token axis, matmul) and of the music encoder's nn.MultiheadAttention
+// (model/model.py:228-236).  One joint softmax over all L = frames*dancers keys, as in the reference.
+//
+// Structure (per workgroup = 4 waves = 128 query rows of one (sequence, head)):
+//   * "swapped" products: S^T = K Q^T and O^T = V^T P^T, so the query index sits on the MFMA lane and the
+//     key / feature index in the accumulator registers.  The row max / row sum of the softmax are then
+//     in-register reductions plus ONE cross-half shuffle, and the P^T accumulator tile is already the B
+//     operand of the PV MFMA (cdna_hip_programming.md section 3 "accumulator tile as the next operand"):
+//     no LDS round trip for P, no transposes.
+//   * K tile [KB keys][64] and V^T tile [64][KB keys] stream through LDS (double buffered, XOR-swizzled
+//     16-byte chunks), KB = 64 keys (bf16) / 32 keys (f32); online softmax across tiles (fp32 m, l).
+//   * V^T is produced directly by the projection GEMM's epilogue (gemm.hip TC_EPI_QKV_HEADS) with the
+//     key order the PV operand wants, so both tiles load as plain 16-byte rows.
+#include "common.h"
+#include "tcdiff_hip.h"
+
+template <class P>
+struct AttnCfg {
+    static constexpr int ES = sizeof(typename P::elem_t);
+    static constexpr int KB = P::KT;                 // keys per staged tile (128 B of V^T row)
+    static constexpr int NKT = KB / 32;              // 32-key MFMA tiles per staged tile
+    static constexpr int DSUB = 64 * ES / TC_ROWB;   // 128-B sub-tiles covering d = 0..63 of a K row
+    static constexpr int NKS = 64 * ES / 32;         // k-steps over d for S^T
+    static constexpr int PV_STEPS = 32 * ES / 32 * 1;  // k-steps over one 32-key tile for O^T: bf16 2, f32 4
+    static constexpr int K_TILE_BYTES = KB * 64 * ES;  // 8 KB
+    static constexpr int V_TILE_BYTES = 64 * TC_ROWB;  // 8 KB
+    static constexpr int STAGE = K_TILE_BYTES + V_TILE_BYTES;
+};
+
+template <class P>
+__global__ __launch_bounds__(256) void attention_kernel(const char* __restrict__ Q, const char* __restrict__ K,
+                                                        const char* __restrict__ Vt, char* __restrict__ O, int H,
+                                                        int Lq, int Lk, int Lp_q, int Lp_k, int ldo,
+                                                        int n_shared) {
+    typedef AttnCfg<P> C;
+    typedef typename P::elem_t T;
+    constexpr int ES = C::ES, KB = C::KB;
+    __shared__ __attribute__((aligned(16))) char smem[2 * C::STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int head = blockIdx.y, seq = blockIdx.z;
+    const int qblk = blockIdx.x * 128;
+    if (qblk >= Lq) return;
+    const int q0 = qblk + wave * 32;
+    const int kv = seq < n_shared ? 0 : seq - n_shared + (n_shared > 0 ? 1 : 0);
+
+    const char* Qg = Q + ((long)(seq * H + head) * Lp_q + q0 + r) * 64 * ES;
+    const char* Kg = K + (long)(kv * H + head) * Lp_k * 64 * ES;
+    const char* Vg = Vt + (long)(kv * H + head) * 64 * (long)Lp_k * ES;
+
+    // Q^T fragments stay in registers for the whole kernel
+    u32x4 qf[C::NKS];
+#pragma unroll
+    for (int ks = 0; ks < C::NKS; ++ks) qf[ks] = *reinterpret_cast<const u32x4*>(Qg + (2 * ks + h) * 16);
+
+    // staging: 512 16-byte chunks per tile, 2 per thread per tile
+    u32x4 sk[2], sv[2];
+    auto load_tiles = [&](int kv0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int c = tid + i * 256;
+            int row = c / (8 * C::DSUB), chk = c % (8 * C::DSUB);
+            sk[i] = *reinterpret_cast<const u32x4*>(Kg + (long)(kv0 + row) * 64 * ES + chk * 16);
+            int d = c >> 3, ch = c & 7;
+            sv[i] = *reinterpret_cast<const u32x4*>(Vg + ((long)d * Lp_k + kv0) * ES + ch * 16);
+        }
+    };
+    auto store_tiles = [&](char* stage) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int c = tid + i * 256;
+            int row = c / (8 * C::DSUB), chk = c % (8 * C::DSUB);
+            int sub = chk >> 3, ch = chk & 7;
+            *reinterpret_cast<u32x4*>(stage + sub * (KB * TC_ROWB) + tile_off(row, ch)) = sk[i];
+            int d = c >> 3, chv = c & 7;
+            *reinterpret_cast<u32x4*>(stage + C::K_TILE_BYTES + tile_off(d, chv)) = sv[i];
+        }
+    };
+
+    f32x16_t o[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) o[dt][q] = 0.0f;
+    float m_run = -INFINITY, l_run = 0.0f;
+
+    const int nb = (Lk + KB - 1) / KB;
+    load_tiles(0);
+    store_tiles(smem);
+    __syncthreads();
+
+    for (int b = 0; b < nb; ++b) {
+        const int cur = b & 1;
+        const int kv0 = b * KB;
+        if (b + 1 < nb) load_tiles(kv0 + KB);
+        const char* kt_base = smem + cur * C::STAGE;
+        const char* vt_base = kt_base + C::K_TILE_BYTES;
+
+        // ---- S^T = K Q^T ---------------------------------------------------------------------------
+        f32x16_t s[C::NKT];
+#pragma unroll
+        for (int kt = 0; kt < C::NKT; ++kt) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) s[kt][q] = 0.0f;
+#pragma unroll
+            for (int ks = 0; ks < C::NKS; ++ks) {
+                const int sub = ks >> 2, ch = 2 * (ks & 3) + h;
+                u32x4 kf = *reinterpret_cast<const u32x4*>(kt_base + sub * (KB * TC_ROWB) + tile_off(kt * 32 + r, ch));
+                P::mma(s[kt], kf, qf[ks]);
+            }
+        }
+        // ---- mask keys beyond Lk (last tile only) -------------------------------------------------
+        if (kv0 + KB > Lk) {
+#pragma unroll
+            for (int kt = 0; kt < C::NKT; ++kt)
+#pragma unroll
+                for (int q = 0; q < 16; ++q)
+                    if (kv0 + kt * 32 + acc_row(q, h) >= Lk) s[kt][q] = -INFINITY;
+        }
+        // ---- online softmax: this lane owns query q0 + r, its half of the keys -----------------------
+        float mx = s[0][0];
+#pragma unroll
+        for (int kt = 0; kt < C::NKT; ++kt)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) mx = fmaxf(mx, s[kt][q]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __expf(m_run - m_new);
+        float rs = 0.0f;
+#pragma unroll
+        for (int kt = 0; kt < C::NKT; ++kt)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                float p = __expf(s[kt][q] - m_new);
+                s[kt][q] = p;
+                rs += p;
+            }
+        rs += __shfl_xor(rs, 32);
+        l_run = l_run * alpha + rs;
+        m_run = m_new;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) o[dt][q] *= alpha;
+
+        // ---- O^T += V^T P^T --------------------------------------------------------------------------
+#pragma unroll
+        for (int kt = 0; kt < C::NKT; ++kt) {
+#pragma unroll
+            for (int st = 0; st < C::PV_STEPS; ++st) {
+                u32x4 pf;
+                if (P::IS_BF16) {
+                    // registers 8st..8st+7 are keys 16st + 8(j>>2) + 4h + (j&3): the V^T image stores keys in
+                    // exactly this order (vt_pos), so chunk (2*step + h) of a V^T row matches element j.
+                    pf.x = pack_bf2(s[kt][8 * st + 0], s[kt][8 * st + 1]);
+                    pf.y = pack_bf2(s[kt][8 * st + 2], s[kt][8 * st + 3]);
+                    pf.z = pack_bf2(s[kt][8 * st + 4], s[kt][8 * st + 5]);
+                    pf.w = pack_bf2(s[kt][8 * st + 6], s[kt][8 * st + 7]);
+                } else {
+                    // f32: MFMA j of the k-step pairs register 4st+j of both halves: keys 8st + j and 8st + 4 + j
+                    pf.x = __builtin_bit_cast(uint32_t, s[kt][4 * st + 0]);
+                    pf.y = __builtin_bit_cast(uint32_t, s[kt][4 * st + 1]);
+                    pf.z = __builtin_bit_cast(uint32_t, s[kt][4 * st + 2]);
+                    pf.w = __builtin_bit_cast(uint32_t, s[kt][4 * st + 3]);
+                }
+                const int ch = (kt * C::PV_STEPS + st) * 2 + h;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    u32x4 vf = *reinterpret_cast<const u32x4*>(vt_base + tile_off(dt * 32 + r, ch));
+                    P::mma(o[dt], vf, pf);
+                }
+            }
+        }
+        if (b + 1 < nb) store_tiles(smem + (cur ^ 1) * C::STAGE);
+        __syncthreads();
+    }
+
+    // ---- O[q][d] = O^T[d][q] / l ---------------------------------------------------------------------
+    const int qg = q0 + r;
+    if (qg < Lq) {
+        const float inv = 1.0f / l_run;
+        T* orow = reinterpret_cast<T*>(O) + ((long)seq * Lq + qg) * ldo + head * 64;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = dt * 32 + 8 * g + 4 * h;
+                float v0 = o[dt][4 * g + 0] * inv, v1 = o[dt][4 * g + 1] * inv;
+                float v2 = o[dt][4 * g + 2] * inv, v3 = o[dt][4 * g + 3] * inv;
+                if (P::IS_BF16) {
+                    uint2 pk;
+                    pk.x = pack_bf2(v0, v1);
+                    pk.y = pack_bf2(v2, v3);
+                    *reinterpret_cast<uint2*>(orow + d0) = pk;
+                } else {
+                    f32x4_t pk = {v0, v1, v2, v3};
+                    *reinterpret_cast<f32x4_t*>(orow + d0) = pk;
+                }
+            }
+    }
+}
+
+extern "C" int tcdiff_attention(int dtype, const void* Q, const void* K, const void* Vt, void* O, int n_seq, int H,
+                                int Lq, int Lk, int Lp_q, int Lp_k, int ldo, int n_shared, hipStream_t stream) {
+    if (!Q || !K || !Vt || !O || n_seq <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return TC_ERR_ARG;
+    if (dtype != TC_DTYPE_BF16 && dtype != TC_DTYPE_F32) return TC_ERR_ARG;
+    if (Lp_q % 128 != 0 || Lp_k % 64 != 0 || Lp_q < Lq || Lp_k < Lk || ldo < H * 64 || ldo % 4 != 0) return TC_ERR_ARG;
+    if (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)Vt | (uintptr_t)O) & 15) return TC_ERR_ALIGN;
+    dim3 grid(Lp_q / 128, H, n_seq);
+    if (dtype == TC_DTYPE_BF16)
+        hipLaunchKernelGGL(attention_kernel<MmaBF16>, grid, dim3(256), 0, stream, (const char*)Q, (const char*)K,
+                           (const char*)Vt, (char*)O, H, Lq, Lk, Lp_q, Lp_k, ldo, n_shared);
+    else
+        hipLaunchKernelGGL(attention_kernel<MmaF32>, grid, dim3(256), 0, stream, (const char*)Q, (const char*)K,
+                           (const char*)Vt, (char*)O, H, Lq, Lk, Lp_q, Lp_k, ldo, n_shared);
+    TC_CHECK_LAUNCH();
+    return TC_OK;
+}

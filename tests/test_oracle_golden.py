@@ -1,0 +1,135 @@
+"""Pin the CPU oracle (oracle/tcdiff_oracle.py) to golden vectors produced by the REAL reference
+(tests/golden/make_golden.py, run in the build container against /root/reference).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import tcdiff_oracle as O
+
+torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+
+
+def g(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def maxabs(a, b):
+    return float(np.max(np.abs(np.asarray(a) - np.asarray(b))))
+
+
+@pytest.mark.parametrize("T", [100, 1000])
+def test_schedule_tables_bit_exact(golden_dir, T):
+    ref = g(golden_dir, f"tables_T{T}")
+    tab = O.make_tables(T, "cosine")
+    for k in ref.files:
+        assert np.array_equal(ref[k], tab[k].numpy()), k
+
+
+def test_state_dict_keys_and_shapes(golden_dir):
+    ref = g(golden_dir, "state_dict_keys_dn3")
+    shapes = O.reference_param_shapes(dn=3, seq_len=150)
+    assert sorted(shapes) == list(ref["keys"])
+    for k, s in zip(ref["keys"], ref["shapes"]):
+        assert str(tuple(shapes[str(k)])) == str(s), k
+    n_params = sum(int(np.prod(shapes[str(k)])) for k in ref["param_order"])
+    assert n_params == 61428181
+
+
+@pytest.fixture(scope="module")
+def c1():
+    sd = O.synth_state_dict(dn=2, seq_len=60)
+    cond = torch.stack([O.synth_cond(0, 60)])
+    xT = torch.stack([O.synth_xT(0, 120)])
+    return sd, cond, xT
+
+
+def test_c1_blocks(golden_dir, c1):
+    sd, _, _ = c1
+    ref = g(golden_dir, "c1_blocks")
+    gen = torch.Generator().manual_seed(77)
+    xb = torch.randn(1, 120, 512, generator=gen)
+    mem = torch.randn(1, 62, 512, generator=gen)
+    tb = torch.randn(1, 512, generator=gen)
+    xe = torch.randn(1, 60, 512, generator=gen)
+    fr = sd["rotary.freqs"]
+    p = "seqTransDecoder.stack.0"
+    assert maxabs(O.rotary(xb, fr), ref["rotary_x"]) < 1e-5
+    assert maxabs(O.sinusoidal_emb(torch.tensor([0, 1, 37, 99, 999]), 512), ref["sinusoidal"]) < 1e-6
+    assert maxabs(O.decoder_layer(xb, mem, tb, sd, p, fr, 8), ref["decoder_layer0"]) < 2e-5
+    assert maxabs(O.encoder_layer(xe, sd, "cond_encoder.0", fr, 8), ref["encoder_layer0"]) < 2e-5
+    assert maxabs(O.sbi_msa(xb, xb, xb, sd, p + ".self_attn", 8), ref["sbi_self"]) < 2e-5
+    sc, sh = O.film(tb, sd, p + ".film1")
+    assert maxabs(sc, ref["film1_scale"]) < 1e-5 and maxabs(sh, ref["film1_shift"]) < 1e-5
+
+
+def test_c1_forward(golden_dir, c1):
+    sd, cond, xT = c1
+    ref = g(golden_dir, "c1_forward")
+    for t in (99, 3):
+        tt = torch.full((1,), t, dtype=torch.long)
+        assert maxabs(O.decoder_forward(sd, xT, cond, tt, 0.0), ref[f"fwd_cond_t{t}"]) < 2e-5
+        assert maxabs(O.decoder_forward(sd, xT, cond, tt, 1.0), ref[f"fwd_unc_t{t}"]) < 2e-5
+        assert maxabs(O.guided_forward(sd, xT, cond, tt, 2), ref[f"guided_w2_t{t}"]) < 5e-5
+
+
+def test_c1_p_sample_loop(golden_dir, c1):
+    """BASELINE config 1: 1 clip, 2 dancers x 60 frames, 100 DDPM steps, injected noise."""
+    sd, cond, xT = c1
+    ref = g(golden_dir, "c1_p_sample_loop")
+    x, chain = O.p_sample_loop(sd, (1, 120, 151), cond, noise=xT, n_timestep=100,
+                               step_noise=O.batch_step_noise([0], 120), return_diffusion=True)
+    assert maxabs(chain[1], ref["after_step_99"]) < 1e-4
+    assert maxabs(chain[50], ref["after_step_50"]) < 1e-4
+    assert maxabs(chain[90], ref["after_step_10"]) < 1e-4
+    assert maxabs(chain[99], ref["after_step_1"]) < 1e-4
+    assert maxabs(x, ref["final"]) < 1e-4
+
+
+@pytest.fixture(scope="module")
+def c2():
+    sd = O.synth_state_dict(dn=3, seq_len=150)
+    cond = torch.stack([O.synth_cond(c, 150) for c in (0, 1)])
+    xT = torch.stack([O.synth_xT(c, 450) for c in (0, 1)])
+    return sd, cond, xT
+
+
+def test_c2_forward(golden_dir, c2):
+    sd, cond, xT = c2
+    ref = g(golden_dir, "c2_forward")
+    for t in (999, 37):
+        tt = torch.full((1,), t, dtype=torch.long)
+        assert maxabs(O.guided_forward(sd, xT[:1], cond[:1], tt, 2), ref[f"guided_w2_t{t}"]) < 5e-5
+    out = O.decoder_forward(sd, xT, cond, torch.tensor([500, 20]), 0.0)
+    assert maxabs(out, ref["fwd_cond_b2_t500_20"]) < 2e-5
+
+
+def test_c2_ddpm_steps(golden_dir, c2):
+    sd, cond, xT = c2
+    ref = g(golden_dir, "c2_ddpm_steps")
+    tab = O.make_tables(1000)
+    eps = O.batch_step_noise([0], 450)
+    for start in (1000, 3):
+        x = xT[:1].clone()
+        for i in reversed(range(start - 3, start)):
+            x, _ = O.p_sample(sd, tab, x, cond[:1], i, 1000, 2, eps(i, x.shape))
+            assert maxabs(x, ref[f"after_step_{i}"]) < 1e-4, i
+
+
+def test_c2_ddim_with_trajectory(golden_dir, c2):
+    sd, cond, xT = c2
+    ref = g(golden_dir, "c2_ddim")
+    x0 = torch.stack([O.synth_traj(0, 450)])
+    x = O.ddim_sample(sd, (1, 450, 151), cond[:1], x_0=x0, init_noise=xT[:1],
+                      step_noise=O.batch_step_noise([0], 450))
+    assert maxabs(x, ref["final"]) < 1e-4
+
+
+def test_c2_long_ddim(golden_dir, c2):
+    sd, cond, xT = c2
+    ref = g(golden_dir, "c2_long_ddim")
+    x0 = torch.stack([O.synth_traj(c, 450) for c in (0, 1)]).reshape(2, 150, 3, 3)
+    x = O.long_ddim_sample(sd, (2, 450, 151), cond, x0, seq_len=150, init_noise=xT,
+                           step_noise=O.batch_step_noise([0, 1], 450))
+    assert maxabs(x, ref["final"]) < 1e-4
