@@ -78,7 +78,7 @@ int tcdiff_gemm_tile(int dtype, const void* A, const void* A2, int split_n, cons
 #define TC_ROW_RES 8        /* v = xres[m][n] + v  (implied by FILM as well)                           */
 #define TC_ROW_STORE_X 16   /* xout[m'][n] = v (fp32)                                                  */
 #define TC_ROW_NEXT_LN 32   /* u = LayerNorm_{nln_eps}(v) * nln_g + nln_b  (the next block's norm, model/model.py:326,332,338,344) */
-#define TC_ROW_STORE_H 64   /* hout[m'][n] = T(u)                                                      */
+#define TC_ROW_STORE_H 64   /* hout[m'][n] = T(u)   (without NEXT_LN: hout[m'][n] = T(v))                      */
 #define TC_ROW_STORE_ROT 128 /* rout[m'][n] = T(rotary(u, pos = m' % L))   (model/model.py:375,387)    */
 
 typedef struct {
@@ -162,7 +162,8 @@ int tcdiff_step_end(int* counter, hipStream_t stream);
  * DDIM: params = {w, sqrt_recip_ac, sqrt_recipm1_ac, sqrt_ac_next, c, sigma, last}  (model/diffusion.py:195-204,407-431)
  *   x0 = clamp(...); pn = (sqrt_recip_ac*x - x0)/sqrt_recipm1_ac; x <- last ? x0 : sqrt_ac_next*x0 + c*pn + sigma*eps
  * out_unc / out_cond: fp32 [n_rows][ldo] network outputs (out_unc may be NULL when w == 1 is known: x0 = clamp(cond)).
- * eps: fp32 [n_rows][nfeat] or NULL -> Philox4x32-10 normal keyed by (seed, clip0 + row / L, timestep, element).
+ * eps: fp32 [n_rows][nfeat] or NULL -> Philox4x32-10 normal keyed by (seed, clip0 + row / L, timestep, element);
+ *      counter[1], counter[2] are device-side seed words XORed into `seed` (re-seed a captured graph).
  * traj: optional fp32 [n_rows][3]: channels 4,5 of x are overwritten with traj[...,0:2] after the update
  * (model/diffusion.py:427-431).  x is updated in place; x0_out (optional) receives x0. */
 #define TC_SAMPLER_DDPM 0
@@ -171,6 +172,10 @@ int tcdiff_sampler_update(int mode, const float* out_unc, const float* out_cond,
                           const float* eps, const float* traj, float* x0_out, int n_rows, int nfeat, int L,
                           const int* counter, const float* params, const int* tseq, uint64_t seed, int clip0,
                           hipStream_t stream);
+
+/* y[row][c] = unc + (cond - unc) * w, c < nfeat  (DanceDecoder.guided_forward, model/model.py:546) */
+int tcdiff_cfg_combine(const float* out_unc, const float* out_cond, int ldo, float w, float* y, int n_rows,
+                       int nfeat, hipStream_t stream);
 
 /* x[1:, :half] = x[:-1, half:] on the (b, seq_len, dn*nfeat) view (model/diffusion.py:502-506,599-601) */
 int tcdiff_window_couple(float* x, int b, int seq_len, int row_elems, hipStream_t stream);

@@ -1,0 +1,92 @@
+"""ctypes binding of libtcdiff_gfx950.so (include/tcdiff_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a launcher returns an error, this
+module raises.  Nothing here touches ``oracle/``.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libtcdiff_gfx950.so")
+
+DT_F32, DT_BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_MISH, ACT_SILU = 0, 1, 2, 3, 4
+EPI_STORE_T, EPI_STORE_F32, EPI_QKV_HEADS = 0, 1, 2
+ROW_BIAS, ROW_LN_POST, ROW_FILM, ROW_RES, ROW_STORE_X, ROW_NEXT_LN, ROW_STORE_H, ROW_STORE_ROT = \
+    1, 2, 4, 8, 16, 32, 64, 128
+SAMPLER_DDPM, SAMPLER_DDIM = 0, 1
+
+_vp, _i, _f, _l = C.c_void_p, C.c_int, C.c_float, C.c_long
+
+
+class TileEpi(C.Structure):
+    _fields_ = [("mode", _i), ("act", _i), ("scale_q", _f), ("bias", _vp), ("out", _vp), ("out_k", _vp),
+                ("out_vt", _vp), ("ldc", _i), ("L", _i), ("Lp", _i), ("H", _i), ("n_q", _i), ("n_k", _i),
+                ("tok_off", _i), ("seq_off", _i)]
+
+
+class RowEpi(C.Structure):
+    _fields_ = [("flags", _i), ("bias", _vp), ("ln_g", _vp), ("ln_b", _vp), ("ln_eps", _f), ("film", _vp),
+                ("film_ld", _i), ("xres", _vp), ("xres_mod", _i), ("xout", _vp), ("L", _i), ("nln_g", _vp),
+                ("nln_b", _vp), ("nln_eps", _f), ("hout", _vp), ("rout", _vp), ("rope", _vp), ("out_mul", _i),
+                ("out_add", _i)]
+
+
+_SIGS = {
+    "tcdiff_gemm_tile": [_i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, C.POINTER(TileEpi), _vp],
+    "tcdiff_gemm_rowln": [_i, _vp, _vp, _i, _i, _i, _i, _i, C.POINTER(RowEpi), _vp],
+    "tcdiff_attention": [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "tcdiff_ln_rot": [_i, _vp, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "tcdiff_rope_table": [_vp, _vp, _i, _vp],
+    "tcdiff_convert_pad": [_i, _vp, _vp, _i, _i, _i, _i, _l, _l, _vp],
+    "tcdiff_sinusoidal": [_i, _vp, _i, _vp, _vp, _vp],
+    "tcdiff_mean_pool": [_vp, _vp, _i, _i, _i, _vp],
+    "tcdiff_add_act": [_i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp],
+    "tcdiff_scatter_time_kv": [_i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "tcdiff_step_begin": [_vp, _vp, _vp, _i, _vp],
+    "tcdiff_step_end": [_vp, _vp],
+    "tcdiff_sampler_update": [_i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, C.c_uint64, _i, _vp],
+    "tcdiff_window_couple": [_vp, _i, _i, _i, _vp],
+    "tcdiff_cfg_combine": [_vp, _vp, _i, _f, _vp, _i, _i, _vp],
+}
+
+EXPORTS = sorted(list(_SIGS) + ["tcdiff_version"])
+
+_lib = None
+
+
+class TcdiffError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library; raises if it has not been built (no CPU fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TcdiffError(f"{LIB_PATH} not found: build it with `python -m tcdiff_amd.build` "
+                          "(the MI355X path has no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    for name, args in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = _i
+    lib.tcdiff_version.restype = C.c_char_p
+    lib.tcdiff_version.argtypes = []
+    _lib = lib
+    return lib
+
+
+_ERR = {-1: "invalid argument", -2: "misaligned pointer / leading dimension", -3: "kernel launch failed",
+        -4: "unsupported configuration"}
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise TcdiffError(f"{what}: {_ERR.get(rc, 'error')} (code {rc})")
+
+
+def ptr(t):
+    """data pointer of a torch tensor (or None)."""
+    return None if t is None else t.data_ptr()

@@ -323,6 +323,18 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(const char* __restrict_
         }
     }
 
+    if (!(f & TC_ROW_NEXT_LN) && (f & TC_ROW_STORE_H)) {  // plain T copy of v (A operand of final_layer)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            int m = m0 + wm * 32 + acc_row(q, h);
+            if (m < M) {
+                long mo = (long)m * e.out_mul + e.out_add;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) reinterpret_cast<T*>(e.hout)[mo * 512 + ncol[j]] = P::from_f32(acc[j][q]);
+            }
+        }
+    }
+
     if (f & TC_ROW_NEXT_LN) {
         layer_norm_rows(e.nln_eps, e.nln_g, e.nln_b, red + 512, red + 768);
 #pragma unroll

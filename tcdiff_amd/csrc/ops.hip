@@ -1,0 +1,421 @@
+// Bandwidth-bound helpers of the TCDiff hot path (gfx950): LayerNorm(+rotary) prologue, rotary table,
+// conditioning-path elementwise ops, per-step K/V scatter and the diffusion update with in-kernel Philox.
+// All loads/stores are 16 bytes per lane where the layout allows (fp32 rows of 512 = 2 x float4 per lane).
+#include "common.h"
+#include "tcdiff_hip.h"
+
+// =================================================================================================
+// LayerNorm (+ rotary): one wave per 512-wide row; lane l owns columns [4l, 4l+4) and [256+4l, 256+4l+4),
+// so every rotary pair (2j, 2j+1) is inside one lane's float4 -- no cross-lane traffic for the rotation.
+// (model/model.py:326,332,338,344 LayerNorm eps 1e-5; rotary model/rotary_embedding_torch.py:46-59)
+// =================================================================================================
+template <class P>
+__global__ __launch_bounds__(256) void ln_rot_kernel(const float* __restrict__ x, int rows, const float* __restrict__ g,
+                                                     const float* __restrict__ b, float eps, void* __restrict__ hout,
+                                                     void* __restrict__ rout, float* __restrict__ y32,
+                                                     const float* __restrict__ rope, int pos_mod, int pos_base) {
+    typedef typename P::elem_t T;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (long)row * 512;
+    f32x4_t v[2];
+    v[0] = *reinterpret_cast<const f32x4_t*>(xr + 4 * lane);
+    v[1] = *reinterpret_cast<const f32x4_t*>(xr + 256 + 4 * lane);
+    float s = (v[0].x + v[0].y) + (v[0].z + v[0].w) + (v[1].x + v[1].y) + (v[1].z + v[1].w);
+    const float mean = wave_sum(s) * (1.0f / 512.0f);
+    float ss = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float d = v[i][j] - mean;
+            ss += d * d;
+        }
+    const float rstd = rsqrtf(wave_sum(ss) * (1.0f / 512.0f) + eps);
+    const int pos = pos_base + (pos_mod > 0 ? row % pos_mod : row);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c0 = i * 256 + 4 * lane;
+        f32x4_t gg = *reinterpret_cast<const f32x4_t*>(g + c0);
+        f32x4_t bb = *reinterpret_cast<const f32x4_t*>(b + c0);
+        f32x4_t u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) u[j] = (v[i][j] - mean) * rstd * gg[j] + bb[j];
+        if (y32) *reinterpret_cast<f32x4_t*>(y32 + (long)row * 512 + c0) = u;
+        if (hout) {
+            T* hp = reinterpret_cast<T*>(hout) + (long)row * 512 + c0;
+            if (P::IS_BF16) {
+                uint2 pk;
+                pk.x = pack_bf2(u[0], u[1]);
+                pk.y = pack_bf2(u[2], u[3]);
+                *reinterpret_cast<uint2*>(hp) = pk;
+            } else {
+                *reinterpret_cast<f32x4_t*>(hp) = u;
+            }
+        }
+        if (rout) {
+            f32x4_t cs = *reinterpret_cast<const f32x4_t*>(rope + (long)pos * 512 + c0);  // cos0 sin0 cos1 sin1
+            f32x4_t y;
+            y[0] = u[0] * cs[0] - u[1] * cs[1];
+            y[1] = u[1] * cs[0] + u[0] * cs[1];
+            y[2] = u[2] * cs[2] - u[3] * cs[3];
+            y[3] = u[3] * cs[2] + u[2] * cs[3];
+            T* rp = reinterpret_cast<T*>(rout) + (long)row * 512 + c0;
+            if (P::IS_BF16) {
+                uint2 pk;
+                pk.x = pack_bf2(y[0], y[1]);
+                pk.y = pack_bf2(y[2], y[3]);
+                *reinterpret_cast<uint2*>(rp) = pk;
+            } else {
+                *reinterpret_cast<f32x4_t*>(rp) = y;
+            }
+        }
+    }
+}
+
+extern "C" int tcdiff_ln_rot(int dtype, const float* x, int rows, const float* g, const float* b, float eps, void* h,
+                             void* rot, float* y32, const float* rope, int pos_mod, int pos_base,
+                             hipStream_t stream) {
+    if (!x || !g || !b || rows <= 0 || (rot && !rope)) return TC_ERR_ARG;
+    if (dtype != TC_DTYPE_BF16 && dtype != TC_DTYPE_F32) return TC_ERR_ARG;
+    dim3 grid((rows + 3) / 4);
+    if (dtype == TC_DTYPE_BF16)
+        hipLaunchKernelGGL(ln_rot_kernel<MmaBF16>, grid, dim3(256), 0, stream, x, rows, g, b, eps, h, rot, y32, rope,
+                           pos_mod, pos_base);
+    else
+        hipLaunchKernelGGL(ln_rot_kernel<MmaF32>, grid, dim3(256), 0, stream, x, rows, g, b, eps, h, rot, y32, rope,
+                           pos_mod, pos_base);
+    TC_CHECK_LAUNCH();
+    return TC_OK;
+}
+
+// rope[p][2j] = cos(p * freqs[j]), rope[p][2j+1] = sin(p * freqs[j]): angle = fp32 product as in the reference
+// (model/rotary_embedding_torch.py:123), accurate sincosf (no fast-math).
+__global__ void rope_table_kernel(const float* __restrict__ freqs, float* __restrict__ rope, int n_pos) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pos * 256) return;
+    int p = i >> 8, j = i & 255;
+    float ang = (float)p * freqs[j];
+    float s, c;
+    sincosf(ang, &s, &c);
+    rope[(long)p * 512 + 2 * j] = c;
+    rope[(long)p * 512 + 2 * j + 1] = s;
+}
+
+extern "C" int tcdiff_rope_table(const float* freqs, float* rope, int n_pos, hipStream_t stream) {
+    if (!freqs || !rope || n_pos <= 0) return TC_ERR_ARG;
+    int n = n_pos * 256;
+    hipLaunchKernelGGL(rope_table_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, freqs, rope, n_pos);
+    TC_CHECK_LAUNCH();
+    return TC_OK;
+}
+
+// =================================================================================================
+// conditioning-path helpers
+// =================================================================================================
+template <class P>
+__global__ void convert_pad_kernel(const float* __restrict__ src, typename P::elem_t* __restrict__ dst, int rows,
+                                   int cols, int ld_dst, int rows_per_batch, long batch_stride, long row_stride) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)rows * ld_dst) return;
+    int r = (int)(i / ld_dst), c = (int)(i % ld_dst);
+    float v = 0.0f;
+    if (c < cols) v = src[(long)(r / rows_per_batch) * batch_stride + (long)(r % rows_per_batch) * row_stride + c];
+    dst[i] = P::from_f32(v);
+}
+
+extern "C" int tcdiff_convert_pad(int dtype, const float* src, void* dst, int rows, int cols, int ld_dst,
+                                  int rows_per_batch, long batch_stride, long row_stride, hipStream_t stream) {
+    if (!src || !dst || rows <= 0 || cols <= 0 || ld_dst < cols || rows_per_batch <= 0) return TC_ERR_ARG;
+    long n = (long)rows * ld_dst;
+    dim3 grid((unsigned)((n + 255) / 256));
+    if (dtype == TC_DTYPE_BF16)
+        hipLaunchKernelGGL(convert_pad_kernel<MmaBF16>, grid, dim3(256), 0, stream, src, (uint16_t*)dst, rows, cols,
+                           ld_dst, rows_per_batch, batch_stride, row_stride);
+    else if (dtype == TC_DTYPE_F32)
+        hipLaunchKernelGGL(convert_pad_kernel<MmaF32>, grid, dim3(256), 0, stream, src, (float*)dst, rows, cols, ld_dst,
+                           rows_per_batch, batch_stride, row_stride);
+    else
+        return TC_ERR_ARG;
+    TC_CHECK_LAUNCH();
+    return TC_OK;
+}
+
+// SinusoidalPosEmb (model/utils.py:36-48): emb = [sin(t*f_k) | cos(t*f_k)], k < 256; f_k supplied by the host
+// (a constant of the architecture, exp(-k ln(1e4)/255) evaluated as the reference does).
+template <class P>
+__global__ void sinusoidal_kernel(const int* __restrict__ times, int n, const float* __restrict__ freq,
+                                  typename P::elem_t* __restrict__ emb) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * 256) return;
+    int row = i >> 8, k = i & 255;
+    float a = (float)times[row] * freq[k];
+    float s, c;
+    sincosf(a, &s, &c);
+    emb[(long)row * 512 + k] = P::from_f32(s);
+    emb[(long)row * 512 + 256 + k] = P::from_f32(c);
+}
+
+extern "C" int tcdiff_sinusoidal(int dtype, const int* times, int n, const float* freq, void* emb,
+                                 hipStream_t stream) {
+    if (!times || !freq || !emb || n <= 0) return TC_ERR_ARG;
+    dim3 grid((n * 256 + 255) / 256);
+    if (dtype == TC_DTYPE_BF16)
+        hipLaunchKernelGGL(sinusoidal_kernel<MmaBF16>, grid, dim3(256), 0, stream, times, n, freq, (uint16_t*)emb);
+    else if (dtype == TC_DTYPE_F32)
+        hipLaunchKernelGGL(sinusoidal_kernel<MmaF32>, grid, dim3(256), 0, stream, times, n, freq, (float*)emb);
+    else
+        return TC_ERR_ARG;
+    TC_CHECK_LAUNCH();
+    return TC_OK;
+}
+
+__global__ void mean_pool_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int S, int C) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * C) return;
+    int b = i / C, c = i % C;
+    const float* p = x + (long)b * S * C + c;
+    float s = 0.0f;
+    for (int t = 0; t < S; ++t) s += p[(long)t * C];
+    out[i] = s / (float)S;
+}
+
+extern "C" int tcdiff_mean_pool(const float* x, float* out, int B, int S, int C, hipStream_t stream) {
+    if (!x || !out || B <= 0 || S <= 0 || C <= 0) return TC_ERR_ARG;
+    hipLaunchKernelGGL(mean_pool_kernel, dim3((B * C + 255) / 256), dim3(256), 0, stream, x, out, B, S, C);
+    TC_CHECK_LAUNCH();
+    return TC_OK;
+}
+
+template <class P>
+__global__ void add_act_kernel(const float* __restrict__ a, const int* __restrict__ ia, const float* __restrict__ b,
+                               int n, int act, typename P::elem_t* __restrict__ out, float* __restrict__ out32) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * 512) return;
+    int row = i >> 9, c = i & 511;
+    int ra = ia ? ia[row] : row;
+    float v = a[(long)ra * 512 + c] + (b ? b[i] : 0.0f);
+    v = apply_act(v, act);
+    if (out) out[i] = P::from_f32(v);
+    if (out32) out32[i] = v;
+}
+
+extern "C" int tcdiff_add_act(int dtype, const float* a, const int* ia, const float* b, int n, int act, void* out,
+                              float* out32, hipStream_t stream) {
+    if (!a || n <= 0 || (!out && !out32)) return TC_ERR_ARG;
+    dim3 grid((n * 512 + 255) / 256);
+    if (dtype == TC_DTYPE_BF16)
+        hipLaunchKernelGGL(add_act_kernel<MmaBF16>, grid, dim3(256), 0, stream, a, ia, b, n, act, (uint16_t*)out, out32);
+    else if (dtype == TC_DTYPE_F32)
+        hipLaunchKernelGGL(add_act_kernel<MmaF32>, grid, dim3(256), 0, stream, a, ia, b, n, act, (float*)out, out32);
+    else
+        return TC_ERR_ARG;
+    TC_CHECK_LAUNCH();
+    return TC_OK;
+}
+
+// per-step: the two time-token rows of every layer's cross-attention K / V^T cache
+template <class P>
+__global__ void scatter_time_kv_kernel(const typename P::elem_t* __restrict__ tab, int n_t,
+                                       const int* __restrict__ tidx, typename P::elem_t* __restrict__ Kc,
+                                       typename P::elem_t* __restrict__ Vtc, int NL, int n_kv, int H, int Lp,
+                                       int tok0) {
+    // one thread per (layer, kv, row r in {0,1}, column c in [0,1024))
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = (long)NL * n_kv * 2 * 1024;
+    if (i >= total) return;
+    int c = (int)(i & 1023);
+    int rr = (int)((i >> 10) & 1);
+    long rest = i >> 11;
+    int kv = (int)(rest % n_kv), l = (int)(rest / n_kv);
+    int t = tidx[kv];
+    typename P::elem_t v = tab[(((long)l * n_t + t) * 2 + rr) * 1024 + c];
+    int tok = tok0 + rr;
+    if (c < 512) {
+        int head = c >> 6, d = c & 63;
+        Kc[((((long)l * n_kv + kv) * H + head) * Lp + tok) * 64 + d] = v;
+    } else {
+        int cc = c - 512;
+        int head = cc >> 6, d = cc & 63;
+        int pos = tok;
+        if (P::IS_BF16) {
+            int kk = tok & 15;
+            pos = (tok & ~15) | (((kk >> 2) & 1) << 3) | ((kk >> 3) << 2) | (kk & 3);
+        }
+        Vtc[((((long)l * n_kv + kv) * H + head) * 64 + d) * Lp + pos] = v;
+    }
+}
+
+extern "C" int tcdiff_scatter_time_kv(int dtype, const void* tab, int n_t, const int* tidx, void* Kc, void* Vtc,
+                                      int NL, int n_kv, int H, int Lp, int tok0, hipStream_t stream) {
+    if (!tab || !tidx || !Kc || !Vtc || NL <= 0 || n_kv <= 0 || H * 64 != 512 || tok0 + 1 >= Lp) return TC_ERR_ARG;
+    long total = (long)NL * n_kv * 2 * 1024;
+    dim3 grid((unsigned)((total + 255) / 256));
+    if (dtype == TC_DTYPE_BF16)
+        hipLaunchKernelGGL(scatter_time_kv_kernel<MmaBF16>, grid, dim3(256), 0, stream, (const uint16_t*)tab, n_t, tidx,
+                           (uint16_t*)Kc, (uint16_t*)Vtc, NL, n_kv, H, Lp, tok0);
+    else if (dtype == TC_DTYPE_F32)
+        hipLaunchKernelGGL(scatter_time_kv_kernel<MmaF32>, grid, dim3(256), 0, stream, (const float*)tab, n_t, tidx,
+                           (float*)Kc, (float*)Vtc, NL, n_kv, H, Lp, tok0);
+    else
+        return TC_ERR_ARG;
+    TC_CHECK_LAUNCH();
+    return TC_OK;
+}
+
+// =================================================================================================
+// sampler: device-resident step state so that ONE captured graph serves every step
+// =================================================================================================
+__global__ void step_begin_kernel(const int* __restrict__ counter, const int* __restrict__ tseq, int* __restrict__ tidx,
+                                  int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) tidx[i] = tseq[counter[0]];
+}
+__global__ void step_end_kernel(int* counter) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) counter[0] += 1;
+}
+
+extern "C" int tcdiff_step_begin(const int* counter, const int* tseq, int* tidx, int n, hipStream_t stream) {
+    if (!counter || !tseq || !tidx || n <= 0) return TC_ERR_ARG;
+    hipLaunchKernelGGL(step_begin_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, counter, tseq, tidx, n);
+    TC_CHECK_LAUNCH();
+    return TC_OK;
+}
+extern "C" int tcdiff_step_end(int* counter, hipStream_t stream) {
+    if (!counter) return TC_ERR_ARG;
+    hipLaunchKernelGGL(step_end_kernel, dim3(1), dim3(64), 0, stream, counter);
+    TC_CHECK_LAUNCH();
+    return TC_OK;
+}
+
+// Philox4x32-10 (Salmon et al. 2011), counter = (element quad, timestep, clip, 0), key = seed
+DEVINL void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+    uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+    uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+    c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+}
+DEVINL void philox4(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+DEVINL float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }  // (0,1)
+
+__global__ void sampler_update_kernel(int mode, const float* __restrict__ out_unc, const float* __restrict__ out_cond,
+                                      int ldo, float* __restrict__ x, const float* __restrict__ eps,
+                                      const float* __restrict__ traj, float* __restrict__ x0_out, int n_rows,
+                                      int nfeat, int L, const int* __restrict__ counter,
+                                      const float* __restrict__ params, const int* __restrict__ tseq, uint64_t seed,
+                                      int clip0) {
+    // one thread per 4 consecutive elements of a row (so one Philox call feeds 4 normals)
+    const int quads = (nfeat + 3) / 4;
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)n_rows * quads) return;
+    const int row = (int)(i / quads), qd = (int)(i % quads);
+    const int step = counter[0];
+    const float* pr = params + (long)step * 8;
+    const float w = pr[0];
+    float z[4] = {0.f, 0.f, 0.f, 0.f};
+    if (!eps) {
+        const int clip = clip0 + row / L, tok = row % L;
+        uint32_t c[4] = {(uint32_t)(tok * quads + qd), (uint32_t)tseq[step], (uint32_t)clip, 0u};
+        // counter[1], counter[2]: device-side seed words (XORed into the by-value seed) so that a captured
+        // graph can be replayed with a new seed
+        philox4(c, (uint32_t)seed ^ (uint32_t)counter[1], (uint32_t)(seed >> 32) ^ (uint32_t)counter[2]);
+        float u0 = u01(c[0]), u1 = u01(c[1]), u2 = u01(c[2]), u3 = u01(c[3]);
+        float r0 = sqrtf(-2.0f * logf(u0)), r1 = sqrtf(-2.0f * logf(u2));
+        float s0, c0, s1, c1;
+        sincosf(6.283185307179586f * u1, &s0, &c0);
+        sincosf(6.283185307179586f * u3, &s1, &c1);
+        z[0] = r0 * c0; z[1] = r0 * s0; z[2] = r1 * c1; z[3] = r1 * s1;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = qd * 4 + j;
+        if (c >= nfeat) break;
+        const long xi = (long)row * nfeat + c;
+        const float oc = out_cond[(long)row * ldo + c];
+        float g;
+        if (out_unc) {
+            const float ou = out_unc[(long)row * ldo + c];
+            g = ou + (oc - ou) * w;  // model/model.py:546
+        } else {
+            g = oc;
+        }
+        const float x0 = fminf(fmaxf(g, -1.0f), 1.0f);  // model/diffusion.py:230-231 / :199-201
+        const float xt = x[xi];
+        const float e = eps ? eps[xi] : z[j];
+        float xn;
+        if (mode == TC_SAMPLER_DDPM) {
+            // model/diffusion.py:207-210,251: mean = coef1*x0 + coef2*x_t ; x = mean + sigma*eps (sigma = 0 at t = 0)
+            xn = (pr[1] * x0 + pr[2] * xt) + pr[3] * e;
+        } else {
+            // model/diffusion.py:189-193,421-425
+            const float pn = (pr[1] * xt - x0) / pr[2];
+            xn = pr[6] != 0.0f ? x0 : (x0 * pr[3] + pr[4] * pn) + pr[5] * e;
+        }
+        if (traj && (c == 4 || c == 5)) xn = traj[(long)row * 3 + (c - 4)];  // model/diffusion.py:427-431
+        x[xi] = xn;
+        if (x0_out) x0_out[xi] = x0;
+    }
+}
+
+extern "C" int tcdiff_sampler_update(int mode, const float* out_unc, const float* out_cond, int ldo, float* x,
+                                     const float* eps, const float* traj, float* x0_out, int n_rows, int nfeat, int L,
+                                     const int* counter, const float* params, const int* tseq, uint64_t seed, int clip0,
+                                     hipStream_t stream) {
+    if (!out_cond || !x || !counter || !params || !tseq || n_rows <= 0 || nfeat <= 0 || L <= 0 || ldo < nfeat)
+        return TC_ERR_ARG;
+    if (mode != TC_SAMPLER_DDPM && mode != TC_SAMPLER_DDIM) return TC_ERR_ARG;
+    long n = (long)n_rows * ((nfeat + 3) / 4);
+    hipLaunchKernelGGL(sampler_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, mode, out_unc,
+                       out_cond, ldo, x, eps, traj, x0_out, n_rows, nfeat, L, counter, params, tseq, seed, clip0);
+    TC_CHECK_LAUNCH();
+    return TC_OK;
+}
+
+// x[1:, :half] = x[:-1, half:] (model/diffusion.py:502-506).  Source and destination ranges of one clip never
+// overlap (first half vs second half), and clip i's second half is only read, so one pass is race-free.
+__global__ void window_couple_kernel(float* __restrict__ x, int b, long half_elems) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)(b - 1) * half_elems) return;
+    long clip = 1 + i / half_elems, e = i % half_elems;
+    x[clip * 2 * half_elems + e] = x[(clip - 1) * 2 * half_elems + half_elems + e];
+}
+
+extern "C" int tcdiff_window_couple(float* x, int b, int seq_len, int row_elems, hipStream_t stream) {
+    if (!x || b <= 0 || seq_len <= 0 || (seq_len & 1) || row_elems <= 0) return TC_ERR_ARG;
+    if (b == 1) return TC_OK;
+    long half = (long)(seq_len / 2) * row_elems;
+    long n = (long)(b - 1) * half;
+    hipLaunchKernelGGL(window_couple_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, b, half);
+    TC_CHECK_LAUNCH();
+    return TC_OK;
+}
+
+__global__ void cfg_combine_kernel(const float* __restrict__ ou, const float* __restrict__ oc, int ldo, float w,
+                                   float* __restrict__ y, int n_rows, int nfeat) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)n_rows * nfeat) return;
+    int row = (int)(i / nfeat), c = (int)(i % nfeat);
+    float u = ou[(long)row * ldo + c], v = oc[(long)row * ldo + c];
+    y[i] = u + (v - u) * w;
+}
+
+extern "C" int tcdiff_cfg_combine(const float* out_unc, const float* out_cond, int ldo, float w, float* y, int n_rows,
+                                  int nfeat, hipStream_t stream) {
+    if (!out_unc || !out_cond || !y || n_rows <= 0 || nfeat <= 0 || ldo < nfeat) return TC_ERR_ARG;
+    long n = (long)n_rows * nfeat;
+    hipLaunchKernelGGL(cfg_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, out_unc, out_cond,
+                       ldo, w, y, n_rows, nfeat);
+    TC_CHECK_LAUNCH();
+    return TC_OK;
+}
+
+extern "C" const char* tcdiff_version(void) { return "tcdiff-gfx950 0.1 (bf16 32x32x16 / f32 32x32x2 MFMA)"; }

@@ -1,0 +1,491 @@
+"""MI355X-native ``GaussianDiffusion`` -- drop-in for the reference's ``model.diffusion.GaussianDiffusion``.
+
+Same constructor arguments, registered buffers and sampler methods (reference model/diffusion.py:79-806).
+Every sampler step is: one stacked (unconditional | conditional) evaluation of the denoiser in HIP kernels,
+then ONE fused kernel doing CFG combine + clamp + the DDPM / DDIM update (+ trajectory in-painting), with the
+step scalars read from device memory so that a single captured hipGraph is replayed for every step.
+
+Out of scope here: the stick-figure renderer behind ``render_sample`` (this class returns
+the samples instead), and the training loss ``p_losses`` (next row, needs backward kernels + SMPL FK).
+"""
+from __future__ import annotations
+
+import copy
+from typing import Callable, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import kernels as K
+
+
+def cosine_beta_schedule(n_timestep: int, cosine_s: float = 8e-3) -> np.ndarray:
+    """fp64 cosine schedule (reference model/utils.py:78-86)."""
+    steps = torch.arange(n_timestep + 1, dtype=torch.float64) / n_timestep + cosine_s
+    ac = torch.cos(steps / (1 + cosine_s) * np.pi / 2).pow(2)
+    ac = ac / ac[0]
+    return np.clip((1 - ac[1:] / ac[:-1]).numpy(), a_min=0, a_max=0.999)
+
+
+def make_beta_schedule(schedule, n_timestep, linear_start=1e-4, linear_end=2e-2, cosine_s=8e-3) -> np.ndarray:
+    if schedule == "cosine":
+        return cosine_beta_schedule(n_timestep, cosine_s)
+    if schedule == "linear":
+        return (torch.linspace(linear_start ** 0.5, linear_end ** 0.5, n_timestep, dtype=torch.float64) ** 2).numpy()
+    if schedule == "sqrt_linear":
+        return torch.linspace(linear_start, linear_end, n_timestep, dtype=torch.float64).numpy()
+    if schedule == "sqrt":
+        return (torch.linspace(linear_start, linear_end, n_timestep, dtype=torch.float64) ** 0.5).numpy()
+    raise ValueError(f"schedule '{schedule}' unknown.")
+
+
+def extract(a, t, x_shape):
+    b, *_ = t.shape
+    return a.gather(-1, t).reshape(b, *((1,) * (len(x_shape) - 1)))
+
+
+class EMA:
+    """Exponential moving average of parameters (reference model/diffusion.py:61-76)."""
+
+    def __init__(self, beta):
+        self.beta = beta
+
+    def update_model_average(self, ma_model, current_model):
+        for cur, ma in zip(current_model.parameters(), ma_model.parameters()):
+            ma.data = self.update_average(ma.data, cur.data)
+
+    def update_average(self, old, new):
+        return new if old is None else old * self.beta + (1 - self.beta) * new
+
+
+FOOT_JOINTS = [1, 2, 3, 4, 5, 7, 8, 10, 11]  # lower-body joints of ddim_sample_Footwork (model/diffusion.py:307)
+
+
+class GaussianDiffusion(nn.Module):
+    def __init__(self, model, horizon, repr_dim, smpl, n_timestep=1000, schedule="linear", loss_type="l1",
+                 clip_denoised=True, predict_epsilon=True, guidance_weight=3, use_p2=False, cond_drop_prob=0.2,
+                 seq_len=150):
+        super().__init__()
+        self.horizon = horizon
+        self.transition_dim = repr_dim
+        self.model = model
+        self.ema = EMA(0.9999)
+        self.master_model = copy.deepcopy(self.model)
+        self.seq_len = seq_len
+        self.cond_drop_prob = cond_drop_prob
+        self.smpl = smpl
+        self.n_timestep = int(n_timestep)
+        self.clip_denoised = clip_denoised
+        self.predict_epsilon = predict_epsilon
+        self.guidance_weight = guidance_weight
+        self.loss_type = loss_type
+
+        # the 13 fp32 [T] tables (reference model/diffusion.py:109-169): betas are rounded to fp32 first and
+        # everything downstream is fp32; coef1/coef2 use numpy's sqrt like the reference does
+        betas = torch.Tensor(make_beta_schedule(schedule=schedule, n_timestep=n_timestep))
+        alphas = 1.0 - betas
+        ac = torch.cumprod(alphas, axis=0)
+        ac_prev = torch.cat([torch.ones(1), ac[:-1]])
+        reg = self.register_buffer
+        reg("betas", betas)
+        reg("alphas_cumprod", ac)
+        reg("alphas_cumprod_prev", ac_prev)
+        reg("sqrt_alphas_cumprod", torch.sqrt(ac))
+        reg("sqrt_one_minus_alphas_cumprod", torch.sqrt(1.0 - ac))
+        reg("log_one_minus_alphas_cumprod", torch.log(1.0 - ac))
+        reg("sqrt_recip_alphas_cumprod", torch.sqrt(1.0 / ac))
+        reg("sqrt_recipm1_alphas_cumprod", torch.sqrt(1.0 / ac - 1))
+        post_var = betas * (1.0 - ac_prev) / (1.0 - ac)
+        reg("posterior_variance", post_var)
+        reg("posterior_log_variance_clipped", torch.log(torch.clamp(post_var, min=1e-20)))
+        reg("posterior_mean_coef1", betas * torch.from_numpy(np.sqrt(ac_prev.numpy())) / (1.0 - ac))
+        reg("posterior_mean_coef2", (1.0 - ac_prev) * torch.from_numpy(np.sqrt(alphas.numpy())) / (1.0 - ac))
+        self.p2_loss_weight_k = 1
+        self.p2_loss_weight_gamma = 0.5 if use_p2 else 0
+        reg("p2_loss_weight", (self.p2_loss_weight_k + ac / (1 - ac)) ** -self.p2_loss_weight_gamma)
+        if predict_epsilon or not clip_denoised:
+            raise L.TcdiffError("the MI355X samplers implement predict_epsilon=False, clip_denoised=True "
+                                "(the production configuration, TCDiff.py:90-102)")
+
+    # ------------------------------------------------------------------------------------------
+    # fused sampler core
+    # ------------------------------------------------------------------------------------------
+    def _device(self):
+        return self.betas.device
+
+    def _guidance_weight_at(self, i: int, w=None) -> float:
+        """Guidance clipping of p_mean_variance (reference model/diffusion.py:219-224)."""
+        w = self.guidance_weight if w is None else w
+        if i > 1.0 * self.n_timestep:
+            return min(w, 0)
+        if i < 0.1 * self.n_timestep:
+            return min(w, 1)
+        return w
+
+    def _prepare(self, B: int, cond: torch.Tensor, tseq):
+        """Step-invariant work, once per sampler call: music encoder, cross-attention caches, time tables."""
+        eng = self.model.engine(B)
+        b = eng.b
+        dev = eng.dev
+        tok, hid = eng.encode_music(cond.to(dev))
+        eng.fill_kv_slots(eng.w["null_embed"], 1, 0)
+        eng.fill_kv_slots(tok, B, 1)
+        b["hidden_all"][:B] = eng.w["null_hidden"]
+        b["hidden_all"][B:2 * B] = hid
+        uniq = sorted(set(int(t) for t in tseq))
+        key = (eng.weights_version, tuple(uniq))
+        if eng.tables_key != key:
+            eng.build_time_tables(torch.tensor(uniq, dtype=torch.int32, device=dev))
+            eng.tables_key = key
+            eng.reset_graphs()
+        row_of = {t: i for i, t in enumerate(uniq)}
+        return eng, [row_of[int(t)] for t in tseq]
+
+    def _run(self, mode: int, shape, cond, x: torch.Tensor, tseq, params: torch.Tensor, *, traj=None,
+             step_noise: Optional[Callable] = None, seed: Optional[int] = None, clip_offset: int = 0,
+             after_step: Optional[Callable] = None, use_graph: bool = True, collect=None):
+        """Run len(tseq) sampler steps on x (fp32 [B, L, nfeat], updated in place on the engine's buffer)."""
+        B, Lq, nf = shape
+        eng, rows = self._prepare(B, cond, tseq)
+        b, dev = eng.b, eng.dev
+        n = len(tseq)
+        st = eng.sampler_state(n, B * Lq, nf)
+        st["x"].copy_(x.reshape(B * Lq, nf))
+        st["counter"].zero_()
+        st["rows"][:n] = torch.tensor(rows, dtype=torch.int32)
+        st["tseq"][:n] = torch.tensor([int(t) for t in tseq], dtype=torch.int32)
+        st["params"][:n] = params.to(torch.float32)
+        if traj is not None:
+            st["traj"].copy_(traj.reshape(B * Lq, 3))
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        # the seed lives in device memory (counter[1..2]) so that a captured graph can be re-seeded
+        st["counter"][1:3] = torch.tensor([seed & 0x7FFFFFFF, (seed >> 31) & 0x7FFFFFFF], dtype=torch.int32)
+        w_eff = params[:, 0].tolist()
+
+        def step(branches: int):
+            K.step_begin(st["counter"], st["rows"], b["tidx"], 2 * B)
+            eng.per_step_conditioning(2 * B)
+            if branches == 2:
+                out = eng.network(st["x"], B, 2, 0, B, 0)
+                unc, con = out, out[B * Lq:]
+            else:
+                out = eng.network(st["x"], B, 1, 1, 0, B)
+                unc, con = None, out
+            K.sampler_update(mode, unc, con, 152, st["x"], st["eps"] if step_noise is not None else None,
+                             st["traj"] if traj is not None else None, None, B * Lq, nf, Lq, st["counter"],
+                             st["params"], st["tseq"], seed=0, clip0=clip_offset)
+            K.step_end(st["counter"])
+
+        for i, t in enumerate(tseq):
+            branches = 1 if w_eff[i] == 1.0 else 2
+            if step_noise is not None:
+                st["eps"].copy_(step_noise(int(t), (B, Lq, nf)).reshape(B * Lq, nf))
+            gkey = (mode, branches, step_noise is not None, traj is not None, clip_offset)
+            if not use_graph:
+                step(branches)
+            elif gkey in eng.graphs:
+                eng.graphs[gkey].replay()
+            elif gkey not in eng.graph_warm:
+                step(branches)                  # first visit: eager (loads code objects, sets kernel attributes)
+                eng.graph_warm.add(gkey)
+            else:                               # second visit: capture the step once, replay from now on
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    step(branches)
+                eng.graphs[gkey] = graph
+                graph.replay()
+            if after_step is not None:
+                after_step(i, int(t), st["x"].view(B, Lq, nf))
+            if collect is not None:
+                collect.append(st["x"].view(B, Lq, nf).clone())
+        return st["x"].view(B, Lq, nf).clone()
+
+    # ------------------------------------------------------------------------------------------
+    # reference sampling API
+    # ------------------------------------------------------------------------------------------
+    def predict_start_from_noise(self, x_t, t, noise):
+        return noise  # predict_epsilon=False: the network predicts x_0 (reference model/diffusion.py:176-187)
+
+    def predict_noise_from_start(self, x_t, t, x0):
+        return (extract(self.sqrt_recip_alphas_cumprod, t, x_t.shape) * x_t - x0) / \
+            extract(self.sqrt_recipm1_alphas_cumprod, t, x_t.shape)
+
+    @torch.no_grad()
+    def model_predictions(self, x, cond, t, weight=None, clip_x_start=False):
+        weight = weight if weight is not None else self.guidance_weight
+        x_start = self.model.guided_forward(x, cond, t, weight)
+        if clip_x_start:
+            x_start = torch.clamp(x_start, min=-1.0, max=1.0)
+        return self.predict_noise_from_start(x, t, x_start), x_start
+
+    def q_posterior(self, x_start, x_t, t):
+        mean = extract(self.posterior_mean_coef1, t, x_t.shape) * x_start + \
+            extract(self.posterior_mean_coef2, t, x_t.shape) * x_t
+        return mean, extract(self.posterior_variance, t, x_t.shape), \
+            extract(self.posterior_log_variance_clipped, t, x_t.shape)
+
+    @torch.no_grad()
+    def p_mean_variance(self, x, cond, t):
+        weight = self._guidance_weight_at(int(t[0]))
+        x_recon = self.model.guided_forward(x, cond, t, weight).clamp_(-1.0, 1.0)
+        mean, var, logvar = self.q_posterior(x_start=x_recon, x_t=x, t=t)
+        return mean, var, logvar, x_recon
+
+    def _ddpm_params(self, tseq, weight=None) -> torch.Tensor:
+        t = torch.tensor([int(i) for i in tseq], dtype=torch.long)
+        c1 = self.posterior_mean_coef1.cpu()[t]
+        c2 = self.posterior_mean_coef2.cpu()[t]
+        sig = (1 - (t == 0).float()) * (0.5 * self.posterior_log_variance_clipped.cpu()[t]).exp()
+        p = torch.zeros(len(tseq), 8)
+        p[:, 0] = torch.tensor([float(self._guidance_weight_at(int(i), weight)) for i in tseq])
+        p[:, 1], p[:, 2], p[:, 3] = c1, c2, sig
+        return p
+
+    @torch.no_grad()
+    def p_sample(self, x, cond, t, *, noise=None, seed=None):
+        """One reverse step (reference model/diffusion.py:241-252); returns (x_{t-1}, x_start)."""
+        i = int(t[0])
+        shape = tuple(x.shape)
+        x0_holder = []
+        eng = self.model.engine(shape[0])
+        out = self._run(L.SAMPLER_DDPM, shape, cond, x.float(), [i], self._ddpm_params([i]),
+                        step_noise=(lambda _t, s: noise) if noise is not None else None, seed=seed, use_graph=False)
+        # x_start = clamp(guided) is recomputed from the network outputs of that step
+        b, B, Lq = eng.b, shape[0], shape[1]
+        w = self._guidance_weight_at(i)
+        y = torch.empty(B, Lq, shape[2], device=out.device, dtype=torch.float32)
+        K.cfg_combine(b["out"], b["out"][B * Lq:] if w != 1.0 else b["out"], 152, float(w), y, B * Lq, shape[2])
+        return out, y.clamp_(-1.0, 1.0)
+
+    @torch.no_grad()
+    def p_sample_loop(self, shape, cond, noise=None, constraint=None, return_diffusion=False, start_point=None, *,
+                      step_noise=None, seed=None, clip_offset=0, use_graph=True):
+        """T sequential DDPM steps (reference model/diffusion.py:255-286).
+
+        Extra keyword-only arguments: ``step_noise(t, shape)`` injects the per-step N(0,1) draw (parity tests);
+        otherwise eps comes from an in-kernel Philox stream keyed by (seed, clip_offset + clip, t, element), so
+        the samples of a clip do not depend on the batch it is in or on how clips are sharded over GPUs."""
+        device = self._device()
+        start_point = self.n_timestep if start_point is None else start_point
+        x = torch.randn(shape, device=device) if noise is None else noise.to(device)
+        tseq = list(reversed(range(0, start_point)))
+        chain = [x] if return_diffusion else None
+        out = self._run(L.SAMPLER_DDPM, tuple(shape), cond, x.float(), tseq, self._ddpm_params(tseq),
+                        step_noise=step_noise, seed=seed, clip_offset=clip_offset, use_graph=use_graph, collect=chain)
+        return (out, chain) if return_diffusion else out
+
+    # ---- DDIM ------------------------------------------------------------------------------------
+    def _ddim_pairs(self, sampling_timesteps=50):
+        times = torch.linspace(-1, self.n_timestep - 1, steps=sampling_timesteps + 1)
+        times = list(reversed(times.int().tolist()))
+        return list(zip(times[:-1], times[1:]))
+
+    def _ddim_params(self, pairs, weights) -> torch.Tensor:
+        ac = self.alphas_cumprod.cpu()
+        sr, srm1 = self.sqrt_recip_alphas_cumprod.cpu(), self.sqrt_recipm1_alphas_cumprod.cpu()
+        p = torch.zeros(len(pairs), 8)
+        for i, ((time, time_next), w) in enumerate(zip(pairs, weights)):
+            p[i, 0], p[i, 1], p[i, 2] = float(w), sr[time], srm1[time]
+            if time_next < 0:
+                p[i, 6] = 1.0
+                continue
+            alpha, alpha_next = ac[time], ac[time_next]
+            sigma = 1 * ((1 - alpha / alpha_next) * (1 - alpha_next) / (1 - alpha)).sqrt()   # eta = 1
+            c = (1 - alpha_next - sigma ** 2).sqrt()
+            p[i, 3], p[i, 4], p[i, 5] = alpha_next.sqrt(), c, sigma
+        return p
+
+    @torch.no_grad()
+    def ddim_sample(self, shape, cond, x_0=None, **kwargs):
+        """50-step DDIM, eta=1, optional trajectory in-painting of channels 4,5 (reference model/diffusion.py:386-442).
+        ``noise=``/``start_point=``/``constraint=`` are accepted and ignored like the reference's **kwargs does;
+        recognised extras: init_noise, step_noise, seed, clip_offset."""
+        device = self._device()
+        B, Lq, nf = shape
+        init = kwargs.get("init_noise")
+        x = torch.randn(shape, device=device) if init is None else init.to(device).float().clone()
+        traj = None
+        if x_0 is not None:
+            traj = x_0.to(device).float().reshape(B, Lq, 3)
+            x.view(B, Lq, nf)[:, :, 4:6] = traj[:, :, 0:2]
+        pairs = self._ddim_pairs()
+        params = self._ddim_params(pairs, [self.guidance_weight] * len(pairs))
+        out = self._run(L.SAMPLER_DDIM, (B, Lq, nf), cond, x, [a for a, _ in pairs], params, traj=traj,
+                        step_noise=kwargs.get("step_noise"), seed=kwargs.get("seed"),
+                        clip_offset=kwargs.get("clip_offset", 0))
+        return out
+
+    @torch.no_grad()
+    def long_ddim_sample(self, shape, cond, x_0, **kwargs):
+        """Half-overlapping windows generated as one batch, coupled every step (reference model/diffusion.py:446-515)."""
+        B, Lq, nf = shape
+        if B == 1:
+            return self.ddim_sample(shape, cond, **{k: v for k, v in kwargs.items()
+                                                    if k in ("init_noise", "step_noise", "seed", "clip_offset")})
+        device = self._device()
+        init = kwargs.get("init_noise")
+        x = torch.randn(shape, device=device) if init is None else init.to(device).float().clone()
+        traj = None
+        if x_0 is not None:
+            traj = x_0.to(device).float().reshape(B, Lq, 3)
+            x.view(B, Lq, nf)[:, :, 4:6] = traj[:, :, 0:2]
+        assert B > 1
+        assert self.seq_len % 2 == 0
+        pairs = self._ddim_pairs()
+        weights = np.clip(np.linspace(0, self.guidance_weight * 2, 50), None, self.guidance_weight)
+        params = self._ddim_params(pairs, weights)
+        row = (Lq // self.seq_len) * nf
+
+        def couple(i, t, xv):
+            if pairs[i][1] >= 0 and t > 0:
+                K.window_couple(xv, B, self.seq_len, row)
+
+        return self._run(L.SAMPLER_DDIM, (B, Lq, nf), cond, x, [a for a, _ in pairs], params, traj=traj,
+                         step_noise=kwargs.get("step_noise"), seed=kwargs.get("seed"),
+                         clip_offset=kwargs.get("clip_offset", 0), after_step=couple)
+
+    def _footwork_mask(self, Lq, nf, dn, device):
+        m = torch.zeros(self.seq_len, dn, nf, dtype=torch.bool, device=device)
+        for j in FOOT_JOINTS:
+            m[75:120, :, 4 + 3 + (j - 1) * 6: 4 + 3 + j * 6] = True
+        return m.reshape(Lq, nf)
+
+    @torch.no_grad()
+    def ddim_sample_Footwork(self, shape, cond, x_0=None, **kwargs):
+        """DDIM with trajectory + lower-body rotation in-painting on frames 75:120 and a 10-frame linear blend at
+        the end (reference model/diffusion.py:289-383).  The in-painting copies are tensor plumbing; the network
+        and the DDIM update are the same kernels as ddim_sample."""
+        device = self._device()
+        B, Lq, nf = shape
+        dn = Lq // self.seq_len
+        init = kwargs.get("init_noise")
+        x = torch.randn(shape, device=device) if init is None else init.to(device).float().clone()
+        pairs = self._ddim_pairs()
+        params = self._ddim_params(pairs, [self.guidance_weight] * len(pairs))
+        traj, after = None, None
+        if x_0 is not None:
+            x_0 = x_0.to(device).float().reshape(B, Lq, nf)
+            mask = self._footwork_mask(Lq, nf, dn, device)
+            traj = torch.zeros(B, Lq, 3, device=device)
+            traj[:, :, 0:2] = x_0[:, :, 0:2]        # the reference copies x_0[...,[0,1]] of the 151-d x_0 into x[...,[4,5]] (:303)
+            x[:, :, 4:6] = x_0[:, :, 0:2]
+            x = torch.where(mask[None], x_0, x)
+
+            def after(i, t, xv):
+                if pairs[i][1] >= 0:
+                    xv.copy_(torch.where(mask[None], x_0, xv))
+        x = self._run(L.SAMPLER_DDIM, (B, Lq, nf), cond, x, [a for a, _ in pairs], params, traj=traj,
+                      step_noise=kwargs.get("step_noise"), seed=kwargs.get("seed"),
+                      clip_offset=kwargs.get("clip_offset", 0), after_step=after)
+        if x_0 is not None:
+            xv = x.view(B, self.seq_len, dn, nf)
+            x0v = x_0.view(B, self.seq_len, dn, nf)
+            xv[:, :, :, 4:6] = x0v[:, :, :, 0:2]
+            width = 10
+            wgt = torch.from_numpy(np.linspace(0, 1, width)).to(xv)[None, :, None, None]
+            for j in FOOT_JOINTS:
+                sl = slice(4 + 3 + (j - 1) * 6, 4 + 3 + j * 6)
+                xv[:, 75:75 + width, :, sl] = wgt * x0v[:, 75:75 + width, :, sl] + (1 - wgt) * xv[:, 75:75 + width, :, sl]
+                xv[:, 75 + width:-width, :, sl] = x0v[:, 75 + width:-width, :, sl]
+                xv[:, 120 - width:120, :, sl] = (1 - wgt) * x0v[:, 120 - width:120, :, sl] + wgt * xv[:, 120 - width:120, :, sl]
+            x = xv.reshape(B, Lq, nf)
+        return x
+
+    # ---- in-painting loops ---------------------------------------------------------------------------
+    @torch.no_grad()
+    def inpaint_loop(self, shape, cond, noise=None, constraint=None, return_diffusion=False, start_point=None, **kw):
+        """DDPM loop with a hard constraint re-imposed after every step (reference model/diffusion.py:519-557)."""
+        device = self._device()
+        x = torch.randn(shape, device=device) if noise is None else noise.to(device)
+        mask = constraint["mask"].to(device)
+        value = constraint["value"].to(device)
+        start_point = self.n_timestep if start_point is None else start_point
+        tseq = list(reversed(range(0, start_point)))
+        chain = [x] if return_diffusion else None
+
+        def after(i, t, xv):
+            if t > 0:
+                tt = torch.full((shape[0],), t - 1, device=device, dtype=torch.long)
+                xv.copy_(self.q_sample(value, tt) * mask + (1.0 - mask) * xv)
+
+        out = self._run(L.SAMPLER_DDPM, tuple(shape), cond, x.float(), tseq, self._ddpm_params(tseq),
+                        step_noise=kw.get("step_noise"), seed=kw.get("seed"), after_step=after, collect=chain)
+        return (out, chain) if return_diffusion else out
+
+    @torch.no_grad()
+    def long_inpaint_loop(self, shape, cond, noise=None, constraint=None, return_diffusion=False, start_point=None,
+                          **kw):
+        """DDPM loop over half-overlapping windows (reference model/diffusion.py:560-608)."""
+        device = self._device()
+        B, Lq, nf = shape
+        x = torch.randn(shape, device=device) if noise is None else noise.to(device)
+        assert x.shape[1] % 2 == 0
+        if B == 1:
+            return self.p_sample_loop(shape, cond, noise=noise, constraint=constraint,
+                                      return_diffusion=return_diffusion, start_point=start_point, **kw)
+        start_point = self.n_timestep if start_point is None else start_point
+        tseq = list(reversed(range(0, start_point)))
+        chain = [x] if return_diffusion else None
+
+        def after(i, t, xv):
+            if t > 0:
+                K.window_couple(xv, B, Lq, nf)
+
+        out = self._run(L.SAMPLER_DDPM, (B, Lq, nf), cond, x.float(), tseq, self._ddpm_params(tseq),
+                        step_noise=kw.get("step_noise"), seed=kw.get("seed"), after_step=after, collect=chain)
+        return (out, chain) if return_diffusion else out
+
+    @torch.no_grad()
+    def conditional_sample(self, shape, cond, constraint=None, *args, horizon=None, **kwargs):
+        return self.p_sample_loop(shape, cond, *args, **kwargs)
+
+    # ---- forward process -----------------------------------------------------------------------------
+    def q_sample(self, x_start, t, noise=None):
+        if noise is None:
+            noise = torch.randn_like(x_start)
+        return extract(self.sqrt_alphas_cumprod, t, x_start.shape) * x_start + \
+            extract(self.sqrt_one_minus_alphas_cumprod, t, x_start.shape) * noise
+
+    def noise_to_t(self, x, timestep):
+        t = torch.full((len(x),), timestep, device=x.device).long()
+        return self.q_sample(x, t) if timestep > 0 else x
+
+    def partial_denoise(self, x, cond, t):
+        return self.p_sample_loop(x.shape, cond, noise=self.noise_to_t(x, t), start_point=t)
+
+    # ---- training (next row) -----------------------------------------------------------
+    def p_losses(self, x_start, cond, t, trj_dist=None):
+        raise NotImplementedError("training loss (p_losses: backward kernels + SMPL FK) is the next row of the "
+                                  "hot-path scope table (SURVEY.md 8(f)); this build covers the samplers")
+
+    def loss(self, x, cond, t_override=None, trj_dist=None):
+        return self.p_losses(x, cond, None, trj_dist)
+
+    def forward(self, x, cond, t_override=None, trj_dist=None):
+        return self.loss(x, cond, t_override, trj_dist)
+
+    # ---- render_sample: sampling only ---------------------------------------------------------------------
+    @torch.no_grad()
+    def render_sample(self, shape, cond, normalizer=None, epoch=None, render_out=None, fk_out=None, name=None,
+                      sound=True, mode="normal", noise=None, constraint=None, sound_folder="ood_sliced",
+                      start_point=None, render=True, required_dancer_num=4, x_0=None, render_len=512):
+        """Mode dispatch of the reference (model/diffusion.py:784-806).  The post-processing that follows in the
+        reference (un-normalise, FK, matplotlib / ffmpeg, pickle) is out of scope: the samples are returned."""
+        if isinstance(shape, tuple):
+            if mode == "inpaint":
+                fn = self.inpaint_loop
+            elif mode == "normal":
+                fn = self.ddim_sample
+            elif mode == "long":
+                fn = self.long_ddim_sample
+            elif mode == "ctrl":
+                fn = self.ddim_sample_Footwork
+            else:
+                assert False, "Unrecognized inference mode"
+            if mode == "inpaint":
+                return fn(shape, cond, noise=noise, constraint=constraint, start_point=start_point).detach().cpu()
+            return fn(shape, cond, noise=noise, constraint=constraint, start_point=start_point, x_0=x_0).detach().cpu()
+        return shape

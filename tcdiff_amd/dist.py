@@ -1,0 +1,68 @@
+"""Clip sharding over the GPUs of one node (one process per GPU, torch.distributed; backend "nccl" is RCCL
+over xGMI on ROCm, "gloo" on CPU for tests).
+
+Sampling is embarrassingly parallel over clips (every op of the denoiser and of p_sample is per clip:
+reference model/model.py:548-624, model/diffusion.py:241-286), so the data path has NO collective inside the
+step loop: clips are dealt to ranks in contiguous blocks, noise is keyed by the GLOBAL clip index
+(tcdiff_sampler_update), and one all-gather collects the finished samples.  Weights are replicated: every rank
+builds the same state_dict (by-name synthetic weights or the same checkpoint file)."""
+from __future__ import annotations
+
+import os
+from typing import Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
+    """Initialise the default process group from RANK / WORLD_SIZE / MASTER_* (torchrun contract).
+    Returns (rank, world_size, local_rank).  A single process without the env vars is world_size 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_range(n_clips: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous block [lo, hi) of global clip indices owned by `rank` (blocks differ by at most one clip;
+    contiguous so that long-mode window coupling only crosses one boundary per rank pair)."""
+    base, rem = divmod(n_clips, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def gather_samples(local: torch.Tensor, n_clips: int) -> torch.Tensor:
+    """All-gather per-rank samples (b_local, L, F) into (n_clips, L, F) on every rank, in global clip order.
+    Equal shards use one all_gather_into_tensor (a single RCCL collective); ragged shards pad to the largest."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return local
+    world = dist.get_world_size()
+    sizes = [shard_range(n_clips, r, world) for r in range(world)]
+    bmax = max(hi - lo for lo, hi in sizes)
+    if local.shape[0] < bmax:
+        pad = torch.zeros(bmax - local.shape[0], *local.shape[1:], device=local.device, dtype=local.dtype)
+        local = torch.cat([local, pad], 0)
+    out = torch.empty(world * bmax, *local.shape[1:], device=local.device, dtype=local.dtype)
+    dist.all_gather_into_tensor(out, local.contiguous())
+    out = out.view(world, bmax, *local.shape[1:])
+    return torch.cat([out[r, : hi - lo] for r, (lo, hi) in enumerate(sizes)], 0)
+
+
+def max_over_ranks(seconds: float, device) -> float:
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return seconds
+    t = torch.tensor([seconds], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()

@@ -1,0 +1,355 @@
+"""Host-side sequencing of the TCDiff denoiser on MI355X.
+
+The engine owns (a) the packed weights (T-typed, K padded, fused [Wq|Wk|Wv] / FiLM stacks), (b) the HBM
+workspaces for one batch plan, (c) the launch sequence of one network evaluation.  Every arithmetic op is a
+launcher of libtcdiff_gfx950.so (tcdiff_amd/kernels.py); torch supplies device memory and the stream only.
+
+Data layout in HBM (T = bf16 or f32 operand type, always fp32 for the residual stream):
+  x          fp32 [B*L, 151]           motion tensor, token index = frame*dn + dancer (model/diffusion.py:640,651)
+  xa         fp32 [R, 512]             residual stream, R = n_branch*B*L rows; branch-major: [uncond clips | cond clips]
+  h, rot     T    [R, 512]             LayerNorm output and its rotary image (GEMM A operands)
+  Q, K       T    [n_seq][8][Lp][64]   head-major attention images, Lp = L rounded up to 128 (zero padded)
+  Vt         T    [n_seq][8][64][Lp]   V transposed, key axis in the PV-operand order (gemm.hip vt_pos)
+  Kc, Vtc    T    [8 layers][B+1][8][Lpc][64] cross-attention K/V^T caches: slot 0 = null conditioning,
+                                       slot 1+i = clip i; rows 0..S-1 step-invariant, rows S,S+1 = time tokens
+  film       fp32 [2B][24*1024]        (scale|shift) of the 24 DenseFiLM blocks for this step
+  tables     t_base fp32 [n_t,512], kv_tab T [8][n_t][2][1024]  time path evaluated once per timestep set
+Step-invariant work (music encoder, cross K/V of the 150 music rows, time tables, rotary table) is hoisted
+out of the DDPM loop; results are identical to recomputing it every step.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib as L
+from . import kernels as K
+
+NL_FILM = 3
+
+
+class DenoiserEngine:
+    def __init__(self, cfg: dict, device: torch.device, compute: str = "bf16"):
+        L.load()  # fail loudly when the HIP library is missing
+        if device.type != "cuda":
+            raise L.TcdiffError("DenoiserEngine needs a HIP device (cuda:N); there is no CPU fallback")
+        self.cfg = dict(cfg)
+        self.dev = device
+        self.dt = K.dtype_id(compute)
+        self.T = K.TORCH_DT[self.dt]
+        self.kt = K.k_tile(self.dt)
+        c = self.cfg
+        if c["latent"] != 512 or c["n_head"] * 64 != 512:
+            raise L.TcdiffError("gfx950 kernels are built for latent_dim=512, 8 heads x 64 (TCDiff.py:76-87)")
+        self.D, self.H, self.NL = 512, c["n_head"], c["n_layers"]
+        self.S, self.dn, self.nf, self.ff = c["seq_len"], c["dn"], c["nfeats"], c["ff"]
+        self.Lseq = self.S * self.dn
+        self.Lp = K.round_up(self.Lseq, 128)
+        self.Lps = K.round_up(self.S, 128)       # music encoder self-attention
+        self.Lpc = K.round_up(self.S + 2, 128)   # cross-attention memory
+        self.w: Dict[str, torch.Tensor] = {}
+        self.weights_version = None
+        self.plan_B = 0
+        self.tables_key = None
+        self._sampler_state = None
+        self.reset_graphs()
+
+    def reset_graphs(self):
+        """Captured step graphs hold raw device pointers: drop them whenever any buffer may have moved."""
+        self.graphs = {}
+        self.graph_warm = set()
+
+    def sampler_state(self, n_steps: int, rows: int, nfeat: int):
+        """Persistent device-side sampler state (addresses are baked into captured graphs)."""
+        st = self._sampler_state
+        if st is None or st["x"].shape != (rows, nfeat) or st["cap"] < n_steps:
+            cap = max(4096, n_steps)
+            dev = self.dev
+            st = dict(cap=cap,
+                      x=torch.zeros(rows, nfeat, device=dev), eps=torch.zeros(rows, nfeat, device=dev),
+                      traj=torch.zeros(rows, 3, device=dev), counter=torch.zeros(4, device=dev, dtype=torch.int32),
+                      rows=torch.zeros(cap, device=dev, dtype=torch.int32),
+                      tseq=torch.zeros(cap, device=dev, dtype=torch.int32),
+                      params=torch.zeros(cap, 8, device=dev))
+            self._sampler_state = st
+            self.reset_graphs()
+        return st
+
+    # ------------------------------------------------------------------------------------------
+    # weights
+    # ------------------------------------------------------------------------------------------
+    def _pack(self, w: torch.Tensor, kpad: Optional[int] = None) -> torch.Tensor:
+        n, k = w.shape
+        kp = K.round_up(k, 64) if kpad is None else kpad
+        out = torch.zeros(n, kp, device=self.dev, dtype=self.T)
+        out[:, :k] = w.to(device=self.dev, dtype=self.T)
+        return out.contiguous()
+
+    def _f32(self, t: torch.Tensor) -> torch.Tensor:
+        return t.detach().to(device=self.dev, dtype=torch.float32).contiguous()
+
+    def load_weights(self, sd: Dict[str, torch.Tensor], version=None):
+        """Repack a reference-keyed state_dict (model/model.py:440-540 names) for the kernels."""
+        w, f, p = {}, self._f32, self._pack
+        g = lambda k: sd[k].detach()
+        w["in.w"], w["in.b"] = p(g("input_projection.weight"), 192), f(g("input_projection.bias"))
+        for i, j in ((0, "f1"), (2, "f2"), (4, "f3")):
+            w[j + ".w"] = p(g(f"relative_projection_layer.{i}.weight"))
+            w[j + ".b"] = f(g(f"relative_projection_layer.{i}.bias"))
+        w["t1.w"], w["t1.b"] = p(g("time_mlp.1.weight")), f(g("time_mlp.1.bias"))
+        w["tc.w"], w["tc.b"] = p(g("to_time_cond.0.weight")), f(g("to_time_cond.0.bias"))
+        w["tt.w"], w["tt.b"] = p(g("to_time_tokens.0.weight")), f(g("to_time_tokens.0.bias"))
+        w["null_embed"] = f(g("null_cond_embed")).reshape(self.S, 512)
+        w["null_hidden"] = f(g("null_cond_hidden")).reshape(1, 512)
+        w["nc.g"], w["nc.b"] = f(g("norm_cond.weight")), f(g("norm_cond.bias"))
+        w["c0.w"], w["c0.b"] = p(g("cond_projection.0.weight")), f(g("cond_projection.0.bias"))
+        w["c2.w"], w["c2.b"] = p(g("cond_projection.2.weight")), f(g("cond_projection.2.bias"))
+        for i in range(2):
+            q = f"cond_encoder.{i}."
+            w[f"e{i}.qkv.w"], w[f"e{i}.qkv.b"] = p(g(q + "self_attn.in_proj_weight")), f(g(q + "self_attn.in_proj_bias"))
+            w[f"e{i}.o.w"], w[f"e{i}.o.b"] = p(g(q + "self_attn.out_proj.weight")), f(g(q + "self_attn.out_proj.bias"))
+            w[f"e{i}.l1.w"], w[f"e{i}.l1.b"] = p(g(q + "linear1.weight")), f(g(q + "linear1.bias"))
+            w[f"e{i}.l2.w"], w[f"e{i}.l2.b"] = p(g(q + "linear2.weight")), f(g(q + "linear2.bias"))
+            for n in ("norm1", "norm2"):
+                w[f"e{i}.{n}.g"], w[f"e{i}.{n}.b"] = f(g(q + n + ".weight")), f(g(q + n + ".bias"))
+        w["na.g"], w["na.b"] = f(g("non_attn_cond_projection.0.weight")), f(g("non_attn_cond_projection.0.bias"))
+        w["na1.w"], w["na1.b"] = p(g("non_attn_cond_projection.1.weight")), f(g("non_attn_cond_projection.1.bias"))
+        w["na3.w"], w["na3.b"] = p(g("non_attn_cond_projection.3.weight")), f(g("non_attn_cond_projection.3.bias"))
+        film_w, film_b = [], []
+        for l in range(self.NL):
+            q = f"seqTransDecoder.stack.{l}."
+            sa, ca = q + "self_attn.", q + "multihead_attn."
+            w[f"l{l}.qkv.w"] = p(torch.cat([g(sa + "w_qs.weight"), g(sa + "w_ks.weight"), g(sa + "w_vs.weight")], 0))
+            w[f"l{l}.sfc.w"] = p(g(sa + "fc.weight"))
+            w[f"l{l}.sln.g"], w[f"l{l}.sln.b"] = f(g(sa + "layer_norm.weight")), f(g(sa + "layer_norm.bias"))
+            w[f"l{l}.cq.w"] = p(g(ca + "w_qs.weight"))
+            w[f"l{l}.ckv.w"] = p(torch.cat([g(ca + "w_ks.weight"), g(ca + "w_vs.weight")], 0))
+            w[f"l{l}.cfc.w"] = p(g(ca + "fc.weight"))
+            w[f"l{l}.cln.g"], w[f"l{l}.cln.b"] = f(g(ca + "layer_norm.weight")), f(g(ca + "layer_norm.bias"))
+            w[f"l{l}.ff1.w"], w[f"l{l}.ff1.b"] = p(g(q + "linear1.weight")), f(g(q + "linear1.bias"))
+            w[f"l{l}.ff2.w"], w[f"l{l}.ff2.b"] = p(g(q + "linear2.weight")), f(g(q + "linear2.bias"))
+            w[f"l{l}.l3.w"], w[f"l{l}.l3.b"] = p(g(q + "linear3.weight")), f(g(q + "linear3.bias"))
+            for n in ("norm1", "norm2", "norm3", "norm4"):
+                w[f"l{l}.{n}.g"], w[f"l{l}.{n}.b"] = f(g(q + n + ".weight")), f(g(q + n + ".bias"))
+            for i in (1, 2, 3):
+                film_w.append(g(q + f"film{i}.block.1.weight"))
+                film_b.append(g(q + f"film{i}.block.1.bias"))
+        w["film.w"] = p(torch.cat(film_w, 0))          # [NL*3*1024, 512]
+        w["film.b"] = f(torch.cat(film_b, 0))
+        w["fin.w"], w["fin.b"] = p(g("final_layer.weight")), f(g("final_layer.bias"))
+        # constants of the architecture
+        half = 256
+        w["sin_freq"] = torch.exp(torch.arange(half) * -(math.log(10000) / (half - 1))).to(self.dev)  # model/utils.py:43-44
+        n_pos = max(self.Lseq, self.S + 2)
+        w["rope"] = torch.empty(n_pos, 512, device=self.dev, dtype=torch.float32)
+        K.rope_table(f(g("rotary.freqs")), w["rope"], n_pos)
+        self.w = w
+        self.weights_version = version
+        self.tables_key = None
+        self.reset_graphs()
+
+    # ------------------------------------------------------------------------------------------
+    # workspaces
+    # ------------------------------------------------------------------------------------------
+    def plan(self, B: int):
+        if B == self.plan_B:
+            return
+        dev, T = self.dev, self.T
+        z = lambda *s, dtype=T: torch.zeros(*s, device=dev, dtype=dtype)
+        Lq, S, H, NL = self.Lseq, self.S, self.H, self.NL
+        R = 2 * B * Lq
+        b = {}
+        b["xin"] = z(B * Lq, 192)
+        b["xp"] = z(B * Lq, 512)
+        b["f1"], b["f2"] = z(B * S, 1024), z(B * S, 1024)
+        b["xs"] = z(B * Lq, 512, dtype=torch.float32)
+        b["h"], b["rot"], b["O"] = z(R, 512), z(R, 512), z(R, 512)
+        b["Q"], b["K"] = z(2 * B, H, self.Lp, 64), z(2 * B, H, self.Lp, 64)
+        b["Vt"] = z(2 * B, H, 64, self.Lp)
+        b["xa"] = z(R, 512, dtype=torch.float32)
+        b["h1"] = z(R, 1024)
+        b["out"] = z(R, 152, dtype=torch.float32)
+        b["film"] = z(2 * B, NL * NL_FILM * 1024, dtype=torch.float32)
+        b["film_in"] = z(2 * B, 512)
+        b["Kc"] = z(NL, 2 * B, H, self.Lpc, 64)      # slots: sampler uses 0..B, generic forward up to 2B
+        b["Vtc"] = z(NL, 2 * B, H, 64, self.Lpc)
+        b["hidden_all"] = z(2 * B, 512, dtype=torch.float32)
+        b["tidx"] = torch.zeros(2 * B, device=dev, dtype=torch.int32)
+        # music encoder (setup only)
+        b["cin"] = z(B * S, K.round_up(2 * self.cfg["cond_dim"], 64))
+        b["c1"] = z(B * S, K.round_up(self.cfg["cond_dim"], 64))
+        b["tok"] = z(B * S, 512, dtype=torch.float32)
+        b["mh"], b["mrot"], b["mO"] = z(B * S, 512), z(B * S, 512), z(B * S, 512)
+        b["mQ"], b["mK"] = z(B, H, self.Lps, 64), z(B, H, self.Lps, 64)
+        b["mVt"] = z(B, H, 64, self.Lps)
+        b["mh1"] = z(B * S, 1024)
+        b["pool"] = z(B, 512, dtype=torch.float32)
+        b["pool_h"], b["pool_h2"] = z(B, 512), z(B, 512)
+        b["hidden"] = z(B, 512, dtype=torch.float32)
+        self.b = b
+        self.plan_B = B
+        self.reset_graphs()
+
+    # ------------------------------------------------------------------------------------------
+    # step-invariant conditioning
+    # ------------------------------------------------------------------------------------------
+    def encode_music(self, cond: torch.Tensor):
+        """cond (B, 2S or 2S+1, C) fp32 on device -> tokens fp32 [B*S,512] (b['tok']), hidden fp32 [B,512].
+        model/model.py:572-583 (pairing, cond_projection, cond_encoder) and :593-597 (pooled projection)."""
+        dt, w, b, S, H = self.dt, self.w, self.b, self.S, self.H
+        B, clen, Cd = cond.shape
+        if clen // 2 != S:
+            raise L.TcdiffError(f"cond length {clen} does not pair into seq_len={S} tokens (model/model.py:572-589)")
+        cond = cond.contiguous().float()
+        M = B * S
+        kc0, kc1 = b["cin"].shape[1], b["c1"].shape[1]
+        K.convert_pad(dt, cond, b["cin"], M, 2 * Cd, kc0, rows_per_batch=S, batch_stride=clen * Cd, row_stride=2 * Cd)
+        K.gemm_tile(dt, b["cin"], w["c0.w"], M, Cd, kc0, bias=w["c0.b"], act=L.ACT_RELU, out=b["c1"], ldc=kc1)
+        K.gemm_tile(dt, b["c1"], w["c2.w"], M, 512, kc1, bias=w["c2.b"], mode=L.EPI_STORE_F32, out=b["tok"], ldc=512)
+        for i in range(2):
+            e = f"e{i}."
+            K.ln_rot(dt, b["tok"], M, w[e + "norm1.g"], w[e + "norm1.b"], 1e-5, h=b["mh"], rot=b["mrot"],
+                     rope=w["rope"], pos_mod=S)
+            K.gemm_tile(dt, b["mrot"], w[e + "qkv.w"], M, 1536, 512, A2=b["mh"], split_n=1024, bias=w[e + "qkv.b"],
+                        mode=L.EPI_QKV_HEADS, out=b["mQ"], out_k=b["mK"], out_vt=b["mVt"], scale_q=0.125, Lseq=S,
+                        Lp=self.Lps, H=H, n_q=512, n_k=512)
+            K.attention(dt, b["mQ"], b["mK"], b["mVt"], b["mO"], B, H, S, S, self.Lps, self.Lps, 512)
+            K.gemm_rowln(dt, b["mO"], w[e + "o.w"], M, 512, bias=w[e + "o.b"], xres=b["tok"], xout=b["tok"], Lseq=S,
+                         flags=L.ROW_BIAS | L.ROW_RES | L.ROW_STORE_X | L.ROW_NEXT_LN | L.ROW_STORE_H,
+                         nln_g=w[e + "norm2.g"], nln_b=w[e + "norm2.b"], nln_eps=1e-5, hout=b["mh"])
+            K.gemm_tile(dt, b["mh"], w[e + "l1.w"], M, 1024, 512, bias=w[e + "l1.b"], act=L.ACT_GELU, out=b["mh1"],
+                        ldc=1024)
+            K.gemm_rowln(dt, b["mh1"], w[e + "l2.w"], M, 1024, bias=w[e + "l2.b"], xres=b["tok"], xout=b["tok"],
+                         Lseq=S, flags=L.ROW_BIAS | L.ROW_RES | L.ROW_STORE_X)
+        self._hidden_of(b["tok"], B, b["hidden"])
+        return b["tok"], b["hidden"]
+
+    def _hidden_of(self, tokens, n, out):
+        """non_attn_cond_projection(mean over tokens) (model/model.py:593-597)."""
+        dt, w, b = self.dt, self.w, self.b
+        K.mean_pool(tokens, b["pool"], n, self.S, 512)
+        K.ln_rot(dt, b["pool"], n, w["na.g"], w["na.b"], 1e-5, h=b["pool_h"])
+        K.gemm_tile(dt, b["pool_h"], w["na1.w"], n, 512, 512, bias=w["na1.b"], act=L.ACT_SILU, out=b["pool_h2"], ldc=512)
+        K.gemm_tile(dt, b["pool_h2"], w["na3.w"], n, 512, 512, bias=w["na3.b"], mode=L.EPI_STORE_F32, out=out, ldc=512)
+
+    def fill_kv_slots(self, tokens: torch.Tensor, n: int, slot0: int):
+        """mem rows 0..S-1 = norm_cond(tokens) (model/model.py:615-616); K = rot(mem) Wk, V = mem Wv for every layer
+        (model/model.py:386-396,78-80) into cache slots slot0..slot0+n-1."""
+        dt, w, b, S = self.dt, self.w, self.b, self.S
+        M = n * S
+        K.ln_rot(dt, tokens, M, w["nc.g"], w["nc.b"], 1e-5, h=b["mh"], rot=b["mrot"], rope=w["rope"], pos_mod=S)
+        for l in range(self.NL):
+            K.gemm_tile(dt, b["mrot"], w[f"l{l}.ckv.w"], M, 1024, 512, A2=b["mh"], split_n=512, mode=L.EPI_QKV_HEADS,
+                        out=None, out_k=b["Kc"][l], out_vt=b["Vtc"][l], Lseq=S, Lp=self.Lpc, H=self.H, n_q=0, n_k=512,
+                        seq_off=slot0)
+
+    def build_time_tables(self, times_i32: torch.Tensor):
+        """time path for a set of timesteps (model/model.py:601-605,615-616 rows S,S+1, and their K/V rows):
+        t_base = to_time_cond(time_mlp(t)) fp32 [n_t,512]; kv_tab T [NL][n_t][2][1024]."""
+        dt, w = self.dt, self.w
+        n = times_i32.numel()
+        dev, T = self.dev, self.T
+        emb = torch.empty(n, 512, device=dev, dtype=T)
+        th = torch.empty(n, 2048, device=dev, dtype=T)
+        t_base = torch.empty(n, 512, device=dev, dtype=torch.float32)
+        ttok = torch.empty(n, 1024, device=dev, dtype=torch.float32)
+        th_h = torch.empty(2 * n, 512, device=dev, dtype=T)
+        th_r = torch.empty(2 * n, 512, device=dev, dtype=T)
+        tab = torch.empty(self.NL, n, 2, 1024, device=dev, dtype=T)
+        K.sinusoidal(dt, times_i32, n, w["sin_freq"], emb)
+        K.gemm_tile(dt, emb, w["t1.w"], n, 2048, 512, bias=w["t1.b"], act=L.ACT_MISH, out=th, ldc=2048)
+        K.gemm_tile(dt, th, w["tc.w"], n, 512, 2048, bias=w["tc.b"], mode=L.EPI_STORE_F32, out=t_base, ldc=512)
+        K.gemm_tile(dt, th, w["tt.w"], n, 1024, 2048, bias=w["tt.b"], mode=L.EPI_STORE_F32, out=ttok, ldc=1024)
+        K.ln_rot(dt, ttok, 2 * n, w["nc.g"], w["nc.b"], 1e-5, h=th_h, rot=th_r, rope=w["rope"], pos_mod=2,
+                 pos_base=self.S)
+        for l in range(self.NL):
+            K.gemm_tile(dt, th_r, w[f"l{l}.ckv.w"], 2 * n, 1024, 512, A2=th_h, split_n=512, out=tab[l], ldc=1024)
+        self.t_base, self.kv_tab, self.n_t = t_base, tab, n
+        self.tables_key = None      # callers that cache tables set the key after this returns
+        self.reset_graphs()         # the tables moved: captured graphs point at the old ones
+        return t_base, tab
+
+    # ------------------------------------------------------------------------------------------
+    # one network evaluation
+    # ------------------------------------------------------------------------------------------
+    def per_step_conditioning(self, n_rows_seq: int):
+        """FiLM (scale, shift) of all 24 blocks for every sequence row (model/model.py:154-168,612) and the two
+        time-token K/V rows of every layer; b['tidx'][i] selects the timestep row of sequence / cache slot i.
+        The cache tensor has 2B slots; slots unused by the current mode receive rows that are never read."""
+        dt, w, b = self.dt, self.w, self.b
+        K.scatter_time_kv(dt, self.kv_tab, self.n_t, b["tidx"], b["Kc"], b["Vtc"], self.NL, b["Kc"].shape[1], self.H,
+                          self.Lpc, self.S)
+        K.add_act(dt, self.t_base, b["tidx"], b["hidden_all"], n_rows_seq, L.ACT_MISH, out=b["film_in"])
+        nfilm = self.NL * NL_FILM * 1024
+        K.gemm_tile(dt, b["film_in"], w["film.w"], n_rows_seq, nfilm, 512, bias=w["film.b"], mode=L.EPI_STORE_F32,
+                    out=b["film"], ldc=nfilm)
+
+    def network(self, x: torch.Tensor, B: int, branches: int, kv_slot0: int, n_shared: int, film_row0: int):
+        """DanceDecoder.forward body after the conditioning prologue (model/model.py:553-561,621-623) for
+        `branches` stacked copies of the B clips in x (fp32 [B*L, nfeats]).  Returns b['out'] fp32 [branches*B*L, 152].
+
+        branches=2: rows [uncond | cond]; layer-0 self-attention (which depends on x only) is evaluated once and
+        shared.  kv_slot0 / n_shared map sequences to cross-attention cache slots; film_row0 is the first FiLM row."""
+        dt, w, b = self.dt, self.w, self.b
+        Lq, S, H, dn, NL = self.Lseq, self.S, self.H, self.dn, self.NL
+        Rs, R = B * Lq, branches * B * Lq
+        nseq = branches * B
+        fld = NL * NL_FILM * 1024
+        film0 = b["film"][film_row0:]
+        rope = w["rope"]
+        # input projection + fusion projection over per-frame concatenated dancers (model/model.py:560-561)
+        K.convert_pad(dt, x, b["xin"], Rs, self.nf, 192)
+        K.gemm_tile(dt, b["xin"], w["in.w"], Rs, 512, 192, bias=w["in.b"], out=b["xp"], ldc=512)
+        K.gemm_tile(dt, b["xp"], w["f1.w"], B * S, 1024, 512 * dn, bias=w["f1.b"], act=L.ACT_RELU, out=b["f1"], ldc=1024)
+        K.gemm_tile(dt, b["f1"], w["f2.w"], B * S, 1024, 1024, bias=w["f2.b"], act=L.ACT_RELU, out=b["f2"], ldc=1024)
+        for d in range(dn):  # de-interleave: frame row m, dancer d -> token m*dn + d; fused with layer-0 norm1 + rotary
+            K.gemm_rowln(dt, b["f2"], w["f3.w"][d * 512:], B * S, 1024, bias=w["f3.b"][d * 512:], xout=b["xs"],
+                         Lseq=Lq, flags=L.ROW_BIAS | L.ROW_STORE_X | L.ROW_NEXT_LN | L.ROW_STORE_H | L.ROW_STORE_ROT,
+                         nln_g=w["l0.norm1.g"], nln_b=w["l0.norm1.b"], nln_eps=1e-5, hout=b["h"], rout=b["rot"],
+                         rope=rope, out_mul=dn, out_add=d)
+        Kc0 = b["Kc"][:, kv_slot0:]
+        Vtc0 = b["Vtc"][:, kv_slot0:]
+        for l in range(NL):
+            p = f"l{l}."
+            rows_sa = Rs if l == 0 else R          # layer-0 self-attention is branch-independent
+            nseq_sa = B if l == 0 else nseq
+            # ---- self-attention block (model/model.py:326-327,374-383,71-107)
+            K.gemm_tile(dt, b["rot"], w[p + "qkv.w"], rows_sa, 1536, 512, A2=b["h"], split_n=1024, mode=L.EPI_QKV_HEADS,
+                        out=b["Q"], out_k=b["K"], out_vt=b["Vt"], scale_q=0.125, Lseq=Lq, Lp=self.Lp, H=H, n_q=512,
+                        n_k=512)
+            K.attention(dt, b["Q"], b["K"], b["Vt"], b["O"], nseq_sa, H, Lq, Lq, self.Lp, self.Lp, 512)
+            K.gemm_rowln(dt, b["O"], w[p + "sfc.w"], R, 512, a_mod=Rs if l == 0 else 0,
+                         flags=L.ROW_LN_POST | L.ROW_FILM | L.ROW_STORE_X | L.ROW_NEXT_LN | L.ROW_STORE_ROT,
+                         ln_g=w[p + "sln.g"], ln_b=w[p + "sln.b"], ln_eps=1e-6, film=film0[:, (l * 3 + 0) * 1024:],
+                         film_ld=fld, xres=b["xs"] if l == 0 else b["xa"], xres_mod=Rs if l == 0 else 0, xout=b["xa"],
+                         Lseq=Lq, nln_g=w[p + "norm2.g"], nln_b=w[p + "norm2.b"], nln_eps=1e-5, rout=b["rot"], rope=rope)
+            # ---- cross-attention block (model/model.py:331-334,386-396)
+            K.gemm_tile(dt, b["rot"], w[p + "cq.w"], R, 512, 512, mode=L.EPI_QKV_HEADS, out=b["Q"], out_k=None,
+                        out_vt=None, scale_q=0.125, Lseq=Lq, Lp=self.Lp, H=H, n_q=512, n_k=0)
+            K.attention(dt, b["Q"], Kc0[l], Vtc0[l], b["O"], nseq, H, Lq, S + 2, self.Lp, self.Lpc, 512,
+                        n_shared=n_shared)
+            K.gemm_rowln(dt, b["O"], w[p + "cfc.w"], R, 512,
+                         flags=L.ROW_LN_POST | L.ROW_FILM | L.ROW_STORE_X | L.ROW_NEXT_LN | L.ROW_STORE_H,
+                         ln_g=w[p + "cln.g"], ln_b=w[p + "cln.b"], ln_eps=1e-6, film=film0[:, (l * 3 + 1) * 1024:],
+                         film_ld=fld, xres=b["xa"], xout=b["xa"], Lseq=Lq, nln_g=w[p + "norm3.g"],
+                         nln_b=w[p + "norm3.b"], nln_eps=1e-5, hout=b["h"])
+            # ---- feed-forward block (model/model.py:338-339,399-401)
+            K.gemm_tile(dt, b["h"], w[p + "ff1.w"], R, 1024, 512, bias=w[p + "ff1.b"], act=L.ACT_GELU, out=b["h1"],
+                        ldc=1024)
+            K.gemm_rowln(dt, b["h1"], w[p + "ff2.w"], R, 1024, flags=L.ROW_BIAS | L.ROW_FILM | L.ROW_NEXT_LN | L.ROW_STORE_H,
+                         bias=w[p + "ff2.b"], film=film0[:, (l * 3 + 2) * 1024:], film_ld=fld, xres=b["xa"], Lseq=Lq,
+                         nln_g=w[p + "norm4.g"], nln_b=w[p + "norm4.b"], nln_eps=1e-5, hout=b["h"])
+            # ---- x = linear3(norm4(x)), no residual (model/model.py:344); fused with the next layer's norm1+rotary
+            if l + 1 < NL:
+                n1 = f"l{l + 1}.norm1."
+                K.gemm_rowln(dt, b["h"], w[p + "l3.w"], R, 512, bias=w[p + "l3.b"], xout=b["xa"], Lseq=Lq,
+                             flags=L.ROW_BIAS | L.ROW_STORE_X | L.ROW_NEXT_LN | L.ROW_STORE_H | L.ROW_STORE_ROT,
+                             nln_g=w[n1 + "g"], nln_b=w[n1 + "b"], nln_eps=1e-5, hout=b["h"], rout=b["rot"], rope=rope)
+            else:
+                K.gemm_rowln(dt, b["h"], w[p + "l3.w"], R, 512, bias=w[p + "l3.b"], Lseq=Lq,
+                             flags=L.ROW_BIAS | L.ROW_STORE_H, hout=b["O"])
+        # final layer (model/model.py:623)
+        K.gemm_tile(dt, b["O"], w["fin.w"], R, self.nf, 512, bias=w["fin.b"], mode=L.EPI_STORE_F32, out=b["out"], ldc=152)
+        return b["out"]

@@ -1,0 +1,122 @@
+"""Thin tensor-level wrappers over the C ABI (include/tcdiff_hip.h).  torch is used only for device
+memory and the current HIP stream; every computation is a launcher of libtcdiff_gfx950.so."""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+TORCH_DT = {L.DT_F32: torch.float32, L.DT_BF16: torch.bfloat16}
+
+
+def dtype_id(name_or_dtype) -> int:
+    if name_or_dtype in ("bf16", torch.bfloat16, L.DT_BF16):
+        return L.DT_BF16
+    if name_or_dtype in ("f32", "fp32", torch.float32, L.DT_F32):
+        return L.DT_F32
+    raise ValueError(f"unsupported compute dtype {name_or_dtype!r} (bf16 or f32)")
+
+
+def k_tile(dt: int) -> int:
+    return 64 if dt == L.DT_BF16 else 32
+
+
+def round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def gemm_tile(dt, A, W, M, N, K, *, lda=None, ldw=None, A2=None, split_n=0, a_mod=0, mode=L.EPI_STORE_T,
+              act=L.ACT_NONE, bias=None, out=None, ldc=0, out_k=None, out_vt=None, scale_q=1.0, Lseq=0, Lp=0, H=0,
+              n_q=0, n_k=0, tok_off=0, seq_off=0):
+    lib = L.load()
+    e = L.TileEpi(mode, act, scale_q, _p(bias), _p(out), _p(out_k), _p(out_vt), ldc, Lseq, Lp, H, n_q, n_k, tok_off,
+                  seq_off)
+    rc = lib.tcdiff_gemm_tile(dt, _p(A), _p(A2), split_n, _p(W), M, N, K, lda if lda else K, ldw if ldw else K,
+                              a_mod, C.byref(e), stream())
+    L.check(rc, "tcdiff_gemm_tile")
+
+
+def gemm_rowln(dt, A, W, M, K, *, flags, lda=None, ldw=None, a_mod=0, bias=None, ln_g=None, ln_b=None, ln_eps=1e-6,
+               film=None, film_ld=0, xres=None, xres_mod=0, xout=None, Lseq=1, nln_g=None, nln_b=None, nln_eps=1e-5,
+               hout=None, rout=None, rope=None, out_mul=1, out_add=0):
+    lib = L.load()
+    e = L.RowEpi(flags, _p(bias), _p(ln_g), _p(ln_b), ln_eps, _p(film), film_ld, _p(xres), xres_mod, _p(xout), Lseq,
+                 _p(nln_g), _p(nln_b), nln_eps, _p(hout), _p(rout), _p(rope), out_mul, out_add)
+    rc = lib.tcdiff_gemm_rowln(dt, _p(A), _p(W), M, K, lda if lda else K, ldw if ldw else K, a_mod, C.byref(e),
+                               stream())
+    L.check(rc, "tcdiff_gemm_rowln")
+
+
+def attention(dt, Q, K, Vt, O, n_seq, H, Lq, Lk, Lp_q, Lp_k, ldo, n_shared=0):
+    rc = L.load().tcdiff_attention(dt, _p(Q), _p(K), _p(Vt), _p(O), n_seq, H, Lq, Lk, Lp_q, Lp_k, ldo, n_shared,
+                                   stream())
+    L.check(rc, "tcdiff_attention")
+
+
+def ln_rot(dt, x, rows, g, b, eps, *, h=None, rot=None, y32=None, rope=None, pos_mod=0, pos_base=0):
+    rc = L.load().tcdiff_ln_rot(dt, _p(x), rows, _p(g), _p(b), eps, _p(h), _p(rot), _p(y32), _p(rope), pos_mod,
+                                pos_base, stream())
+    L.check(rc, "tcdiff_ln_rot")
+
+
+def rope_table(freqs, rope, n_pos):
+    L.check(L.load().tcdiff_rope_table(_p(freqs), _p(rope), n_pos, stream()), "tcdiff_rope_table")
+
+
+def convert_pad(dt, src, dst, rows, cols, ld_dst, rows_per_batch=None, batch_stride=0, row_stride=None):
+    rpb = rows if rows_per_batch is None else rows_per_batch
+    rs = cols if row_stride is None else row_stride
+    rc = L.load().tcdiff_convert_pad(dt, _p(src), _p(dst), rows, cols, ld_dst, rpb, batch_stride, rs, stream())
+    L.check(rc, "tcdiff_convert_pad")
+
+
+def sinusoidal(dt, times_i32, n, freq, emb):
+    L.check(L.load().tcdiff_sinusoidal(dt, _p(times_i32), n, _p(freq), _p(emb), stream()), "tcdiff_sinusoidal")
+
+
+def mean_pool(x, out, B, S, Cn):
+    L.check(L.load().tcdiff_mean_pool(_p(x), _p(out), B, S, Cn, stream()), "tcdiff_mean_pool")
+
+
+def add_act(dt, a, ia, b, n, act, out=None, out32=None):
+    L.check(L.load().tcdiff_add_act(dt, _p(a), _p(ia), _p(b), n, act, _p(out), _p(out32), stream()),
+            "tcdiff_add_act")
+
+
+def scatter_time_kv(dt, tab, n_t, tidx, Kc, Vtc, NL, n_kv, H, Lp, tok0):
+    rc = L.load().tcdiff_scatter_time_kv(dt, _p(tab), n_t, _p(tidx), _p(Kc), _p(Vtc), NL, n_kv, H, Lp, tok0,
+                                         stream())
+    L.check(rc, "tcdiff_scatter_time_kv")
+
+
+def step_begin(counter, tseq, tidx, n):
+    L.check(L.load().tcdiff_step_begin(_p(counter), _p(tseq), _p(tidx), n, stream()), "tcdiff_step_begin")
+
+
+def step_end(counter):
+    L.check(L.load().tcdiff_step_end(_p(counter), stream()), "tcdiff_step_end")
+
+
+def sampler_update(mode, out_unc, out_cond, ldo, x, eps, traj, x0_out, n_rows, nfeat, Lseq, counter, params, tseq,
+                   seed=0, clip0=0):
+    rc = L.load().tcdiff_sampler_update(mode, _p(out_unc), _p(out_cond), ldo, _p(x), _p(eps), _p(traj), _p(x0_out),
+                                        n_rows, nfeat, Lseq, _p(counter), _p(params), _p(tseq), seed, clip0,
+                                        stream())
+    L.check(rc, "tcdiff_sampler_update")
+
+
+def window_couple(x, b, seq_len, row_elems):
+    L.check(L.load().tcdiff_window_couple(_p(x), b, seq_len, row_elems, stream()), "tcdiff_window_couple")
+
+
+def cfg_combine(out_unc, out_cond, ldo, w, y, n_rows, nfeat):
+    L.check(L.load().tcdiff_cfg_combine(_p(out_unc), _p(out_cond), ldo, float(w), _p(y), n_rows, nfeat, stream()),
+            "tcdiff_cfg_combine")

@@ -1,0 +1,265 @@
+"""MI355X-native ``DanceDecoder`` -- drop-in for the reference's ``model.model.DanceDecoder``.
+
+Same constructor, same ``forward`` / ``guided_forward`` signatures, same ``state_dict()`` keys, shapes and
+parameter order (reference model/model.py:416-624), so checkpoints, ``Adan(model.parameters())`` and the EMA
+zip order (TCDiff.py:110, model/diffusion.py:67-69) work unchanged.  The module tree below only declares the
+parameters (torch.nn containers); the arithmetic of ``forward`` runs in hand-written gfx950 kernels through
+``tcdiff_amd.engine.DenoiserEngine``.  There is no CPU / eager fallback: calling ``forward`` without the HIP
+library or off-GPU raises.
+
+Parameters that do not influence the output in the reference (``traj_Modulation``, ``traj_embedding``,
+``embeddings_table``: model/model.py:346-355,371,557,82-83) are kept for checkpoint compatibility and are not
+executed.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch import Tensor
+
+from . import _lib as L
+from . import kernels as K
+from .engine import DenoiserEngine
+
+
+class RotaryEmbedding(nn.Module):
+    """Holds the ``freqs`` buffer (model/rotary_embedding_torch.py:75-105, freqs_for='lang', theta=1e4)."""
+
+    def __init__(self, dim: int, theta: float = 10000.0):
+        super().__init__()
+        self.register_buffer("freqs", 1.0 / (theta ** (torch.arange(0, dim, 2)[: dim // 2].float() / dim)))
+
+
+class _NoParam(nn.Module):
+    """Placeholder occupying a Sequential slot that has no parameters in the reference."""
+
+
+class DenseFiLM(nn.Module):
+    def __init__(self, d: int):
+        super().__init__()
+        self.block = nn.Sequential(nn.Mish(), nn.Linear(d, 2 * d))
+
+
+class SBI_MSA(nn.Module):
+    def __init__(self, n_head: int, d_model: int, dropout: float = 0.1, dk: int = 64):
+        super().__init__()
+        self.n_head, self.d_k = n_head, dk
+        self.w_qs = nn.Linear(d_model, n_head * dk, bias=False)
+        self.w_ks = nn.Linear(d_model, n_head * dk, bias=False)
+        self.w_vs = nn.Linear(d_model, n_head * dk, bias=False)
+        self.fc = nn.Linear(n_head * dk, d_model, bias=False)
+        self.layer_norm = nn.LayerNorm(d_model, eps=1e-6)
+
+
+class ConcatSquashLinear(nn.Module):
+    def __init__(self, dim_in, dim_out, dim_ctx):
+        super().__init__()
+        self._layer = nn.Linear(dim_in, dim_out)
+        self._hyper_bias = nn.Linear(dim_ctx, dim_out, bias=False)
+        self._hyper_gate = nn.Linear(dim_ctx, dim_out)
+
+
+class TransformerEncoderLayer(nn.Module):
+    def __init__(self, d_model, nhead, dim_feedforward, dropout, rotary):
+        super().__init__()
+        self.self_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout, batch_first=True)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model, eps=1e-5)
+        self.norm2 = nn.LayerNorm(d_model, eps=1e-5)
+        self.rotary = rotary
+
+
+class FiLMTransformerDecoderLayer(nn.Module):
+    def __init__(self, d_model, nhead, dim_feedforward, dropout, rotary, context_dim=512):
+        super().__init__()
+        self.self_attn = SBI_MSA(nhead, d_model, dropout=dropout)
+        self.multihead_attn = SBI_MSA(nhead, d_model, dropout=dropout)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model, eps=1e-5)
+        self.norm2 = nn.LayerNorm(d_model, eps=1e-5)
+        self.norm3 = nn.LayerNorm(d_model, eps=1e-5)
+        self.film1 = DenseFiLM(d_model)
+        self.film2 = DenseFiLM(d_model)
+        self.film3 = DenseFiLM(d_model)
+        self.rotary = rotary
+        self.linear3 = nn.Linear(d_model, d_model)
+        self.norm4 = nn.LayerNorm(d_model, eps=1e-5)
+        self.traj_Modulation = nn.ModuleList([
+            ConcatSquashLinear(d_model, 128, context_dim),
+            ConcatSquashLinear(128, 128, context_dim),
+            ConcatSquashLinear(128, d_model, context_dim),
+        ])
+
+
+class DecoderLayerStack(nn.Module):
+    def __init__(self, stack):
+        super().__init__()
+        self.stack = stack
+
+
+class DanceDecoder(nn.Module):
+    def __init__(
+        self,
+        nfeats: int,
+        seq_len: int = 150,
+        latent_dim: int = 256,
+        ff_size: int = 1024,
+        num_layers: int = 4,
+        num_heads: int = 4,
+        dropout: float = 0.1,
+        cond_feature_dim: int = 4800,
+        activation: Callable[[Tensor], Tensor] = F.gelu,
+        use_rotary=True,
+        required_dancer_num=4,
+        compute_dtype: str = "bf16",
+        **kwargs,
+    ) -> None:
+        super().__init__()
+        if not use_rotary:
+            raise L.TcdiffError("the MI355X path implements the rotary configuration only (TCDiff.py:76-87)")
+        if activation is not F.gelu:
+            raise L.TcdiffError("the MI355X path implements activation=F.gelu (TCDiff.py:85)")
+        self.nfeats = nfeats
+        self.latent_dim = latent_dim
+        self.required_dancer_num = required_dancer_num
+        self.seq_len = seq_len
+        self.cond_feature_dim = cond_feature_dim
+        self.ff_size, self.num_layers, self.num_heads = ff_size, num_layers, num_heads
+        self.compute_dtype = compute_dtype
+        D = latent_dim
+
+        self.rotary = RotaryEmbedding(dim=D)
+        self.abs_pos_encoding = nn.Identity()
+        self.time_mlp = nn.Sequential(_NoParam(), nn.Linear(D, D * 4), nn.Mish())
+        self.to_time_cond = nn.Sequential(nn.Linear(D * 4, D))
+        self.to_time_tokens = nn.Sequential(nn.Linear(D * 4, D * 2), _NoParam())
+        self.null_cond_embed = nn.Parameter(torch.randn(1, seq_len, D))
+        self.null_cond_hidden = nn.Parameter(torch.randn(1, D))
+        self.norm_cond = nn.LayerNorm(D)
+        self.input_projection = nn.Linear(nfeats, D)
+        self.cond_encoder = nn.Sequential()
+        for _ in range(2):
+            self.cond_encoder.append(TransformerEncoderLayer(D, num_heads, ff_size, dropout, self.rotary))
+        self.cond_projection = nn.Sequential(
+            nn.Linear(cond_feature_dim * 2, cond_feature_dim), nn.ReLU(), nn.Linear(cond_feature_dim, D))
+        self.non_attn_cond_projection = nn.Sequential(nn.LayerNorm(D), nn.Linear(D, D), nn.SiLU(), nn.Linear(D, D))
+        stack = nn.ModuleList([FiLMTransformerDecoderLayer(D, num_heads, ff_size, dropout, self.rotary)
+                               for _ in range(num_layers)])
+        self.seqTransDecoder = DecoderLayerStack(stack)
+        self.final_layer = nn.Linear(D, nfeats)
+        self.relative_projection_layer = nn.Sequential(
+            nn.Linear(D * required_dancer_num, D * 2), nn.ReLU(), nn.Linear(D * 2, D * 2), nn.ReLU(),
+            nn.Linear(D * 2, D * required_dancer_num))
+        self.d_k = 64
+        self.embeddings_table = nn.Embedding(10, self.d_k * num_heads)
+        self.traj_embedding = nn.Sequential(nn.Linear(2, 64), nn.ReLU(), nn.Linear(64, D))
+        self._engine: Optional[DenoiserEngine] = None
+
+    # ------------------------------------------------------------------------------------------
+    # engine plumbing
+    # ------------------------------------------------------------------------------------------
+    def engine_config(self) -> dict:
+        return dict(latent=self.latent_dim, nfeats=self.nfeats, dn=self.required_dancer_num, seq_len=self.seq_len,
+                    n_layers=self.num_layers, n_head=self.num_heads, ff=self.ff_size, cond_dim=self.cond_feature_dim)
+
+    def _weights_version(self):
+        return tuple(p._version for p in self.parameters()) + (str(next(self.parameters()).device),)
+
+    def engine(self, batch: int) -> DenoiserEngine:
+        """The (lazily built) kernel engine, with weights re-packed whenever a parameter changed in place."""
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise L.TcdiffError("DanceDecoder.forward runs on MI355X only: move the module to cuda "
+                                "(no CPU fallback; the CPU oracle lives in oracle/ and is test-only)")
+        if self._engine is None or self._engine.dev != dev or self._engine.dt != K.dtype_id(self.compute_dtype):
+            self._engine = DenoiserEngine(self.engine_config(), dev, self.compute_dtype)
+        ver = self._weights_version()
+        if self._engine.weights_version != ver:
+            self._engine.load_weights(self.state_dict(), version=ver)
+        self._engine.plan(batch)
+        return self._engine
+
+    def set_compute_dtype(self, compute_dtype: str):
+        """'bf16' (throughput) or 'f32' (exact-fp32 MFMA, parity mode)."""
+        K.dtype_id(compute_dtype)
+        self.compute_dtype = compute_dtype
+        self._engine = None
+
+    # ------------------------------------------------------------------------------------------
+    # reference API
+    # ------------------------------------------------------------------------------------------
+    def guided_forward(self, x, cond_embed, times, guidance_weight):
+        """unc + (cond - unc) * w (model/model.py:542-546); both branches in one stacked evaluation."""
+        with torch.no_grad():
+            B = x.shape[0]
+            x = x.reshape(B, -1, self.nfeats).float().contiguous()
+            eng = self.engine(B)
+            b, Lq, dev = eng.b, eng.Lseq, x.device
+            tok, hid = eng.encode_music(cond_embed.to(dev))
+            times = times.to(device=dev, dtype=torch.int32).reshape(-1).contiguous()
+            b["hidden_all"][:B] = eng.w["null_hidden"]
+            b["hidden_all"][B:2 * B] = hid
+            if bool((times == times[0]).all()):
+                # one timestep for the whole batch (every sampler): cache slot 0 <- null conditioning, shared by
+                # all unconditional rows; slots 1..B <- clips
+                eng.build_time_tables(times[:1])
+                b["tidx"].zero_()
+                eng.fill_kv_slots(eng.w["null_embed"], 1, 0)
+                eng.fill_kv_slots(tok, B, 1)
+                n_shared = B
+            else:
+                # per-clip timesteps: the time-token rows differ per clip, so the null slot is replicated
+                eng.build_time_tables(times)
+                ar = torch.arange(B, device=dev, dtype=torch.int32)
+                b["tidx"][:B] = ar
+                b["tidx"][B:2 * B] = ar
+                eng.fill_kv_slots(eng.w["null_embed"][None].expand(B, -1, -1).contiguous(), B, 0)
+                eng.fill_kv_slots(tok, B, B)
+                n_shared = 0
+            eng.per_step_conditioning(2 * B)
+            out = eng.network(x.reshape(B * Lq, self.nfeats), B, 2, 0, n_shared, 0)
+            y = torch.empty(B, Lq, self.nfeats, device=dev, dtype=torch.float32)
+            K.cfg_combine(out, out[B * Lq:], 152, float(guidance_weight), y, B * Lq, self.nfeats)
+            return y
+
+    def forward(self, x: Tensor, cond_embed: Tensor, times: Tensor, cond_drop_prob: float = 0.0, trj_dist=None):
+        """One denoiser evaluation (model/model.py:548-624), inference only (no autograd graph is recorded).
+
+        ``trj_dist`` is accepted for signature parity; the reference never passes it (TCDiff.py:227-229)."""
+        if trj_dist is not None:
+            raise L.TcdiffError("trj_dist is not supported (never used by the reference's callers)")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
+            raise L.TcdiffError("the MI355X path is inference-only in this round: wrap the call in torch.no_grad() "
+                                "and .eval() (training step = SURVEY.md 8(f) 'next' row)")
+        with torch.no_grad():
+            B = x.shape[0]
+            x = x.reshape(B, -1, self.nfeats).float().contiguous()
+            eng = self.engine(B)
+            b, Lq = eng.b, eng.Lseq
+            dev = x.device
+            # keep mask (model/utils.py:52-58): no RNG when the probability is 0 or 1
+            p_keep = 1 - cond_drop_prob
+            if p_keep == 1:
+                keep = torch.ones(B, dtype=torch.bool, device=dev)
+            elif p_keep == 0:
+                keep = torch.zeros(B, dtype=torch.bool, device=dev)
+            else:
+                keep = torch.zeros(B, device=dev).float().uniform_(0, 1) < p_keep
+            tok, hid = eng.encode_music(cond_embed.to(dev))
+            # select per clip between the music conditioning and the null embeddings (model/model.py:585-589,609-610)
+            sel_tok = torch.where(keep[:, None, None], tok.view(B, eng.S, 512), eng.w["null_embed"][None])
+            sel_hid = torch.where(keep[:, None], hid, eng.w["null_hidden"])
+            times = times.to(device=dev, dtype=torch.int32).reshape(-1).contiguous()
+            eng.build_time_tables(times)
+            b["hidden_all"][:B] = sel_hid
+            b["tidx"][:B] = torch.arange(B, device=dev, dtype=torch.int32)
+            b["tidx"][B:] = 0
+            eng.fill_kv_slots(sel_tok.contiguous(), B, 0)
+            eng.per_step_conditioning(B)
+            out = eng.network(x.reshape(B * Lq, self.nfeats), B, 1, 0, 0, 0)
+            return out[: B * Lq, : self.nfeats].reshape(B, Lq, self.nfeats).clone()

@@ -1,0 +1,112 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol the header declares, argument
+validation happens before any launch, the host classes mirror the reference's parameter surface and schedule
+tables, and the product path refuses to run off-GPU (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tcdiff_amd import _lib as L
+from tcdiff_amd.diffusion import GaussianDiffusion
+from tcdiff_amd.model import DanceDecoder
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from tcdiff_amd import build
+    build.build(verbose=False)
+    return L.load()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "tcdiff_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(tcdiff_[a-z_0-9]+)\s*\(", hdr)))
+    assert len(declared) >= 16
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/tcdiff_hip.h but not exported"
+    assert sorted(L.EXPORTS) == declared
+    assert b"gfx950" in lib.tcdiff_version()
+
+
+def test_argument_validation_without_gpu(lib):
+    e = L.TileEpi()
+    assert lib.tcdiff_gemm_tile(L.DT_BF16, None, None, 0, None, 1, 1, 64, 64, 64, 0, ctypes.byref(e), None) == -1
+    r = L.RowEpi()
+    assert lib.tcdiff_gemm_rowln(L.DT_F32, None, None, 1, 32, 32, 32, 0, ctypes.byref(r), None) == -1
+    assert lib.tcdiff_attention(L.DT_F32, None, None, None, None, 1, 8, 1, 1, 128, 128, 512, 0, None) == -1
+    assert lib.tcdiff_ln_rot(L.DT_F32, None, 1, None, None, 1e-5, None, None, None, None, 0, 0, None) == -1
+    assert lib.tcdiff_step_end(None, None) == -1
+    with pytest.raises(L.TcdiffError):
+        L.check(-2, "x")
+
+
+@pytest.fixture(scope="module")
+def small():
+    model = DanceDecoder(nfeats=151, seq_len=150, latent_dim=512, ff_size=1024, num_layers=8, num_heads=8, dropout=0.1,
+                         cond_feature_dim=438, activation=F.gelu, required_dancer_num=3)
+    diff = GaussianDiffusion(model, 150, 151, None, schedule="cosine", n_timestep=1000, predict_epsilon=False,
+                             loss_type="l2", use_p2=False, cond_drop_prob=0.25, guidance_weight=2, seq_len=150)
+    return model, diff
+
+
+def test_state_dict_surface_matches_reference(golden_dir, small):
+    model, diff = small
+    ref = np.load(os.path.join(golden_dir, "state_dict_keys_dn3.npz"))
+    sd = model.state_dict()
+    assert sorted(sd) == list(ref["keys"])
+    for k, s in zip(ref["keys"], ref["shapes"]):
+        assert str(tuple(sd[str(k)].shape)) == str(s), k
+    assert [n for n, _ in model.named_parameters()] == list(ref["param_order"])   # Adan / EMA zip order
+    assert sum(p.numel() for p in model.parameters()) == 61428181
+    # the deep-copied EMA model exposes the same surface (TCDiff.py:267)
+    assert sorted(diff.master_model.state_dict()) == sorted(sd)
+    # module.-prefixed checkpoints load with strict=False like TCDiff.py:113-120
+    missing, unexpected = model.load_state_dict({("module." + k): v for k, v in sd.items()}, strict=False)
+    assert len(unexpected) == len(sd)
+
+
+def test_schedule_tables_bit_exact(golden_dir, small):
+    _, diff = small
+    ref = np.load(os.path.join(golden_dir, "tables_T1000.npz"))
+    for k in ref.files:
+        assert np.array_equal(ref[k], getattr(diff, k).numpy()), k
+
+
+def test_guidance_clipping_and_ddim_schedule(small):
+    _, diff = small
+    assert diff._guidance_weight_at(999) == 2 and diff._guidance_weight_at(100) == 2
+    assert diff._guidance_weight_at(99) == 1 and diff._guidance_weight_at(0) == 1
+    pairs = diff._ddim_pairs()
+    assert len(pairs) == 50 and pairs[0] == (999, 979) and pairs[-1][1] == -1
+    p = diff._ddim_params(pairs, [2] * 50)
+    assert p[-1, 6] == 1 and float(p[:-1, 6].abs().max()) == 0
+    from oracle import tcdiff_oracle as O
+    assert pairs == O.ddim_time_pairs(1000)
+    ddpm = diff._ddpm_params([999, 5, 0])
+    assert ddpm[2, 3] == 0 and ddpm[0, 0] == 2 and ddpm[1, 0] == 1
+    tab = O.make_tables(1000)
+    assert float(ddpm[0, 1]) == float(tab["posterior_mean_coef1"][999])
+
+
+def test_no_cpu_fallback(small):
+    model, diff = small
+    with pytest.raises(L.TcdiffError):
+        model(torch.zeros(1, 450, 151), torch.zeros(1, 301, 438), torch.zeros(1, dtype=torch.long))
+    with pytest.raises(L.TcdiffError):
+        diff.p_sample_loop((1, 450, 151), torch.zeros(1, 301, 438))
+    with pytest.raises(NotImplementedError):
+        diff(torch.zeros(1, 3, 150, 151), torch.zeros(1, 301, 438))
+
+
+def test_product_code_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "tcdiff_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "import oracle" not in src and "from oracle" not in src, fn

@@ -1,0 +1,377 @@
+"""Kernel-level parity (MI355X only): every launcher of the C ABI against an fp64/fp32 torch evaluation of the
+same op on the same device.  f32 mode must match to fp32 rounding; bf16 mode is compared against a reference
+fed the SAME bf16-rounded operands, so only accumulation order and the bf16 output rounding differ."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tcdiff_amd import _lib as L  # noqa: E402
+from tcdiff_amd import kernels as K  # noqa: E402
+
+DEV = "cuda"
+DTS = [L.DT_F32, L.DT_BF16]
+
+
+def T(dt):
+    return K.TORCH_DT[dt]
+
+
+def tol(dt, f32=2e-4, bf16=2e-2):
+    return f32 if dt == L.DT_F32 else bf16
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+def relerr(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def act_ref(v, act):
+    import torch.nn.functional as F
+    return {L.ACT_NONE: lambda t: t, L.ACT_RELU: F.relu, L.ACT_GELU: F.gelu, L.ACT_MISH: F.mish, L.ACT_SILU: F.silu}[act](v)
+
+
+def vt_pos(tok, dt):
+    if dt == L.DT_F32:
+        return tok
+    kk = tok & 15
+    return (tok & ~15) | (((kk >> 2) & 1) << 3) | ((kk >> 3) << 2) | (kk & 3)
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("M,N,Kd,act", [(300, 200, 192, L.ACT_NONE), (128, 128, 64, L.ACT_GELU), (77, 1536, 512, L.ACT_RELU),
+                                        (1000, 151, 512, L.ACT_MISH), (32, 640, 2048, L.ACT_SILU)])
+def test_gemm_tile_store(dt, M, N, Kd, act):
+    A = rnd(M, Kd, seed=1).to(T(dt))
+    W = (rnd(N, Kd, seed=2) / math.sqrt(Kd)).to(T(dt))
+    bias = rnd(N, seed=3)
+    ref = act_ref(A.double() @ W.double().T + bias.double(), act)
+    for mode, odt in ((L.EPI_STORE_F32, torch.float32), (L.EPI_STORE_T, T(dt))):
+        ldc = N + 5
+        out = torch.full((M, ldc), 7.0, device=DEV, dtype=odt)
+        K.gemm_tile(dt, A, W, M, N, Kd, bias=bias, act=act, mode=mode, out=out, ldc=ldc)
+        torch.cuda.synchronize()
+        assert relerr(out[:, :N], ref) < tol(dt), (mode, relerr(out[:, :N], ref))
+        assert bool((out[:, N:] == 7.0).all()), "wrote outside the N columns"
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_gemm_tile_split_and_amod(dt):
+    M, Kd, N = 260, 128, 512
+    A1, A2 = rnd(100, Kd, seed=4).to(T(dt)), rnd(100, Kd, seed=5).to(T(dt))
+    W = (rnd(N, Kd, seed=6) / math.sqrt(Kd)).to(T(dt))
+    out = torch.zeros(M, N, device=DEV)
+    K.gemm_tile(dt, A1, W, M, N, Kd, A2=A2, split_n=256, a_mod=100, mode=L.EPI_STORE_F32, out=out, ldc=N)
+    idx = torch.arange(M, device=DEV) % 100
+    ref = torch.cat([A1.double()[idx] @ W.double()[:256].T, A2.double()[idx] @ W.double()[256:].T], 1)
+    assert relerr(out, ref) < tol(dt)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_gemm_tile_qkv_heads(dt):
+    Lq, nseq, H, Lp = 70, 3, 8, 128
+    M, Kd = nseq * Lq, 128
+    A1, A2 = rnd(M, Kd, seed=7).to(T(dt)), rnd(M, Kd, seed=8).to(T(dt))
+    W = (rnd(1536, Kd, seed=9) / math.sqrt(Kd)).to(T(dt))
+    bias = rnd(1536, seed=10)
+    Q = torch.zeros(nseq + 1, H, Lp, 64, device=DEV, dtype=T(dt))
+    Kk = torch.zeros_like(Q)
+    Vt = torch.zeros(nseq + 1, H, 64, Lp, device=DEV, dtype=T(dt))
+    K.gemm_tile(dt, A1, W, M, 1536, Kd, A2=A2, split_n=1024, bias=bias, mode=L.EPI_QKV_HEADS, out=Q, out_k=Kk,
+                out_vt=Vt, scale_q=0.125, Lseq=Lq, Lp=Lp, H=H, n_q=512, n_k=512, tok_off=2, seq_off=1)
+    q = ((A1.double() @ W.double()[:512].T + bias.double()[:512]) * 0.125).view(nseq, Lq, H, 64).permute(0, 2, 1, 3)
+    k = (A1.double() @ W.double()[512:1024].T + bias.double()[512:1024]).view(nseq, Lq, H, 64).permute(0, 2, 1, 3)
+    v = (A2.double() @ W.double()[1024:].T + bias.double()[1024:]).view(nseq, Lq, H, 64).permute(0, 2, 1, 3)
+    assert relerr(Q[1:, :, 2:2 + Lq], q) < tol(dt)
+    assert relerr(Kk[1:, :, 2:2 + Lq], k) < tol(dt)
+    pos = torch.tensor([vt_pos(t + 2, dt) for t in range(Lq)], device=DEV)
+    assert relerr(Vt[1:][:, :, :, pos], v.transpose(2, 3)) < tol(dt)
+    assert float(Q[0].abs().max()) == 0 and float(Vt[0].abs().max()) == 0
+    used = torch.zeros(Lp, dtype=torch.bool, device=DEV)
+    used[pos] = True
+    assert float(Vt[1:][:, :, :, ~used].abs().max()) == 0
+
+
+def rope_ref(n_pos, freqs):
+    ang = torch.arange(n_pos, device=DEV, dtype=torch.float32)[:, None] * freqs[None, :]
+    return torch.stack((ang.cos(), ang.sin()), -1).reshape(n_pos, 512)
+
+
+def rot_ref(u, pos, freqs):
+    ang = (pos.float()[:, None] * freqs[None, :]).repeat_interleave(2, -1).double()
+    up = u.double().reshape(u.shape[0], -1, 2)
+    rh = torch.stack((-up[..., 1], up[..., 0]), -1).reshape(u.shape)
+    return u.double() * ang.cos() + rh * ang.sin()
+
+
+def freqs512():
+    return (1.0 / (10000 ** (torch.arange(0, 512, 2).float() / 512))).to(DEV)
+
+
+def test_rope_table():
+    fr = freqs512()
+    rope = torch.empty(460, 512, device=DEV)
+    K.rope_table(fr, rope, 460)
+    assert float((rope - rope_ref(460, fr)).abs().max()) < 5e-6
+
+
+def ln_ref(x, g, b, eps):
+    x = x.double()
+    mu = x.mean(-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(-1, keepdim=True)
+    return (x - mu) / torch.sqrt(var + eps) * g.double() + b.double()
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_ln_rot(dt):
+    rows, Lq = 333, 50
+    x = rnd(rows, 512, seed=11, scale=3.0) + 0.7
+    g, b = 1 + 0.1 * rnd(512, seed=12), 0.1 * rnd(512, seed=13)
+    fr = freqs512()
+    rope = torch.empty(64, 512, device=DEV)
+    K.rope_table(fr, rope, 64)
+    h = torch.zeros(rows, 512, device=DEV, dtype=T(dt))
+    r = torch.zeros_like(h)
+    y = torch.zeros(rows, 512, device=DEV)
+    K.ln_rot(dt, x, rows, g, b, 1e-5, h=h, rot=r, y32=y, rope=rope, pos_mod=Lq, pos_base=3)
+    u = ln_ref(x, g, b, 1e-5)
+    assert relerr(y, u) < 1e-5
+    assert relerr(h, u) < tol(dt, 1e-5, 1e-2)
+    pos = torch.arange(rows, device=DEV) % Lq + 3
+    assert relerr(r, rot_ref(u.float(), pos, fr)) < tol(dt, 1e-5, 1e-2)
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("Kd", [512, 1024])
+def test_gemm_rowln_full_epilogue(dt, Kd):
+    """fc -> LayerNorm(1e-6) -> FiLM -> residual -> store x; next LayerNorm(1e-5) -> h and rotary(h)."""
+    Lq, nseq = 90, 3
+    M = nseq * Lq  # 270: not a multiple of 64
+    A = rnd(M, Kd, seed=20).to(T(dt))
+    W = (rnd(512, Kd, seed=21) / math.sqrt(Kd)).to(T(dt))
+    bias = rnd(512, seed=22)
+    g1, b1 = 1 + 0.1 * rnd(512, seed=23), 0.1 * rnd(512, seed=24)
+    g2, b2 = 1 + 0.1 * rnd(512, seed=25), 0.1 * rnd(512, seed=26)
+    film = rnd(nseq, 3000, seed=27, scale=0.5)
+    xres = rnd(M, 512, seed=28)
+    fr = freqs512()
+    rope = torch.empty(Lq, 512, device=DEV)
+    K.rope_table(fr, rope, Lq)
+    xout = torch.zeros(M, 512, device=DEV)
+    h = torch.zeros(M, 512, device=DEV, dtype=T(dt))
+    r = torch.zeros_like(h)
+    K.gemm_rowln(dt, A, W, M, Kd, bias=bias, ln_g=g1, ln_b=b1, ln_eps=1e-6, film=film[:, 100:], film_ld=3000, xres=xres,
+                 xout=xout, Lseq=Lq, nln_g=g2, nln_b=b2, nln_eps=1e-5, hout=h, rout=r, rope=rope,
+                 flags=L.ROW_BIAS | L.ROW_LN_POST | L.ROW_FILM | L.ROW_STORE_X | L.ROW_NEXT_LN | L.ROW_STORE_H | L.ROW_STORE_ROT)
+    v = ln_ref(A.double() @ W.double().T + bias.double(), g1, b1, 1e-6)
+    seq = torch.arange(M, device=DEV) // Lq
+    sc, sh = film[seq, 100:612].double(), film[seq, 612:1124].double()
+    xr = xres.double() + (sc + 1) * v + sh
+    assert relerr(xout, xr) < tol(dt, 2e-5, 5e-3), relerr(xout, xr)
+    u = ln_ref(xr, g2, b2, 1e-5)
+    assert relerr(h, u) < tol(dt, 2e-5, 1e-2)
+    pos = torch.arange(M, device=DEV) % Lq
+    assert relerr(r, rot_ref(u.float(), pos, fr)) < tol(dt, 2e-5, 1e-2)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_gemm_rowln_variants(dt):
+    M, Kd = 200, 512
+    A = rnd(300, Kd, seed=30).to(T(dt))
+    W = (rnd(512, Kd, seed=31) / math.sqrt(Kd)).to(T(dt))
+    bias = rnd(512, seed=32)
+    xres = rnd(100, 512, seed=33)
+    acc = A.double() @ W.double().T + bias.double()
+    # bias + residual with modulo rows (shared layer-0 input) + plain T copy
+    xout = torch.zeros(M, 512, device=DEV)
+    h = torch.zeros(M, 512, device=DEV, dtype=T(dt))
+    K.gemm_rowln(dt, A, W, M, Kd, bias=bias, xres=xres, xres_mod=100, a_mod=150, xout=xout, hout=h, Lseq=50,
+                 flags=L.ROW_BIAS | L.ROW_RES | L.ROW_STORE_X | L.ROW_STORE_H)
+    idx = torch.arange(M, device=DEV)
+    ref = xres.double()[idx % 100] + acc[idx % 150]
+    assert relerr(xout, ref) < tol(dt, 2e-5, 5e-3)
+    assert relerr(h, ref) < tol(dt, 2e-5, 1e-2)
+    # de-interleaving output rows (fusion projection): m -> m*3 + 1
+    xo = torch.zeros(3 * M, 512, device=DEV)
+    K.gemm_rowln(dt, A, W, M, Kd, bias=bias, xout=xo, Lseq=50, out_mul=3, out_add=1, flags=L.ROW_BIAS | L.ROW_STORE_X)
+    assert relerr(xo[1::3], acc[:M]) < tol(dt, 2e-5, 5e-3)
+    assert float(xo[0::3].abs().max()) == 0 and float(xo[2::3].abs().max()) == 0
+
+
+def attn_ref(q, k, v):
+    s = q.double() @ k.double().transpose(-1, -2)
+    return torch.softmax(s, -1) @ v.double()
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("Lq,Lk,nseq,n_shared", [(450, 450, 3, 0), (450, 152, 4, 2), (120, 62, 2, 1), (150, 150, 2, 0),
+                                                 (300, 1500, 1, 0)])
+def test_attention(dt, Lq, Lk, nseq, n_shared):
+    H = 8
+    Lpq, Lpk = K.round_up(Lq, 128), K.round_up(Lk, 128)
+    n_kv = nseq if n_shared == 0 else nseq - n_shared + 1
+    q = (rnd(nseq, H, Lq, 64, seed=40) * 0.5).to(T(dt))
+    k = rnd(n_kv, H, Lk, 64, seed=41).to(T(dt))
+    v = rnd(n_kv, H, Lk, 64, seed=42).to(T(dt))
+    Q = torch.zeros(nseq, H, Lpq, 64, device=DEV, dtype=T(dt))
+    Kk = torch.zeros(n_kv, H, Lpk, 64, device=DEV, dtype=T(dt))
+    Vt = torch.zeros(n_kv, H, 64, Lpk, device=DEV, dtype=T(dt))
+    Q[:, :, :Lq] = q
+    Kk[:, :, :Lk] = k
+    pos = torch.tensor([vt_pos(t, dt) for t in range(Lk)], device=DEV)
+    Vt[:, :, :, pos] = v.transpose(2, 3)
+    O = torch.zeros(nseq * Lq, 512, device=DEV, dtype=T(dt))
+    K.attention(dt, Q, Kk, Vt, O, nseq, H, Lq, Lk, Lpq, Lpk, 512, n_shared=n_shared)
+    kv = torch.tensor([0 if s < n_shared else s - n_shared + (1 if n_shared > 0 else 0) for s in range(nseq)], device=DEV)
+    ref = attn_ref(q, k[kv], v[kv]).permute(0, 2, 1, 3).reshape(nseq * Lq, 512)
+    err = float((O.double() - ref).abs().max())
+    assert err < tol(dt, 2e-5, 2e-2), err
+
+
+def test_attention_large_logits_online_softmax():
+    """force the running-max rescale branch: one key far above the rest, placed in a late tile"""
+    dt, H, Lq, Lk = L.DT_F32, 8, 128, 200
+    q = rnd(1, H, Lq, 64, seed=43)
+    k = rnd(1, H, Lk, 64, seed=44)
+    k[:, :, 170] = 4.0 * q[:, :, 5]
+    v = rnd(1, H, Lk, 64, seed=45)
+    Q = torch.zeros(1, H, 128, 64, device=DEV)
+    Kk = torch.zeros(1, H, 256, 64, device=DEV)
+    Vt = torch.zeros(1, H, 64, 256, device=DEV)
+    Q[:, :, :Lq], Kk[:, :, :Lk], Vt[:, :, :, :Lk] = q, k, v.transpose(2, 3)
+    O = torch.zeros(Lq, 512, device=DEV)
+    K.attention(dt, Q, Kk, Vt, O, 1, H, Lq, Lk, 128, 256, 512)
+    ref = attn_ref(q, k, v).permute(0, 2, 1, 3).reshape(Lq, 512)
+    assert float((O.double() - ref).abs().max()) < 5e-5
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_small_ops(dt):
+    # convert_pad with batch/row strides (music frame pairing, model/model.py:572-576)
+    B, S, Cd = 3, 10, 438
+    cond = rnd(B, 2 * S + 1, Cd, seed=50)
+    dst = torch.full((B * S, 896), 9.0, device=DEV, dtype=T(dt))
+    K.convert_pad(dt, cond, dst, B * S, 2 * Cd, 896, rows_per_batch=S, batch_stride=(2 * S + 1) * Cd, row_stride=2 * Cd)
+    ref = cond[:, :-1].reshape(B * S, 2 * Cd)
+    assert relerr(dst[:, :876], ref) < tol(dt, 1e-7, 5e-3) and float(dst[:, 876:].abs().max()) == 0
+    # sinusoidal
+    times = torch.tensor([0, 1, 37, 999], dtype=torch.int32, device=DEV)
+    f = torch.exp(torch.arange(256) * -(math.log(10000) / 255)).to(DEV)
+    emb = torch.zeros(4, 512, device=DEV, dtype=T(dt))
+    K.sinusoidal(dt, times, 4, f, emb)
+    e = times.float()[:, None] * f[None]
+    assert relerr(emb, torch.cat((e.sin(), e.cos()), -1)) < tol(dt, 2e-6, 5e-3)
+    # mean pool
+    x = rnd(B, S, 512, seed=51)
+    out = torch.zeros(B, 512, device=DEV)
+    K.mean_pool(x, out, B, S, 512)
+    assert relerr(out, x.mean(1)) < 1e-6
+    # add + mish
+    a, bb = rnd(5, 512, seed=52), rnd(4, 512, seed=53)
+    ia = torch.tensor([4, 0, 0, 2], dtype=torch.int32, device=DEV)
+    o = torch.zeros(4, 512, device=DEV, dtype=T(dt))
+    o32 = torch.zeros(4, 512, device=DEV)
+    K.add_act(dt, a, ia, bb, 4, L.ACT_MISH, out=o, out32=o32)
+    ref = torch.nn.functional.mish(a[ia.long()] + bb)
+    assert relerr(o32, ref) < 2e-6 and relerr(o, ref) < tol(dt, 2e-6, 5e-3)
+    # cfg combine
+    ou, oc = rnd(7, 152, seed=54), rnd(7, 152, seed=55)
+    y = torch.zeros(7, 151, device=DEV)
+    K.cfg_combine(ou, oc, 152, 2.0, y, 7, 151)
+    assert relerr(y, ou[:, :151] + (oc[:, :151] - ou[:, :151]) * 2.0) < 1e-6
+    # window coupling
+    xw = rnd(3, 6, 10, seed=56)
+    exp = xw.clone()
+    exp[1:, :3] = xw[:-1, 3:]
+    K.window_couple(xw, 3, 6, 10)
+    assert torch.equal(xw, exp)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_scatter_time_kv(dt):
+    NL, n_t, n_kv, H, Lp, S = 2, 5, 3, 8, 128, 60
+    tab = rnd(NL, n_t, 2, 1024, seed=60).to(T(dt))
+    tidx = torch.tensor([4, 0, 2], dtype=torch.int32, device=DEV)
+    Kc = torch.zeros(NL, n_kv, H, Lp, 64, device=DEV, dtype=T(dt))
+    Vtc = torch.zeros(NL, n_kv, H, 64, Lp, device=DEV, dtype=T(dt))
+    K.scatter_time_kv(dt, tab, n_t, tidx, Kc, Vtc, NL, n_kv, H, Lp, S)
+    for l in range(NL):
+        for s in range(n_kv):
+            for r in range(2):
+                row = tab[l, tidx[s].item(), r]
+                assert torch.equal(Kc[l, s, :, S + r].reshape(-1), row[:512])
+                assert torch.equal(Vtc[l, s, :, :, vt_pos(S + r, dt)].reshape(-1), row[512:])
+    assert float(Kc[:, :, :, :S].abs().max()) == 0
+
+
+def test_sampler_update_ddpm_ddim_and_philox():
+    rows, nf, Lq = 240, 151, 120
+    ou, oc = rnd(rows, 152, seed=70), rnd(rows, 152, seed=71)
+    x = rnd(rows, nf, seed=72)
+    eps = rnd(rows, nf, seed=73)
+    traj = rnd(rows, 3, seed=74)
+    counter = torch.tensor([1, 0, 0, 0], dtype=torch.int32, device=DEV)
+    tseq = torch.tensor([9, 8], dtype=torch.int32, device=DEV)
+    params = torch.tensor([[0] * 8, [2.0, 0.3, 0.6, 0.2, 0.5, 0.1, 0.0, 0]], device=DEV)
+    g = ou[:, :nf] + (oc[:, :nf] - ou[:, :nf]) * 2.0
+    x0 = g.clamp(-1, 1)
+    # DDPM
+    x1 = x.clone()
+    x0o = torch.zeros_like(x)
+    K.sampler_update(L.SAMPLER_DDPM, ou, oc, 152, x1, eps, None, x0o, rows, nf, Lq, counter, params, tseq)
+    assert relerr(x1, (0.3 * x0 + 0.6 * x) + 0.2 * eps) < 1e-6 and relerr(x0o, x0) < 1e-7
+    # DDPM, cond-only branch
+    x1 = x.clone()
+    K.sampler_update(L.SAMPLER_DDPM, None, oc, 152, x1, eps, None, None, rows, nf, Lq, counter, params, tseq)
+    assert relerr(x1, (0.3 * oc[:, :nf].clamp(-1, 1) + 0.6 * x) + 0.2 * eps) < 1e-6
+    # DDIM with trajectory overwrite
+    x1 = x.clone()
+    K.sampler_update(L.SAMPLER_DDIM, ou, oc, 152, x1, eps, traj, None, rows, nf, Lq, counter, params, tseq)
+    pn = (0.3 * x - x0) / 0.6
+    ref = (x0 * 0.2 + 0.5 * pn) + 0.1 * eps
+    ref[:, 4:6] = traj[:, 0:2]
+    assert relerr(x1, ref) < 1e-6
+    # DDIM last step -> x0
+    params[1, 6] = 1.0
+    x1 = x.clone()
+    K.sampler_update(L.SAMPLER_DDIM, ou, oc, 152, x1, eps, None, None, rows, nf, Lq, counter, params, tseq)
+    assert relerr(x1, x0) < 1e-7
+    # Philox noise: N(0,1) statistics, reproducible, keyed by global clip index (partition invariance)
+    params[1] = torch.tensor([1.0, 0.0, 0.0, 1.0, 0, 0, 0, 0], device=DEV)
+    z = torch.zeros(rows, nf, device=DEV)
+    K.sampler_update(L.SAMPLER_DDPM, None, oc, 152, z, None, None, None, rows, nf, Lq, counter, params, tseq, seed=123, clip0=4)
+    assert abs(float(z.mean())) < 0.02 and abs(float(z.std()) - 1.0) < 0.02
+    z2 = torch.zeros(Lq, nf, device=DEV)
+    K.sampler_update(L.SAMPLER_DDPM, None, oc, 152, z2, None, None, None, Lq, nf, Lq, counter, params, tseq, seed=123, clip0=5)
+    assert torch.equal(z2, z[Lq:])          # clip 5 alone == second clip of the (4,5) batch
+    z3 = torch.zeros(rows, nf, device=DEV)
+    K.sampler_update(L.SAMPLER_DDPM, None, oc, 152, z3, None, None, None, rows, nf, Lq, counter, params, tseq, seed=124, clip0=4)
+    assert not torch.equal(z3, z)
+
+
+def test_step_counter():
+    counter = torch.zeros(4, dtype=torch.int32, device=DEV)
+    tseq = torch.tensor([7, 5, 3], dtype=torch.int32, device=DEV)
+    tidx = torch.zeros(6, dtype=torch.int32, device=DEV)
+    for want in (7, 5, 3):
+        K.step_begin(counter, tseq, tidx, 6)
+        assert tidx.tolist() == [want] * 6
+        K.step_end(counter)
+    assert counter[0].item() == 3
+
+
+def test_argument_errors():
+    a = torch.zeros(64, 64, device=DEV)
+    with pytest.raises(L.TcdiffError):
+        K.gemm_tile(L.DT_F32, a, a, 64, 64, 60, mode=L.EPI_STORE_F32, out=a, ldc=64)      # K not a multiple of 32
+    with pytest.raises(L.TcdiffError):
+        K.attention(L.DT_F32, a, a, a, a, 1, 8, 10, 10, 100, 128, 512)                      # Lp_q not a multiple of 128
+    with pytest.raises(L.TcdiffError):
+        K.gemm_rowln(L.DT_F32, a, a, 64, 64, flags=L.ROW_BIAS, Lseq=1)                      # bias flag without bias
