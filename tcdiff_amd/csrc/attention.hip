@@ -162,10 +162,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const char* __restrict__
                     pf.w = pack_bf2(s[kt][8 * st + 6], s[kt][8 * st + 7]);
                 } else {
                     // f32: MFMA j of the k-step pairs register 4st+j of both halves: keys 8st + j and 8st + 4 + j
-                    pf.x = __builtin_bit_cast(uint32_t, s[kt][4 * st + 0]);
-                    pf.y = __builtin_bit_cast(uint32_t, s[kt][4 * st + 1]);
-                    pf.z = __builtin_bit_cast(uint32_t, s[kt][4 * st + 2]);
-                    pf.w = __builtin_bit_cast(uint32_t, s[kt][4 * st + 3]);
+                    const f32x4_t pv = {s[kt][4 * st + 0], s[kt][4 * st + 1], s[kt][4 * st + 2], s[kt][4 * st + 3]};
+                    pf = __builtin_bit_cast(u32x4, pv);  // whole-vector cast (element-wise bit_cast is miscompiled)
                 }
                 const int ch = (kt * C::PV_STEPS + st) * 2 + h;
 #pragma unroll

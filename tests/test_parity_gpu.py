@@ -59,9 +59,14 @@ def c1():
 
 def test_tables_match_reference(golden_dir, c1):
     _, _, diff, _, _ = c1
+    # The tables are evaluated by the HOST's libm/SIMD paths: bit-exact against the reference in the build
+    # container (tests/test_host_cpu.py, tests/test_oracle_golden.py); on another CPU model the last bit of a few
+    # entries can differ, so here the bound is 2 ulp of fp32.
     ref = gold(golden_dir, "tables_T100")
     for k in ref.files:
-        assert np.array_equal(ref[k], getattr(diff, k).cpu().numpy()), k
+        got = getattr(diff, k).cpu().numpy()
+        err = np.max(np.abs(got.astype(np.float64) - ref[k]) / (np.abs(ref[k]) + 1e-30))
+        assert err < 2.5e-7, (k, err)
 
 
 def test_c1_forward_vs_reference_golden(golden_dir, c1):
