@@ -73,7 +73,7 @@ def kernel_roofline(eng, B, dtype):
     specs = {
         "gemm_tile[qkv 1536x512]": (NLy, 2.0 * R * 1536 * 512, lambda: K.gemm_tile(
             dt, b["rot"], w["l1.qkv.w"], R, 1536, 512, A2=b["h"], split_n=1024, mode=L.EPI_QKV_HEADS, out=b["Q"],
-            out_k=b["K"], out_vt=b["Vt"], scale_q=0.125, Lseq=Lq, Lp=eng.Lp, H=H, n_q=512, n_k=512)),
+            out_k=b["K"], out_v=b["V"], scale_q=0.125, Lseq=Lq, Lp=eng.Lp, H=H, n_q=512, n_k=512)),
         "gemm_tile[ffn1 1024x512]": (NLy, 2.0 * R * 1024 * 512, lambda: K.gemm_tile(
             dt, b["h"], w["l1.ff1.w"], R, 1024, 512, bias=w["l1.ff1.b"], act=L.ACT_GELU, out=b["h1"], ldc=1024)),
         "gemm_tile[q 512x512]": (NLy, 2.0 * R * 512 * 512, lambda: K.gemm_tile(
@@ -89,9 +89,9 @@ def kernel_roofline(eng, B, dtype):
             bias=w["l1.ff2.b"], film=b["film"], film_ld=fld, xres=b["xa"], Lseq=Lq, nln_g=w["l1.norm4.g"],
             nln_b=w["l1.norm4.b"], nln_eps=1e-5, hout=b["h"])),
         "attention[self L=%d]" % Lq: (NLy, 4.0 * 2 * B * H * Lq * Lq * 64, lambda: K.attention(
-            dt, b["Q"], b["K"], b["Vt"], b["O"], 2 * B, H, Lq, Lq, eng.Lp, eng.Lp, 512)),
+            dt, b["Q"], b["K"], b["V"], b["O"], 2 * B, H, Lq, Lq, eng.Lp, eng.Lp, 512)),
         "attention[cross M=%d]" % (S + 2): (NLy, 4.0 * 2 * B * H * Lq * (S + 2) * 64, lambda: K.attention(
-            dt, b["Q"], b["Kc"][1], b["Vtc"][1], b["O"], 2 * B, H, Lq, S + 2, eng.Lp, eng.Lpc, 512, n_shared=B)),
+            dt, b["Q"], b["Kc"][1], b["Vc"][1], b["O"], 2 * B, H, Lq, S + 2, eng.Lp, eng.Lpc, 512, n_shared=B)),
     }
     peak = PEAK_BF16_TFLOPS if dtype == "bf16" else PEAK_F32_TFLOPS
     rows = {}

@@ -47,7 +47,7 @@ typedef struct ihipStream_t* hipStream_t;
 /* ---- gemm_tile epilogues ------------------------------------------------------------------------ */
 #define TC_EPI_STORE_T 0   /* out[m][n] = T(act(acc + bias[n]))                                       */
 #define TC_EPI_STORE_F32 1 /* out[m][n] = act(acc + bias[n]) as fp32                                  */
-#define TC_EPI_QKV_HEADS 2 /* scatter to the head-major Q / K / V^T images read by tcdiff_attention   */
+#define TC_EPI_QKV_HEADS 2 /* scatter to the head-major Q / K / V images read by tcdiff_attention     */
 
 typedef struct {
     int mode;          /* TC_EPI_* */
@@ -56,10 +56,10 @@ typedef struct {
     const float* bias; /* [N] or NULL */
     void* out;         /* STORE_T: T[M][ldc]; STORE_F32: float[M][ldc]; QKV: Q image */
     void* out_k;       /* QKV: K image    T[n_seq][H][Lp][64]                       */
-    void* out_vt;      /* QKV: V^T image  T[n_seq][H][64][Lp] (key order: see tcdiff_attention) */
+    void* out_v;       /* QKV: V image    T[n_seq][H][Lp][64]                       */
     int ldc;
     int L, Lp, H;      /* QKV: tokens per sequence (row m -> sequence m / L, token m % L), padded length, heads */
-    int n_q, n_k;      /* QKV: columns [0,n_q) are Q, [n_q,n_q+n_k) are K, the rest V */
+    int n_q, n_k;      /* QKV: columns [0,n_q) are Q, [n_q,n_q+n_k) are K, the rest V (multiples of 128) */
     int tok_off;       /* QKV: added to the token index  */
     int seq_off;       /* QKV: added to the sequence index */
 } tcdiff_tile_epi;
@@ -111,13 +111,11 @@ int tcdiff_gemm_rowln(int dtype, const void* A, const void* W, int M, int K, int
 /* ---- fused attention ------------------------------------------------------------------------------
  * O[(seq*Lq + q)*ldo + head*64 + d] = softmax_k(Q[seq][head][q] . K[kv][head][k]) V[kv][head][k][d]
  * Q  : T[n_seq][H][Lp_q][64]   (already scaled by 1/sqrt(64))
- * K  : T[n_kv ][H][Lp_k][64]
- * Vt : T[n_kv ][H][64][Lp_k]   key axis in "vt order": f32 natural; bf16: inside every group of 16 keys,
- *                               index bits 2 and 3 are swapped (written by TC_EPI_QKV_HEADS / tcdiff_scatter_time_kv)
+ * K,V: T[n_kv ][H][Lp_k][64]   natural [key][feature] rows (written by TC_EPI_QKV_HEADS / tcdiff_scatter_time_kv)
  * kv = seq < n_shared ? 0 : seq - n_shared + (n_shared > 0)   (the unconditional CFG branch shares one K/V)
- * Lp_q % 128 == 0, Lp_k % 64 == 0, pad rows of Q/K/Vt must be finite (zero).  Keys >= Lk are masked.
+ * Lp_q % 128 == 0, Lp_k % 64 == 0, pad rows of Q/K/V must be finite (zero).  Keys >= Lk are masked.
  * Replaces model/model.py:97-102 (SBI_MSA core) and nn.MultiheadAttention's core (model/model.py:228-236). */
-int tcdiff_attention(int dtype, const void* Q, const void* K, const void* Vt, void* O, int n_seq, int H, int Lq,
+int tcdiff_attention(int dtype, const void* Q, const void* K, const void* V, void* O, int n_seq, int H, int Lq,
                      int Lk, int Lp_q, int Lp_k, int ldo, int n_shared, hipStream_t stream);
 
 /* ---- LayerNorm (+ rotary) prologue: one wave per 512-wide row ---------------------------------------
@@ -146,8 +144,8 @@ int tcdiff_add_act(int dtype, const float* a, const int* ia, const float* b, int
                    float* out32, hipStream_t stream);
 /* per-step: copy the two time-token K/V rows of every layer into the cross-attention caches.
  * tab: T[NL][n_t][2][1024] (K cols 0..511, V cols 512..1023); tidx[seq] selects the row set.
- * Kc: T[NL][n_kv][H][Lp][64], Vtc: T[NL][n_kv][H][64][Lp]; rows tok0, tok0+1.  */
-int tcdiff_scatter_time_kv(int dtype, const void* tab, int n_t, const int* tidx, void* Kc, void* Vtc, int NL,
+ * Kc, Vc: T[NL][n_kv][H][Lp][64]; rows tok0, tok0+1.  */
+int tcdiff_scatter_time_kv(int dtype, const void* tab, int n_t, const int* tidx, void* Kc, void* Vc, int NL,
                            int n_kv, int H, int Lp, int tok0, hipStream_t stream);
 
 /* ---- sampler steps --------------------------------------------------------------------------------

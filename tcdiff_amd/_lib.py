@@ -21,7 +21,7 @@ _vp, _i, _f, _l = C.c_void_p, C.c_int, C.c_float, C.c_long
 
 class TileEpi(C.Structure):
     _fields_ = [("mode", _i), ("act", _i), ("scale_q", _f), ("bias", _vp), ("out", _vp), ("out_k", _vp),
-                ("out_vt", _vp), ("ldc", _i), ("L", _i), ("Lp", _i), ("H", _i), ("n_q", _i), ("n_k", _i),
+                ("out_v", _vp), ("ldc", _i), ("L", _i), ("Lp", _i), ("H", _i), ("n_q", _i), ("n_k", _i),
                 ("tok_off", _i), ("seq_off", _i)]
 
 

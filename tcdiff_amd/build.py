@@ -31,7 +31,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         o = os.path.join(HERE, "build", os.path.basename(s) + ".o")
         objs.append(o)
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
-               "-I" + os.path.join(HERE, "csrc"), "-c", s, "-o", o]
+               "-I" + os.path.join(HERE, "csrc"), "-c", s, "-o", o] + os.environ.get("TCDIFF_EXTRA_HIPCC_FLAGS", "").split()
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append(subprocess.Popen(cmd))

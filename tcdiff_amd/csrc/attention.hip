@@ -9,30 +9,71 @@
 //     key / feature index in the accumulator registers.  The row max / row sum of the softmax are then
 //     in-register reductions plus ONE cross-half shuffle, and the P^T accumulator tile is already the B
 //     operand of the PV MFMA (cdna_hip_programming.md section 3 "accumulator tile as the next operand"):
-//     no LDS round trip for P, no transposes.
-//   * K tile [KB keys][64] and V^T tile [64][KB keys] stream through LDS (double buffered, XOR-swizzled
-//     16-byte chunks), KB = 64 keys (bf16) / 32 keys (f32); online softmax across tiles (fp32 m, l).
-//   * V^T is produced directly by the projection GEMM's epilogue (gemm.hip TC_EPI_QKV_HEADS) with the
-//     key order the PV operand wants, so both tiles load as plain 16-byte rows.
+//     no LDS round trip for P.
+//   * K and V tiles [KB keys][64] stream through LDS in their natural [key][d] layout (double buffered,
+//     XOR-swizzled 16-byte chunks), KB = 64 keys (bf16) / 32 keys (f32); online softmax across tiles (fp32 m, l).
+//   * the PV A operand is V^T: bf16 reads it with the hardware transpose read ds_read_b64_tr_b16 (two reads per
+//     fragment, in the key order the P^T registers are in); f32 reads one dword per MFMA (lanes = consecutive d).
 #include "common.h"
 #include "tcdiff_hip.h"
+
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
 
 template <class P>
 struct AttnCfg {
     static constexpr int ES = sizeof(typename P::elem_t);
-    static constexpr int KB = P::KT;                 // keys per staged tile (128 B of V^T row)
+    static constexpr int KB = P::KT;                 // keys per staged tile
     static constexpr int NKT = KB / 32;              // 32-key MFMA tiles per staged tile
-    static constexpr int DSUB = 64 * ES / TC_ROWB;   // 128-B sub-tiles covering d = 0..63 of a K row
+    static constexpr int DSUB = 64 * ES / TC_ROWB;   // 128-B sub-tiles covering d = 0..63 of a row (bf16 1, f32 2)
     static constexpr int NKS = 64 * ES / 32;         // k-steps over d for S^T
-    static constexpr int PV_STEPS = 32 * ES / 32 * 1;  // k-steps over one 32-key tile for O^T: bf16 2, f32 4
-    static constexpr int K_TILE_BYTES = KB * 64 * ES;  // 8 KB
-    static constexpr int V_TILE_BYTES = 64 * TC_ROWB;  // 8 KB
-    static constexpr int STAGE = K_TILE_BYTES + V_TILE_BYTES;
+    static constexpr int PV_STEPS = ES;              // k-steps over one 32-key tile for O^T: bf16 2 (16 keys), f32 4 (8 keys)
+    static constexpr int TILE_BYTES = KB * 64 * ES;  // 8 KB
+    static constexpr int STAGE = 2 * TILE_BYTES;     // [K tile | V tile]
 };
+
+// byte offset of element (row, d) inside a staged [KB][64] tile (sub-tiles of 128-B rows, swizzled chunks)
+template <class P>
+DEVINL int kv_off(int row, int d) {
+    constexpr int ES = sizeof(typename P::elem_t);
+    constexpr int EPR = TC_ROWB / ES;   // elements per 128-B sub-row: bf16 64, f32 32
+    constexpr int EPC = 16 / ES;
+    const int sub = d / EPR, dd = d % EPR;
+    return sub * (P::KT * TC_ROWB) + tile_off(row, dd / EPC) + (dd % EPC) * ES;
+}
+
+// A operand of O^T += V^T P^T for output features d = dt*32 + (lane & 31) and the keys of k-step `st` of the
+// 32-key tile `kt` (element order matches the P^T accumulator registers, see attention_kernel).
+template <class P>
+DEVINL u32x4 v_frag(const char* vt, int dt, int kt, int st, int lane) {
+    if (P::IS_BF16) {
+        // element j <-> key kt*32 + 16*st + 8*(j>>2) + 4*h + (j&3): two transposed reads of 4 keys x 16 features
+        const int h = lane >> 5, i16 = lane & 15, q = i16 >> 2, p = i16 & 3, g1 = (lane >> 4) & 1;
+        const int kb = kt * 32 + 16 * st + 4 * h;
+        const int d = dt * 32 + 16 * g1 + 4 * p;
+        typedef __attribute__((address_space(3))) s16x4_t lds_s16x4;
+        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vt + kv_off<P>(kb + q, d)));
+        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vt + kv_off<P>(kb + 8 + q, d)));
+        const u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
+        u32x4 out = {l2[0], l2[1], h2[0], h2[1]};
+        return out;
+    } else {
+        // MFMA j of the k-step takes key kt*32 + 8*st + 4*h + j
+        const int r = lane & 31, h = lane >> 5;
+        const int d = dt * 32 + r;
+        const int k0 = kt * 32 + 8 * st + 4 * h;
+        u32x4 out;
+        out[0] = *reinterpret_cast<const uint32_t*>(vt + kv_off<P>(k0 + 0, d));
+        out[1] = *reinterpret_cast<const uint32_t*>(vt + kv_off<P>(k0 + 1, d));
+        out[2] = *reinterpret_cast<const uint32_t*>(vt + kv_off<P>(k0 + 2, d));
+        out[3] = *reinterpret_cast<const uint32_t*>(vt + kv_off<P>(k0 + 3, d));
+        return out;
+    }
+}
 
 template <class P>
 __global__ __launch_bounds__(256) void attention_kernel(const char* __restrict__ Q, const char* __restrict__ K,
-                                                        const char* __restrict__ Vt, char* __restrict__ O, int H,
+                                                        const char* __restrict__ V, char* __restrict__ O, int H,
                                                         int Lq, int Lk, int Lp_q, int Lp_k, int ldo,
                                                         int n_shared) {
     typedef AttnCfg<P> C;
@@ -42,42 +83,43 @@ __global__ __launch_bounds__(256) void attention_kernel(const char* __restrict__
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int head = blockIdx.y, seq = blockIdx.z;
-    const int qblk = blockIdx.x * 128;
+    // 1-D grid, XCD-remapped: the query blocks of one (sequence, head) share K/V through one XCD's L2, and an XCD
+    // owns a contiguous range of sequences (the same rows it owns in the GEMMs)
+    const int nqb = Lp_q / 128;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int qblk = (wg % nqb) * 128;
+    const int head = (wg / nqb) % H, seq = wg / (nqb * H);
     if (qblk >= Lq) return;
     const int q0 = qblk + wave * 32;
     const int kv = seq < n_shared ? 0 : seq - n_shared + (n_shared > 0 ? 1 : 0);
 
     const char* Qg = Q + ((long)(seq * H + head) * Lp_q + q0 + r) * 64 * ES;
     const char* Kg = K + (long)(kv * H + head) * Lp_k * 64 * ES;
-    const char* Vg = Vt + (long)(kv * H + head) * 64 * (long)Lp_k * ES;
+    const char* Vg = V + (long)(kv * H + head) * Lp_k * 64 * ES;
 
     // Q^T fragments stay in registers for the whole kernel
     u32x4 qf[C::NKS];
 #pragma unroll
     for (int ks = 0; ks < C::NKS; ++ks) qf[ks] = *reinterpret_cast<const u32x4*>(Qg + (2 * ks + h) * 16);
 
-    // staging: 512 16-byte chunks per tile, 2 per thread per tile
+    // staging: 512 16-byte chunks per tile, 2 per thread per tile; a tile is KB consecutive rows = 8 KB contiguous
     u32x4 sk[2], sv[2];
     auto load_tiles = [&](int kv0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            int c = tid + i * 256;
-            int row = c / (8 * C::DSUB), chk = c % (8 * C::DSUB);
-            sk[i] = *reinterpret_cast<const u32x4*>(Kg + (long)(kv0 + row) * 64 * ES + chk * 16);
-            int d = c >> 3, ch = c & 7;
-            sv[i] = *reinterpret_cast<const u32x4*>(Vg + ((long)d * Lp_k + kv0) * ES + ch * 16);
+            const int c = tid + i * 256;
+            sk[i] = *reinterpret_cast<const u32x4*>(Kg + (long)kv0 * 64 * ES + c * 16);
+            sv[i] = *reinterpret_cast<const u32x4*>(Vg + (long)kv0 * 64 * ES + c * 16);
         }
     };
     auto store_tiles = [&](char* stage) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            int c = tid + i * 256;
-            int row = c / (8 * C::DSUB), chk = c % (8 * C::DSUB);
-            int sub = chk >> 3, ch = chk & 7;
-            *reinterpret_cast<u32x4*>(stage + sub * (KB * TC_ROWB) + tile_off(row, ch)) = sk[i];
-            int d = c >> 3, chv = c & 7;
-            *reinterpret_cast<u32x4*>(stage + C::K_TILE_BYTES + tile_off(d, chv)) = sv[i];
+            const int c = tid + i * 256;
+            const int row = c / (8 * C::DSUB), chk = c % (8 * C::DSUB);
+            const int off = (chk >> 3) * (KB * TC_ROWB) + tile_off(row, chk & 7);
+            *reinterpret_cast<u32x4*>(stage + off) = sk[i];
+            *reinterpret_cast<u32x4*>(stage + C::TILE_BYTES + off) = sv[i];
         }
     };
 
@@ -98,7 +140,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const char* __restrict__
         const int kv0 = b * KB;
         if (b + 1 < nb) load_tiles(kv0 + KB);
         const char* kt_base = smem + cur * C::STAGE;
-        const char* vt_base = kt_base + C::K_TILE_BYTES;
+        const char* vt_base = kt_base + C::TILE_BYTES;
 
         // ---- S^T = K Q^T ---------------------------------------------------------------------------
         f32x16_t s[C::NKT];
@@ -154,21 +196,19 @@ __global__ __launch_bounds__(256) void attention_kernel(const char* __restrict__
             for (int st = 0; st < C::PV_STEPS; ++st) {
                 u32x4 pf;
                 if (P::IS_BF16) {
-                    // registers 8st..8st+7 are keys 16st + 8(j>>2) + 4h + (j&3): the V^T image stores keys in
-                    // exactly this order (vt_pos), so chunk (2*step + h) of a V^T row matches element j.
-                    pf.x = pack_bf2(s[kt][8 * st + 0], s[kt][8 * st + 1]);
-                    pf.y = pack_bf2(s[kt][8 * st + 2], s[kt][8 * st + 3]);
-                    pf.z = pack_bf2(s[kt][8 * st + 4], s[kt][8 * st + 5]);
-                    pf.w = pack_bf2(s[kt][8 * st + 6], s[kt][8 * st + 7]);
+                    // registers 8st..8st+7 hold keys 16st + 8(j>>2) + 4h + (j&3), j = 0..7
+                    pf[0] = pack_bf2(s[kt][8 * st + 0], s[kt][8 * st + 1]);
+                    pf[1] = pack_bf2(s[kt][8 * st + 2], s[kt][8 * st + 3]);
+                    pf[2] = pack_bf2(s[kt][8 * st + 4], s[kt][8 * st + 5]);
+                    pf[3] = pack_bf2(s[kt][8 * st + 6], s[kt][8 * st + 7]);
                 } else {
                     // f32: MFMA j of the k-step pairs register 4st+j of both halves: keys 8st + j and 8st + 4 + j
                     const f32x4_t pv = {s[kt][4 * st + 0], s[kt][4 * st + 1], s[kt][4 * st + 2], s[kt][4 * st + 3]};
                     pf = __builtin_bit_cast(u32x4, pv);  // whole-vector cast (element-wise bit_cast is miscompiled)
                 }
-                const int ch = (kt * C::PV_STEPS + st) * 2 + h;
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
-                    u32x4 vf = *reinterpret_cast<const u32x4*>(vt_base + tile_off(dt * 32 + r, ch));
+                    const u32x4 vf = v_frag<P>(vt_base, dt, kt, st, lane);
                     P::mma(o[dt], vf, pf);
                 }
             }
@@ -202,19 +242,19 @@ __global__ __launch_bounds__(256) void attention_kernel(const char* __restrict__
     }
 }
 
-extern "C" int tcdiff_attention(int dtype, const void* Q, const void* K, const void* Vt, void* O, int n_seq, int H,
+extern "C" int tcdiff_attention(int dtype, const void* Q, const void* K, const void* V, void* O, int n_seq, int H,
                                 int Lq, int Lk, int Lp_q, int Lp_k, int ldo, int n_shared, hipStream_t stream) {
-    if (!Q || !K || !Vt || !O || n_seq <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return TC_ERR_ARG;
+    if (!Q || !K || !V || !O || n_seq <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return TC_ERR_ARG;
     if (dtype != TC_DTYPE_BF16 && dtype != TC_DTYPE_F32) return TC_ERR_ARG;
     if (Lp_q % 128 != 0 || Lp_k % 64 != 0 || Lp_q < Lq || Lp_k < Lk || ldo < H * 64 || ldo % 4 != 0) return TC_ERR_ARG;
-    if (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)Vt | (uintptr_t)O) & 15) return TC_ERR_ALIGN;
-    dim3 grid(Lp_q / 128, H, n_seq);
+    if (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O) & 15) return TC_ERR_ALIGN;
+    dim3 grid((Lp_q / 128) * H * n_seq);
     if (dtype == TC_DTYPE_BF16)
         hipLaunchKernelGGL(attention_kernel<MmaBF16>, grid, dim3(256), 0, stream, (const char*)Q, (const char*)K,
-                           (const char*)Vt, (char*)O, H, Lq, Lk, Lp_q, Lp_k, ldo, n_shared);
+                           (const char*)V, (char*)O, H, Lq, Lk, Lp_q, Lp_k, ldo, n_shared);
     else
         hipLaunchKernelGGL(attention_kernel<MmaF32>, grid, dim3(256), 0, stream, (const char*)Q, (const char*)K,
-                           (const char*)Vt, (char*)O, H, Lq, Lk, Lp_q, Lp_k, ldo, n_shared);
+                           (const char*)V, (char*)O, H, Lq, Lk, Lp_q, Lp_k, ldo, n_shared);
     TC_CHECK_LAUNCH();
     return TC_OK;
 }

@@ -1,51 +1,60 @@
-// MFMA GEMMs of the TCDiff denoiser: C[M,N] = A[M,K] * W[N,K]^T (+ fused epilogues).
+// MFMA GEMMs of the TCDiff denoiser: C[M,N] = A[M,K] * W[N,K]^T (+ fused epilogues), gfx950.
 //
 // A is an activation matrix (row-major, K contiguous), W is an nn.Linear weight as stored by torch
 // ([out, in] = [N, K], K contiguous), so both operands stage as rows of K and every MFMA fragment is a
 // single 16-byte LDS read (common.h).  Two kernels:
 //
-//   gemm_tile   128x128 block tile, 4 waves (2x2), general epilogues (bias/act/store, head-major QKV
-//               scatter for the attention kernel).  Replaces the aten addmm/linear calls of
+//   gemm_tile   128x128 block tile, 4 waves (2x2), 2 workgroups per CU.  Replaces the aten addmm/linear calls of
 //               model/model.py:78-80 (w_qs/w_ks/w_vs), :399 (linear1), :522-528 (fusion projection),
 //               :560 (input_projection), :623 (final_layer), :454-465 (time MLP), :164-166 (FiLM).
 //   gemm_rowln  64x512 block tile, 8 waves (2x4): one workgroup owns complete 512-wide rows, so the
 //               LayerNorm / FiLM / residual that follow fc, linear2 and linear3 in the reference
-//               (model/model.py:103-106,327,334,339,344) run in the epilogue from the accumulators,
-//               and the NEXT op's LayerNorm(+rotary) input is emitted too (model/model.py:326,332,338,
-//               375,387).  No intermediate ever round-trips HBM between the GEMM and its norm.
+//               (model/model.py:103-106,327,334,339,344) run in the epilogue, and the NEXT op's
+//               LayerNorm(+rotary) input is emitted too (model/model.py:326,332,338,375,387).  No intermediate
+//               round-trips HBM between a GEMM and the norm that follows it.
+//
+// Staging: global -> LDS directly with global_load_lds_dwordx4 (no VGPR staging, no ds_write pass).  One
+// wave-instruction lands 64 lanes x 16 B = 8 tile rows linearly in LDS; the XOR swizzle of common.h::tile_off
+// is applied on the per-lane SOURCE address (cdna_hip_programming.md rule 21).  Two LDS stages; the
+// __syncthreads() that closes a k-step also drains the in-flight loads of the next tile.
+//
+// Epilogue stores go through LDS so that global writes are whole 16-byte chunks of contiguous rows:
+//   gemm_tile issues the MFMAs with the operand roles swapped (A operand = weight rows, B operand = activation
+//   rows), so each lane ends up holding 4 CONSECUTIVE output columns of one output row per register quad;
+//   gemm_rowln dumps its fp32 64x512 tile to LDS and finishes LayerNorm/FiLM/residual/rotary in a row-wise pass
+//   (one wave per row, 16-byte loads/stores, wave-wide shuffle reductions) exactly like ops.hip::ln_rot.
 #include "common.h"
 #include "tcdiff_hip.h"
 
-// =================================================================================================
-// staging: global -> registers -> LDS (swizzled), 16 B per thread per access
-// =================================================================================================
-// Per-thread staging registers are plain local arrays indexed only by unrolled constants.
-#define STG_PER(ROWS, NT) (((ROWS) * 8 + (NT) - 1) / (NT))
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
 
-// src: base pointer of row 0 / k-chunk 0 for this k-tile; ld_bytes: row stride in bytes.
+// Issue the global->LDS DMA of a [ROWS][128 B] tile.  `wave` must be wave-uniform.
 // rows >= row_limit are clamped to row_limit-1 (their results are never stored).
-template <int ROWS, int NT>
-DEVINL void stage_load(u32x4 (&r)[STG_PER(ROWS, NT)], const char* src, long ld_bytes, int row0, int row_limit,
-                       int row_mod, int tid) {
+template <int ROWS, int NWAVES>
+DEVINL void stage_glds(char* lds_tile, const char* src, long ld_bytes, int row0, int row_limit, int row_mod, int wave,
+                       int lane) {
+    constexpr int PER = ROWS / 8 / NWAVES;
+    static_assert(ROWS % (8 * NWAVES) == 0, "tile rows must divide over the waves");
 #pragma unroll
-    for (int i = 0; i < STG_PER(ROWS, NT); ++i) {
-        int c = tid + i * NT;
-        int row = c >> 3, ch = c & 7;
+    for (int i = 0; i < PER; ++i) {
+        const int blk = wave * PER + i;           // 1-KiB block = 8 tile rows
+        const int row = blk * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
         int gr = row0 + row;
         gr = gr < row_limit ? gr : row_limit - 1;
         if (row_mod > 0) gr = gr % row_mod;
-        r[i] = *reinterpret_cast<const u32x4*>(src + (long)gr * ld_bytes + ch * 16);
+        const char* g = src + (long)gr * ld_bytes + chunk * 16;
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)g, (lds_void_t*)(lds_tile + blk * 1024), 16, 0, 0);
     }
 }
-template <int ROWS, int NT>
-DEVINL void stage_store(const u32x4 (&r)[STG_PER(ROWS, NT)], char* lds, int tid) {
-    static_assert((ROWS * 8) % NT == 0, "tile chunks must divide evenly over the threads");
-#pragma unroll
-    for (int i = 0; i < STG_PER(ROWS, NT); ++i) {
-        int c = tid + i * NT;
-        *reinterpret_cast<u32x4*>(lds + tile_off(c >> 3, c & 7)) = r[i];
-    }
-}
+
+#ifdef TC_STAMP
+// diagnostic build: per-block timestamps (100 MHz realtime counter) written to a side buffer; never in the product
+#define TC_STAMP_AT(i) do { if (tid == 0 && e.out_k) reinterpret_cast<unsigned long long*>(e.out_k)[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define TC_STAMP_AT(i) do { } while (0)
+#endif
 
 DEVINL u32x4 lds_frag(const char* tile, int row, int chunk) {
     return *reinterpret_cast<const u32x4*>(tile + tile_off(row, chunk));
@@ -54,31 +63,24 @@ DEVINL u32x4 lds_frag(const char* tile, int row, int chunk) {
 // =================================================================================================
 // gemm_tile: 128 x 128 x (128 B of K) tiles, 256 threads
 // =================================================================================================
-// position of key `tok` along the key axis of the V^T image (see attention.hip): bf16 swaps bits 2
-// and 3 of the index inside each group of 16 keys so that a P^T accumulator tile feeds the PV MFMA
-// as its B operand with no lane movement; fp32 keeps natural order.
-template <class P>
-DEVINL int vt_pos(int tok) {
-    if (P::IS_BF16) {
-        int kk = tok & 15;
-        return (tok & ~15) | (((kk >> 2) & 1) << 3) | ((kk >> 3) << 2) | (kk & 3);
-    }
-    return tok;
-}
-
-template <class P>
+template <class P, int ACT>
 __global__ __launch_bounds__(256) void gemm_tile_kernel(const char* __restrict__ A, const char* __restrict__ A2,
                                                         int split_n, const char* __restrict__ W, int M, int N,
                                                         int K, long lda_b, long ldw_b, int a_mod, tcdiff_tile_epi e) {
     typedef typename P::elem_t T;
+    constexpr int ES = sizeof(T);
     __shared__ __attribute__((aligned(16))) char smem[2 * 2 * 128 * TC_ROWB];  // 64 KB
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 31, h = lane >> 5;
-    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+    // 1-D grid, XCD-remapped: an XCD owns a contiguous range of row panels with all their column tiles
+    const int ntn = (N + 127) / 128;
+    const int tile_id = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile_id / ntn) * 128, n0 = (tile_id % ntn) * 128;
     const char* Ause = (A2 != nullptr && n0 >= split_n) ? A2 : A;
 
-    u32x4 sa[STG_PER(128, 256)], sw[STG_PER(128, 256)];
+    // acc[i][j]: operand roles swapped -> column (lane & 31) = output ROW m, rows (registers) = output COLUMN n
     f32x16_t acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -91,17 +93,19 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(const char* __restrict__
     constexpr int STAGE = 2 * 128 * TC_ROWB;  // [A tile | W tile]
     constexpr int WOFF = 128 * TC_ROWB;
 
-    stage_load<128, 256>(sa, Ause, lda_b, m0, M, a_mod, tid);
-    stage_load<128, 256>(sw, W, ldw_b, n0, N, 0, tid);
-    stage_store<128, 256>(sa, smem, tid);
-    stage_store<128, 256>(sw, smem + WOFF, tid);
+    TC_STAMP_AT(0);
+    stage_glds<128, 4>(smem, Ause, lda_b, m0, M, a_mod, wave, lane);
+    stage_glds<128, 4>(smem + WOFF, W, ldw_b, n0, N, 0, wave, lane);
+    TC_STAMP_AT(1);
     __syncthreads();
+    TC_STAMP_AT(2);
 
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) {
-            stage_load<128, 256>(sa, Ause + (long)(kt + 1) * TC_ROWB, lda_b, m0, M, a_mod, tid);
-            stage_load<128, 256>(sw, W + (long)(kt + 1) * TC_ROWB, ldw_b, n0, N, 0, tid);
+            char* nxt = smem + (cur ^ 1) * STAGE;
+            stage_glds<128, 4>(nxt, Ause + (long)(kt + 1) * TC_ROWB, lda_b, m0, M, a_mod, wave, lane);
+            stage_glds<128, 4>(nxt + WOFF, W + (long)(kt + 1) * TC_ROWB, ldw_b, n0, N, 0, wave, lane);
         }
         const char* ta = smem + cur * STAGE + (wm * 64) * TC_ROWB;
         const char* tw = smem + cur * STAGE + WOFF + (wn * 64) * TC_ROWB;
@@ -115,67 +119,131 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(const char* __restrict__
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) P::mma(acc[i][j], fa[i], fw[j]);
+                for (int j = 0; j < 2; ++j) P::mma(acc[i][j], fw[j], fa[i]);
         }
-        if (kt + 1 < nk) {
-            stage_store<128, 256>(sa, smem + (cur ^ 1) * STAGE, tid);
-            stage_store<128, 256>(sw, smem + (cur ^ 1) * STAGE + WOFF, tid);
-        }
-        __syncthreads();
+        __syncthreads();  // all waves done with buf[cur]; also drains the DMA of tile kt+1
     }
 
+    TC_STAMP_AT(3);
     // ---- epilogue --------------------------------------------------------------------------------
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + r;
-        const bool n_ok = n < N;
-        const float bv = (e.bias && n_ok) ? e.bias[n] : 0.0f;
+    // this lane: output rows m = m0 + wm*64 + i*32 + r; columns n = n0 + wn*64 + j*32 + 8g + 4h + {0..3}
+    const bool qkv = e.mode == TC_EPI_QKV_HEADS;
+    float colscale = 1.0f;
+    if (qkv && n0 < e.n_q) colscale = e.scale_q;  // n_q is a multiple of 128: a block is all-Q or no-Q
+
+    if (e.mode == TC_EPI_STORE_F32) {
+        float* out = reinterpret_cast<float*>(e.out);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int mb = m0 + wm * 64 + i * 32;
-            if (e.mode == TC_EPI_STORE_T) {
-                T* out = reinterpret_cast<T*>(e.out);
+            const int m = m0 + wm * 64 + i * 32 + r;
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    int m = mb + acc_row(q, h);
-                    if (m < M && n_ok) out[(long)m * e.ldc + n] = P::from_f32(apply_act(acc[i][j][q] + bv, e.act));
-                }
-            } else if (e.mode == TC_EPI_STORE_F32) {
-                float* out = reinterpret_cast<float*>(e.out);
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    int m = mb + acc_row(q, h);
-                    if (m < M && n_ok) out[(long)m * e.ldc + n] = apply_act(acc[i][j][q] + bv, e.act);
-                }
-            } else {  // TC_EPI_QKV_HEADS
-                // column n -> (which of Q/K/V, head, d); row m -> (sequence, token)
-                int which = n < e.n_q ? 0 : (n < e.n_q + e.n_k ? 1 : 2);
-                int nn = n - (which == 0 ? 0 : (which == 1 ? e.n_q : e.n_q + e.n_k));
-                int head = nn >> 6, d = nn & 63;
-                float sc = which == 0 ? e.scale_q : 1.0f;
+                for (int g = 0; g < 4; ++g) {
+                    const int n = n0 + wn * 64 + j * 32 + 8 * g + 4 * h;
+                    if (m >= M || n >= N) continue;
+                    float v[4];
+                    f32x4_t bq = {0.f, 0.f, 0.f, 0.f};
+                    if (e.bias) {
+                        if (n + 3 < N) bq = *reinterpret_cast<const f32x4_t*>(e.bias + n);
+                        else
+                            for (int t = 0; t < 4; ++t) if (n + t < N) bq[t] = e.bias[n + t];
+                    }
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    int m = mb + acc_row(q, h);
-                    if (m >= M || !n_ok) continue;
-                    int seq = m / e.L + e.seq_off, tok = m % e.L + e.tok_off;
-                    T v = P::from_f32((acc[i][j][q] + bv) * sc);
-                    if (which < 2) {
-                        T* dst = reinterpret_cast<T*>(which == 0 ? e.out : e.out_k);
-                        dst[(((long)seq * e.H + head) * e.Lp + tok) * 64 + d] = v;
+                    for (int t = 0; t < 4; ++t) v[t] = act_ct<ACT>(acc[i][j][4 * g + t] + bq[t], e.act);
+                    float* dst = out + (long)m * e.ldc + n;
+                    if (n + 3 < N && (e.ldc & 3) == 0) {
+                        f32x4_t pk = {v[0], v[1], v[2], v[3]};
+                        *reinterpret_cast<f32x4_t*>(dst) = pk;
                     } else {
-                        T* dst = reinterpret_cast<T*>(e.out_vt);
-                        dst[(((long)seq * e.H + head) * 64 + d) * e.Lp + vt_pos<P>(tok)] = v;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            if (n + t < N) dst[t] = v[t];
                     }
                 }
+        }
+        return;
+    }
+
+    // T-typed outputs: stage the tile in LDS as [rows][128 cols] T with a padded row stride, then write whole
+    // 16-byte chunks of contiguous output rows.  f32 needs two passes of 64 rows to fit the 64 KB.
+    constexpr int RS = 128 * ES + 16;            // staged row stride in bytes
+    constexpr int NPASS = ES / 2;                // bf16: 1 pass of 128 rows; f32: 2 passes of 64 rows
+    constexpr int PROWS = 128 / NPASS;
+    constexpr int CPR = 128 * ES / 16;           // 16-B chunks per staged row
+    constexpr int EPC = 16 / ES;                 // elements per chunk
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+        if (NPASS == 1 || wm == pass) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int ml = (NPASS == 1 ? wm * 64 : 0) + i * 32 + r;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int nl = wn * 64 + j * 32 + 8 * g + 4 * h;
+                        const int n = n0 + nl;
+                        float v[4];
+                        f32x4_t bq = {0.f, 0.f, 0.f, 0.f};
+                        if (e.bias) {
+                            if (n + 3 < N) bq = *reinterpret_cast<const f32x4_t*>(e.bias + n);
+                            else
+                                for (int t = 0; t < 4; ++t) if (n + t < N) bq[t] = e.bias[n + t];
+                        }
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) v[t] = act_ct<ACT>(acc[i][j][4 * g + t] + bq[t], e.act) * colscale;
+                        char* dst = smem + ml * RS + nl * ES;
+                        if (P::IS_BF16) {
+                            uint2 pk;
+                            pk.x = pack_bf2(v[0], v[1]);
+                            pk.y = pack_bf2(v[2], v[3]);
+                            *reinterpret_cast<uint2*>(dst) = pk;
+                        } else {
+                            f32x4_t pk = {v[0], v[1], v[2], v[3]};
+                            *reinterpret_cast<f32x4_t*>(dst) = pk;
+                        }
+                    }
             }
         }
+        __syncthreads();
+        TC_STAMP_AT(4);
+#pragma unroll 4
+        for (int c = tid; c < PROWS * CPR; c += 256) {
+            const int row = c / CPR, ch = c % CPR;
+            const int m = m0 + pass * PROWS + row;
+            const int n = n0 + ch * EPC;
+            if (m >= M || n >= N) continue;
+            const u32x4 val = *reinterpret_cast<const u32x4*>(smem + row * RS + ch * 16);
+            T* dst;
+            if (!qkv) {
+                dst = reinterpret_cast<T*>(e.out) + (long)m * e.ldc + n;
+            } else {
+                // column n -> (Q | K | V, head, d); row m -> (sequence, token): head-major images for attention
+                const int which = n < e.n_q ? 0 : (n < e.n_q + e.n_k ? 1 : 2);
+                const int nn = n - (which == 0 ? 0 : (which == 1 ? e.n_q : e.n_q + e.n_k));
+                const int head = nn >> 6, d = nn & 63;
+                const int seq = m / e.L + e.seq_off, tok = m % e.L + e.tok_off;
+                T* base = reinterpret_cast<T*>(which == 0 ? e.out : (which == 1 ? e.out_k : e.out_v));
+                dst = base + (((long)seq * e.H + head) * e.Lp + tok) * 64 + d;
+            }
+            if (n + EPC <= N && (qkv || ((long)e.ldc * ES) % 16 == 0)) {
+                *reinterpret_cast<u32x4*>(dst) = val;
+            } else {
+                const T* sv = reinterpret_cast<const T*>(smem + row * RS + ch * 16);
+                for (int t = 0; t < EPC; ++t)
+                    if (n + t < N) dst[t] = sv[t];
+            }
+        }
+        if (pass + 1 < NPASS) __syncthreads();
     }
+    TC_STAMP_AT(5);
 }
 
 // =================================================================================================
 // gemm_rowln: 64 x 512 tiles, 512 threads; row-complete epilogue
 // =================================================================================================
-#define ROWLN_SMEM (2 * (64 + 512) * TC_ROWB + 4 * 64 * 4 * 4)
+#define ROWLN_SMEM (2 * (64 + 512) * TC_ROWB)
 
 template <class P>
 __global__ __launch_bounds__(512) void gemm_rowln_kernel(const char* __restrict__ A, const char* __restrict__ W,
@@ -183,16 +251,15 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(const char* __restrict_
                                                          tcdiff_row_epi e) {
     typedef typename P::elem_t T;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const int r = lane & 31, h = lane >> 5;
-    const int m0 = blockIdx.x * 64;
+    const int m0 = xcd_remap(blockIdx.x, gridDim.x) * 64;  // an XCD owns a contiguous range of rows (as gemm_tile)
 
     constexpr int STAGE = (64 + 512) * TC_ROWB;  // [A tile | W tile]
     constexpr int WOFF = 64 * TC_ROWB;
-    float* red = reinterpret_cast<float*>(smem + 2 * STAGE);  // [4][64][4]
 
-    u32x4 sa[STG_PER(64, 512)], sw[STG_PER(512, 512)];
     f32x16_t acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -200,16 +267,15 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(const char* __restrict_
         for (int q = 0; q < 16; ++q) acc[j][q] = 0.0f;
 
     const int nk = K / P::KT;
-    stage_load<64, 512>(sa, A, lda_b, m0, M, a_mod, tid);
-    stage_load<512, 512>(sw, W, ldw_b, 0, 512, 0, tid);
-    stage_store<64, 512>(sa, smem, tid);
-    stage_store<512, 512>(sw, smem + WOFF, tid);
+    stage_glds<64, 8>(smem, A, lda_b, m0, M, a_mod, wave, lane);
+    stage_glds<512, 8>(smem + WOFF, W, ldw_b, 0, 512, 0, wave, lane);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) {
-            stage_load<64, 512>(sa, A + (long)(kt + 1) * TC_ROWB, lda_b, m0, M, a_mod, tid);
-            stage_load<512, 512>(sw, W + (long)(kt + 1) * TC_ROWB, ldw_b, 0, 512, 0, tid);
+            char* nxt = smem + (cur ^ 1) * STAGE;
+            stage_glds<64, 8>(nxt, A + (long)(kt + 1) * TC_ROWB, lda_b, m0, M, a_mod, wave, lane);
+            stage_glds<512, 8>(nxt + WOFF, W + (long)(kt + 1) * TC_ROWB, ldw_b, 0, 512, 0, wave, lane);
         }
         const char* ta = smem + cur * STAGE + (wm * 32) * TC_ROWB;
         const char* tw = smem + cur * STAGE + WOFF + (wn * 128) * TC_ROWB;
@@ -222,142 +288,139 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(const char* __restrict_
                 P::mma(acc[j], fa, fw);
             }
         }
-        if (kt + 1 < nk) {
-            stage_store<64, 512>(sa, smem + (cur ^ 1) * STAGE, tid);
-            stage_store<512, 512>(sw, smem + (cur ^ 1) * STAGE + WOFF, tid);
-        }
         __syncthreads();
     }
 
-    // ---- row-complete epilogue ---------------------------------------------------------------------
-    // this lane: columns n_j = wn*128 + j*32 + r (j=0..3); rows lr_q = wm*32 + acc_row(q,h) (q=0..15)
+    // ---- phase 1: dump the fp32 accumulator tile to LDS as [64 rows][512 cols] --------------------------
+    // lane: column n = wn*128 + j*32 + r, rows wm*32 + acc_row(q,h).  32 lanes write 32 consecutive floats.
+    float* tile = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = wn * 128 + j * 32 + r;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) tile[(wm * 32 + acc_row(q, h)) * 512 + n] = acc[j][q];
+    }
+    __syncthreads();
+
+    // ---- phase 2: one wave per row; lane owns columns [4l,4l+4) and [256+4l, 256+4l+4) -------------------
     const int f = e.flags;
-    int ncol[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) ncol[j] = wn * 128 + j * 32 + r;
-
+    const int c0 = 4 * lane, c1 = 256 + 4 * lane;
+    f32x4_t bias0 = {0, 0, 0, 0}, bias1 = {0, 0, 0, 0};
     if (f & TC_ROW_BIAS) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float b = e.bias[ncol[j]];
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc[j][q] += b;
-        }
+        bias0 = *reinterpret_cast<const f32x4_t*>(e.bias + c0);
+        bias1 = *reinterpret_cast<const f32x4_t*>(e.bias + c1);
     }
-
-    // full-row (512-wide) sum of a per-lane quantity: in-lane over j, 32-lane shuffle, 4 waves via LDS
-    auto row_reduce = [&](float (&part)[16], float* scratch) {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) part[q] = half_sum(part[q]);
-        if (r == 0) {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) scratch[(wm * 32 + acc_row(q, h)) * 4 + wn] = part[q];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            float4 v = *reinterpret_cast<const float4*>(&scratch[(wm * 32 + acc_row(q, h)) * 4]);
-            part[q] = (v.x + v.y) + (v.z + v.w);
-        }
-    };
-    auto layer_norm_rows = [&](float eps, const float* g, const float* b, float* scratch0, float* scratch1) {
-        float part[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) part[q] = (acc[0][q] + acc[1][q]) + (acc[2][q] + acc[3][q]);
-        row_reduce(part, scratch0);
-        float mean[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) mean[q] = part[q] * (1.0f / 512.0f);
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            float s = 0.0f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float d = acc[j][q] - mean[q];
-                s += d * d;
-            }
-            part[q] = s;
-        }
-        row_reduce(part, scratch1);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float gg = g[ncol[j]], bb = b[ncol[j]];
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                float rstd = rsqrtf(part[q] * (1.0f / 512.0f) + eps);
-                acc[j][q] = (acc[j][q] - mean[q]) * rstd * gg + bb;
-            }
-        }
-    };
-
-    if (f & TC_ROW_LN_POST) layer_norm_rows(e.ln_eps, e.ln_g, e.ln_b, red, red + 256);
-
-    if (f & (TC_ROW_FILM | TC_ROW_RES)) {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            int m = m0 + wm * 32 + acc_row(q, h);
-            int mc = m < M ? m : M - 1;
-            int seq = mc / e.L;
-            int mr = e.xres_mod > 0 ? mc % e.xres_mod : mc;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float v = acc[j][q];
-                if (f & TC_ROW_FILM) {
-                    const float* fp = e.film + (long)seq * e.film_ld + ncol[j];
-                    v = (fp[0] + 1.0f) * v + fp[512];
-                }
-                acc[j][q] = e.xres[(long)mr * 512 + ncol[j]] + v;
-            }
-        }
+    f32x4_t g1a = {0, 0, 0, 0}, g1b = g1a, b1a = g1a, b1b = g1a, g2a = g1a, g2b = g1a, b2a = g1a, b2b = g1a;
+    if (f & TC_ROW_LN_POST) {
+        g1a = *reinterpret_cast<const f32x4_t*>(e.ln_g + c0);
+        g1b = *reinterpret_cast<const f32x4_t*>(e.ln_g + c1);
+        b1a = *reinterpret_cast<const f32x4_t*>(e.ln_b + c0);
+        b1b = *reinterpret_cast<const f32x4_t*>(e.ln_b + c1);
     }
-
-    if (f & TC_ROW_STORE_X) {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            int m = m0 + wm * 32 + acc_row(q, h);
-            if (m < M) {
-                long mo = (long)m * e.out_mul + e.out_add;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) e.xout[mo * 512 + ncol[j]] = acc[j][q];
-            }
-        }
-    }
-
-    if (!(f & TC_ROW_NEXT_LN) && (f & TC_ROW_STORE_H)) {  // plain T copy of v (A operand of final_layer)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            int m = m0 + wm * 32 + acc_row(q, h);
-            if (m < M) {
-                long mo = (long)m * e.out_mul + e.out_add;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) reinterpret_cast<T*>(e.hout)[mo * 512 + ncol[j]] = P::from_f32(acc[j][q]);
-            }
-        }
-    }
-
     if (f & TC_ROW_NEXT_LN) {
-        layer_norm_rows(e.nln_eps, e.nln_g, e.nln_b, red + 512, red + 768);
+        g2a = *reinterpret_cast<const f32x4_t*>(e.nln_g + c0);
+        g2b = *reinterpret_cast<const f32x4_t*>(e.nln_g + c1);
+        b2a = *reinterpret_cast<const f32x4_t*>(e.nln_b + c0);
+        b2b = *reinterpret_cast<const f32x4_t*>(e.nln_b + c1);
+    }
+
+    auto normalize = [&](f32x4_t& va, f32x4_t& vb, float eps, const f32x4_t& ga, const f32x4_t& gb,
+                         const f32x4_t& ba, const f32x4_t& bb) {
+        const float mean = wave_sum((va[0] + va[1]) + (va[2] + va[3]) + (vb[0] + vb[1]) + (vb[2] + vb[3])) * (1.0f / 512.0f);
+        float ss = 0.0f;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            int m = m0 + wm * 32 + acc_row(q, h);
-            long mo = (long)m * e.out_mul + e.out_add;
-            int pos = (int)(mo % e.L);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float v = acc[j][q];
-                float partner = __shfl_xor(v, 1);  // the other element of the rotary pair (adjacent column)
-                if (m < M) {
-                    if (f & TC_ROW_STORE_H) reinterpret_cast<T*>(e.hout)[mo * 512 + ncol[j]] = P::from_f32(v);
-                    if (f & TC_ROW_STORE_ROT) {
-                        int n = ncol[j];
-                        const float* cs = e.rope + (long)pos * 512 + (n & ~1);
-                        float c = cs[0], s = cs[1];
-                        float y = (n & 1) ? (v * c + partner * s) : (v * c - partner * s);
-                        reinterpret_cast<T*>(e.rout)[mo * 512 + n] = P::from_f32(y);
-                    }
-                }
-            }
+        for (int t = 0; t < 4; ++t) {
+            const float da = va[t] - mean, db = vb[t] - mean;
+            ss += da * da + db * db;
         }
+        const float rstd = rsqrtf(wave_sum(ss) * (1.0f / 512.0f) + eps);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            va[t] = (va[t] - mean) * rstd * ga[t] + ba[t];
+            vb[t] = (vb[t] - mean) * rstd * gb[t] + bb[t];
+        }
+    };
+    auto store_T = [&](void* base, long row, const f32x4_t& va, const f32x4_t& vb) {
+        T* p = reinterpret_cast<T*>(base) + row * 512;
+        if (P::IS_BF16) {
+            uint2 pa, pb;
+            pa.x = pack_bf2(va[0], va[1]); pa.y = pack_bf2(va[2], va[3]);
+            pb.x = pack_bf2(vb[0], vb[1]); pb.y = pack_bf2(vb[2], vb[3]);
+            *reinterpret_cast<uint2*>(p + c0) = pa;
+            *reinterpret_cast<uint2*>(p + c1) = pb;
+        } else {
+            *reinterpret_cast<f32x4_t*>(p + c0) = va;
+            *reinterpret_cast<f32x4_t*>(p + c1) = vb;
+        }
+    };
+
+    // Global operands of a row (FiLM scale/shift, residual, rotary cos/sin) do not depend on the arithmetic, so the
+    // loads of row rr+1 are issued before row rr is reduced: their latency hides under the shuffle chains.
+    struct RowIn { f32x4_t sa, sb, ha, hb, xa, xb, ca, cb; };
+    auto fetch = [&](int rr, RowIn& in) {
+        const int m = m0 + wave * 8 + rr;
+        if (rr >= 8 || m >= M) return;
+        if (f & TC_ROW_FILM) {
+            const float* fp = e.film + (long)(m / e.L) * e.film_ld;
+            in.sa = *reinterpret_cast<const f32x4_t*>(fp + c0); in.sb = *reinterpret_cast<const f32x4_t*>(fp + c1);
+            in.ha = *reinterpret_cast<const f32x4_t*>(fp + 512 + c0); in.hb = *reinterpret_cast<const f32x4_t*>(fp + 512 + c1);
+        }
+        if (f & (TC_ROW_FILM | TC_ROW_RES)) {
+            const int mr = e.xres_mod > 0 ? m % e.xres_mod : m;
+            in.xa = *reinterpret_cast<const f32x4_t*>(e.xres + (long)mr * 512 + c0);
+            in.xb = *reinterpret_cast<const f32x4_t*>(e.xres + (long)mr * 512 + c1);
+        }
+        if (f & TC_ROW_STORE_ROT) {
+            const int pos = (int)(((long)m * e.out_mul + e.out_add) % e.L);
+            in.ca = *reinterpret_cast<const f32x4_t*>(e.rope + (long)pos * 512 + c0);  // cos0 sin0 cos1 sin1
+            in.cb = *reinterpret_cast<const f32x4_t*>(e.rope + (long)pos * 512 + c1);
+        }
+    };
+    auto process = [&](int rr, const RowIn& in) {
+        const int row = wave * 8 + rr;
+        const int m = m0 + row;
+        if (m >= M) return;
+        f32x4_t va = *reinterpret_cast<const f32x4_t*>(tile + row * 512 + c0);
+        f32x4_t vb = *reinterpret_cast<const f32x4_t*>(tile + row * 512 + c1);
+        va += bias0;
+        vb += bias1;
+        if (f & TC_ROW_LN_POST) normalize(va, vb, e.ln_eps, g1a, g1b, b1a, b1b);
+        if (f & TC_ROW_FILM) {
+            va = (in.sa + 1.0f) * va + in.ha;
+            vb = (in.sb + 1.0f) * vb + in.hb;
+        }
+        if (f & (TC_ROW_FILM | TC_ROW_RES)) {
+            va = in.xa + va;
+            vb = in.xb + vb;
+        }
+        const long mo = (long)m * e.out_mul + e.out_add;
+        if (f & TC_ROW_STORE_X) {
+            *reinterpret_cast<f32x4_t*>(e.xout + mo * 512 + c0) = va;
+            *reinterpret_cast<f32x4_t*>(e.xout + mo * 512 + c1) = vb;
+        }
+        if (!(f & TC_ROW_NEXT_LN)) {
+            if (f & TC_ROW_STORE_H) store_T(e.hout, mo, va, vb);
+            return;
+        }
+        normalize(va, vb, e.nln_eps, g2a, g2b, b2a, b2b);
+        if (f & TC_ROW_STORE_H) store_T(e.hout, mo, va, vb);
+        if (f & TC_ROW_STORE_ROT) {
+            f32x4_t ya, yb;
+            ya[0] = va[0] * in.ca[0] - va[1] * in.ca[1]; ya[1] = va[1] * in.ca[0] + va[0] * in.ca[1];
+            ya[2] = va[2] * in.ca[2] - va[3] * in.ca[3]; ya[3] = va[3] * in.ca[2] + va[2] * in.ca[3];
+            yb[0] = vb[0] * in.cb[0] - vb[1] * in.cb[1]; yb[1] = vb[1] * in.cb[0] + vb[0] * in.cb[1];
+            yb[2] = vb[2] * in.cb[2] - vb[3] * in.cb[3]; yb[3] = vb[3] * in.cb[2] + vb[2] * in.cb[3];
+            store_T(e.rout, mo, ya, yb);
+        }
+    };
+    RowIn inA, inB;
+    fetch(0, inA);
+#pragma unroll 1
+    for (int rr = 0; rr < 8; rr += 2) {
+        fetch(rr + 1, inB);
+        process(rr, inA);
+        fetch(rr + 2, inA);
+        process(rr + 1, inB);
     }
 }
 
@@ -370,22 +433,43 @@ extern "C" int tcdiff_gemm_tile(int dtype, const void* A, const void* A2, int sp
                                 int K, int lda, int ldw, int a_mod, const tcdiff_tile_epi* epi,
                                 hipStream_t stream) {
     if (!A || !W || !epi || M <= 0 || N <= 0 || K <= 0) return TC_ERR_ARG;
+    if (dtype != TC_DTYPE_BF16 && dtype != TC_DTYPE_F32) return TC_ERR_ARG;
     const int es = dtype == TC_DTYPE_BF16 ? 2 : 4;
     const int kt = dtype == TC_DTYPE_BF16 ? 64 : 32;
-    if (dtype != TC_DTYPE_BF16 && dtype != TC_DTYPE_F32) return TC_ERR_ARG;
     if (K % kt != 0) return TC_ERR_ARG;
     if (!aligned16(A) || !aligned16(W) || (A2 && !aligned16(A2)) || ((long)lda * es) % 16 || ((long)ldw * es) % 16)
         return TC_ERR_ALIGN;
     if (A2 && (split_n % 128 != 0)) return TC_ERR_ARG;
-    if (epi->mode == TC_EPI_QKV_HEADS && (epi->L <= 0 || epi->Lp <= 0 || epi->H <= 0)) return TC_ERR_ARG;
+    if (epi->bias && !aligned16(epi->bias)) return TC_ERR_ALIGN;
+    if (epi->act < TC_ACT_NONE || epi->act > TC_ACT_SILU) return TC_ERR_ARG;
+    if (epi->mode == TC_EPI_QKV_HEADS) {
+        if (epi->L <= 0 || epi->Lp <= 0 || epi->H <= 0 || epi->n_q % 128 || epi->n_k % 128 || N % 64) return TC_ERR_ARG;
+        if ((epi->n_q > 0 && (!epi->out || !aligned16(epi->out))) ||
+            (epi->n_k > 0 && (!epi->out_k || !aligned16(epi->out_k))) ||
+            (N > epi->n_q + epi->n_k && (!epi->out_v || !aligned16(epi->out_v))))
+            return TC_ERR_ALIGN;
+    } else {
+        if (!epi->out) return TC_ERR_ARG;
+        if (!aligned16(epi->out)) return TC_ERR_ALIGN;
+    }
     tcdiff_tile_epi e = *epi;
-    dim3 grid((N + 127) / 128, (M + 127) / 128);
-    if (dtype == TC_DTYPE_BF16)
-        hipLaunchKernelGGL(gemm_tile_kernel<MmaBF16>, grid, dim3(256), 0, stream, (const char*)A, (const char*)A2,
-                           split_n, (const char*)W, M, N, K, (long)lda * es, (long)ldw * es, a_mod, e);
-    else
-        hipLaunchKernelGGL(gemm_tile_kernel<MmaF32>, grid, dim3(256), 0, stream, (const char*)A, (const char*)A2,
-                           split_n, (const char*)W, M, N, K, (long)lda * es, (long)ldw * es, a_mod, e);
+    dim3 grid(((N + 127) / 128) * ((M + 127) / 128));
+    const int actk = e.act <= TC_ACT_GELU ? e.act : 3;   // 3 = runtime choice between the setup-only Mish / SiLU
+#define TC_LAUNCH_TILE(POL, ACTK)                                                                                \
+    hipLaunchKernelGGL((gemm_tile_kernel<POL, ACTK>), grid, dim3(256), 0, stream, (const char*)A, (const char*)A2, \
+                       split_n, (const char*)W, M, N, K, (long)lda * es, (long)ldw * es, a_mod, e)
+#define TC_DISPATCH_TILE(POL)                                      \
+    switch (actk) {                                                \
+        case 0: TC_LAUNCH_TILE(POL, 0); break;                     \
+        case 1: TC_LAUNCH_TILE(POL, 1); break;                     \
+        case 2: TC_LAUNCH_TILE(POL, 2); break;                     \
+        default: TC_LAUNCH_TILE(POL, 3); break;                    \
+    }
+    if (dtype == TC_DTYPE_BF16) {
+        TC_DISPATCH_TILE(MmaBF16)
+    } else {
+        TC_DISPATCH_TILE(MmaF32)
+    }
     TC_CHECK_LAUNCH();
     return TC_OK;
 }
@@ -401,13 +485,17 @@ extern "C" int tcdiff_gemm_rowln(int dtype, const void* A, const void* W, int M,
     const int f = epi->flags;
     if ((f & TC_ROW_BIAS) && !epi->bias) return TC_ERR_ARG;
     if ((f & TC_ROW_LN_POST) && (!epi->ln_g || !epi->ln_b)) return TC_ERR_ARG;
-    if ((f & TC_ROW_FILM) && !epi->film) return TC_ERR_ARG;
+    if ((f & TC_ROW_FILM) && (!epi->film || epi->film_ld % 4)) return TC_ERR_ARG;
     if ((f & (TC_ROW_FILM | TC_ROW_RES)) && !epi->xres) return TC_ERR_ARG;
     if ((f & TC_ROW_STORE_X) && !epi->xout) return TC_ERR_ARG;
     if ((f & TC_ROW_NEXT_LN) && (!epi->nln_g || !epi->nln_b)) return TC_ERR_ARG;
     if ((f & TC_ROW_STORE_H) && !epi->hout) return TC_ERR_ARG;
-    if ((f & TC_ROW_STORE_ROT) && (!epi->rout || !epi->rope)) return TC_ERR_ARG;
+    if ((f & TC_ROW_STORE_ROT) && (!epi->rout || !epi->rope || !(f & TC_ROW_NEXT_LN))) return TC_ERR_ARG;
     if (epi->L <= 0) return TC_ERR_ARG;
+    const void* vec16[] = {epi->bias, epi->ln_g, epi->ln_b, epi->film, epi->xres, epi->xout, epi->nln_g, epi->nln_b,
+                           epi->hout, epi->rout, epi->rope};
+    for (const void* p : vec16)
+        if (p && !aligned16(p)) return TC_ERR_ALIGN;
     tcdiff_row_epi e = *epi;
     if (e.out_mul <= 0) e.out_mul = 1;
     static bool attr_set = false;

@@ -215,11 +215,11 @@ extern "C" int tcdiff_add_act(int dtype, const float* a, const int* ia, const fl
     return TC_OK;
 }
 
-// per-step: the two time-token rows of every layer's cross-attention K / V^T cache
+// per-step: the two time-token rows of every layer's cross-attention K / V cache
 template <class P>
 __global__ void scatter_time_kv_kernel(const typename P::elem_t* __restrict__ tab, int n_t,
                                        const int* __restrict__ tidx, typename P::elem_t* __restrict__ Kc,
-                                       typename P::elem_t* __restrict__ Vtc, int NL, int n_kv, int H, int Lp,
+                                       typename P::elem_t* __restrict__ Vc, int NL, int n_kv, int H, int Lp,
                                        int tok0) {
     // one thread per (layer, kv, row r in {0,1}, column c in [0,1024))
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -232,32 +232,23 @@ __global__ void scatter_time_kv_kernel(const typename P::elem_t* __restrict__ ta
     int t = tidx[kv];
     typename P::elem_t v = tab[(((long)l * n_t + t) * 2 + rr) * 1024 + c];
     int tok = tok0 + rr;
-    if (c < 512) {
-        int head = c >> 6, d = c & 63;
-        Kc[((((long)l * n_kv + kv) * H + head) * Lp + tok) * 64 + d] = v;
-    } else {
-        int cc = c - 512;
-        int head = cc >> 6, d = cc & 63;
-        int pos = tok;
-        if (P::IS_BF16) {
-            int kk = tok & 15;
-            pos = (tok & ~15) | (((kk >> 2) & 1) << 3) | ((kk >> 3) << 2) | (kk & 3);
-        }
-        Vtc[((((long)l * n_kv + kv) * H + head) * 64 + d) * Lp + pos] = v;
-    }
+    const int cc = c & 511;
+    const int head = cc >> 6, d = cc & 63;
+    typename P::elem_t* dst = c < 512 ? Kc : Vc;
+    dst[((((long)l * n_kv + kv) * H + head) * Lp + tok) * 64 + d] = v;
 }
 
-extern "C" int tcdiff_scatter_time_kv(int dtype, const void* tab, int n_t, const int* tidx, void* Kc, void* Vtc,
+extern "C" int tcdiff_scatter_time_kv(int dtype, const void* tab, int n_t, const int* tidx, void* Kc, void* Vc,
                                       int NL, int n_kv, int H, int Lp, int tok0, hipStream_t stream) {
-    if (!tab || !tidx || !Kc || !Vtc || NL <= 0 || n_kv <= 0 || H * 64 != 512 || tok0 + 1 >= Lp) return TC_ERR_ARG;
+    if (!tab || !tidx || !Kc || !Vc || NL <= 0 || n_kv <= 0 || H * 64 != 512 || tok0 + 1 >= Lp) return TC_ERR_ARG;
     long total = (long)NL * n_kv * 2 * 1024;
     dim3 grid((unsigned)((total + 255) / 256));
     if (dtype == TC_DTYPE_BF16)
         hipLaunchKernelGGL(scatter_time_kv_kernel<MmaBF16>, grid, dim3(256), 0, stream, (const uint16_t*)tab, n_t, tidx,
-                           (uint16_t*)Kc, (uint16_t*)Vtc, NL, n_kv, H, Lp, tok0);
+                           (uint16_t*)Kc, (uint16_t*)Vc, NL, n_kv, H, Lp, tok0);
     else if (dtype == TC_DTYPE_F32)
         hipLaunchKernelGGL(scatter_time_kv_kernel<MmaF32>, grid, dim3(256), 0, stream, (const float*)tab, n_t, tidx,
-                           (float*)Kc, (float*)Vtc, NL, n_kv, H, Lp, tok0);
+                           (float*)Kc, (float*)Vc, NL, n_kv, H, Lp, tok0);
     else
         return TC_ERR_ARG;
     TC_CHECK_LAUNCH();

@@ -8,9 +8,8 @@ Data layout in HBM (T = bf16 or f32 operand type, always fp32 for the residual s
   x          fp32 [B*L, 151]           motion tensor, token index = frame*dn + dancer (model/diffusion.py:640,651)
   xa         fp32 [R, 512]             residual stream, R = n_branch*B*L rows; branch-major: [uncond clips | cond clips]
   h, rot     T    [R, 512]             LayerNorm output and its rotary image (GEMM A operands)
-  Q, K       T    [n_seq][8][Lp][64]   head-major attention images, Lp = L rounded up to 128 (zero padded)
-  Vt         T    [n_seq][8][64][Lp]   V transposed, key axis in the PV-operand order (gemm.hip vt_pos)
-  Kc, Vtc    T    [8 layers][B+1][8][Lpc][64] cross-attention K/V^T caches: slot 0 = null conditioning,
+  Q, K, V    T    [n_seq][8][Lp][64]   head-major attention images, Lp = L rounded up to 128 (zero padded)
+  Kc, Vc     T    [8 layers][2B][8][Lpc][64] cross-attention K/V caches: slot 0 = null conditioning,
                                        slot 1+i = clip i; rows 0..S-1 step-invariant, rows S,S+1 = time tokens
   film       fp32 [2B][24*1024]        (scale|shift) of the 24 DenseFiLM blocks for this step
   tables     t_base fp32 [n_t,512], kv_tab T [8][n_t][2][1024]  time path evaluated once per timestep set
@@ -167,14 +166,14 @@ class DenoiserEngine:
         b["xs"] = z(B * Lq, 512, dtype=torch.float32)
         b["h"], b["rot"], b["O"] = z(R, 512), z(R, 512), z(R, 512)
         b["Q"], b["K"] = z(2 * B, H, self.Lp, 64), z(2 * B, H, self.Lp, 64)
-        b["Vt"] = z(2 * B, H, 64, self.Lp)
+        b["V"] = z(2 * B, H, self.Lp, 64)
         b["xa"] = z(R, 512, dtype=torch.float32)
         b["h1"] = z(R, 1024)
         b["out"] = z(R, 152, dtype=torch.float32)
         b["film"] = z(2 * B, NL * NL_FILM * 1024, dtype=torch.float32)
         b["film_in"] = z(2 * B, 512)
         b["Kc"] = z(NL, 2 * B, H, self.Lpc, 64)      # slots: sampler uses 0..B, generic forward up to 2B
-        b["Vtc"] = z(NL, 2 * B, H, 64, self.Lpc)
+        b["Vc"] = z(NL, 2 * B, H, self.Lpc, 64)
         b["hidden_all"] = z(2 * B, 512, dtype=torch.float32)
         b["tidx"] = torch.zeros(2 * B, device=dev, dtype=torch.int32)
         # music encoder (setup only)
@@ -183,7 +182,7 @@ class DenoiserEngine:
         b["tok"] = z(B * S, 512, dtype=torch.float32)
         b["mh"], b["mrot"], b["mO"] = z(B * S, 512), z(B * S, 512), z(B * S, 512)
         b["mQ"], b["mK"] = z(B, H, self.Lps, 64), z(B, H, self.Lps, 64)
-        b["mVt"] = z(B, H, 64, self.Lps)
+        b["mV"] = z(B, H, self.Lps, 64)
         b["mh1"] = z(B * S, 1024)
         b["pool"] = z(B, 512, dtype=torch.float32)
         b["pool_h"], b["pool_h2"] = z(B, 512), z(B, 512)
@@ -213,9 +212,9 @@ class DenoiserEngine:
             K.ln_rot(dt, b["tok"], M, w[e + "norm1.g"], w[e + "norm1.b"], 1e-5, h=b["mh"], rot=b["mrot"],
                      rope=w["rope"], pos_mod=S)
             K.gemm_tile(dt, b["mrot"], w[e + "qkv.w"], M, 1536, 512, A2=b["mh"], split_n=1024, bias=w[e + "qkv.b"],
-                        mode=L.EPI_QKV_HEADS, out=b["mQ"], out_k=b["mK"], out_vt=b["mVt"], scale_q=0.125, Lseq=S,
+                        mode=L.EPI_QKV_HEADS, out=b["mQ"], out_k=b["mK"], out_v=b["mV"], scale_q=0.125, Lseq=S,
                         Lp=self.Lps, H=H, n_q=512, n_k=512)
-            K.attention(dt, b["mQ"], b["mK"], b["mVt"], b["mO"], B, H, S, S, self.Lps, self.Lps, 512)
+            K.attention(dt, b["mQ"], b["mK"], b["mV"], b["mO"], B, H, S, S, self.Lps, self.Lps, 512)
             K.gemm_rowln(dt, b["mO"], w[e + "o.w"], M, 512, bias=w[e + "o.b"], xres=b["tok"], xout=b["tok"], Lseq=S,
                          flags=L.ROW_BIAS | L.ROW_RES | L.ROW_STORE_X | L.ROW_NEXT_LN | L.ROW_STORE_H,
                          nln_g=w[e + "norm2.g"], nln_b=w[e + "norm2.b"], nln_eps=1e-5, hout=b["mh"])
@@ -242,7 +241,7 @@ class DenoiserEngine:
         K.ln_rot(dt, tokens, M, w["nc.g"], w["nc.b"], 1e-5, h=b["mh"], rot=b["mrot"], rope=w["rope"], pos_mod=S)
         for l in range(self.NL):
             K.gemm_tile(dt, b["mrot"], w[f"l{l}.ckv.w"], M, 1024, 512, A2=b["mh"], split_n=512, mode=L.EPI_QKV_HEADS,
-                        out=None, out_k=b["Kc"][l], out_vt=b["Vtc"][l], Lseq=S, Lp=self.Lpc, H=self.H, n_q=0, n_k=512,
+                        out=None, out_k=b["Kc"][l], out_v=b["Vc"][l], Lseq=S, Lp=self.Lpc, H=self.H, n_q=0, n_k=512,
                         seq_off=slot0)
 
     def build_time_tables(self, times_i32: torch.Tensor):
@@ -279,7 +278,7 @@ class DenoiserEngine:
         time-token K/V rows of every layer; b['tidx'][i] selects the timestep row of sequence / cache slot i.
         The cache tensor has 2B slots; slots unused by the current mode receive rows that are never read."""
         dt, w, b = self.dt, self.w, self.b
-        K.scatter_time_kv(dt, self.kv_tab, self.n_t, b["tidx"], b["Kc"], b["Vtc"], self.NL, b["Kc"].shape[1], self.H,
+        K.scatter_time_kv(dt, self.kv_tab, self.n_t, b["tidx"], b["Kc"], b["Vc"], self.NL, b["Kc"].shape[1], self.H,
                           self.Lpc, self.S)
         K.add_act(dt, self.t_base, b["tidx"], b["hidden_all"], n_rows_seq, L.ACT_MISH, out=b["film_in"])
         nfilm = self.NL * NL_FILM * 1024
@@ -310,16 +309,16 @@ class DenoiserEngine:
                          nln_g=w["l0.norm1.g"], nln_b=w["l0.norm1.b"], nln_eps=1e-5, hout=b["h"], rout=b["rot"],
                          rope=rope, out_mul=dn, out_add=d)
         Kc0 = b["Kc"][:, kv_slot0:]
-        Vtc0 = b["Vtc"][:, kv_slot0:]
+        Vc0 = b["Vc"][:, kv_slot0:]
         for l in range(NL):
             p = f"l{l}."
             rows_sa = Rs if l == 0 else R          # layer-0 self-attention is branch-independent
             nseq_sa = B if l == 0 else nseq
             # ---- self-attention block (model/model.py:326-327,374-383,71-107)
             K.gemm_tile(dt, b["rot"], w[p + "qkv.w"], rows_sa, 1536, 512, A2=b["h"], split_n=1024, mode=L.EPI_QKV_HEADS,
-                        out=b["Q"], out_k=b["K"], out_vt=b["Vt"], scale_q=0.125, Lseq=Lq, Lp=self.Lp, H=H, n_q=512,
+                        out=b["Q"], out_k=b["K"], out_v=b["V"], scale_q=0.125, Lseq=Lq, Lp=self.Lp, H=H, n_q=512,
                         n_k=512)
-            K.attention(dt, b["Q"], b["K"], b["Vt"], b["O"], nseq_sa, H, Lq, Lq, self.Lp, self.Lp, 512)
+            K.attention(dt, b["Q"], b["K"], b["V"], b["O"], nseq_sa, H, Lq, Lq, self.Lp, self.Lp, 512)
             K.gemm_rowln(dt, b["O"], w[p + "sfc.w"], R, 512, a_mod=Rs if l == 0 else 0,
                          flags=L.ROW_LN_POST | L.ROW_FILM | L.ROW_STORE_X | L.ROW_NEXT_LN | L.ROW_STORE_ROT,
                          ln_g=w[p + "sln.g"], ln_b=w[p + "sln.b"], ln_eps=1e-6, film=film0[:, (l * 3 + 0) * 1024:],
@@ -327,8 +326,8 @@ class DenoiserEngine:
                          Lseq=Lq, nln_g=w[p + "norm2.g"], nln_b=w[p + "norm2.b"], nln_eps=1e-5, rout=b["rot"], rope=rope)
             # ---- cross-attention block (model/model.py:331-334,386-396)
             K.gemm_tile(dt, b["rot"], w[p + "cq.w"], R, 512, 512, mode=L.EPI_QKV_HEADS, out=b["Q"], out_k=None,
-                        out_vt=None, scale_q=0.125, Lseq=Lq, Lp=self.Lp, H=H, n_q=512, n_k=0)
-            K.attention(dt, b["Q"], Kc0[l], Vtc0[l], b["O"], nseq, H, Lq, S + 2, self.Lp, self.Lpc, 512,
+                        out_v=None, scale_q=0.125, Lseq=Lq, Lp=self.Lp, H=H, n_q=512, n_k=0)
+            K.attention(dt, b["Q"], Kc0[l], Vc0[l], b["O"], nseq, H, Lq, S + 2, self.Lp, self.Lpc, 512,
                         n_shared=n_shared)
             K.gemm_rowln(dt, b["O"], w[p + "cfc.w"], R, 512,
                          flags=L.ROW_LN_POST | L.ROW_FILM | L.ROW_STORE_X | L.ROW_NEXT_LN | L.ROW_STORE_H,

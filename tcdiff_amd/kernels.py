@@ -34,10 +34,10 @@ def _p(t):
 
 
 def gemm_tile(dt, A, W, M, N, K, *, lda=None, ldw=None, A2=None, split_n=0, a_mod=0, mode=L.EPI_STORE_T,
-              act=L.ACT_NONE, bias=None, out=None, ldc=0, out_k=None, out_vt=None, scale_q=1.0, Lseq=0, Lp=0, H=0,
+              act=L.ACT_NONE, bias=None, out=None, ldc=0, out_k=None, out_v=None, scale_q=1.0, Lseq=0, Lp=0, H=0,
               n_q=0, n_k=0, tok_off=0, seq_off=0):
     lib = L.load()
-    e = L.TileEpi(mode, act, scale_q, _p(bias), _p(out), _p(out_k), _p(out_vt), ldc, Lseq, Lp, H, n_q, n_k, tok_off,
+    e = L.TileEpi(mode, act, scale_q, _p(bias), _p(out), _p(out_k), _p(out_v), ldc, Lseq, Lp, H, n_q, n_k, tok_off,
                   seq_off)
     rc = lib.tcdiff_gemm_tile(dt, _p(A), _p(A2), split_n, _p(W), M, N, K, lda if lda else K, ldw if ldw else K,
                               a_mod, C.byref(e), stream())
@@ -55,8 +55,8 @@ def gemm_rowln(dt, A, W, M, K, *, flags, lda=None, ldw=None, a_mod=0, bias=None,
     L.check(rc, "tcdiff_gemm_rowln")
 
 
-def attention(dt, Q, K, Vt, O, n_seq, H, Lq, Lk, Lp_q, Lp_k, ldo, n_shared=0):
-    rc = L.load().tcdiff_attention(dt, _p(Q), _p(K), _p(Vt), _p(O), n_seq, H, Lq, Lk, Lp_q, Lp_k, ldo, n_shared,
+def attention(dt, Q, K, V, O, n_seq, H, Lq, Lk, Lp_q, Lp_k, ldo, n_shared=0):
+    rc = L.load().tcdiff_attention(dt, _p(Q), _p(K), _p(V), _p(O), n_seq, H, Lq, Lk, Lp_q, Lp_k, ldo, n_shared,
                                    stream())
     L.check(rc, "tcdiff_attention")
 
@@ -91,8 +91,8 @@ def add_act(dt, a, ia, b, n, act, out=None, out32=None):
             "tcdiff_add_act")
 
 
-def scatter_time_kv(dt, tab, n_t, tidx, Kc, Vtc, NL, n_kv, H, Lp, tok0):
-    rc = L.load().tcdiff_scatter_time_kv(dt, _p(tab), n_t, _p(tidx), _p(Kc), _p(Vtc), NL, n_kv, H, Lp, tok0,
+def scatter_time_kv(dt, tab, n_t, tidx, Kc, Vc, NL, n_kv, H, Lp, tok0):
+    rc = L.load().tcdiff_scatter_time_kv(dt, _p(tab), n_t, _p(tidx), _p(Kc), _p(Vc), NL, n_kv, H, Lp, tok0,
                                          stream())
     L.check(rc, "tcdiff_scatter_time_kv")
 

@@ -38,13 +38,6 @@ def act_ref(v, act):
     return {L.ACT_NONE: lambda t: t, L.ACT_RELU: F.relu, L.ACT_GELU: F.gelu, L.ACT_MISH: F.mish, L.ACT_SILU: F.silu}[act](v)
 
 
-def vt_pos(tok, dt):
-    if dt == L.DT_F32:
-        return tok
-    kk = tok & 15
-    return (tok & ~15) | (((kk >> 2) & 1) << 3) | ((kk >> 3) << 2) | (kk & 3)
-
-
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("M,N,Kd,act", [(300, 200, 192, L.ACT_NONE), (128, 128, 64, L.ACT_GELU), (77, 1536, 512, L.ACT_RELU),
                                         (1000, 151, 512, L.ACT_MISH), (32, 640, 2048, L.ACT_SILU)])
@@ -83,20 +76,17 @@ def test_gemm_tile_qkv_heads(dt):
     bias = rnd(1536, seed=10)
     Q = torch.zeros(nseq + 1, H, Lp, 64, device=DEV, dtype=T(dt))
     Kk = torch.zeros_like(Q)
-    Vt = torch.zeros(nseq + 1, H, 64, Lp, device=DEV, dtype=T(dt))
+    Vv = torch.zeros_like(Q)
     K.gemm_tile(dt, A1, W, M, 1536, Kd, A2=A2, split_n=1024, bias=bias, mode=L.EPI_QKV_HEADS, out=Q, out_k=Kk,
-                out_vt=Vt, scale_q=0.125, Lseq=Lq, Lp=Lp, H=H, n_q=512, n_k=512, tok_off=2, seq_off=1)
+                out_v=Vv, scale_q=0.125, Lseq=Lq, Lp=Lp, H=H, n_q=512, n_k=512, tok_off=2, seq_off=1)
     q = ((A1.double() @ W.double()[:512].T + bias.double()[:512]) * 0.125).view(nseq, Lq, H, 64).permute(0, 2, 1, 3)
     k = (A1.double() @ W.double()[512:1024].T + bias.double()[512:1024]).view(nseq, Lq, H, 64).permute(0, 2, 1, 3)
     v = (A2.double() @ W.double()[1024:].T + bias.double()[1024:]).view(nseq, Lq, H, 64).permute(0, 2, 1, 3)
     assert relerr(Q[1:, :, 2:2 + Lq], q) < tol(dt)
     assert relerr(Kk[1:, :, 2:2 + Lq], k) < tol(dt)
-    pos = torch.tensor([vt_pos(t + 2, dt) for t in range(Lq)], device=DEV)
-    assert relerr(Vt[1:][:, :, :, pos], v.transpose(2, 3)) < tol(dt)
-    assert float(Q[0].abs().max()) == 0 and float(Vt[0].abs().max()) == 0
-    used = torch.zeros(Lp, dtype=torch.bool, device=DEV)
-    used[pos] = True
-    assert float(Vt[1:][:, :, :, ~used].abs().max()) == 0
+    assert relerr(Vv[1:, :, 2:2 + Lq], v) < tol(dt)
+    assert float(Q[0].abs().max()) == 0 and float(Vv[0].abs().max()) == 0
+    assert float(Vv[1:, :, 2 + Lq:].abs().max()) == 0 and float(Q[1:, :, :2].abs().max()) == 0
 
 
 def rope_ref(n_pos, freqs):
@@ -222,13 +212,12 @@ def test_attention(dt, Lq, Lk, nseq, n_shared):
     v = rnd(n_kv, H, Lk, 64, seed=42).to(T(dt))
     Q = torch.zeros(nseq, H, Lpq, 64, device=DEV, dtype=T(dt))
     Kk = torch.zeros(n_kv, H, Lpk, 64, device=DEV, dtype=T(dt))
-    Vt = torch.zeros(n_kv, H, 64, Lpk, device=DEV, dtype=T(dt))
+    Vv = torch.zeros_like(Kk)
     Q[:, :, :Lq] = q
     Kk[:, :, :Lk] = k
-    pos = torch.tensor([vt_pos(t, dt) for t in range(Lk)], device=DEV)
-    Vt[:, :, :, pos] = v.transpose(2, 3)
+    Vv[:, :, :Lk] = v
     O = torch.zeros(nseq * Lq, 512, device=DEV, dtype=T(dt))
-    K.attention(dt, Q, Kk, Vt, O, nseq, H, Lq, Lk, Lpq, Lpk, 512, n_shared=n_shared)
+    K.attention(dt, Q, Kk, Vv, O, nseq, H, Lq, Lk, Lpq, Lpk, 512, n_shared=n_shared)
     kv = torch.tensor([0 if s < n_shared else s - n_shared + (1 if n_shared > 0 else 0) for s in range(nseq)], device=DEV)
     ref = attn_ref(q, k[kv], v[kv]).permute(0, 2, 1, 3).reshape(nseq * Lq, 512)
     err = float((O.double() - ref).abs().max())
@@ -244,10 +233,10 @@ def test_attention_large_logits_online_softmax():
     v = rnd(1, H, Lk, 64, seed=45)
     Q = torch.zeros(1, H, 128, 64, device=DEV)
     Kk = torch.zeros(1, H, 256, 64, device=DEV)
-    Vt = torch.zeros(1, H, 64, 256, device=DEV)
-    Q[:, :, :Lq], Kk[:, :, :Lk], Vt[:, :, :, :Lk] = q, k, v.transpose(2, 3)
+    Vv = torch.zeros(1, H, 256, 64, device=DEV)
+    Q[:, :, :Lq], Kk[:, :, :Lk], Vv[:, :, :Lk] = q, k, v
     O = torch.zeros(Lq, 512, device=DEV)
-    K.attention(dt, Q, Kk, Vt, O, 1, H, Lq, Lk, 128, 256, 512)
+    K.attention(dt, Q, Kk, Vv, O, 1, H, Lq, Lk, 128, 256, 512)
     ref = attn_ref(q, k, v).permute(0, 2, 1, 3).reshape(Lq, 512)
     assert float((O.double() - ref).abs().max()) < 5e-5
 
@@ -300,14 +289,14 @@ def test_scatter_time_kv(dt):
     tab = rnd(NL, n_t, 2, 1024, seed=60).to(T(dt))
     tidx = torch.tensor([4, 0, 2], dtype=torch.int32, device=DEV)
     Kc = torch.zeros(NL, n_kv, H, Lp, 64, device=DEV, dtype=T(dt))
-    Vtc = torch.zeros(NL, n_kv, H, 64, Lp, device=DEV, dtype=T(dt))
-    K.scatter_time_kv(dt, tab, n_t, tidx, Kc, Vtc, NL, n_kv, H, Lp, S)
+    Vc = torch.zeros_like(Kc)
+    K.scatter_time_kv(dt, tab, n_t, tidx, Kc, Vc, NL, n_kv, H, Lp, S)
     for l in range(NL):
         for s in range(n_kv):
             for r in range(2):
                 row = tab[l, tidx[s].item(), r]
                 assert torch.equal(Kc[l, s, :, S + r].reshape(-1), row[:512])
-                assert torch.equal(Vtc[l, s, :, :, vt_pos(S + r, dt)].reshape(-1), row[512:])
+                assert torch.equal(Vc[l, s, :, S + r].reshape(-1), row[512:])
     assert float(Kc[:, :, :, :S].abs().max()) == 0
 
 
