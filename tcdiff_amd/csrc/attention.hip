@@ -91,6 +91,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const char* __restrict__
     const int head = (wg / nqb) % H, seq = wg / (nqb * H);
     if (qblk >= Lq) return;
     const int q0 = qblk + wave * 32;
+    const bool active = q0 < Lq;   // wave-uniform
     const int kv = seq < n_shared ? 0 : seq - n_shared + (n_shared > 0 ? 1 : 0);
 
     const char* Qg = Q + ((long)(seq * H + head) * Lp_q + q0 + r) * 64 * ES;
@@ -142,6 +143,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const char* __restrict__
         const char* kt_base = smem + cur * C::STAGE;
         const char* vt_base = kt_base + C::TILE_BYTES;
 
+        if (active) {   // waves whose 32 query rows are all padding only help with the staging
         // ---- S^T = K Q^T ---------------------------------------------------------------------------
         f32x16_t s[C::NKT];
 #pragma unroll
@@ -163,31 +165,36 @@ __global__ __launch_bounds__(256) void attention_kernel(const char* __restrict__
                 for (int q = 0; q < 16; ++q)
                     if (kv0 + kt * 32 + acc_row(q, h) >= Lk) s[kt][q] = -INFINITY;
         }
-        // ---- online softmax: this lane owns query q0 + r, its half of the keys -----------------------
+        // ---- online softmax in base 2: p = 2^(s*log2e - m), one fma + one v_exp_f32 per score.  This lane owns
+        //      query q0 + r and half of the keys; the other half sits 32 lanes away.
+        constexpr float LOG2E = 1.4426950408889634f;
         float mx = s[0][0];
 #pragma unroll
         for (int kt = 0; kt < C::NKT; ++kt)
 #pragma unroll
             for (int q = 0; q < 16; ++q) mx = fmaxf(mx, s[kt][q]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        mx = fmaxf(mx, other_half(mx)) * LOG2E;
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = __expf(m_run - m_new);
         float rs = 0.0f;
 #pragma unroll
         for (int kt = 0; kt < C::NKT; ++kt)
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                float p = __expf(s[kt][q] - m_new);
+                const float p = __builtin_amdgcn_exp2f(fmaf(s[kt][q], LOG2E, -m_new));
                 s[kt][q] = p;
                 rs += p;
             }
-        rs += __shfl_xor(rs, 32);
-        l_run = l_run * alpha + rs;
-        m_run = m_new;
+        rs += other_half(rs);
+        if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {   // some row's running max grew: rescale (wave-uniform)
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            l_run *= alpha;
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
+            for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) o[dt][q] *= alpha;
+                for (int q = 0; q < 16; ++q) o[dt][q] *= alpha;
+            m_run = m_new;
+        }
+        l_run += rs;
 
         // ---- O^T += V^T P^T --------------------------------------------------------------------------
 #pragma unroll
@@ -213,6 +220,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const char* __restrict__
                 }
             }
         }
+        }  // active
         if (b + 1 < nb) store_tiles(smem + (cur ^ 1) * C::STAGE);
         __syncthreads();
     }

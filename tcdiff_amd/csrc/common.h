@@ -33,7 +33,13 @@ DEVINL uint16_t f2bf(float f) {
     return __builtin_bit_cast(uint16_t, b);
 }
 DEVINL float bf2f(uint16_t u) { return __builtin_bit_cast(float, (uint32_t)u << 16); }
-DEVINL uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+// two floats -> one dword of two bf16 (lo in bits 0..15): a single v_cvt_pk_bf16_f32, no shift/or
+DEVINL uint32_t pack_bf2(float lo, float hi) {
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
 
 struct MmaBF16 {
     typedef uint16_t elem_t;
@@ -116,28 +122,38 @@ DEVINL float apply_act(float v, int act) {
     }
 }
 
-// ---- wave reductions over the 32 lanes of a half-wave (xor masks < 32 never cross halves) -------
-DEVINL float half_sum(float v) {
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 4);
-    v += __shfl_xor(v, 8);
-    v += __shfl_xor(v, 16);
+// ---- wave reductions ---------------------------------------------------------------------------------
+// __shfl_xor lowers to ds_bpermute_b32 (an LDS round trip, >100 cycles each, 6 dependent ones per wave-wide sum).
+// These use DPP row operations for the 16-lane rows (4 VALU ops) and v_readlane for the 4 row totals.
+template <int CTRL>
+DEVINL float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+#define TC_DPP_QUAD_XOR1 0xB1     // quad_perm [1,0,3,2]
+#define TC_DPP_QUAD_XOR2 0x4E     // quad_perm [2,3,0,1]
+#define TC_DPP_ROW_HALF_MIRROR 0x141
+#define TC_DPP_ROW_MIRROR 0x140
+DEVINL float row16_sum(float v) {   // every lane ends with the sum over its 16-lane row
+    v += dpp_mov<TC_DPP_QUAD_XOR1>(v);
+    v += dpp_mov<TC_DPP_QUAD_XOR2>(v);
+    v += dpp_mov<TC_DPP_ROW_HALF_MIRROR>(v);
+    v += dpp_mov<TC_DPP_ROW_MIRROR>(v);
     return v;
+}
+DEVINL float lane_bcast(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
 DEVINL float wave_sum(float v) {
-    v = half_sum(v);
-    v += __shfl_xor(v, 32);
-    return v;
+    v = row16_sum(v);
+    return (lane_bcast(v, 0) + lane_bcast(v, 16)) + (lane_bcast(v, 32) + lane_bcast(v, 48));
 }
-DEVINL float wave_max(float v) {
-    v = fmaxf(v, __shfl_xor(v, 1));
-    v = fmaxf(v, __shfl_xor(v, 2));
-    v = fmaxf(v, __shfl_xor(v, 4));
-    v = fmaxf(v, __shfl_xor(v, 8));
-    v = fmaxf(v, __shfl_xor(v, 16));
-    v = fmaxf(v, __shfl_xor(v, 32));
-    return v;
+// value held by the lane 32 positions away (lane l <-> l ^ 32), via v_permlane32_swap
+DEVINL float other_half(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    // lanes < 32: r[0] = own, r[1] = partner; lanes >= 32: r[0] = partner, r[1] = own
+    const unsigned own_lo = r[0], own_hi = r[1];
+    return __builtin_bit_cast(float, (threadIdx.x & 32) ? own_lo : own_hi);
 }
 
 // ---- XCD-aware workgroup remap ---------------------------------------------------------------------

@@ -50,8 +50,13 @@ DEVINL void stage_glds(char* lds_tile, const char* src, long ld_bytes, int row0,
 }
 
 #ifdef TC_STAMP
-// diagnostic build: per-block timestamps (100 MHz realtime counter) written to a side buffer; never in the product
-#define TC_STAMP_AT(i) do { if (tid == 0 && e.out_k) reinterpret_cast<unsigned long long*>(e.out_k)[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+// diagnostic build (-DTC_STAMP, tools/microbench3.py): per-block timestamps (100 MHz realtime counter) written to a
+// side buffer that nothing else reads; never compiled into the product library.
+__device__ unsigned long long* g_tc_stamp = nullptr;
+extern "C" int tcdiff_debug_stamp_buffer(void* p) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_tc_stamp), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#define TC_STAMP_AT(i) do { if (tid == 0 && g_tc_stamp) g_tc_stamp[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define TC_STAMP_AT(i) do { } while (0)
 #endif
@@ -260,6 +265,23 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(const char* __restrict_
     constexpr int STAGE = (64 + 512) * TC_ROWB;  // [A tile | W tile]
     constexpr int WOFF = 64 * TC_ROWB;
 
+    // Residual rows of this wave's 8 output rows (fp32, 2 KB each) are fetched into registers BEFORE the main loop:
+    // the per-CU fabric rate (~25 GB/s) makes these reads as expensive as the GEMM itself, and the main loop only
+    // uses the L2 -> LDS DMA path, so they overlap completely.
+    const int f = e.flags;
+    const int c0 = 4 * lane, c1 = 256 + 4 * lane;
+    f32x4_t xra[8], xrb[8];
+    if (f & (TC_ROW_FILM | TC_ROW_RES)) {
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            int m = m0 + wave * 8 + rr;
+            m = m < M ? m : M - 1;
+            const int mr = e.xres_mod > 0 ? m % e.xres_mod : m;
+            xra[rr] = *reinterpret_cast<const f32x4_t*>(e.xres + (long)mr * 512 + c0);
+            xrb[rr] = *reinterpret_cast<const f32x4_t*>(e.xres + (long)mr * 512 + c1);
+        }
+    }
+
     f32x16_t acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -267,6 +289,7 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(const char* __restrict_
         for (int q = 0; q < 16; ++q) acc[j][q] = 0.0f;
 
     const int nk = K / P::KT;
+    TC_STAMP_AT(0);
     stage_glds<64, 8>(smem, A, lda_b, m0, M, a_mod, wave, lane);
     stage_glds<512, 8>(smem + WOFF, W, ldw_b, 0, 512, 0, wave, lane);
     __syncthreads();
@@ -291,6 +314,7 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(const char* __restrict_
         __syncthreads();
     }
 
+    TC_STAMP_AT(1);
     // ---- phase 1: dump the fp32 accumulator tile to LDS as [64 rows][512 cols] --------------------------
     // lane: column n = wn*128 + j*32 + r, rows wm*32 + acc_row(q,h).  32 lanes write 32 consecutive floats.
     float* tile = reinterpret_cast<float*>(smem);
@@ -302,9 +326,8 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(const char* __restrict_
     }
     __syncthreads();
 
+    TC_STAMP_AT(2);
     // ---- phase 2: one wave per row; lane owns columns [4l,4l+4) and [256+4l, 256+4l+4) -------------------
-    const int f = e.flags;
-    const int c0 = 4 * lane, c1 = 256 + 4 * lane;
     f32x4_t bias0 = {0, 0, 0, 0}, bias1 = {0, 0, 0, 0};
     if (f & TC_ROW_BIAS) {
         bias0 = *reinterpret_cast<const f32x4_t*>(e.bias + c0);
@@ -356,7 +379,7 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(const char* __restrict_
 
     // Global operands of a row (FiLM scale/shift, residual, rotary cos/sin) do not depend on the arithmetic, so the
     // loads of row rr+1 are issued before row rr is reduced: their latency hides under the shuffle chains.
-    struct RowIn { f32x4_t sa, sb, ha, hb, xa, xb, ca, cb; };
+    struct RowIn { f32x4_t sa, sb, ha, hb, ca, cb; };
     auto fetch = [&](int rr, RowIn& in) {
         const int m = m0 + wave * 8 + rr;
         if (rr >= 8 || m >= M) return;
@@ -365,18 +388,13 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(const char* __restrict_
             in.sa = *reinterpret_cast<const f32x4_t*>(fp + c0); in.sb = *reinterpret_cast<const f32x4_t*>(fp + c1);
             in.ha = *reinterpret_cast<const f32x4_t*>(fp + 512 + c0); in.hb = *reinterpret_cast<const f32x4_t*>(fp + 512 + c1);
         }
-        if (f & (TC_ROW_FILM | TC_ROW_RES)) {
-            const int mr = e.xres_mod > 0 ? m % e.xres_mod : m;
-            in.xa = *reinterpret_cast<const f32x4_t*>(e.xres + (long)mr * 512 + c0);
-            in.xb = *reinterpret_cast<const f32x4_t*>(e.xres + (long)mr * 512 + c1);
-        }
         if (f & TC_ROW_STORE_ROT) {
             const int pos = (int)(((long)m * e.out_mul + e.out_add) % e.L);
             in.ca = *reinterpret_cast<const f32x4_t*>(e.rope + (long)pos * 512 + c0);  // cos0 sin0 cos1 sin1
             in.cb = *reinterpret_cast<const f32x4_t*>(e.rope + (long)pos * 512 + c1);
         }
     };
-    auto process = [&](int rr, const RowIn& in) {
+    auto process = [&](int rr, const RowIn& in, const f32x4_t& xa, const f32x4_t& xb) {
         const int row = wave * 8 + rr;
         const int m = m0 + row;
         if (m >= M) return;
@@ -390,8 +408,8 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(const char* __restrict_
             vb = (in.sb + 1.0f) * vb + in.hb;
         }
         if (f & (TC_ROW_FILM | TC_ROW_RES)) {
-            va = in.xa + va;
-            vb = in.xb + vb;
+            va = xa + va;
+            vb = xb + vb;
         }
         const long mo = (long)m * e.out_mul + e.out_add;
         if (f & TC_ROW_STORE_X) {
@@ -415,13 +433,14 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(const char* __restrict_
     };
     RowIn inA, inB;
     fetch(0, inA);
-#pragma unroll 1
+#pragma unroll
     for (int rr = 0; rr < 8; rr += 2) {
         fetch(rr + 1, inB);
-        process(rr, inA);
+        process(rr, inA, xra[rr], xrb[rr]);
         fetch(rr + 2, inA);
-        process(rr + 1, inB);
+        process(rr + 1, inB, xra[rr + 1], xrb[rr + 1]);
     }
+    TC_STAMP_AT(3);
 }
 
 // =================================================================================================
