@@ -29,6 +29,7 @@ import torch.nn.functional as F  # noqa: E402
 GFLOP_PER_CLIP_STEP = {(3, 150): 55.81, (2, 60): 13.73, (5, 300): 240.60}  # SURVEY.md Appendix B (algorithmic)
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3
+PEAK_HBM_GBPS = 8000.0      # HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
 
 
 def parse():
@@ -94,15 +95,46 @@ def kernel_roofline(eng, B, dtype):
             dt, b["Q"], b["Kc"][1], b["Vc"][1], b["O"], 2 * B, H, Lq, S + 2, eng.Lp, eng.Lpc, 512, n_shared=B)),
     }
     peak = PEAK_BF16_TFLOPS if dtype == "bf16" else PEAK_F32_TFLOPS
+    es = 2 if dtype == "bf16" else 4
+    act = lambda cols, e=es: R * cols * e            # one [R, cols] activation matrix
+    x32 = R * 512 * 4                                # fp32 residual stream
+    qkv_img = 2 * B * H * eng.Lp * 64 * es           # one padded head-major image
+    # ALGORITHMIC HBM bytes per launch: every operand read once, every result written once (weights included)
+    algo_bytes = {
+        "gemm_tile[qkv 1536x512]": 2 * act(512) + 1536 * 512 * es + 3 * act(512),
+        "gemm_tile[ffn1 1024x512]": act(512) + 1024 * 512 * es + act(1024),
+        "gemm_tile[q 512x512]": act(512) + 512 * 512 * es + act(512),
+        "gemm_rowln[K=512, ln+film+res+ln]": act(512) + 512 * 512 * es + x32 + x32 + act(512),
+        "gemm_rowln[K=1024, film+res+ln]": act(1024) + 512 * 1024 * es + x32 + act(512),
+        "attention[self L=%d]" % Lq: 3 * qkv_img + act(512),
+        "attention[cross M=%d]" % (S + 2): qkv_img + 2 * (B + 1) * H * eng.Lpc * 64 * es + act(512),
+    }
     rows = {}
     for name, (count, flops, fn) in specs.items():
         ms = event_time_ms(fn)
+        nbytes = algo_bytes[name]
         rows[name] = dict(launches_per_step=count, ms=round(ms, 5), tflops=round(flops / ms / 1e9, 2),
-                          frac=round(flops / ms / 1e9 / peak, 4), step_share_ms=round(count * ms, 4))
+                          frac=round(flops / ms / 1e9 / peak, 4), step_share_ms=round(count * ms, 4),
+                          algo_mb=round(nbytes / 1e6, 1), gbps=round(nbytes / ms / 1e6, 1),
+                          hbm_frac=round(nbytes / ms / 1e6 / PEAK_HBM_GBPS, 4),
+                          flop_per_byte=round(flops / nbytes, 1))
     dom = max(rows, key=lambda k: rows[k]["step_share_ms"])
     d = rows[dom]
-    roof = dict(bound="mfma", kernel=dom, achieved=d["tflops"], peak=peak, unit="TFLOP/s", frac=d["frac"],
-                traffic=None, avg_launch_ms=d["ms"], launches_per_ddpm_step=d["launches_per_step"])
+    # the roofline that bounds a kernel: HBM when its arithmetic intensity is below the machine balance
+    balance = peak * 1e3 / PEAK_HBM_GBPS   # FLOP per byte
+    traffic = None
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
+        traffic = pm[dom.split("[")[0]]["bytes_per_launch"]
+    except Exception:
+        pass
+    if d["flop_per_byte"] < balance:
+        roof = dict(bound="hbm", kernel=dom, achieved=d["gbps"], peak=PEAK_HBM_GBPS, unit="GB/s", frac=d["hbm_frac"],
+                    traffic=traffic, algorithmic_bytes_per_launch=algo_bytes[dom], avg_launch_ms=d["ms"],
+                    launches_per_ddpm_step=d["launches_per_step"], mfma_tflops=d["tflops"], mfma_frac=d["frac"])
+    else:
+        roof = dict(bound="mfma", kernel=dom, achieved=d["tflops"], peak=peak, unit="TFLOP/s", frac=d["frac"],
+                    traffic=traffic, avg_launch_ms=d["ms"], launches_per_ddpm_step=d["launches_per_step"])
     return roof, rows
 
 
