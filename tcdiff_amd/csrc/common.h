@@ -167,6 +167,13 @@ DEVINL int xcd_remap(int bid, int nblocks) {
     return (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
 }
 
+// Barrier that also retires this wave's global->LDS DMA (global_load_lds): hipcc does NOT reliably put the
+// s_waitcnt vmcnt(0) in front of __syncthreads() for LDS-DMA issued in an earlier basic block, so it is explicit.
+DEVINL void sync_dma() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
 // error codes of the C ABI
 #define TC_OK 0
 #define TC_ERR_ARG (-1)

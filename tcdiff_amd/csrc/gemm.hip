@@ -15,8 +15,11 @@
 //
 // Staging: global -> LDS directly with global_load_lds_dwordx4 (no VGPR staging, no ds_write pass).  One
 // wave-instruction lands 64 lanes x 16 B = 8 tile rows linearly in LDS; the XOR swizzle of common.h::tile_off
-// is applied on the per-lane SOURCE address (cdna_hip_programming.md rule 21).  Two LDS stages; the
-// __syncthreads() that closes a k-step also drains the in-flight loads of the next tile.
+// is applied on the per-lane SOURCE address (cdna_hip_programming.md rule 21).  Two LDS stages; the barrier that
+// closes a k-step is preceded by an explicit s_waitcnt vmcnt(0) (common.h sync_dma) that retires the next tile's DMA.
+// Measured (tools/microbench*.py, tools/dma/): one global_load_lds costs the issuing wave ~200 cycles, and a CU pulls
+// ~55-60 GB/s from L2 into LDS at this tile shape whether by LDS-DMA or by register staging: that rate, not the MFMA
+// pipe, bounds the main loop at B = 16 (56 rows of activations per CU against all the weights).
 //
 // Epilogue stores go through LDS so that global writes are whole 16-byte chunks of contiguous rows:
 //   gemm_tile issues the MFMAs with the operand roles swapped (A operand = weight rows, B operand = activation
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(const char* __restrict__
     stage_glds<128, 4>(smem, Ause, lda_b, m0, M, a_mod, wave, lane);
     stage_glds<128, 4>(smem + WOFF, W, ldw_b, n0, N, 0, wave, lane);
     TC_STAMP_AT(1);
-    __syncthreads();
+    sync_dma();
     TC_STAMP_AT(2);
 
     for (int kt = 0; kt < nk; ++kt) {
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(const char* __restrict__
 #pragma unroll
                 for (int j = 0; j < 2; ++j) P::mma(acc[i][j], fw[j], fa[i]);
         }
-        __syncthreads();  // all waves done with buf[cur]; also drains the DMA of tile kt+1
+        sync_dma();  // all waves done with buf[cur]; the DMA of tile kt+1 has landed
     }
 
     TC_STAMP_AT(3);
@@ -292,7 +295,7 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(const char* __restrict_
     TC_STAMP_AT(0);
     stage_glds<64, 8>(smem, A, lda_b, m0, M, a_mod, wave, lane);
     stage_glds<512, 8>(smem + WOFF, W, ldw_b, 0, 512, 0, wave, lane);
-    __syncthreads();
+    sync_dma();
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) {
@@ -311,7 +314,7 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(const char* __restrict_
                 P::mma(acc[j], fa, fw);
             }
         }
-        __syncthreads();
+        sync_dma();
     }
 
     TC_STAMP_AT(1);
