@@ -250,12 +250,188 @@ __global__ __launch_bounds__(256) void attention_kernel(const char* __restrict__
     }
 }
 
+
+// =================================================================================================
+// K/V-resident variant (bf16, Lk <= 512): one workgroup of 8 waves per (sequence, head).
+// The streaming kernel above is latency-bound per 64-key tile (stamped: ~6500 cycles per tile for 512 cycles of MFMA:
+// LDS-read -> MFMA chains, one barrier per tile, 32 query rows of independent work per wave).  For the denoiser's
+// shapes (L = 450 tokens, 152 memory rows) all of K and V of one (sequence, head) fits in LDS (2 x 64 KB), so this
+// kernel loads them ONCE (LDS-DMA, one barrier), gives every wave 64 query rows as two independent 32-row groups that
+// share every K / V^T fragment read, and runs the whole key loop without barriers.  At B = 16 that is 2*16*8 = 256
+// workgroups: one per CU.
+// =================================================================================================
+#define ATT_RES_MAXT 8   // up to 8 tiles of 64 keys
+
+__global__ __launch_bounds__(512) void attention_res_kernel(const char* __restrict__ Q, const char* __restrict__ K,
+                                                            const char* __restrict__ V, char* __restrict__ O, int H, int Lq,
+                                                            int Lk, int Lp_q, int Lp_k, int ldo, int n_shared) {
+    typedef MmaBF16 P;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int head = wg % H, seq = wg / H;
+    const int kv = seq < n_shared ? 0 : seq - n_shared + (n_shared > 0 ? 1 : 0);
+    const int nt = (Lk + 63) / 64;
+    char* Ks = smem;                       // [nt][64 keys][128 B], chunk-swizzled (common.h tile_off)
+    char* Vs = smem + nt * 8192;
+    const char* Kg = K + (long)(kv * H + head) * Lp_k * 128;
+    const char* Vg = V + (long)(kv * H + head) * Lp_k * 128;
+    // ---- K, V -> LDS: nt*8 one-KiB blocks per matrix, nt per wave per matrix
+    for (int i = 0; i < nt; ++i) {
+        const int blk = wave * nt + i;     // 8 consecutive keys
+        const int row = blk * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        typedef __attribute__((address_space(3))) void lds_void_t;
+        typedef const __attribute__((address_space(1))) void gbl_void_t;
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(Kg + (long)row * 128 + chunk * 16), (lds_void_t*)(Ks + blk * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(Vg + (long)row * 128 + chunk * 16), (lds_void_t*)(Vs + blk * 1024), 16, 0, 0);
+    }
+    // ---- Q^T fragments of the two row groups (registers for the whole kernel)
+    const int qbase = wave * 64;
+    u32x4 qf[2][4];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const char* Qg = Q + ((long)(seq * H + head) * Lp_q + qbase + g * 32 + r) * 128;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[g][ks] = *reinterpret_cast<const u32x4*>(Qg + (2 * ks + h) * 16);
+    }
+    const bool act0 = qbase < Lq, act1 = qbase + 32 < Lq;   // wave-uniform
+    f32x16_t o[2][2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) o[g][dt][q] = 0.0f;
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.0f, 0.0f};
+    sync_dma();
+
+    if (act0) {
+#pragma unroll 1
+        for (int b = 0; b < nt; ++b) {
+            const char* kt_base = Ks + b * 8192;
+            const char* vt_base = Vs + b * 8192;
+            const int kv0 = b * 64;
+            // ---- S^T = K Q^T for both row groups: every K fragment read feeds two MFMAs
+            f32x16_t s[2][2];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) { s[0][kt][q] = 0.0f; s[1][kt][q] = 0.0f; }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const u32x4 kf = *reinterpret_cast<const u32x4*>(kt_base + tile_off(kt * 32 + r, 2 * ks + h));
+                    P::mma(s[0][kt], kf, qf[0][ks]);
+                    P::mma(s[1][kt], kf, qf[1][ks]);
+                }
+            }
+            if (kv0 + 64 > Lk) {
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                        for (int q = 0; q < 16; ++q)
+                            if (kv0 + kt * 32 + acc_row(q, h) >= Lk) s[g][kt][q] = -INFINITY;
+            }
+            // ---- online softmax (base 2), the two groups are independent instruction streams
+            constexpr float LOG2E = 1.4426950408889634f;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                float mx = s[g][0][0];
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) mx = fmaxf(mx, s[g][kt][q]);
+                mx = fmaxf(mx, other_half(mx)) * LOG2E;
+                const float m_new = fmaxf(m_run[g], mx);
+                float rs = 0.0f;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const float p = __builtin_amdgcn_exp2f(fmaf(s[g][kt][q], LOG2E, -m_new));
+                        s[g][kt][q] = p;
+                        rs += p;
+                    }
+                rs += other_half(rs);
+                if (__builtin_amdgcn_ballot_w64(m_new > m_run[g]) != 0) {
+                    const float alpha = __builtin_amdgcn_exp2f(m_run[g] - m_new);
+                    l_run[g] *= alpha;
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) o[g][dt][q] *= alpha;
+                    m_run[g] = m_new;
+                }
+                l_run[g] += rs;
+            }
+            // ---- O^T += V^T P^T: every V^T fragment (two transposed reads) feeds both groups
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    u32x4 pf[2];
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        pf[g][0] = pack_bf2(s[g][kt][8 * st + 0], s[g][kt][8 * st + 1]);
+                        pf[g][1] = pack_bf2(s[g][kt][8 * st + 2], s[g][kt][8 * st + 3]);
+                        pf[g][2] = pack_bf2(s[g][kt][8 * st + 4], s[g][kt][8 * st + 5]);
+                        pf[g][3] = pack_bf2(s[g][kt][8 * st + 6], s[g][kt][8 * st + 7]);
+                    }
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        const u32x4 vf = v_frag<P>(vt_base, dt, kt, st, lane);
+                        P::mma(o[0][dt], vf, pf[0]);
+                        P::mma(o[1][dt], vf, pf[1]);
+                    }
+                }
+        }
+    }
+    // ---- O[q][d] = O^T[d][q] / l
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int qg = qbase + g * 32 + r;
+        if ((g == 0 ? act0 : act1) && qg < Lq) {
+            const float inv = 1.0f / l_run[g];
+            uint16_t* orow = reinterpret_cast<uint16_t*>(O) + ((long)seq * Lq + qg) * ldo + head * 64;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int d0 = dt * 32 + 8 * q4 + 4 * h;
+                    uint2 pk;
+                    pk.x = pack_bf2(o[g][dt][4 * q4 + 0] * inv, o[g][dt][4 * q4 + 1] * inv);
+                    pk.y = pack_bf2(o[g][dt][4 * q4 + 2] * inv, o[g][dt][4 * q4 + 3] * inv);
+                    *reinterpret_cast<uint2*>(orow + d0) = pk;
+                }
+        }
+    }
+}
+
 extern "C" int tcdiff_attention(int dtype, const void* Q, const void* K, const void* V, void* O, int n_seq, int H,
                                 int Lq, int Lk, int Lp_q, int Lp_k, int ldo, int n_shared, hipStream_t stream) {
     if (!Q || !K || !V || !O || n_seq <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return TC_ERR_ARG;
     if (dtype != TC_DTYPE_BF16 && dtype != TC_DTYPE_F32) return TC_ERR_ARG;
     if (Lp_q % 128 != 0 || Lp_k % 64 != 0 || Lp_q < Lq || Lp_k < Lk || ldo < H * 64 || ldo % 4 != 0) return TC_ERR_ARG;
     if (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O) & 15) return TC_ERR_ALIGN;
+    if (dtype == TC_DTYPE_BF16 && Lk <= 64 * ATT_RES_MAXT && Lq <= 512 && Lp_q >= 512) {
+        // K/V-resident kernel: one workgroup per (sequence, head), every wave 64 query rows (Q image padded to >= 512 rows)
+        const int nt = (Lk + 63) / 64;
+        const int smem_bytes = 2 * nt * 8192;
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_res_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_RES_MAXT * 8192);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(attention_res_kernel, dim3(H * n_seq), dim3(512), smem_bytes, stream, (const char*)Q,
+                           (const char*)K, (const char*)V, (char*)O, H, Lq, Lk, Lp_q, Lp_k, ldo, n_shared);
+        TC_CHECK_LAUNCH();
+        return TC_OK;
+    }
     dim3 grid((Lp_q / 128) * H * n_seq);
     if (dtype == TC_DTYPE_BF16)
         hipLaunchKernelGGL(attention_kernel<MmaBF16>, grid, dim3(256), 0, stream, (const char*)Q, (const char*)K,
