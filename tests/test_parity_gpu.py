@@ -216,3 +216,44 @@ def test_product_path_fails_loudly_off_gpu():
                          cond_feature_dim=438, required_dancer_num=2)
     with pytest.raises(_lib.TcdiffError):
         model(torch.zeros(1, 120, 151), torch.zeros(1, 121, 438), torch.zeros(1, dtype=torch.long))
+
+
+def test_c4_long_sequence_forward_and_steps_vs_oracle():
+    """BASELINE config 4 (5 dancers x 300 frames, L = 1500 tokens, 302 memory rows): the streaming attention path
+    (K/V do not fit LDS) and the 2560-wide fusion projection, f32 mode against the CPU oracle."""
+    dn, S, T = 5, 300, 1000
+    sd, model, diff = build(dn, S, T)
+    Lq = dn * S
+    cond = torch.stack([O.synth_cond(0, S)])
+    xT = torch.stack([O.synth_xT(0, Lq)])
+    tt = torch.full((1,), 700, dtype=torch.long)
+    want = O.guided_forward(sd, xT, cond, tt, 2)
+    got = model.guided_forward(xT.to(DEV), cond.to(DEV), tt.to(DEV), 2)
+    e = maxabs(got, want)
+    print(f"C4 guided forward (L=1500): {e:.2e}")
+    assert e < 4e-4
+    eps = O.batch_step_noise([0], Lq)
+    tab = O.make_tables(T)
+    x = xT.clone()
+    for i in (999, 998):
+        x, _ = O.p_sample(sd, tab, x, cond, i, T, 2, eps(i, x.shape))
+    from tcdiff_amd import _lib as L
+    chain = []
+    diff._run(L.SAMPLER_DDPM, (1, Lq, 151), cond, xT.to(DEV), [999, 998], diff._ddpm_params([999, 998]),
+              step_noise=dev_noise([0], Lq), collect=chain)
+    e = maxabs(chain[-1], x)
+    print(f"C4 two DDPM steps: {e:.2e}")
+    assert e < 5e-4
+
+
+def test_c4_bf16_runs_and_is_close():
+    dn, S = 5, 300
+    sd, model, diff = build(dn, S, 1000, compute="bf16")
+    cond = torch.stack([O.synth_cond(c, S) for c in (0, 1)])
+    xT = torch.stack([O.synth_xT(c, dn * S) for c in (0, 1)])
+    tt = torch.full((2,), 500, dtype=torch.long)
+    want = O.guided_forward(sd, xT[:1], cond[:1], tt[:1], 2)
+    got = model.guided_forward(xT.to(DEV), cond.to(DEV), tt.to(DEV), 2)
+    e = maxabs(got[:1], want)
+    print(f"C4 bf16 guided forward vs fp32 oracle: {e:.2e}")
+    assert e < 5e-2 and bool(torch.isfinite(got).all())
