@@ -85,19 +85,41 @@ DEVINL int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; 
 DEVINL int tile_off(int row, int chunk) { return row * TC_ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
 // ---- activations ---------------------------------------------------------------------------------
-// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, i.e. fp32 rounding level): 1 exp + 1 rcp + 6 fma instead of
-// libm's ~50-instruction erff.  GELU keeps the reference's exact-erf definition (F.gelu default, TCDiff.py:85).
-DEVINL float erf_as(float x) {
-    const float ax = fabsf(x);
-    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float y = 1.0f - p * t * __expf(-ax * ax);
-    return copysignf(y, x);
+// GELU keeps the reference's exact-erf definition (F.gelu default, TCDiff.py:85) with erf by Abramowitz-Stegun 7.1.28,
+//   erf(z) = 1 - 1 / (1 + a1 z + ... + a6 z^6)^16,  |error| <= 3e-7 for z >= 0,
+// i.e. six FMAs, four squarings and ONE quarter-rate op (v_rcp_f32) per element instead of libm's ~50 instructions
+// (7.1.26, used before, needs an exp as well).  With r = 1 / (...)^16 and erf odd,
+//   gelu(x) = 0.5 x (1 + erf(x / sqrt 2)) = max(x, 0) - |0.5 x r|.
+// The epilogue of linear1 evaluates 14.7 M of these per step and layer, more VALU time than the GEMM has MFMA time,
+// so the two-element form below is written on float2 vectors for v_pk_fma_f32 / v_pk_mul_f32.
+DEVINL float gelu_erf(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    float p = fmaf(0.0000430638f, z, 0.0002765672f);
+    p = fmaf(p, z, 0.0001520143f);
+    p = fmaf(p, z, 0.0092705272f);
+    p = fmaf(p, z, 0.0422820123f);
+    p = fmaf(p, z, 0.0705230784f);
+    p = fmaf(p, z, 1.0f);
+    p = p * p; p = p * p; p = p * p; p = p * p;
+    const float hr = 0.5f * x * __builtin_amdgcn_rcpf(p);   // v_rcp_f32 (1 ulp); __frcp_rn expands to an 11-instruction division
+    return fmaxf(x, 0.0f) - fabsf(hr);
 }
-DEVINL float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f)); }
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+DEVINL f32x2_t gelu_erf2(f32x2_t x) {
+    f32x2_t z = {fabsf(x[0]), fabsf(x[1])};
+    z = z * 0.70710678118654752440f;
+    f32x2_t p = __builtin_elementwise_fma((f32x2_t)(0.0000430638f), z, (f32x2_t)(0.0002765672f));
+    p = __builtin_elementwise_fma(p, z, (f32x2_t)(0.0001520143f));
+    p = __builtin_elementwise_fma(p, z, (f32x2_t)(0.0092705272f));
+    p = __builtin_elementwise_fma(p, z, (f32x2_t)(0.0422820123f));
+    p = __builtin_elementwise_fma(p, z, (f32x2_t)(0.0705230784f));
+    p = __builtin_elementwise_fma(p, z, (f32x2_t)(1.0f));
+    p = p * p; p = p * p; p = p * p; p = p * p;
+    const f32x2_t r = {__builtin_amdgcn_rcpf(p[0]), __builtin_amdgcn_rcpf(p[1])};
+    const f32x2_t hr = (x * 0.5f) * r;
+    f32x2_t y = {fmaxf(x[0], 0.0f) - fabsf(hr[0]), fmaxf(x[1], 0.0f) - fabsf(hr[1])};
+    return y;
+}
 DEVINL float softplus_t(float x) { return x > 20.0f ? x : log1pf(expf(x)); }  // torch threshold 20
 DEVINL float mish_f(float x) { return x * tanhf(softplus_t(x)); }
 DEVINL float silu_f(float x) { return x / (1.0f + expf(-x)); }
@@ -111,6 +133,17 @@ DEVINL float act_ct(float v, int act_rt) {
     if (ACT == ACT_RELU) return fmaxf(v, 0.0f);
     if (ACT == ACT_GELU) return gelu_erf(v);
     return act_rt == ACT_MISH ? mish_f(v) : silu_f(v);   // ACT == 3: the two setup-only activations
+}
+// four consecutive outputs at once (GELU in its packed form)
+template <int ACT>
+DEVINL void act4_ct(float (&v)[4], int act_rt) {
+    if (ACT == ACT_GELU) {
+        const f32x2_t a = gelu_erf2(f32x2_t{v[0], v[1]}), b = gelu_erf2(f32x2_t{v[2], v[3]});
+        v[0] = a[0]; v[1] = a[1]; v[2] = b[0]; v[3] = b[1];
+    } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = act_ct<ACT>(v[t], act_rt);
+    }
 }
 DEVINL float apply_act(float v, int act) {
     switch (act) {

@@ -20,6 +20,12 @@
 // Measured (tools/microbench*.py, tools/dma/): one global_load_lds costs the issuing wave ~200 cycles, and a CU pulls
 // ~55-60 GB/s from L2 into LDS at this tile shape whether by LDS-DMA or by register staging: that rate, not the MFMA
 // pipe, bounds the main loop at B = 16 (56 rows of activations per CU against all the weights).
+// Two restructurings were built and measured against this kernel and dropped (profiles/README.md):
+//   * a persistent 256x128 kernel with 4 dedicated loader waves and a 3-slot ring: 34 GB/s per CU - a wave issues one
+//     global_load_lds per ~120 cycles, so the DMA rate follows the NUMBER of issuing waves, not the ring depth;
+//   * one near-square tile per CU (16 waves, 225..343 rows x 256 columns, half the staged bytes, separate A / W rings):
+//     with the DMA off a K step took 80 % of the MFMA rate at the 1.72 GHz the clock drops to, with it on 61 %; end to
+//     end within 3 % of this kernel on the step's three shapes, because prologue + epilogue are not overlapped there.
 //
 // Epilogue stores go through LDS so that global writes are whole 16-byte chunks of contiguous rows:
 //   gemm_tile issues the MFMAs with the operand roles swapped (A operand = weight rows, B operand = activation
@@ -60,8 +66,10 @@ extern "C" int tcdiff_debug_stamp_buffer(void* p) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_tc_stamp), &p, sizeof(p)) == hipSuccess ? 0 : -1;
 }
 #define TC_STAMP_AT(i) do { if (tid == 0 && g_tc_stamp) g_tc_stamp[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define TC_STAMP_W(i) do { if (lane == 0 && g_tc_stamp && (i) < 32) g_tc_stamp[blockIdx.x * 32 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define TC_STAMP_AT(i) do { } while (0)
+#define TC_STAMP_W(i) do { } while (0)
 #endif
 
 DEVINL u32x4 lds_frag(const char* tile, int row, int chunk) {
@@ -200,7 +208,10 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(const char* __restrict__
                                 for (int t = 0; t < 4; ++t) if (n + t < N) bq[t] = e.bias[n + t];
                         }
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) v[t] = act_ct<ACT>(acc[i][j][4 * g + t] + bq[t], e.act) * colscale;
+                        for (int t = 0; t < 4; ++t) v[t] = acc[i][j][4 * g + t] + bq[t];
+                        act4_ct<ACT>(v, e.act);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) v[t] *= colscale;
                         char* dst = smem + ml * RS + nl * ES;
                         if (P::IS_BF16) {
                             uint2 pk;
@@ -475,8 +486,8 @@ extern "C" int tcdiff_gemm_tile(int dtype, const void* A, const void* A2, int sp
         if (!aligned16(epi->out)) return TC_ERR_ALIGN;
     }
     tcdiff_tile_epi e = *epi;
-    dim3 grid(((N + 127) / 128) * ((M + 127) / 128));
     const int actk = e.act <= TC_ACT_GELU ? e.act : 3;   // 3 = runtime choice between the setup-only Mish / SiLU
+    dim3 grid(((N + 127) / 128) * ((M + 127) / 128));
 #define TC_LAUNCH_TILE(POL, ACTK)                                                                                \
     hipLaunchKernelGGL((gemm_tile_kernel<POL, ACTK>), grid, dim3(256), 0, stream, (const char*)A, (const char*)A2, \
                        split_n, (const char*)W, M, N, K, (long)lda * es, (long)ldw * es, a_mod, e)

@@ -11,6 +11,7 @@ the samples instead), and the training loss ``p_losses`` (next row, needs backwa
 from __future__ import annotations
 
 import copy
+import os
 from typing import Callable, Optional
 
 import numpy as np
@@ -124,9 +125,9 @@ class GaussianDiffusion(nn.Module):
             return min(w, 1)
         return w
 
-    def _prepare(self, B: int, cond: torch.Tensor, tseq):
+    def _prepare(self, B: int, cond: torch.Tensor, tseq, slot: int = 0):
         """Step-invariant work, once per sampler call: music encoder, cross-attention caches, time tables."""
-        eng = self.model.engine(B)
+        eng = self.model.engine(B, slot)
         b = eng.b
         dev = eng.dev
         tok, hid = eng.encode_music(cond.to(dev))
@@ -143,65 +144,141 @@ class GaussianDiffusion(nn.Module):
         row_of = {t: i for i, t in enumerate(uniq)}
         return eng, [row_of[int(t)] for t in tseq]
 
+    # Two-stream sampling: the batch is split into two halves that run as parallel branches of the captured graph.
+    # Every kernel of the step alternates between a DMA/MFMA-bound main loop and an HBM-bound epilogue; two
+    # independent half-size launch chains let one half's memory-bound phases overlap the other's compute phases.
+    # Clips are independent (and the noise is keyed by the global clip index), so the samples are bit-identical.
+    dual_stream = os.environ.get("TCDIFF_DUAL", "1") != "0"
+    dual_skew_us = float(os.environ.get("TCDIFF_DUAL_SKEW_US", "40"))   # < 0: lock-step halves inside one graph
+
     def _run(self, mode: int, shape, cond, x: torch.Tensor, tseq, params: torch.Tensor, *, traj=None,
              step_noise: Optional[Callable] = None, seed: Optional[int] = None, clip_offset: int = 0,
              after_step: Optional[Callable] = None, use_graph: bool = True, collect=None):
-        """Run len(tseq) sampler steps on x (fp32 [B, L, nfeat], updated in place on the engine's buffer)."""
+        """Run len(tseq) sampler steps on x (fp32 [B, L, nfeat]); returns the updated tensor."""
         B, Lq, nf = shape
-        eng, rows = self._prepare(B, cond, tseq)
-        b, dev = eng.b, eng.dev
         n = len(tseq)
-        st = eng.sampler_state(n, B * Lq, nf)
-        st["x"].copy_(x.reshape(B * Lq, nf))
-        st["counter"].zero_()
-        st["rows"][:n] = torch.tensor(rows, dtype=torch.int32)
-        st["tseq"][:n] = torch.tensor([int(t) for t in tseq], dtype=torch.int32)
-        st["params"][:n] = params.to(torch.float32)
-        if traj is not None:
-            st["traj"].copy_(traj.reshape(B * Lq, 3))
+        dual = self.dual_stream and use_graph and after_step is None and B >= 4 and B % 2 == 0 and n > 2
+        bounds = [(0, B // 2), (B // 2, B)] if dual else [(0, B)]
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-        # the seed lives in device memory (counter[1..2]) so that a captured graph can be re-seeded
-        st["counter"][1:3] = torch.tensor([seed & 0x7FFFFFFF, (seed >> 31) & 0x7FFFFFFF], dtype=torch.int32)
         w_eff = params[:, 0].tolist()
+        x = x.reshape(B, Lq, nf)
+        parts = []
+        for k, (lo, hi) in enumerate(bounds):
+            Bp = hi - lo
+            eng, rows = self._prepare(Bp, cond[lo:hi], tseq, slot=k)
+            st = eng.sampler_state(n, Bp * Lq, nf)
+            st["x"].copy_(x[lo:hi].reshape(Bp * Lq, nf))
+            st["counter"].zero_()
+            st["rows"][:n] = torch.tensor(rows, dtype=torch.int32)
+            st["tseq"][:n] = torch.tensor([int(t) for t in tseq], dtype=torch.int32)
+            st["params"][:n] = params.to(torch.float32)
+            if traj is not None:
+                st["traj"].copy_(traj.reshape(B, Lq, 3)[lo:hi].reshape(Bp * Lq, 3))
+            # the seed lives in device memory (counter[1..2]) so that a captured graph can be re-seeded
+            st["counter"][1:3] = torch.tensor([seed & 0x7FFFFFFF, (seed >> 31) & 0x7FFFFFFF], dtype=torch.int32)
+            parts.append(dict(eng=eng, st=st, B=Bp, lo=lo, hi=hi))
 
-        def step(branches: int):
-            K.step_begin(st["counter"], st["rows"], b["tidx"], 2 * B)
-            eng.per_step_conditioning(2 * B)
+        def step_part(p, branches: int):
+            eng, st, Bp = p["eng"], p["st"], p["B"]
+            b = eng.b
+            K.step_begin(st["counter"], st["rows"], b["tidx"], 2 * Bp)
+            eng.per_step_conditioning(2 * Bp)
             if branches == 2:
-                out = eng.network(st["x"], B, 2, 0, B, 0)
-                unc, con = out, out[B * Lq:]
+                out = eng.network(st["x"], Bp, 2, 0, Bp, 0)
+                unc, con = out, out[Bp * Lq:]
             else:
-                out = eng.network(st["x"], B, 1, 1, 0, B)
+                out = eng.network(st["x"], Bp, 1, 1, 0, Bp)
                 unc, con = None, out
             K.sampler_update(mode, unc, con, 152, st["x"], st["eps"] if step_noise is not None else None,
-                             st["traj"] if traj is not None else None, None, B * Lq, nf, Lq, st["counter"],
-                             st["params"], st["tseq"], seed=0, clip0=clip_offset)
+                             st["traj"] if traj is not None else None, None, Bp * Lq, nf, Lq, st["counter"],
+                             st["params"], st["tseq"], seed=0, clip0=clip_offset + p["lo"])
             K.step_end(st["counter"])
 
+        def step(branches: int, parallel: bool):
+            if len(parts) == 1 or not parallel:
+                for p in parts:
+                    step_part(p, branches)
+                return
+            main = torch.cuda.current_stream()
+            side = self._side_stream(main.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                step_part(parts[1], branches)
+            step_part(parts[0], branches)
+            main.wait_stream(side)
+
+        graphs = self.__dict__.setdefault("_graphs", {})
+        gens = tuple(p["eng"].generation for p in parts)
+        full = lambda: torch.cat([p["st"]["x"].view(p["B"], Lq, nf) for p in parts], 0) if len(parts) > 1 \
+            else parts[0]["st"]["x"].view(B, Lq, nf)
+        # Free-running halves: each half replays its own step graph on its own stream with no per-step join, the second
+        # one started `dual_skew_us` late, so that the two launch chains stay out of phase (one half's HBM-bound
+        # epilogues beside the other's MFMA-bound main loops) instead of running the same kernel side by side.
+        skewed = len(parts) == 2 and self.dual_skew_us >= 0 and step_noise is None and collect is None
+        side = self._side_stream(x.device) if len(parts) == 2 else None
+        side_started = False
         for i, t in enumerate(tseq):
             branches = 1 if w_eff[i] == 1.0 else 2
             if step_noise is not None:
-                st["eps"].copy_(step_noise(int(t), (B, Lq, nf)).reshape(B * Lq, nf))
-            gkey = (mode, branches, step_noise is not None, traj is not None, clip_offset)
+                eps = step_noise(int(t), (B, Lq, nf))
+                for p in parts:
+                    p["st"]["eps"].copy_(eps[p["lo"]:p["hi"]].reshape(p["B"] * Lq, nf))
+            gkey = (mode, branches, step_noise is not None, traj is not None, clip_offset, B, len(parts), gens, id(self.model),
+                    skewed)
             if not use_graph:
-                step(branches)
-            elif gkey in eng.graphs:
-                eng.graphs[gkey].replay()
-            elif gkey not in eng.graph_warm:
-                step(branches)                  # first visit: eager (loads code objects, sets kernel attributes)
-                eng.graph_warm.add(gkey)
+                step(branches, False)
+            elif gkey in graphs:
+                if not skewed:
+                    graphs[gkey].replay()
+                else:
+                    main = torch.cuda.current_stream()
+                    if not side_started:
+                        side.wait_stream(main)
+                        with torch.cuda.stream(side):
+                            torch.cuda._sleep(int(self.dual_skew_us * 2100))
+                        side_started = True
+                    graphs[gkey][0].replay()
+                    with torch.cuda.stream(side):
+                        graphs[gkey][1].replay()
+            elif ("warm", gkey) not in graphs:
+                step(branches, False)           # first visit: eager (loads code objects, sets kernel attributes)
+                graphs[("warm", gkey)] = True
             else:                               # second visit: capture the step once, replay from now on
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
-                    step(branches)
-                eng.graphs[gkey] = graph
-                graph.replay()
+                if side_started:
+                    torch.cuda.current_stream().wait_stream(side)
+                    side_started = False
+                for k in [k for k in graphs if isinstance(k, tuple) and len(k) == 10 and k[8] == id(self.model) and k[7] != gens]:
+                    del graphs[k]               # graphs of engines whose buffers have moved
+                if not skewed:
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        step(branches, True)
+                    graphs[gkey] = graph
+                    graph.replay()
+                else:
+                    pair = []
+                    for p in parts:
+                        graph = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(graph):
+                            step_part(p, branches)
+                        graph.replay()
+                        pair.append(graph)
+                    graphs[gkey] = pair
             if after_step is not None:
-                after_step(i, int(t), st["x"].view(B, Lq, nf))
+                after_step(i, int(t), parts[0]["st"]["x"].view(B, Lq, nf))
             if collect is not None:
-                collect.append(st["x"].view(B, Lq, nf).clone())
-        return st["x"].view(B, Lq, nf).clone()
+                collect.append(full().clone())
+        if side_started:
+            torch.cuda.current_stream().wait_stream(side)
+        return full().clone()
+
+    def _side_stream(self, device):
+        s = self.__dict__.get("_side")
+        if s is None or s.device != device:
+            s = torch.cuda.Stream(device=device)
+            self.__dict__["_side"] = s
+        return s
 
     # ------------------------------------------------------------------------------------------
     # reference sampling API

@@ -65,6 +65,7 @@ class DenoiserEngine:
         """Captured step graphs hold raw device pointers: drop them whenever any buffer may have moved."""
         self.graphs = {}
         self.graph_warm = set()
+        self.generation = getattr(self, "generation", 0) + 1
 
     def sampler_state(self, n_steps: int, rows: int, nfeat: int):
         """Persistent device-side sampler state (addresses are baked into captured graphs)."""

@@ -159,6 +159,7 @@ class DanceDecoder(nn.Module):
         self.embeddings_table = nn.Embedding(10, self.d_k * num_heads)
         self.traj_embedding = nn.Sequential(nn.Linear(2, 64), nn.ReLU(), nn.Linear(64, D))
         self._engine: Optional[DenoiserEngine] = None
+        self._engines = {}
 
     # ------------------------------------------------------------------------------------------
     # engine plumbing
@@ -170,25 +171,31 @@ class DanceDecoder(nn.Module):
     def _weights_version(self):
         return tuple(p._version for p in self.parameters()) + (str(next(self.parameters()).device),)
 
-    def engine(self, batch: int) -> DenoiserEngine:
-        """The (lazily built) kernel engine, with weights re-packed whenever a parameter changed in place."""
+    def engine(self, batch: int, slot: int = 0) -> DenoiserEngine:
+        """The (lazily built) kernel engine, with weights re-packed whenever a parameter changed in place.
+        `slot` selects one of several independent engines (own workspaces) used by the two-stream sampler."""
         dev = next(self.parameters()).device
         if dev.type != "cuda":
             raise L.TcdiffError("DanceDecoder.forward runs on MI355X only: move the module to cuda "
                                 "(no CPU fallback; the CPU oracle lives in oracle/ and is test-only)")
-        if self._engine is None or self._engine.dev != dev or self._engine.dt != K.dtype_id(self.compute_dtype):
-            self._engine = DenoiserEngine(self.engine_config(), dev, self.compute_dtype)
+        eng = self._engines.get(slot)
+        if eng is None or eng.dev != dev or eng.dt != K.dtype_id(self.compute_dtype):
+            eng = DenoiserEngine(self.engine_config(), dev, self.compute_dtype)
+            self._engines[slot] = eng
         ver = self._weights_version()
-        if self._engine.weights_version != ver:
-            self._engine.load_weights(self.state_dict(), version=ver)
-        self._engine.plan(batch)
-        return self._engine
+        if eng.weights_version != ver:
+            eng.load_weights(self.state_dict(), version=ver)
+        eng.plan(batch)
+        if slot == 0:
+            self._engine = eng
+        return eng
 
     def set_compute_dtype(self, compute_dtype: str):
         """'bf16' (throughput) or 'f32' (exact-fp32 MFMA, parity mode)."""
         K.dtype_id(compute_dtype)
         self.compute_dtype = compute_dtype
         self._engine = None
+        self._engines = {}
 
     # ------------------------------------------------------------------------------------------
     # reference API

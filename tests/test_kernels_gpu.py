@@ -89,6 +89,64 @@ def test_gemm_tile_qkv_heads(dt):
     assert float(Vv[1:, :, 2 + Lq:].abs().max()) == 0 and float(Q[1:, :, :2].abs().max()) == 0
 
 
+# ---- large problems (thousands of tiles, ragged edges): same ABI entry, larger problems -------------------
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("M,N,Kd,act", [(14400, 1024, 512, L.ACT_GELU), (3300, 1000, 192, L.ACT_NONE),
+                                        (7201, 512, 1024, L.ACT_RELU), (25000, 151, 64, L.ACT_SILU)])
+def test_gemm_tile_large_store(dt, M, N, Kd, act):
+    A = rnd(M, Kd, seed=11).to(T(dt))
+    W = (rnd(N, Kd, seed=12) / math.sqrt(Kd)).to(T(dt))
+    bias = rnd(N, seed=13)
+    ref = act_ref(A.double() @ W.double().T + bias.double(), act)
+    for mode, odt in ((L.EPI_STORE_F32, torch.float32), (L.EPI_STORE_T, T(dt))):
+        ldc = N + (8 if mode == L.EPI_STORE_T else 5)
+        out = torch.full((M, ldc), 7.0, device=DEV, dtype=odt)
+        K.gemm_tile(dt, A, W, M, N, Kd, bias=bias, act=act, mode=mode, out=out, ldc=ldc)
+        torch.cuda.synchronize()
+        assert relerr(out[:, :N], ref) < tol(dt), (mode, relerr(out[:, :N], ref))
+        assert bool((out[:, N:] == 7.0).all()), "wrote outside the N columns"
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_gemm_tile_large_equals_row_pieces_bitwise(dt):
+    """An output element does not depend on where its tile sits in the grid (XCD remap, ragged last panel)."""
+    M, N, Kd = 14400, 1536, 512
+    A = rnd(M, Kd, seed=14).to(T(dt))
+    W = (rnd(N, Kd, seed=15) / math.sqrt(Kd)).to(T(dt))
+    out = torch.empty(M, N, device=DEV, dtype=T(dt))
+    K.gemm_tile(dt, A, W, M, N, Kd, act=L.ACT_GELU, mode=L.EPI_STORE_T, out=out, ldc=N)
+    parts = []
+    for lo in range(0, M, 1200):
+        o = torch.empty(1200, N, device=DEV, dtype=T(dt))
+        K.gemm_tile(dt, A[lo:lo + 1200], W, 1200, N, Kd, act=L.ACT_GELU, mode=L.EPI_STORE_T, out=o, ldc=N)
+        parts.append(o)
+    assert torch.equal(out, torch.cat(parts))
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_gemm_tile_large_split_amod_qkv_heads(dt):
+    Lq, nseq, H, Lp = 450, 32, 8, 512
+    M, Kd = nseq * Lq, 512
+    A1, A2 = rnd(M, Kd, seed=16).to(T(dt)), rnd(M, Kd, seed=17).to(T(dt))
+    W = (rnd(1536, Kd, seed=18) / math.sqrt(Kd)).to(T(dt))
+    Q = torch.zeros(nseq + 1, H, Lp, 64, device=DEV, dtype=T(dt))
+    Kk, Vv = torch.zeros_like(Q), torch.zeros_like(Q)
+    K.gemm_tile(dt, A1, W, M, 1536, Kd, A2=A2, split_n=1024, mode=L.EPI_QKV_HEADS, out=Q, out_k=Kk,
+                out_v=Vv, scale_q=0.125, Lseq=Lq, Lp=Lp, H=H, n_q=512, n_k=512, tok_off=1, seq_off=1)
+    q = ((A1.double() @ W.double()[:512].T) * 0.125).view(nseq, Lq, H, 64).permute(0, 2, 1, 3)
+    k = (A1.double() @ W.double()[512:1024].T).view(nseq, Lq, H, 64).permute(0, 2, 1, 3)
+    v = (A2.double() @ W.double()[1024:].T).view(nseq, Lq, H, 64).permute(0, 2, 1, 3)
+    assert relerr(Q[1:, :, 1:1 + Lq], q) < tol(dt)
+    assert relerr(Kk[1:, :, 1:1 + Lq], k) < tol(dt)
+    assert relerr(Vv[1:, :, 1:1 + Lq], v) < tol(dt)
+    assert float(Q[0].abs().max()) == 0 and float(Vv[1:, :, 1 + Lq:].abs().max()) == 0 and float(Q[1:, :, :1].abs().max()) == 0
+    # a_mod: 450 rows of A broadcast over 40 repeats
+    out = torch.zeros(18000, 512, device=DEV)
+    K.gemm_tile(dt, A1[:450], W[:512], 18000, 512, Kd, a_mod=450, mode=L.EPI_STORE_F32, out=out, ldc=512)
+    ref = (A1[:450].double() @ W[:512].double().T).repeat(40, 1)
+    assert relerr(out, ref) < tol(dt)
+
+
 def rope_ref(n_pos, freqs):
     ang = torch.arange(n_pos, device=DEV, dtype=torch.float32)[:, None] * freqs[None, :]
     return torch.stack((ang.cos(), ang.sin()), -1).reshape(n_pos, 512)
