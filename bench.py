@@ -61,8 +61,10 @@ def event_time_ms(fn, iters=20, warm=3):
     return s.elapsed_time(e) / iters
 
 
-def kernel_roofline(eng, B, dtype):
-    """Per-kernel achieved rate at the shapes of one guided step (R = 2*B*L rows).  Returns (dominant, all)."""
+def kernel_roofline(eng, B, dtype, streams=1):
+    """Per-kernel achieved rate at the shapes the sampler LAUNCHES: with `streams` free-running sub-batches of B clips
+    each (tcdiff_amd/diffusion.py, dual_parts) one launch covers R = 2*B*L rows and every kernel is launched `streams`
+    times per DDPM step, two launches of different kernels running side by side.  Returns (dominant, all)."""
     from tcdiff_amd import _lib as L
     from tcdiff_amd import kernels as K
     dt, w, b = eng.dt, eng.w, eng.b
@@ -113,6 +115,7 @@ def kernel_roofline(eng, B, dtype):
     for name, (count, flops, fn) in specs.items():
         ms = event_time_ms(fn)
         nbytes = algo_bytes[name]
+        count *= streams
         rows[name] = dict(launches_per_step=count, ms=round(ms, 5), tflops=round(flops / ms / 1e9, 2),
                           frac=round(flops / ms / 1e9 / peak, 4), step_share_ms=round(count * ms, 4),
                           algo_mb=round(nbytes / 1e6, 1), gbps=round(nbytes / ms / 1e6, 1),
@@ -131,10 +134,12 @@ def kernel_roofline(eng, B, dtype):
     if d["flop_per_byte"] < balance:
         roof = dict(bound="hbm", kernel=dom, achieved=d["gbps"], peak=PEAK_HBM_GBPS, unit="GB/s", frac=d["hbm_frac"],
                     traffic=traffic, algorithmic_bytes_per_launch=algo_bytes[dom], avg_launch_ms=d["ms"],
-                    launches_per_ddpm_step=d["launches_per_step"], mfma_tflops=d["tflops"], mfma_frac=d["frac"])
+                    launches_per_ddpm_step=d["launches_per_step"], mfma_tflops=d["tflops"], mfma_frac=d["frac"],
+                    rows_per_launch=R, concurrent_streams=streams)
     else:
         roof = dict(bound="mfma", kernel=dom, achieved=d["tflops"], peak=peak, unit="TFLOP/s", frac=d["frac"],
-                    traffic=traffic, avg_launch_ms=d["ms"], launches_per_ddpm_step=d["launches_per_step"])
+                    traffic=traffic, avg_launch_ms=d["ms"], launches_per_ddpm_step=d["launches_per_step"],
+                    rows_per_launch=R, concurrent_streams=streams)
     return roof, rows
 
 
@@ -218,7 +223,12 @@ def main():
     if rank == 0:
         clips_per_s = n_total * a.steps / dt
         gf = GFLOP_PER_CLIP_STEP.get((dn, S))
-        roof, rows = kernel_roofline(model.engine(hi - lo), hi - lo, a.dtype)
+        # the sampler splits the rank's clips over `streams` sub-batches (tcdiff_amd/diffusion.py); measure those launches
+        nb = hi - lo
+        streams = diff.dual_parts if diff.dual_stream else 1
+        while streams > 1 and (nb % streams != 0 or nb // streams < 2):
+            streams -= 1
+        roof, rows = kernel_roofline(model.engine(nb // streams), nb // streams, a.dtype, streams)
         res = {
             "metric": "sampled clips/sec (3 dancers x 150 frames, 1000 DDPM steps)",
             "value": round(clips_per_s, 4), "unit": "clips/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,

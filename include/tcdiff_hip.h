@@ -108,43 +108,6 @@ typedef struct {
 int tcdiff_gemm_rowln(int dtype, const void* A, const void* W, int M, int K, int lda, int ldw, int a_mod,
                       const tcdiff_row_epi* epi, hipStream_t stream);
 
-/* ---- row-block chain (bf16 only): the row-local tail of one decoder layer in ONE launch ----------------------
- * c  = LayerNorm_1e-6(O Wfc^T) * lnp_g + lnp_b;          x2 = xres + (film2.scale + 1) c + film2.shift   (model/model.py:103-106,334)
- * f  = W2 gelu(W1 LN3(x2) + b1) + b2;                      x3 = x2 + (film3.scale + 1) f + film3.shift     (:338-339,399-401)
- * x' = W3 LN4(x3) + b3  -> xout (fp32);  h' = LN1next(x') -> hout, rotary(h') -> rout (bf16)                 (:344, next :326,375)
- * ln1n_g == NULL (last layer): hout = bf16(x'), rout unused.   Rows are 512 wide; O/hout/rout are bf16 [M][512];
- * Wfc, W3: bf16 [512][512]; W1: bf16 [1024][512]; W2: bf16 [512][1024]; film2/film3 as tcdiff_row_epi.film.
- * A workgroup keeps its 64 rows on chip (fp32 residual in registers, GEMM operands in LDS) and streams only weights;
- * the unfused equivalent is 3 x tcdiff_gemm_rowln + 1 x tcdiff_gemm_tile (xres may alias xout). */
-typedef struct {
-    const void* O;
-    const void* Wfc;
-    const float* lnp_g;
-    const float* lnp_b;
-    const float* film2;
-    const float* film3;
-    int film_ld;
-    const float* xres;
-    const float* ln3_g;
-    const float* ln3_b;
-    const void* W1;
-    const float* b1;
-    const void* W2;
-    const float* b2;
-    const float* ln4_g;
-    const float* ln4_b;
-    const void* W3;
-    const float* b3;
-    float* xout;
-    const float* ln1n_g;
-    const float* ln1n_b;
-    void* hout;
-    void* rout;
-    const float* rope;
-    int M, L;
-} tcdiff_tail_args;
-int tcdiff_chain_tail(const tcdiff_tail_args* args, hipStream_t stream);
-
 /* ---- fused attention ------------------------------------------------------------------------------
  * O[(seq*Lq + q)*ldo + head*64 + d] = softmax_k(Q[seq][head][q] . K[kv][head][k]) V[kv][head][k][d]
  * Q  : T[n_seq][H][Lp_q][64]   (already scaled by 1/sqrt(64))

@@ -32,15 +32,7 @@ class RowEpi(C.Structure):
                 ("out_add", _i)]
 
 
-class TailArgs(C.Structure):
-    _fields_ = [("O", _vp), ("Wfc", _vp), ("lnp_g", _vp), ("lnp_b", _vp), ("film2", _vp), ("film3", _vp), ("film_ld", _i),
-                ("xres", _vp), ("ln3_g", _vp), ("ln3_b", _vp), ("W1", _vp), ("b1", _vp), ("W2", _vp), ("b2", _vp),
-                ("ln4_g", _vp), ("ln4_b", _vp), ("W3", _vp), ("b3", _vp), ("xout", _vp), ("ln1n_g", _vp), ("ln1n_b", _vp),
-                ("hout", _vp), ("rout", _vp), ("rope", _vp), ("M", _i), ("L", _i)]
-
-
 _SIGS = {
-    "tcdiff_chain_tail": [C.POINTER(TailArgs), _vp],
     "tcdiff_gemm_tile": [_i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, C.POINTER(TileEpi), _vp],
     "tcdiff_gemm_rowln": [_i, _vp, _vp, _i, _i, _i, _i, _i, C.POINTER(RowEpi), _vp],
     "tcdiff_attention": [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],

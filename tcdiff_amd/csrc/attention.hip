@@ -319,10 +319,13 @@ __global__ __launch_bounds__(512) void attention_res_kernel(const char* __restri
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
-                for (int q = 0; q < 16; ++q) { s[0][kt][q] = 0.0f; s[1][kt][q] = 0.0f; }
-#pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     const u32x4 kf = *reinterpret_cast<const u32x4*>(kt_base + tile_off(kt * 32 + r, 2 * ks + h));
+                    if (ks == 0) {   // C = literal 0: the MFMA takes the inline constant, no 64 v_mov per tile
+                        const f32x16_t z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                        s[0][kt] = z;
+                        s[1][kt] = z;
+                    }
                     P::mma(s[0][kt], kf, qf[0][ks]);
                     P::mma(s[1][kt], kf, qf[1][ks]);
                 }
@@ -347,15 +350,20 @@ __global__ __launch_bounds__(512) void attention_res_kernel(const char* __restri
                     for (int q = 0; q < 16; ++q) mx = fmaxf(mx, s[g][kt][q]);
                 mx = fmaxf(mx, other_half(mx)) * LOG2E;
                 const float m_new = fmaxf(m_run[g], mx);
-                float rs = 0.0f;
+                // x = s * log2(e) - m and the row sum as float2 ops (v_pk_fma_f32 / v_pk_add_f32); exp2 stays scalar
+                f32x2_t rs2 = {0.0f, 0.0f};
+                const f32x2_t l2 = {LOG2E, LOG2E}, nm = {-m_new, -m_new};
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        const float p = __builtin_amdgcn_exp2f(fmaf(s[g][kt][q], LOG2E, -m_new));
-                        s[g][kt][q] = p;
-                        rs += p;
+                    for (int q = 0; q < 16; q += 2) {
+                        const f32x2_t x = __builtin_elementwise_fma(f32x2_t{s[g][kt][q], s[g][kt][q + 1]}, l2, nm);
+                        const f32x2_t p = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+                        s[g][kt][q] = p[0];
+                        s[g][kt][q + 1] = p[1];
+                        rs2 += p;
                     }
+                float rs = rs2[0] + rs2[1];
                 rs += other_half(rs);
                 if (__builtin_amdgcn_ballot_w64(m_new > m_run[g]) != 0) {
                     const float alpha = __builtin_amdgcn_exp2f(m_run[g] - m_new);

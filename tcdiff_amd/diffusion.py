@@ -149,6 +149,7 @@ class GaussianDiffusion(nn.Module):
     # independent half-size launch chains let one half's memory-bound phases overlap the other's compute phases.
     # Clips are independent (and the noise is keyed by the global clip index), so the samples are bit-identical.
     dual_stream = os.environ.get("TCDIFF_DUAL", "1") != "0"
+    dual_parts = int(os.environ.get("TCDIFF_DUAL_PARTS", "2"))
     dual_skew_us = float(os.environ.get("TCDIFF_DUAL_SKEW_US", "40"))   # < 0: lock-step halves inside one graph
 
     def _run(self, mode: int, shape, cond, x: torch.Tensor, tseq, params: torch.Tensor, *, traj=None,
@@ -157,8 +158,10 @@ class GaussianDiffusion(nn.Module):
         """Run len(tseq) sampler steps on x (fp32 [B, L, nfeat]); returns the updated tensor."""
         B, Lq, nf = shape
         n = len(tseq)
-        dual = self.dual_stream and use_graph and after_step is None and B >= 4 and B % 2 == 0 and n > 2
-        bounds = [(0, B // 2), (B // 2, B)] if dual else [(0, B)]
+        nparts = self.dual_parts if (self.dual_stream and use_graph and after_step is None and n > 2) else 1
+        while nparts > 1 and (B % nparts != 0 or B // nparts < 2):
+            nparts -= 1
+        bounds = [(k * (B // nparts), (k + 1) * (B // nparts)) for k in range(nparts)]
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         w_eff = params[:, 0].tolist()
@@ -201,12 +204,14 @@ class GaussianDiffusion(nn.Module):
                     step_part(p, branches)
                 return
             main = torch.cuda.current_stream()
-            side = self._side_stream(main.device)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                step_part(parts[1], branches)
+            for k in range(1, len(parts)):
+                sk = self._side_stream(main.device, k)
+                sk.wait_stream(main)
+                with torch.cuda.stream(sk):
+                    step_part(parts[k], branches)
             step_part(parts[0], branches)
-            main.wait_stream(side)
+            for k in range(1, len(parts)):
+                main.wait_stream(self._side_stream(main.device, k))
 
         graphs = self.__dict__.setdefault("_graphs", {})
         gens = tuple(p["eng"].generation for p in parts)
@@ -215,8 +220,8 @@ class GaussianDiffusion(nn.Module):
         # Free-running halves: each half replays its own step graph on its own stream with no per-step join, the second
         # one started `dual_skew_us` late, so that the two launch chains stay out of phase (one half's HBM-bound
         # epilogues beside the other's MFMA-bound main loops) instead of running the same kernel side by side.
-        skewed = len(parts) == 2 and self.dual_skew_us >= 0 and step_noise is None and collect is None
-        side = self._side_stream(x.device) if len(parts) == 2 else None
+        skewed = len(parts) > 1 and self.dual_skew_us >= 0 and step_noise is None and collect is None
+        sides = [self._side_stream(x.device, k) for k in range(1, len(parts))]
         side_started = False
         for i, t in enumerate(tseq):
             branches = 1 if w_eff[i] == 1.0 else 2
@@ -234,19 +239,22 @@ class GaussianDiffusion(nn.Module):
                 else:
                     main = torch.cuda.current_stream()
                     if not side_started:
-                        side.wait_stream(main)
-                        with torch.cuda.stream(side):
-                            torch.cuda._sleep(int(self.dual_skew_us * 2100))
+                        for k, sk in enumerate(sides):
+                            sk.wait_stream(main)
+                            with torch.cuda.stream(sk):
+                                torch.cuda._sleep(int(self.dual_skew_us * (k + 1) * 2100))
                         side_started = True
                     graphs[gkey][0].replay()
-                    with torch.cuda.stream(side):
-                        graphs[gkey][1].replay()
+                    for k, sk in enumerate(sides):
+                        with torch.cuda.stream(sk):
+                            graphs[gkey][k + 1].replay()
             elif ("warm", gkey) not in graphs:
                 step(branches, False)           # first visit: eager (loads code objects, sets kernel attributes)
                 graphs[("warm", gkey)] = True
             else:                               # second visit: capture the step once, replay from now on
                 if side_started:
-                    torch.cuda.current_stream().wait_stream(side)
+                    for sk in sides:
+                        torch.cuda.current_stream().wait_stream(sk)
                     side_started = False
                 for k in [k for k in graphs if isinstance(k, tuple) and len(k) == 10 and k[8] == id(self.model) and k[7] != gens]:
                     del graphs[k]               # graphs of engines whose buffers have moved
@@ -270,14 +278,16 @@ class GaussianDiffusion(nn.Module):
             if collect is not None:
                 collect.append(full().clone())
         if side_started:
-            torch.cuda.current_stream().wait_stream(side)
+            for sk in sides:
+                torch.cuda.current_stream().wait_stream(sk)
         return full().clone()
 
-    def _side_stream(self, device):
-        s = self.__dict__.get("_side")
+    def _side_stream(self, device, k: int = 1):
+        pool = self.__dict__.setdefault("_sides", {})
+        s = pool.get(k)
         if s is None or s.device != device:
             s = torch.cuda.Stream(device=device)
-            self.__dict__["_side"] = s
+            pool[k] = s
         return s
 
     # ------------------------------------------------------------------------------------------

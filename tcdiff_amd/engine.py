@@ -48,12 +48,6 @@ class DenoiserEngine:
         self.Lp = K.round_up(self.Lseq, 128)
         self.Lps = K.round_up(self.S, 128)       # music encoder self-attention
         self.Lpc = K.round_up(self.S + 2, 128)   # cross-attention memory
-        # TCDIFF_FUSE=1 (bf16 only): run the row-local tail of each layer as ONE chain kernel (csrc/chain.hip).
-        # Bit-identical to the unfused sequence, but measured no faster on MI355X at B=16 (117 us vs 4 kernels of
-        # 143 us in isolation, +-1 % end to end): both are bound by the ~55 GB/s per-CU L2->LDS weight stream.  Off by
-        # default; kept as the starting point of the next round's fusion work.
-        import os
-        self.fuse_tail = self.dt == L.DT_BF16 and os.environ.get("TCDIFF_FUSE", "0") == "1"
         self.w: Dict[str, torch.Tensor] = {}
         self.weights_version = None
         self.plan_B = 0
@@ -336,17 +330,6 @@ class DenoiserEngine:
                         out_v=None, scale_q=0.125, Lseq=Lq, Lp=self.Lp, H=H, n_q=512, n_k=0)
             K.attention(dt, b["Q"], Kc0[l], Vc0[l], b["O"], nseq, H, Lq, S + 2, self.Lp, self.Lpc, 512,
                         n_shared=n_shared)
-            if self.fuse_tail:
-                # cross out-proj -> LN/FiLM2/residual -> LN3 -> FFN -> FiLM3/residual -> LN4 -> linear3 -> LN1'(+rotary)
-                # in one launch (model/model.py:334-344 and the next layer's :326,375)
-                last = l + 1 == NL
-                n1 = None if last else f"l{l + 1}.norm1."
-                K.chain_tail(b["O"], w[p + "cfc.w"], w[p + "cln.g"], w[p + "cln.b"], film0[:, (l * 3 + 1) * 1024:],
-                             film0[:, (l * 3 + 2) * 1024:], fld, b["xa"], w[p + "norm3.g"], w[p + "norm3.b"], w[p + "ff1.w"],
-                             w[p + "ff1.b"], w[p + "ff2.w"], w[p + "ff2.b"], w[p + "norm4.g"], w[p + "norm4.b"], w[p + "l3.w"],
-                             w[p + "l3.b"], None if last else b["xa"], None if last else w[n1 + "g"],
-                             None if last else w[n1 + "b"], b["h"], None if last else b["rot"], None if last else rope, R, Lq)
-                continue
             K.gemm_rowln(dt, b["O"], w[p + "cfc.w"], R, 512,
                          flags=L.ROW_LN_POST | L.ROW_FILM | L.ROW_STORE_X | L.ROW_NEXT_LN | L.ROW_STORE_H,
                          ln_g=w[p + "cln.g"], ln_b=w[p + "cln.b"], ln_eps=1e-6, film=film0[:, (l * 3 + 1) * 1024:],

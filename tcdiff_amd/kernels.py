@@ -122,9 +122,3 @@ def cfg_combine(out_unc, out_cond, ldo, w, y, n_rows, nfeat):
             "tcdiff_cfg_combine")
 
 
-def chain_tail(O, Wfc, lnp_g, lnp_b, film2, film3, film_ld, xres, ln3_g, ln3_b, W1, b1, W2, b2, ln4_g, ln4_b, W3, b3,
-               xout, ln1n_g, ln1n_b, hout, rout, rope, M, Lseq):
-    a = L.TailArgs(_p(O), _p(Wfc), _p(lnp_g), _p(lnp_b), _p(film2), _p(film3), film_ld, _p(xres), _p(ln3_g), _p(ln3_b),
-                   _p(W1), _p(b1), _p(W2), _p(b2), _p(ln4_g), _p(ln4_b), _p(W3), _p(b3), _p(xout), _p(ln1n_g),
-                   _p(ln1n_b), _p(hout), _p(rout), _p(rope), M, Lseq)
-    L.check(L.load().tcdiff_chain_tail(C.byref(a), stream()), "tcdiff_chain_tail")

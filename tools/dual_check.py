@@ -18,9 +18,10 @@ def main():
     xT = torch.stack([W.synth_xT(c, L) for c in range(B)]).cuda()
     res = {}
     skews = [float(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else []
-    for dual in [False, True, False, True] + skews:
+    for dual in [False, False] + skews:
         diff.dual_stream = dual is not False
-        diff.dual_skew_us = -1.0 if isinstance(dual, bool) else dual
+        diff.dual_skew_us = -1.0 if isinstance(dual, bool) else abs(dual) % 1000
+        diff.dual_parts = 2 if isinstance(dual, bool) else int(abs(dual) // 1000) or 2
         tseq = list(range(T - 1, T - 1 - steps, -1))
         torch.cuda.synchronize(); t0 = time.time()
         x = diff._run(0, (B, L, 151), cond, xT.clone().float(), tseq, diff._ddpm_params(tseq), seed=1234)
