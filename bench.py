@@ -125,21 +125,34 @@ def kernel_roofline(eng, B, dtype, streams=1):
     d = rows[dom]
     # the roofline that bounds a kernel: HBM when its arithmetic intensity is below the machine balance
     balance = peak * 1e3 / PEAK_HBM_GBPS   # FLOP per byte
-    traffic = None
+    # measured beside this line, from the committed rocprofv3 runs of the same command (profiles/README.md): HBM-side
+    # bytes per launch (PMC) and the kernel's average duration INSIDE the sampler, where two free-running streams contend
+    traffic, in_step_ms = None, None
+    fam = dom.split("[")[0]
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
-        traffic = pm[dom.split("[")[0]]["bytes_per_launch"]
+        traffic = pm[fam]["bytes_per_launch"]
+    except Exception:
+        pass
+    try:
+        import csv
+        sym = {"gemm_rowln": "gemm_rowln_kernel", "gemm_tile": "gemm_tile_kernel", "attention": "attention"}[fam]
+        tot = calls = 0
+        for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r01_kernel_stats_bench_200steps.csv"))):
+            if sym in r["Name"]:
+                tot += float(r["TotalDurationNs"]); calls += int(r["Calls"])
+        in_step_ms = round(tot / calls / 1e6, 5) if calls else None
     except Exception:
         pass
     if d["flop_per_byte"] < balance:
         roof = dict(bound="hbm", kernel=dom, achieved=d["gbps"], peak=PEAK_HBM_GBPS, unit="GB/s", frac=d["hbm_frac"],
                     traffic=traffic, algorithmic_bytes_per_launch=algo_bytes[dom], avg_launch_ms=d["ms"],
                     launches_per_ddpm_step=d["launches_per_step"], mfma_tflops=d["tflops"], mfma_frac=d["frac"],
-                    rows_per_launch=R, concurrent_streams=streams)
+                    rows_per_launch=R, concurrent_streams=streams, rocprof_in_step_avg_launch_ms=in_step_ms)
     else:
         roof = dict(bound="mfma", kernel=dom, achieved=d["tflops"], peak=peak, unit="TFLOP/s", frac=d["frac"],
                     traffic=traffic, avg_launch_ms=d["ms"], launches_per_ddpm_step=d["launches_per_step"],
-                    rows_per_launch=R, concurrent_streams=streams)
+                    rows_per_launch=R, concurrent_streams=streams, rocprof_in_step_avg_launch_ms=in_step_ms)
     return roof, rows
 
 
