@@ -260,7 +260,8 @@ def attn_ref(q, k, v):
 
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("Lq,Lk,nseq,n_shared", [(450, 450, 3, 0), (450, 152, 4, 2), (120, 62, 2, 1), (150, 150, 2, 0),
-                                                 (300, 1500, 1, 0)])
+                                                 (300, 1500, 1, 0), (1500, 1500, 2, 0), (1500, 302, 3, 1),
+                                                 (700, 577, 2, 0), (513, 1025, 1, 0)])
 def test_attention(dt, Lq, Lk, nseq, n_shared):
     H = 8
     Lpq, Lpk = K.round_up(Lq, 128), K.round_up(Lk, 128)
