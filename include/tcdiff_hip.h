@@ -100,6 +100,9 @@ typedef struct {
     void* rout;
     const float* rope; /* [Lmax][512]: rope[p][2j] = cos(p*freq_j), rope[p][2j+1] = sin(p*freq_j) */
     int out_mul, out_add; /* output row m' = m * out_mul + out_add (0 -> 1) */
+    int groups;           /* > 1: `groups` GEMMs of the same A in one launch; group g takes weight rows
+                             [512 g, 512 g + 512), bias[512 g ..] and out_add + g (the per-dancer slices of the last
+                             fusion-projection linear, model/model.py:527-528,561) */
 } tcdiff_row_epi;
 
 /* out rows[M,512] = epilogue(A[M,K] * W[512,K]^T).  Replaces fc+layer_norm+FiLM+residual

@@ -29,7 +29,7 @@ class RowEpi(C.Structure):
     _fields_ = [("flags", _i), ("bias", _vp), ("ln_g", _vp), ("ln_b", _vp), ("ln_eps", _f), ("film", _vp),
                 ("film_ld", _i), ("xres", _vp), ("xres_mod", _i), ("xout", _vp), ("L", _i), ("nln_g", _vp),
                 ("nln_b", _vp), ("nln_eps", _f), ("hout", _vp), ("rout", _vp), ("rope", _vp), ("out_mul", _i),
-                ("out_add", _i)]
+                ("out_add", _i), ("groups", _i)]
 
 
 _SIGS = {

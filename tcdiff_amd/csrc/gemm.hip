@@ -274,7 +274,17 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(const char* __restrict_
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const int r = lane & 31, h = lane >> 5;
-    const int m0 = xcd_remap(blockIdx.x, gridDim.x) * 64;  // an XCD owns a contiguous range of rows (as gemm_tile)
+    // grid = row tiles x groups; an XCD owns a contiguous range of rows (as gemm_tile); group g (tcdiff_hip.h) shifts
+    // the weight rows, the bias and the output row offset.  Measured and dropped: shorter tiles for launches with few
+    // rows (48 / 32 valid rows, to cover the chip: 2.38 / 2.46 ms per step against 2.25) and, in gemm_tile, 8-wave
+    // workgroups that compute two tiles so that small launches pack two tiles per CU (2.33 against 2.24).
+    const int ntile = (M + 63) / 64;
+    const int blk = xcd_remap(blockIdx.x, gridDim.x);
+    const int grp = blk / ntile;
+    const int m0 = (blk - grp * ntile) * 64;
+    W += (long)grp * 512 * ldw_b;
+    if (e.bias) e.bias += grp * 512;
+    e.out_add += grp;
 
     constexpr int STAGE = (64 + 512) * TC_ROWB;  // [A tile | W tile]
     constexpr int WOFF = 64 * TC_ROWB;
@@ -531,6 +541,7 @@ extern "C" int tcdiff_gemm_rowln(int dtype, const void* A, const void* W, int M,
         if (p && !aligned16(p)) return TC_ERR_ALIGN;
     tcdiff_row_epi e = *epi;
     if (e.out_mul <= 0) e.out_mul = 1;
+    if (e.groups <= 0) e.groups = 1;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rowln_kernel<MmaBF16>),
@@ -539,7 +550,7 @@ extern "C" int tcdiff_gemm_rowln(int dtype, const void* A, const void* W, int M,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, ROWLN_SMEM);
         attr_set = true;
     }
-    dim3 grid((M + 63) / 64);
+    dim3 grid(((M + 63) / 64) * e.groups);
     if (dtype == TC_DTYPE_BF16)
         hipLaunchKernelGGL(gemm_rowln_kernel<MmaBF16>, grid, dim3(512), ROWLN_SMEM, stream, (const char*)A,
                            (const char*)W, M, K, (long)lda * es, (long)ldw * es, a_mod, e);

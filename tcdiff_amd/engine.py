@@ -304,11 +304,12 @@ class DenoiserEngine:
         K.gemm_tile(dt, b["xin"], w["in.w"], Rs, 512, 192, bias=w["in.b"], out=b["xp"], ldc=512)
         K.gemm_tile(dt, b["xp"], w["f1.w"], B * S, 1024, 512 * dn, bias=w["f1.b"], act=L.ACT_RELU, out=b["f1"], ldc=1024)
         K.gemm_tile(dt, b["f1"], w["f2.w"], B * S, 1024, 1024, bias=w["f2.b"], act=L.ACT_RELU, out=b["f2"], ldc=1024)
-        for d in range(dn):  # de-interleave: frame row m, dancer d -> token m*dn + d; fused with layer-0 norm1 + rotary
-            K.gemm_rowln(dt, b["f2"], w["f3.w"][d * 512:], B * S, 1024, bias=w["f3.b"][d * 512:], xout=b["xs"],
-                         Lseq=Lq, flags=L.ROW_BIAS | L.ROW_STORE_X | L.ROW_NEXT_LN | L.ROW_STORE_H | L.ROW_STORE_ROT,
-                         nln_g=w["l0.norm1.g"], nln_b=w["l0.norm1.b"], nln_eps=1e-5, hout=b["h"], rout=b["rot"],
-                         rope=rope, out_mul=dn, out_add=d)
+        # last fusion linear, one group per dancer in ONE launch: group d writes token rows m*dn + d (de-interleave:
+        # frame row m, dancer d -> token m*dn + d); fused with layer-0 norm1 + rotary
+        K.gemm_rowln(dt, b["f2"], w["f3.w"], B * S, 1024, bias=w["f3.b"], xout=b["xs"], Lseq=Lq,
+                     flags=L.ROW_BIAS | L.ROW_STORE_X | L.ROW_NEXT_LN | L.ROW_STORE_H | L.ROW_STORE_ROT,
+                     nln_g=w["l0.norm1.g"], nln_b=w["l0.norm1.b"], nln_eps=1e-5, hout=b["h"], rout=b["rot"],
+                     rope=rope, out_mul=dn, out_add=0, groups=dn)
         Kc0 = b["Kc"][:, kv_slot0:]
         Vc0 = b["Vc"][:, kv_slot0:]
         for l in range(NL):

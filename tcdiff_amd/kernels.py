@@ -46,10 +46,10 @@ def gemm_tile(dt, A, W, M, N, K, *, lda=None, ldw=None, A2=None, split_n=0, a_mo
 
 def gemm_rowln(dt, A, W, M, K, *, flags, lda=None, ldw=None, a_mod=0, bias=None, ln_g=None, ln_b=None, ln_eps=1e-6,
                film=None, film_ld=0, xres=None, xres_mod=0, xout=None, Lseq=1, nln_g=None, nln_b=None, nln_eps=1e-5,
-               hout=None, rout=None, rope=None, out_mul=1, out_add=0):
+               hout=None, rout=None, rope=None, out_mul=1, out_add=0, groups=1):
     lib = L.load()
     e = L.RowEpi(flags, _p(bias), _p(ln_g), _p(ln_b), ln_eps, _p(film), film_ld, _p(xres), xres_mod, _p(xout), Lseq,
-                 _p(nln_g), _p(nln_b), nln_eps, _p(hout), _p(rout), _p(rope), out_mul, out_add)
+                 _p(nln_g), _p(nln_b), nln_eps, _p(hout), _p(rout), _p(rope), out_mul, out_add, groups)
     rc = lib.tcdiff_gemm_rowln(dt, _p(A), _p(W), M, K, lda if lda else K, ldw if ldw else K, a_mod, C.byref(e),
                                stream())
     L.check(rc, "tcdiff_gemm_rowln")

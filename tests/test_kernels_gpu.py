@@ -251,6 +251,29 @@ def test_gemm_rowln_variants(dt):
     K.gemm_rowln(dt, A, W, M, Kd, bias=bias, xout=xo, Lseq=50, out_mul=3, out_add=1, flags=L.ROW_BIAS | L.ROW_STORE_X)
     assert relerr(xo[1::3], acc[:M]) < tol(dt, 2e-5, 5e-3)
     assert float(xo[0::3].abs().max()) == 0 and float(xo[2::3].abs().max()) == 0
+    # grouped launch (all dancers' slices of the fusion projection at once) == one launch per group, bit for bit
+    G = 3
+    Wg = (rnd(G * 512, Kd, seed=34) / math.sqrt(Kd)).to(T(dt))
+    bg = rnd(G * 512, seed=35)
+    g2, b2 = 1 + 0.1 * rnd(512, seed=36), 0.1 * rnd(512, seed=37)
+    rope = rope_ref(60, freqs512())
+    kw = dict(Lseq=60, flags=L.ROW_BIAS | L.ROW_STORE_X | L.ROW_NEXT_LN | L.ROW_STORE_H | L.ROW_STORE_ROT, nln_g=g2, nln_b=b2,
+              nln_eps=1e-5, rope=rope, out_mul=G)
+    outs = []
+    for grouped in (True, False):
+        xg = torch.zeros(G * M, 512, device=DEV)
+        hg = torch.zeros(G * M, 512, device=DEV, dtype=T(dt))
+        rg = torch.zeros(G * M, 512, device=DEV, dtype=T(dt))
+        if grouped:
+            K.gemm_rowln(dt, A, Wg, M, Kd, bias=bg, xout=xg, hout=hg, rout=rg, out_add=0, groups=G, **kw)
+        else:
+            for g in range(G):
+                K.gemm_rowln(dt, A, Wg[g * 512:], M, Kd, bias=bg[g * 512:], xout=xg, hout=hg, rout=rg, out_add=g, **kw)
+        outs.append((xg, hg, rg))
+    for a_, b_ in zip(*outs):
+        assert torch.equal(a_, b_)
+    accg = A.double()[:M] @ Wg.double().T + bg.double()
+    assert relerr(outs[0][0].view(M, G, 512), accg.view(M, G, 512)) < tol(dt, 2e-5, 5e-3)
 
 
 def attn_ref(q, k, v):
