@@ -66,7 +66,8 @@ typedef struct {
 
 /* C[M,N] = A[M,K] * W[N,K]^T with epilogue.  If A2 != NULL, output columns >= split_n (a multiple of 128)
  * take their A operand from A2 (same shape/ld as A): one launch computes Q,K from rot(h) and V from h
- * (model/model.py:374-383).  a_mod > 0: A row = m % a_mod.
+ * (model/model.py:374-383).  a_mod > 0: A row = m % a_mod.  An operand (rows x ld x element size) must span less than
+ * 4 GB: tiles are staged with 32-bit offsets from the operand base (TC_ERR_ARG otherwise; same for tcdiff_gemm_rowln).
  * Replaces: nn.Linear calls model/model.py:78-80,399,454-465,490-494,522-528,560,623,164-166. */
 int tcdiff_gemm_tile(int dtype, const void* A, const void* A2, int split_n, const void* W, int M, int N, int K,
                      int lda, int ldw, int a_mod, const tcdiff_tile_epi* epi, hipStream_t stream);

@@ -38,6 +38,20 @@
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
 
+// One LDS-DMA instruction in its SGPR-base form: global_load_lds_dwordx4 voffset, s[base:base+1] with M0 = the LDS
+// destination (one address VGPR instead of two; the main loops got 3-13 % shorter).  Written in asm because hipcc picks
+// the 64-bit VGPR address form whenever the base moves inside a loop.  M0 is compiler-reserved, so it is saved and
+// restored inside the statement (cdna_hip_programming.md section 5.7); completion is waited for by sync_dma().
+DEVINL void glds16(const char* base, unsigned voff, const char* lds_dst) {
+    const uintptr_t b = reinterpret_cast<uintptr_t>(base);
+    const uint64_t sb = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) |
+                        (uint32_t)__builtin_amdgcn_readfirstlane((int)(b & 0xffffffffu));
+    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)reinterpret_cast<uintptr_t>(lds_dst));
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sb), "s"(dst) : "memory");
+}
+
 // Issue the global->LDS DMA of a [ROWS][128 B] tile.  `wave` must be wave-uniform.
 // rows >= row_limit are clamped to row_limit-1 (their results are never stored).
 template <int ROWS, int NWAVES>
@@ -53,8 +67,9 @@ DEVINL void stage_glds(char* lds_tile, const char* src, long ld_bytes, int row0,
         int gr = row0 + row;
         gr = gr < row_limit ? gr : row_limit - 1;
         if (row_mod > 0) gr = gr % row_mod;
-        const char* g = src + (long)gr * ld_bytes + chunk * 16;
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)g, (lds_void_t*)(lds_tile + blk * 1024), 16, 0, 0);
+        // 32-bit per-lane offset from the wave-uniform base (the launchers check that an operand spans < 4 GB)
+        const unsigned off = (unsigned)gr * (unsigned)ld_bytes + (unsigned)(chunk * 16);
+        glds16(src, off, lds_tile + blk * 1024);
     }
 }
 
@@ -483,6 +498,8 @@ extern "C" int tcdiff_gemm_tile(int dtype, const void* A, const void* A2, int sp
     if (!aligned16(A) || !aligned16(W) || (A2 && !aligned16(A2)) || ((long)lda * es) % 16 || ((long)ldw * es) % 16)
         return TC_ERR_ALIGN;
     if (A2 && (split_n % 128 != 0)) return TC_ERR_ARG;
+    // staging addresses are 32-bit offsets from the operand base
+    if ((long)(a_mod > 0 ? a_mod : M) * lda * es >= (1L << 32) || (long)N * ldw * es >= (1L << 32)) return TC_ERR_ARG;
     if (epi->bias && !aligned16(epi->bias)) return TC_ERR_ALIGN;
     if (epi->act < TC_ACT_NONE || epi->act > TC_ACT_SILU) return TC_ERR_ARG;
     if (epi->mode == TC_EPI_QKV_HEADS) {
@@ -525,6 +542,8 @@ extern "C" int tcdiff_gemm_rowln(int dtype, const void* A, const void* W, int M,
     const int kt = dtype == TC_DTYPE_BF16 ? 64 : 32;
     if (K % kt != 0) return TC_ERR_ARG;
     if (!aligned16(A) || !aligned16(W) || ((long)lda * es) % 16 || ((long)ldw * es) % 16) return TC_ERR_ALIGN;
+    // staging addresses are 32-bit offsets from the operand base
+    if ((long)(a_mod > 0 ? a_mod : M) * lda * es >= (1L << 32) || (long)512 * ldw * es >= (1L << 32)) return TC_ERR_ARG;
     const int f = epi->flags;
     if ((f & TC_ROW_BIAS) && !epi->bias) return TC_ERR_ARG;
     if ((f & TC_ROW_LN_POST) && (!epi->ln_g || !epi->ln_b)) return TC_ERR_ARG;
