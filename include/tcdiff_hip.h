@@ -182,6 +182,18 @@ int tcdiff_cfg_combine(const float* out_unc, const float* out_cond, int ldo, flo
 /* x[1:, :half] = x[:-1, half:] on the (b, seq_len, dn*nfeat) view (model/diffusion.py:502-506,599-601) */
 int tcdiff_window_couple(float* x, int b, int seq_len, int row_elems, hipStream_t stream);
 
+/* ---- EMA of the master weights (training-side, model/diffusion.py:61-76 EMA.update_model_average) -------------
+ * ma = ma * beta + (1 - beta) * cur over a list of fp32 tensors in ONE launch (the reference issues three elementwise
+ * kernels per parameter tensor, 435 tensors).  `chunks` is a DEVICE array: chunk i covers chunks[i].n <= 65536 elements.
+ * Rounding as torch's `old * beta + (1 - beta) * new`: two products rounded to fp32, then the sum (no fma). */
+typedef struct {
+    float* ma;
+    const float* cur;
+    long n;
+} tcdiff_ema_chunk;
+int tcdiff_ema_update(const tcdiff_ema_chunk* chunks, int n_chunks, float beta, float one_minus_beta,
+                      hipStream_t stream);
+
 /* library identification */
 const char* tcdiff_version(void);
 

@@ -409,4 +409,36 @@ extern "C" int tcdiff_cfg_combine(const float* out_unc, const float* out_cond, i
     return TC_OK;
 }
 
+// ---- EMA (model/diffusion.py:61-76): one workgroup per chunk of <= 65536 elements ----------------------------------
+__global__ __launch_bounds__(256) void ema_update_kernel(const tcdiff_ema_chunk* __restrict__ chunks, float beta,
+                                                         float omb) {
+#pragma clang fp contract(off)   // the reference rounds both products before the sum: no fma (HIP's __fmul_rn is a plain *)
+    const tcdiff_ema_chunk c = chunks[blockIdx.x];
+    float* ma = c.ma;
+    const float* cur = c.cur;
+    const long n = c.n;
+    const bool vec = ((reinterpret_cast<uintptr_t>(ma) | reinterpret_cast<uintptr_t>(cur)) & 15) == 0;
+    long i0 = 0;
+    if (vec) {
+        const long n4 = n >> 2;
+        for (long i = threadIdx.x; i < n4; i += 256) {
+            f32x4_t a = reinterpret_cast<const f32x4_t*>(ma)[i];
+            const f32x4_t b = reinterpret_cast<const f32x4_t*>(cur)[i];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) a[t] = a[t] * beta + omb * b[t];
+            reinterpret_cast<f32x4_t*>(ma)[i] = a;
+        }
+        i0 = n4 << 2;
+    }
+    for (long i = i0 + threadIdx.x; i < n; i += 256) ma[i] = ma[i] * beta + omb * cur[i];
+}
+
+extern "C" int tcdiff_ema_update(const tcdiff_ema_chunk* chunks, int n_chunks, float beta, float one_minus_beta,
+                                 hipStream_t stream) {
+    if (!chunks || n_chunks <= 0) return TC_ERR_ARG;
+    hipLaunchKernelGGL(ema_update_kernel, dim3(n_chunks), dim3(256), 0, stream, chunks, beta, one_minus_beta);
+    TC_CHECK_LAUNCH();
+    return TC_OK;
+}
+
 extern "C" const char* tcdiff_version(void) { return "tcdiff-gfx950 0.1 (bf16 32x32x16 / f32 32x32x2 MFMA)"; }

@@ -48,14 +48,30 @@ def extract(a, t, x_shape):
 
 
 class EMA:
-    """Exponential moving average of parameters (reference model/diffusion.py:61-76)."""
+    """Exponential moving average of parameters (reference model/diffusion.py:61-76).
+
+    On the GPU the whole parameter list is updated by ONE launch of tcdiff_ema_update (the reference issues three
+    elementwise kernels per tensor, 435 tensors); the rounding is the reference's (`old * beta + (1 - beta) * new`,
+    products rounded separately).  Parameters that are not fp32 CUDA tensors take the reference's tensor arithmetic."""
 
     def __init__(self, beta):
         self.beta = beta
+        self._table = None
+        self._table_key = None
 
     def update_model_average(self, ma_model, current_model):
-        for cur, ma in zip(current_model.parameters(), ma_model.parameters()):
-            ma.data = self.update_average(ma.data, cur.data)
+        cur = [p.data for p in current_model.parameters()]
+        ma = [p.data for p in ma_model.parameters()]
+        fused = len(cur) > 0 and all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in cur + ma)
+        if not fused:
+            for c, m in zip(current_model.parameters(), ma_model.parameters()):
+                m.data = self.update_average(m.data, c.data)
+            return
+        key = tuple(t.data_ptr() for t in cur + ma)
+        if key != self._table_key:
+            self._table = K.ema_chunk_table(ma, cur, cur[0].device)
+            self._table_key = key
+        K.ema_update(self._table, self.beta)
 
     def update_average(self, old, new):
         return new if old is None else old * self.beta + (1 - self.beta) * new

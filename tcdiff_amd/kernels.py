@@ -122,3 +122,17 @@ def cfg_combine(out_unc, out_cond, ldo, w, y, n_rows, nfeat):
             "tcdiff_cfg_combine")
 
 
+def ema_chunk_table(ma_tensors, cur_tensors, device):
+    """Device table of (ma ptr, cur ptr, n) chunks of <= 65536 elements for tcdiff_ema_update (int64 [n_chunks, 3])."""
+    rows = []
+    for a, c in zip(ma_tensors, cur_tensors):
+        n = a.numel()
+        for lo in range(0, n, 65536):
+            rows.append((a.data_ptr() + 4 * lo, c.data_ptr() + 4 * lo, min(65536, n - lo)))
+    return torch.tensor(rows, dtype=torch.int64, device=device).reshape(-1, 3)
+
+
+def ema_update(table, beta):
+    L.check(L.load().tcdiff_ema_update(_p(table), table.shape[0], float(beta), float(1.0 - beta), stream()),
+            "tcdiff_ema_update")
+

@@ -110,3 +110,15 @@ def test_product_code_never_imports_the_oracle():
         if fn.endswith(".py"):
             src = open(os.path.join(pkg, fn)).read()
             assert "import oracle" not in src and "from oracle" not in src, fn
+
+
+def test_ema_cpu_path_is_the_reference_formula():
+    """EMA over CPU parameters uses the reference's tensor arithmetic (model/diffusion.py:61-76)."""
+    import torch
+    from tcdiff_amd.diffusion import EMA
+    a, b = torch.nn.Linear(7, 5), torch.nn.Linear(7, 5)
+    want = [pa.data * 0.9999 + (1 - 0.9999) * pb.data for pa, pb in zip(a.parameters(), b.parameters())]
+    EMA(0.9999).update_model_average(a, b)
+    for pa, w in zip(a.parameters(), want):
+        assert torch.equal(pa.data, w)
+

@@ -446,3 +446,28 @@ def test_argument_errors():
         K.attention(L.DT_F32, a, a, a, a, 1, 8, 10, 10, 100, 128, 512)                      # Lp_q not a multiple of 128
     with pytest.raises(L.TcdiffError):
         K.gemm_rowln(L.DT_F32, a, a, 64, 64, flags=L.ROW_BIAS, Lseq=1)                      # bias flag without bias
+
+
+def test_ema_update_matches_reference_rounding():
+    """model/diffusion.py:61-76: ma = ma * beta + (1 - beta) * cur, bit for bit, ragged sizes, one launch."""
+    from tcdiff_amd.diffusion import EMA
+    sizes = [(512, 512), (151,), (1024, 1536), (3,), (70001,)]
+    cur = [torch.nn.Parameter(rnd(*s, seed=90 + i)) for i, s in enumerate(sizes)]
+    ma = [torch.nn.Parameter(rnd(*s, seed=190 + i)) for i, s in enumerate(sizes)]
+
+    class Bag(torch.nn.Module):
+        def __init__(self, ps):
+            super().__init__()
+            self.ps = torch.nn.ParameterList(ps)
+
+    ref = [m.data * 0.9999 + (1 - 0.9999) * c.data for m, c in zip(ma, cur)]
+    ema = EMA(0.9999)
+    ema.update_model_average(Bag(ma), Bag(cur))
+    torch.cuda.synchronize()
+    for m, r in zip(ma, ref):
+        assert torch.equal(m.data, r)
+    ref2 = [r * 0.9999 + (1 - 0.9999) * c.data for r, c in zip(ref, cur)]
+    ema.update_model_average(Bag(ma), Bag(cur))      # cached chunk table
+    for m, r in zip(ma, ref2):
+        assert torch.equal(m.data, r)
+
