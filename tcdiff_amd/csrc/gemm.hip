@@ -21,8 +21,10 @@
 // ~55-60 GB/s from L2 into LDS at this tile shape whether by LDS-DMA or by register staging: that rate, not the MFMA
 // pipe, bounds the main loop at B = 16 (56 rows of activations per CU against all the weights).
 // Two restructurings were built and measured against this kernel and dropped (profiles/README.md):
-//   * a persistent 256x128 kernel with 4 dedicated loader waves and a 3-slot ring: 34 GB/s per CU - a wave issues one
-//     global_load_lds per ~120 cycles, so the DMA rate follows the NUMBER of issuing waves, not the ring depth;
+//   * a persistent 256x128 kernel with dedicated loader waves and a 3-slot ring across tiles: with 4 loader waves a
+//     48 KB stage took 1.4 us, with 8 loader waves 1.0 us, of which 0.72 us is the burst in which the eight waves issue
+//     their 48 DMA instructions: ~67 GB/s is the rate at which a CU takes LDS-DMA instructions whoever issues them
+//     (a wave alone needs ~120 cycles per instruction, eight together ~230 each); end to end 5 % slower than this kernel;
 //   * one near-square tile per CU (16 waves, 225..343 rows x 256 columns, half the staged bytes, separate A / W rings):
 //     with the DMA off a K step took 80 % of the MFMA rate at the 1.72 GHz the clock drops to, with it on 61 %; end to
 //     end within 3 % of this kernel on the step's three shapes, because prologue + epilogue are not overlapped there.

@@ -33,7 +33,7 @@ def run(M, N, Kd, mode, act, iters=50):
     print(f"pad={PAD} kernel={os.environ.get('TCDIFF_GEMM_KERNEL','auto')} M={M} N={N} K={Kd} mode={mode} act={act}: {us:.1f} us  "
           f"{2.0 * M * N * Kd / us * 1e-6:.0f} TFLOP/s", flush=True)
 
-for M in (14400,):
+for M in (14400, 7200):
     run(M, 1536, 512, L.EPI_QKV_HEADS, 0)
     run(M, 1024, 512, L.EPI_STORE_T, L.ACT_GELU)
     run(M, 512, 512, L.EPI_QKV_HEADS, 0)
