@@ -365,6 +365,101 @@ def ddim_sample(sd: SD, shape, cond, x_0: Optional[torch.Tensor] = None, n_times
     return x
 
 
+def long_inpaint_loop(sd: SD, shape, cond, noise: Optional[torch.Tensor] = None, n_timestep: int = 1000,
+                      guidance_weight: float = 2, schedule: str = "cosine", start_point: Optional[int] = None,
+                      step_noise: NoiseFn = _default_noise):
+    """GaussianDiffusion.long_inpaint_loop (model/diffusion.py:560-608): DDPM steps with the first half of every
+    clip's tokens overwritten by the second half of the previous clip after each step but the last."""
+    if shape[0] == 1:
+        return p_sample_loop(sd, shape, cond, noise, n_timestep, guidance_weight, schedule, start_point, step_noise)
+    tab = make_tables(n_timestep, schedule)
+    start = n_timestep if start_point is None else start_point
+    x = torch.randn(shape) if noise is None else noise.clone()
+    half = x.shape[1] // 2
+    for i in reversed(range(0, start)):
+        x, _ = p_sample(sd, tab, x, cond, i, n_timestep, guidance_weight, step_noise(i, x.shape))
+        if i > 0:
+            x[1:, :half] = x[:-1, half:].clone()
+    return x
+
+
+FOOT_JOINTS = (1, 2, 3, 4, 5, 7, 8, 10, 11)   # model/diffusion.py:307,338,375
+
+
+def _overwrite_footwork(x, x0, frames: int, nf: int):
+    """Trajectory channels [4,5] <- x_0[...,[0,1]] and the lower-body 6-D rotations of frames 75:120 <- x_0
+    (model/diffusion.py:300-309, 335-341) on the (b, frames, dn, nf) view."""
+    b, seq, _ = x.shape
+    xv = x.reshape(b, frames, seq // frames, nf)
+    x0v = x0.reshape(b, frames, seq // frames, nf)
+    xv[:, :, :, [4, 5]] = x0v[:, :, :, [0, 1]]
+    for i in FOOT_JOINTS:
+        sl = slice(4 + 3 + (i - 1) * 6, 4 + 3 + i * 6)
+        xv[:, 75:120, :, sl] = x0v[:, 75:120, :, sl]
+    return xv.reshape(b, seq, nf)
+
+
+def ddim_sample_footwork(sd: SD, shape, cond, x_0: Optional[torch.Tensor] = None, n_timestep: int = 1000,
+                         guidance_weight: float = 2, schedule: str = "cosine",
+                         init_noise: Optional[torch.Tensor] = None, step_noise: NoiseFn = _default_noise,
+                         frames: int = 150):
+    """GaussianDiffusion.ddim_sample_Footwork (model/diffusion.py:289-383): DDIM (50 steps, eta 1) with the trajectory
+    channels and the lower-body rotations of frames 75:120 re-imposed after every step, and a 10-frame linear blend at
+    the segment borders at the end.  x_0 is a full motion tensor (b, seq*dn, nf)."""
+    tab = make_tables(n_timestep, schedule)
+    ac = tab["alphas_cumprod"]
+    nf = shape[-1]
+    x = torch.randn(shape) if init_noise is None else init_noise.clone()
+    if x_0 is not None:
+        x = _overwrite_footwork(x, x_0, frames, nf)
+    for time, time_next in ddim_time_pairs(n_timestep):
+        pred_noise, x_start = model_predictions(sd, tab, x, cond, time, guidance_weight)
+        if time_next < 0:
+            x = x_start
+            continue
+        alpha, alpha_next = ac[time], ac[time_next]
+        sigma = 1 * ((1 - alpha / alpha_next) * (1 - alpha_next) / (1 - alpha)).sqrt()
+        c = (1 - alpha_next - sigma ** 2).sqrt()
+        x = x_start * alpha_next.sqrt() + c * pred_noise + sigma * step_noise(time, x.shape)
+        if x_0 is not None:
+            x = _overwrite_footwork(x, x_0, frames, nf)
+    if x_0 is not None:
+        b, seq, _ = x.shape
+        xv = x.reshape(b, frames, seq // frames, nf)
+        x0v = x_0.reshape(b, frames, seq // frames, nf)
+        xv[:, :, :, [4, 5]] = x0v[:, :, :, [0, 1]]
+        width = 10
+        wgt = torch.from_numpy(np.linspace(0, 1, width)).to(xv)[None, :, None, None]      # :364-365
+        for i in FOOT_JOINTS:
+            sl = slice(4 + 3 + (i - 1) * 6, 4 + 3 + i * 6)
+            xv[:, 75:75 + width, :, sl] = wgt * x0v[:, 75:75 + width, :, sl] + (1 - wgt) * xv[:, 75:75 + width, :, sl]
+            xv[:, 75 + width:-width, :, sl] = x0v[:, 75 + width:-width, :, sl]              # :373: up to frame -10, not 110
+            xv[:, 120 - width:120, :, sl] = (1 - wgt) * x0v[:, 120 - width:120, :, sl] + wgt * xv[:, 120 - width:120, :, sl]
+        x = xv.reshape(b, seq, nf)
+    return x
+
+
+def inpaint_loop(sd: SD, shape, cond, noise: Optional[torch.Tensor], mask: torch.Tensor, value: torch.Tensor,
+                 n_timestep: int = 1000, guidance_weight: float = 2, schedule: str = "cosine",
+                 start_point: Optional[int] = None, step_noise: NoiseFn = _default_noise,
+                 q_noise: NoiseFn = _default_noise):
+    """GaussianDiffusion.inpaint_loop (model/diffusion.py:519-557): after every p_sample the constrained entries are
+    replaced by q_sample(value, i-1) (by x itself at i == 0).  ``q_noise(i, shape)`` is the randn_like drawn inside
+    q_sample in step i (not drawn at i == 0)."""
+    tab = make_tables(n_timestep, schedule)
+    start = n_timestep if start_point is None else start_point
+    x = torch.randn(shape) if noise is None else noise.clone()
+    for i in reversed(range(0, start)):
+        x, _ = p_sample(sd, tab, x, cond, i, n_timestep, guidance_weight, step_noise(i, x.shape))
+        if i > 0:
+            t = torch.full((x.shape[0],), i - 1, dtype=torch.long)
+            value_ = q_sample(tab, value, t, q_noise(i, x.shape))
+        else:
+            value_ = x
+        x = value_ * mask + (1.0 - mask) * x
+    return x
+
+
 def long_ddim_sample(sd: SD, shape, cond, x_0, seq_len: int, n_timestep: int = 1000,
                      guidance_weight: float = 2, schedule: str = "cosine",
                      init_noise: Optional[torch.Tensor] = None, step_noise: NoiseFn = _default_noise):
@@ -526,6 +621,25 @@ def synth_step_eps(clip_idx: int, step: int, L: int, nfeats: int = 151) -> torch
 def synth_traj(clip_idx: int, L: int) -> torch.Tensor:
     g = torch.Generator().manual_seed(4000 + clip_idx)
     return torch.rand(L, 3, generator=g) * 2 - 1
+
+
+def synth_motion(clip_idx: int, L: int, nfeats: int = 151) -> torch.Tensor:
+    """A full motion tensor in [-1, 1] (the x_0 of ddim_sample_Footwork, the `value` of the in-painting loops)."""
+    g = torch.Generator().manual_seed(5000 + clip_idx)
+    return torch.rand(L, nfeats, generator=g) * 2 - 1
+
+
+def synth_inpaint_mask(L: int, nfeats: int = 151) -> torch.Tensor:
+    """Constraint mask of the in-painting tests: trajectory channels everywhere plus the first sixth of the tokens."""
+    m = torch.zeros(L, nfeats)
+    m[:, 4:6] = 1.0
+    m[: L // 6] = 1.0
+    return m
+
+
+def synth_q_eps(clip_idx: int, step: int, L: int, nfeats: int = 151) -> torch.Tensor:
+    g = torch.Generator().manual_seed((6000 + clip_idx) * 100003 + step)
+    return torch.randn(L, nfeats, generator=g)
 
 
 def batch_step_noise(clip_ids, L: int, nfeats: int = 151) -> NoiseFn:

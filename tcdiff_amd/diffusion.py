@@ -509,10 +509,13 @@ class GaussianDiffusion(nn.Module):
         tseq = list(reversed(range(0, start_point)))
         chain = [x] if return_diffusion else None
 
+        q_noise = kw.get("q_noise")      # optional callable(t, shape): the randn_like q_sample draws in step t
+
         def after(i, t, xv):
             if t > 0:
                 tt = torch.full((shape[0],), t - 1, device=device, dtype=torch.long)
-                xv.copy_(self.q_sample(value, tt) * mask + (1.0 - mask) * xv)
+                qn = None if q_noise is None else q_noise(t, tuple(value.shape)).to(device)
+                xv.copy_(self.q_sample(value, tt, qn) * mask + (1.0 - mask) * xv)
 
         out = self._run(L.SAMPLER_DDPM, tuple(shape), cond, x.float(), tseq, self._ddpm_params(tseq),
                         step_noise=kw.get("step_noise"), seed=kw.get("seed"), after_step=after, collect=chain)

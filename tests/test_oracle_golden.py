@@ -133,3 +133,36 @@ def test_c2_long_ddim(golden_dir, c2):
     x = O.long_ddim_sample(sd, (2, 450, 151), cond, x0, seq_len=150, init_noise=xT,
                            step_noise=O.batch_step_noise([0, 1], 450))
     assert maxabs(x, ref["final"]) < 1e-4
+
+
+def test_c2_footwork_ddim(golden_dir, c2):
+    """ddim_sample_Footwork (model/diffusion.py:289-383), golden from tests/golden/make_golden_inpaint.py."""
+    sd, cond, xT = c2
+    ref = g(golden_dir, "c2_footwork")
+    x0 = torch.stack([O.synth_motion(0, 450)])
+    x = O.ddim_sample_footwork(sd, (1, 450, 151), cond[:1], x_0=x0, init_noise=xT[:1],
+                               step_noise=O.batch_step_noise([0], 450))
+    assert maxabs(x, ref["final"]) < 1e-4
+
+
+def test_c1_inpaint_loop(golden_dir, c1):
+    """inpaint_loop (model/diffusion.py:519-557) with the q_sample draws injected."""
+    sd, cond, xT = c1
+    ref = g(golden_dir, "c1_inpaint")
+    value = torch.stack([O.synth_motion(0, 120)])
+    mask = torch.stack([O.synth_inpaint_mask(120)])
+    x = O.inpaint_loop(sd, (1, 120, 151), cond, xT, mask, value, n_timestep=100,
+                       step_noise=O.batch_step_noise([0], 120),
+                       q_noise=lambda i, shape: torch.stack([O.synth_q_eps(0, i, 120)]))
+    assert maxabs(x, ref["final"]) < 1e-4
+
+
+def test_c1_long_inpaint_loop(golden_dir):
+    """long_inpaint_loop (model/diffusion.py:560-608), two half-overlapping windows."""
+    sd = O.synth_state_dict(dn=2, seq_len=60)
+    cond = torch.stack([O.synth_cond(c, 60) for c in (0, 1)])
+    xT = torch.stack([O.synth_xT(c, 120) for c in (0, 1)])
+    ref = g(golden_dir, "c1_long_inpaint")
+    x = O.long_inpaint_loop(sd, (2, 120, 151), cond, xT, n_timestep=100, step_noise=O.batch_step_noise([0, 1], 120))
+    assert maxabs(x, ref["final"]) < 1e-4
+

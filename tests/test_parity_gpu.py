@@ -167,6 +167,44 @@ def test_c2_long_ddim_vs_reference_golden(golden_dir, c2):
     assert e < 1e-3
 
 
+def test_c2_footwork_ddim_vs_reference_golden(golden_dir, c2):
+    """ddim_sample_Footwork (model/diffusion.py:289-383): trajectory + lower-body rotations of frames 75:120 re-imposed
+    every step, 10-frame blend at the end."""
+    _, _, diff, cond, xT = c2
+    ref = gold(golden_dir, "c2_footwork")
+    x0 = torch.stack([O.synth_motion(0, 450)])
+    x = diff.ddim_sample_Footwork((1, 450, 151), cond[:1], x_0=x0, init_noise=xT[:1], step_noise=dev_noise([0], 450))
+    e = maxabs(x, ref["final"])
+    print(f"C2 ddim_sample_Footwork (50 steps): {e:.2e}")
+    assert e < 1e-3
+
+
+def test_c1_inpaint_loop_vs_reference_golden(golden_dir, c1):
+    """inpaint_loop (model/diffusion.py:519-557), 100 DDPM steps with the constraint re-imposed through q_sample."""
+    _, _, diff, cond, xT = c1
+    ref = gold(golden_dir, "c1_inpaint")
+    value = torch.stack([O.synth_motion(0, 120)]).to(DEV)
+    mask = torch.stack([O.synth_inpaint_mask(120)]).to(DEV)
+    x = diff.inpaint_loop((1, 120, 151), cond, noise=xT, constraint={"mask": mask, "value": value},
+                          step_noise=dev_noise([0], 120),
+                          q_noise=lambda t, shape: torch.stack([O.synth_q_eps(0, t, 120)]))
+    e = maxabs(x, ref["final"])
+    print(f"C1 inpaint_loop (100 steps): {e:.2e}")
+    assert e < 1e-3
+
+
+def test_c1_long_inpaint_loop_vs_reference_golden(golden_dir, c1):
+    """long_inpaint_loop (model/diffusion.py:560-608): B=2, first half of clip 1 <- second half of clip 0 every step."""
+    _, _, diff, _, _ = c1
+    ref = gold(golden_dir, "c1_long_inpaint")
+    cond = torch.stack([O.synth_cond(c, 60) for c in (0, 1)])
+    xT = torch.stack([O.synth_xT(c, 120) for c in (0, 1)])
+    x = diff.long_inpaint_loop((2, 120, 151), cond, noise=xT, step_noise=dev_noise([0, 1], 120))
+    e = maxabs(x, ref["final"])
+    print(f"C1 long_inpaint_loop (100 steps, B=2): {e:.2e}")
+    assert e < 1e-3
+
+
 def test_batch_independence_and_partition_invariance(c2):
     """a clip's sample does not depend on its batch or on the shard it lands in (in-kernel Philox keyed by the
     global clip index): [clip0, clip1] in one batch == clip1 alone with clip_offset=1, bit for bit."""
