@@ -14,6 +14,7 @@
 //     XOR-swizzled 16-byte chunks), KB = 64 keys (bf16) / 32 keys (f32); online softmax across tiles (fp32 m, l).
 //   * the PV A operand is V^T: bf16 reads it with the hardware transpose read ds_read_b64_tr_b16 (two reads per
 //     fragment, in the key order the P^T registers are in); f32 reads one dword per MFMA (lanes = consecutive d).
+#include <cstdlib>
 #include "common.h"
 #include "tcdiff_hip.h"
 
@@ -262,6 +263,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const char* __restrict__
 // =================================================================================================
 #define ATT_RES_MAXT 8   // up to 8 tiles of 64 keys
 
+template <int NG>
 __global__ __launch_bounds__(512) void attention_res_kernel(const char* __restrict__ Q, const char* __restrict__ K,
                                                             const char* __restrict__ V, char* __restrict__ O, int H, int Lq,
                                                             int Lk, int Lp_q, int Lp_k, int ldo, int n_shared) {
@@ -270,8 +272,11 @@ __global__ __launch_bounds__(512) void attention_res_kernel(const char* __restri
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
+    // NG row groups of 32 per wave: a workgroup covers 256 * NG query rows; with NG = 1 a 450-token sequence is two
+    // workgroups (each loads all of K and V), which puts a half-batch launch on every CU instead of half of them
+    const int nqb = (Lq + 256 * NG - 1) / (256 * NG);
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
-    const int head = wg % H, seq = wg / H;
+    const int qb = wg % nqb, head = (wg / nqb) % H, seq = wg / (nqb * H);
     const int kv = seq < n_shared ? 0 : seq - n_shared + (n_shared > 0 ? 1 : 0);
     const int nt = (Lk + 63) / 64;
     char* Ks = smem;                       // [nt][64 keys][128 B], chunk-swizzled (common.h tile_off)
@@ -288,24 +293,28 @@ __global__ __launch_bounds__(512) void attention_res_kernel(const char* __restri
         __builtin_amdgcn_global_load_lds((gbl_void_t*)(Kg + (long)row * 128 + chunk * 16), (lds_void_t*)(Ks + blk * 1024), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((gbl_void_t*)(Vg + (long)row * 128 + chunk * 16), (lds_void_t*)(Vs + blk * 1024), 16, 0, 0);
     }
-    // ---- Q^T fragments of the two row groups (registers for the whole kernel)
-    const int qbase = wave * 64;
-    u32x4 qf[2][4];
+    // ---- Q^T fragments of the NG row groups (registers for the whole kernel)
+    const int qbase = qb * 256 * NG + wave * 32 * NG;
+    u32x4 qf[NG][4];
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        const char* Qg = Q + ((long)(seq * H + head) * Lp_q + qbase + g * 32 + r) * 128;
+    for (int g = 0; g < NG; ++g) {
+        int qrow = qbase + g * 32 + r;
+        qrow = qrow < Lp_q ? qrow : Lp_q - 1;          // rows past the padded image belong to inactive groups
+        const char* Qg = Q + ((long)(seq * H + head) * Lp_q + qrow) * 128;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) qf[g][ks] = *reinterpret_cast<const u32x4*>(Qg + (2 * ks + h) * 16);
     }
-    const bool act0 = qbase < Lq, act1 = qbase + 32 < Lq;   // wave-uniform
-    f32x16_t o[2][2];
+    const bool act0 = qbase < Lq, act1 = NG > 1 && qbase + 32 < Lq;   // wave-uniform
+    f32x16_t o[NG][2];
 #pragma unroll
-    for (int g = 0; g < 2; ++g)
+    for (int g = 0; g < NG; ++g)
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
             for (int q = 0; q < 16; ++q) o[g][dt][q] = 0.0f;
-    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.0f, 0.0f};
+    float m_run[NG], l_run[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) { m_run[g] = -INFINITY; l_run[g] = 0.0f; }
     sync_dma();
 
     if (act0) {
@@ -315,7 +324,7 @@ __global__ __launch_bounds__(512) void attention_res_kernel(const char* __restri
             const char* vt_base = Vs + b * 8192;
             const int kv0 = b * 64;
             // ---- S^T = K Q^T for both row groups: every K fragment read feeds two MFMAs
-            f32x16_t s[2][2];
+            f32x16_t s[NG][2];
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
@@ -323,16 +332,16 @@ __global__ __launch_bounds__(512) void attention_res_kernel(const char* __restri
                     const u32x4 kf = *reinterpret_cast<const u32x4*>(kt_base + tile_off(kt * 32 + r, 2 * ks + h));
                     if (ks == 0) {   // C = literal 0: the MFMA takes the inline constant, no 64 v_mov per tile
                         const f32x16_t z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-                        s[0][kt] = z;
-                        s[1][kt] = z;
+#pragma unroll
+                        for (int g = 0; g < NG; ++g) s[g][kt] = z;
                     }
-                    P::mma(s[0][kt], kf, qf[0][ks]);
-                    P::mma(s[1][kt], kf, qf[1][ks]);
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) P::mma(s[g][kt], kf, qf[g][ks]);
                 }
             }
             if (kv0 + 64 > Lk) {
 #pragma unroll
-                for (int g = 0; g < 2; ++g)
+                for (int g = 0; g < NG; ++g)
 #pragma unroll
                     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -342,7 +351,7 @@ __global__ __launch_bounds__(512) void attention_res_kernel(const char* __restri
             // ---- online softmax (base 2), the two groups are independent instruction streams
             constexpr float LOG2E = 1.4426950408889634f;
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
+            for (int g = 0; g < NG; ++g) {
                 float mx = s[g][0][0];
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt)
@@ -381,9 +390,9 @@ __global__ __launch_bounds__(512) void attention_res_kernel(const char* __restri
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int st = 0; st < 2; ++st) {
-                    u32x4 pf[2];
+                    u32x4 pf[NG];
 #pragma unroll
-                    for (int g = 0; g < 2; ++g) {
+                    for (int g = 0; g < NG; ++g) {
                         pf[g][0] = pack_bf2(s[g][kt][8 * st + 0], s[g][kt][8 * st + 1]);
                         pf[g][1] = pack_bf2(s[g][kt][8 * st + 2], s[g][kt][8 * st + 3]);
                         pf[g][2] = pack_bf2(s[g][kt][8 * st + 4], s[g][kt][8 * st + 5]);
@@ -392,15 +401,15 @@ __global__ __launch_bounds__(512) void attention_res_kernel(const char* __restri
 #pragma unroll
                     for (int dt = 0; dt < 2; ++dt) {
                         const u32x4 vf = v_frag<P>(vt_base, dt, kt, st, lane);
-                        P::mma(o[0][dt], vf, pf[0]);
-                        P::mma(o[1][dt], vf, pf[1]);
+#pragma unroll
+                        for (int g = 0; g < NG; ++g) P::mma(o[g][dt], vf, pf[g]);
                     }
                 }
         }
     }
     // ---- O[q][d] = O^T[d][q] / l
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
+    for (int g = 0; g < NG; ++g) {
         const int qg = qbase + g * 32 + r;
         if ((g == 0 ? act0 : act1) && qg < Lq) {
             const float inv = 1.0f / l_run[g];
@@ -429,14 +438,34 @@ extern "C" int tcdiff_attention(int dtype, const void* Q, const void* K, const v
         // K/V-resident kernel: one workgroup per (sequence, head), every wave 64 query rows (Q image padded to >= 512 rows)
         const int nt = (Lk + 63) / 64;
         const int smem_bytes = 2 * nt * 8192;
+        // 32 query rows per wave (two workgroups per 450-token sequence) while that still fits one round over the CUs,
+        // 64 rows per wave (K / V fragment reads shared by two row groups) beyond
+        static const int force_ng = [] { const char* v = getenv("TCDIFF_ATT_NG"); return v ? atoi(v) : 0; }();
+        static int n_cu = 0;
+        if (n_cu == 0) {
+            int dev = 0, v = 0;
+            if (hipGetDevice(&dev) != hipSuccess ||
+                hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+                v = 256;
+            n_cu = v;
+        }
+        int ng = ((Lq + 255) / 256) * H * n_seq <= n_cu ? 1 : 2;
+        if (force_ng == 1 || force_ng == 2) ng = force_ng;
         static bool attr_set = false;
         if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_res_kernel),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_res_kernel<1>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_RES_MAXT * 8192);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_res_kernel<2>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_RES_MAXT * 8192);
             attr_set = true;
         }
-        hipLaunchKernelGGL(attention_res_kernel, dim3(H * n_seq), dim3(512), smem_bytes, stream, (const char*)Q,
-                           (const char*)K, (const char*)V, (char*)O, H, Lq, Lk, Lp_q, Lp_k, ldo, n_shared);
+        const int nqb = (Lq + 256 * ng - 1) / (256 * ng);
+        if (ng == 1)
+            hipLaunchKernelGGL(attention_res_kernel<1>, dim3(nqb * H * n_seq), dim3(512), smem_bytes, stream,
+                               (const char*)Q, (const char*)K, (const char*)V, (char*)O, H, Lq, Lk, Lp_q, Lp_k, ldo, n_shared);
+        else
+            hipLaunchKernelGGL(attention_res_kernel<2>, dim3(nqb * H * n_seq), dim3(512), smem_bytes, stream,
+                               (const char*)Q, (const char*)K, (const char*)V, (char*)O, H, Lq, Lk, Lp_q, Lp_k, ldo, n_shared);
         TC_CHECK_LAUNCH();
         return TC_OK;
     }
