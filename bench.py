@@ -239,7 +239,7 @@ def main():
         # the sampler splits the rank's clips over `streams` sub-batches (tcdiff_amd/diffusion.py); measure those launches
         nb = hi - lo
         streams = diff.dual_parts if diff.dual_stream else 1
-        while streams > 1 and (nb % streams != 0 or nb // streams < 2):
+        while streams > 1 and nb // streams < 2:
             streams -= 1
         roof, rows = kernel_roofline(model.engine(nb // streams), nb // streams, a.dtype, streams)
         res = {

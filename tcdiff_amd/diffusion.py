@@ -175,9 +175,10 @@ class GaussianDiffusion(nn.Module):
         B, Lq, nf = shape
         n = len(tseq)
         nparts = self.dual_parts if (self.dual_stream and use_graph and after_step is None and n > 2) else 1
-        while nparts > 1 and (B % nparts != 0 or B // nparts < 2):
+        while nparts > 1 and B // nparts < 2:
             nparts -= 1
-        bounds = [(k * (B // nparts), (k + 1) * (B // nparts)) for k in range(nparts)]
+        cuts = [(k * B) // nparts for k in range(nparts + 1)]        # near-equal contiguous sub-batches
+        bounds = [(cuts[k], cuts[k + 1]) for k in range(nparts)]
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         w_eff = params[:, 0].tolist()

@@ -25,9 +25,19 @@ def main():
         tseq = list(range(T - 1, T - 1 - steps, -1))
         torch.cuda.synchronize(); t0 = time.time()
         x = diff._run(0, (B, L, 151), cond, xT.clone().float(), tseq, diff._ddpm_params(tseq), seed=1234)
+        t_enq = time.time() - t0
         torch.cuda.synchronize(); dt = time.time() - t0
-        print(f"dual={dual}: {dt / steps * 1e3:.3f} ms/step", flush=True)
+        print(f"dual={dual}: {dt / steps * 1e3:.3f} ms/step (host enqueue {t_enq / steps * 1e3:.3f} ms/step)", flush=True)
         res.setdefault(dual, x)
+    # CPU cost of one graph launch on an idle queue
+    graphs = [g for k, g in diff.__dict__.get("_graphs", {}).items() if not (isinstance(k, tuple) and k and k[0] == "warm")]
+    for g in graphs[:3]:
+        gl = g if isinstance(g, list) else [g]
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(5):
+            t0 = time.time(); gl[0].replay(); ts.append(time.time() - t0); torch.cuda.synchronize()
+        print("graph.replay() host time (ms):", [round(t * 1e3, 3) for t in ts], flush=True)
     for k, v in res.items():
         print(k, "bitwise equal to single-stream:", torch.equal(res[False], v))
 
