@@ -214,6 +214,32 @@ def test_batch_independence_and_partition_invariance(c2):
     assert maxabs(both[1:], one) < 2e-5
 
 
+@pytest.mark.parametrize("compute", ["bf16", "f32"])
+def test_full_batch_properties_two_streams_partition_determinism(compute):
+    """BASELINE config 2 at its full batch (16 clips, 3 x 150), 24 DDPM steps across the guidance-clip boundary
+    (t = 111..88: both CFG branches, then the conditional one only), in-kernel Philox noise.  Size-independent
+    properties, bit for bit: (1) the two free-running half-batch streams give the single-stream samples, (2) so do two
+    separate 8-clip calls with clip_offset (what two ranks would compute), (3) the same seed gives the same samples,
+    a different seed different ones."""
+    _, _, diff = build(3, 150, 1000, compute)
+    cond = torch.stack([O.synth_cond(c, 150) for c in range(16)])
+    xT = torch.stack([O.synth_xT(c, 450) for c in range(16)])
+    diff.dual_stream = False
+    single = diff.p_sample_loop((16, 450, 151), cond, noise=xT, start_point=112, seed=4242)
+    diff.dual_stream = True
+    for skew in (-1.0, 40.0):          # lock-step halves inside one graph / free-running halves
+        diff.dual_skew_us = skew
+        dual = diff.p_sample_loop((16, 450, 151), cond, noise=xT, start_point=112, seed=4242)
+        assert torch.equal(single, dual), f"two-stream sampling (skew {skew}) changed the samples"
+    halves = [diff.p_sample_loop((8, 450, 151), cond[lo:lo + 8], noise=xT[lo:lo + 8], start_point=112, seed=4242,
+                                 clip_offset=lo) for lo in (0, 8)]
+    assert torch.equal(single, torch.cat(halves)), "a clip's sample depends on its shard"
+    again = diff.p_sample_loop((16, 450, 151), cond, noise=xT, start_point=112, seed=4242)
+    other = diff.p_sample_loop((16, 450, 151), cond, noise=xT, start_point=112, seed=4243)
+    assert torch.equal(single, again) and not torch.equal(single, other)
+    assert bool(torch.isfinite(single).all()) and float(single.abs().max()) < 20.0
+
+
 def test_dead_parameters_do_not_change_the_output(c1):
     sd, model, diff, cond, xT = c1
     tt = torch.full((1,), 50, dtype=torch.long, device=DEV)
