@@ -1,0 +1,59 @@
+"""Do two HIP streams really run half-batch kernels side by side?  N launches of one kernel on one stream against N
+launches on each of two streams (different buffers), for the step's main kernels at 7200 rows."""
+import sys, os, math, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from tcdiff_amd import _lib as L, kernels as K
+dev, dt, T = "cuda", L.DT_BF16, torch.bfloat16
+M, Lq, N = 7200, 450, 200
+
+def mk():
+    v = lambda *s: torch.randn(*s, device=dev)
+    d = dict(A=v(M, 512).to(T), A1=v(M, 1024).to(T), W=(v(512, 512) / 22).to(T), W1=(v(512, 1024) / 32).to(T),
+             Wq=(v(1536, 512) / 22).to(T), g1=v(512), b1=v(512), g2=v(512), b2=v(512), film=v(16, 24576), x=v(M, 512),
+             xo=torch.zeros(M, 512, device=dev), h=torch.zeros(M, 512, device=dev, dtype=T),
+             r=torch.zeros(M, 512, device=dev, dtype=T), rope=v(Lq, 512),
+             Q=torch.zeros(16, 8, 512, 64, device=dev, dtype=T), Kk=torch.zeros(16, 8, 512, 64, device=dev, dtype=T),
+             V=torch.zeros(16, 8, 512, 64, device=dev, dtype=T), O=torch.zeros(M, 512, device=dev, dtype=T),
+             h1=torch.zeros(M, 1024, device=dev, dtype=T))
+    return d
+
+def kernels(d):
+    return {
+        "gemm_rowln K=512 (113 WGs)": lambda: K.gemm_rowln(dt, d["A"], d["W"], M, 512, Lseq=Lq,
+            flags=L.ROW_LN_POST | L.ROW_FILM | L.ROW_STORE_X | L.ROW_NEXT_LN | L.ROW_STORE_ROT, ln_g=d["g1"], ln_b=d["b1"],
+            film=d["film"], film_ld=24576, xres=d["x"], xout=d["xo"], nln_g=d["g2"], nln_b=d["b2"], rout=d["r"], rope=d["rope"]),
+        "gemm_tile qkv (684 WGs)": lambda: K.gemm_tile(dt, d["A"], d["Wq"], M, 1536, 512, A2=d["A"], split_n=1024,
+            mode=L.EPI_QKV_HEADS, out=d["Q"], out_k=d["Kk"], out_v=d["V"], scale_q=0.125, Lseq=Lq, Lp=512, H=8, n_q=512, n_k=512),
+        "gemm_tile q (228 WGs)": lambda: K.gemm_tile(dt, d["A"], d["W"], M, 512, 512, mode=L.EPI_QKV_HEADS, out=d["Q"],
+            scale_q=0.125, Lseq=Lq, Lp=512, H=8, n_q=512, n_k=0),
+        "attention self (256 WGs)": lambda: K.attention(dt, d["Q"], d["Kk"], d["V"], d["O"], 16, 8, Lq, Lq, 512, 512, 512),
+    }
+
+da, db = mk(), mk()
+ka, kb = kernels(da), kernels(db)
+sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+for name in ka:
+    fa, fb = ka[name], kb[name]
+    for f, s in ((fa, sa), (fb, sb)):
+        with torch.cuda.stream(s):
+            for _ in range(3): f()
+    torch.cuda.synchronize()
+    # N launches per stream captured as one graph each (host launch cost out of the picture)
+    ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+    with torch.cuda.graph(ga, stream=sa):
+        for _ in range(N): fa()
+    with torch.cuda.graph(gb, stream=sb):
+        for _ in range(N): fb()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(sa): ga.replay()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    with torch.cuda.stream(sa): ga.replay()
+    torch.cuda.synchronize(); t1 = time.time() - t0
+    t0 = time.time()
+    with torch.cuda.stream(sa): ga.replay()
+    with torch.cuda.stream(sb): gb.replay()
+    torch.cuda.synchronize(); t2 = time.time() - t0
+    print(f"{name:32s} one stream {t1 / N * 1e6:6.1f} us/launch; two streams {t2 / N * 1e6:6.1f} us per pair "
+          f"-> overlap factor {2 * t1 / t2:.2f} (2 = side by side, 1 = serialised)", flush=True)
