@@ -15,7 +15,8 @@ def mk():
              r=torch.zeros(M, 512, device=dev, dtype=T), rope=v(Lq, 512),
              Q=torch.zeros(16, 8, 512, 64, device=dev, dtype=T), Kk=torch.zeros(16, 8, 512, 64, device=dev, dtype=T),
              V=torch.zeros(16, 8, 512, 64, device=dev, dtype=T), O=torch.zeros(M, 512, device=dev, dtype=T),
-             h1=torch.zeros(M, 1024, device=dev, dtype=T))
+             h1=torch.zeros(M, 1024, device=dev, dtype=T), W1t=(v(1024, 512) / 22).to(T),
+             Kc=torch.zeros(9, 8, 256, 64, device=dev, dtype=T), Vc=torch.zeros(9, 8, 256, 64, device=dev, dtype=T))
     return d
 
 def kernels(d):
@@ -28,32 +29,42 @@ def kernels(d):
         "gemm_tile q (228 WGs)": lambda: K.gemm_tile(dt, d["A"], d["W"], M, 512, 512, mode=L.EPI_QKV_HEADS, out=d["Q"],
             scale_q=0.125, Lseq=Lq, Lp=512, H=8, n_q=512, n_k=0),
         "attention self (256 WGs)": lambda: K.attention(dt, d["Q"], d["Kk"], d["V"], d["O"], 16, 8, Lq, Lq, 512, 512, 512),
+        "attention cross (256 WGs, 48 KB)": lambda: K.attention(dt, d["Q"], d["Kc"], d["Vc"], d["O"], 16, 8, Lq, 152, 512, 256, 512,
+                                                                  n_shared=8),
+        "gemm_tile ffn1 (456 WGs)": lambda: K.gemm_tile(dt, d["A"], d["W1t"], M, 1024, 512, act=L.ACT_GELU, out=d["h1"], ldc=1024),
     }
 
 da, db = mk(), mk()
 ka, kb = kernels(da), kernels(db)
 sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
-for name in ka:
-    fa, fb = ka[name], kb[name]
-    for f, s in ((fa, sa), (fb, sb)):
-        with torch.cuda.stream(s):
-            for _ in range(3): f()
+def graph_of(f, s):
+    with torch.cuda.stream(s):
+        for _ in range(3): f()
     torch.cuda.synchronize()
-    # N launches per stream captured as one graph each (host launch cost out of the picture)
-    ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-    with torch.cuda.graph(ga, stream=sa):
-        for _ in range(N): fa()
-    with torch.cuda.graph(gb, stream=sb):
-        for _ in range(N): fb()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        for _ in range(N): f()
     torch.cuda.synchronize()
-    with torch.cuda.stream(sa): ga.replay()
+    with torch.cuda.stream(s): g.replay()
     torch.cuda.synchronize()
+    return g
+
+def timed(*pairs):
     t0 = time.time()
-    with torch.cuda.stream(sa): ga.replay()
-    torch.cuda.synchronize(); t1 = time.time() - t0
-    t0 = time.time()
-    with torch.cuda.stream(sa): ga.replay()
-    with torch.cuda.stream(sb): gb.replay()
-    torch.cuda.synchronize(); t2 = time.time() - t0
-    print(f"{name:32s} one stream {t1 / N * 1e6:6.1f} us/launch; two streams {t2 / N * 1e6:6.1f} us per pair "
-          f"-> overlap factor {2 * t1 / t2:.2f} (2 = side by side, 1 = serialised)", flush=True)
+    for g, s in pairs:
+        with torch.cuda.stream(s): g.replay()
+    torch.cuda.synchronize()
+    return (time.time() - t0) / N * 1e6
+
+names = list(ka)
+ga = {n: graph_of(ka[n], sa) for n in names}
+gb = {n: graph_of(kb[n], sb) for n in names}
+single = {n: timed((ga[n], sa)) for n in names}
+for n in names:
+    print(f"{n:36s} alone {single[n]:6.1f} us", flush=True)
+print("pairs (stream A kernel | stream B kernel): time per pair, and the sum of the two alone")
+for i, na in enumerate(names):
+    for nb in names[i:]:
+        t = timed((ga[na], sa), (gb[nb], sb))
+        print(f"  {na:34s} | {nb:34s} {t:6.1f} us  (sum {single[na] + single[nb]:6.1f}, max {max(single[na], single[nb]):6.1f})"
+              f"  overlap {(single[na] + single[nb]) / t:.2f}", flush=True)
