@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const char* __restrict__
 
 
 // =================================================================================================
-// K/V-resident variant (bf16, Lk <= 512): one workgroup of 8 waves per (sequence, head).
+// K/V-resident variant (bf16): workgroups of 8 waves per (sequence, head, block of 256 or 512 query rows).
 // The streaming kernel above is latency-bound per 64-key tile (stamped: ~6500 cycles per tile for 512 cycles of MFMA:
 // LDS-read -> MFMA chains, one barrier per tile, 32 query rows of independent work per wave).  For the denoiser's
 // shapes (L = 450 tokens, 152 memory rows) all of K and V of one (sequence, head) fits in LDS (2 x 64 KB), so this
@@ -278,21 +278,11 @@ __global__ __launch_bounds__(512) void attention_res_kernel(const char* __restri
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
     const int qb = wg % nqb, head = (wg / nqb) % H, seq = wg / (nqb * H);
     const int kv = seq < n_shared ? 0 : seq - n_shared + (n_shared > 0 ? 1 : 0);
-    const int nt = (Lk + 63) / 64;
-    char* Ks = smem;                       // [nt][64 keys][128 B], chunk-swizzled (common.h tile_off)
-    char* Vs = smem + nt * 8192;
+    const int ntm = (Lk + 63) / 64 < ATT_RES_MAXT ? (Lk + 63) / 64 : ATT_RES_MAXT;   // tiles of the largest key chunk
+    char* Ks = smem;                       // [ntm][64 keys][128 B], chunk-swizzled (common.h tile_off)
+    char* Vs = smem + ntm * 8192;
     const char* Kg = K + (long)(kv * H + head) * Lp_k * 128;
     const char* Vg = V + (long)(kv * H + head) * Lp_k * 128;
-    // ---- K, V -> LDS: nt*8 one-KiB blocks per matrix, nt per wave per matrix
-    for (int i = 0; i < nt; ++i) {
-        const int blk = wave * nt + i;     // 8 consecutive keys
-        const int row = blk * 8 + (lane >> 3);
-        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-        typedef __attribute__((address_space(3))) void lds_void_t;
-        typedef const __attribute__((address_space(1))) void gbl_void_t;
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)(Kg + (long)row * 128 + chunk * 16), (lds_void_t*)(Ks + blk * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)(Vg + (long)row * 128 + chunk * 16), (lds_void_t*)(Vs + blk * 1024), 16, 0, 0);
-    }
     // ---- Q^T fragments of the NG row groups (registers for the whole kernel)
     const int qbase = qb * 256 * NG + wave * 32 * NG;
     u32x4 qf[NG][4];
@@ -315,6 +305,20 @@ __global__ __launch_bounds__(512) void attention_res_kernel(const char* __restri
     float m_run[NG], l_run[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g) { m_run[g] = -INFINITY; l_run[g] = 0.0f; }
+
+    // keys in LDS-resident chunks of up to 512 (ONE chunk when L <= 512): a chunk is loaded by LDS-DMA, then its tiles
+    // run barrier-free; longer sequences (config 4: L = 1500) pay one barrier pair per chunk
+    for (int c0 = 0; c0 < Lk; c0 += 64 * ATT_RES_MAXT) {
+    const int nt = (Lk - c0 + 63) / 64 < ATT_RES_MAXT ? (Lk - c0 + 63) / 64 : ATT_RES_MAXT;
+    if (c0 > 0) __syncthreads();           // every wave is done with the previous chunk
+    for (int blk = wave; blk < nt * 8; blk += 8) {      // blk = 8 consecutive keys of the chunk
+        const int row = blk * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        typedef __attribute__((address_space(3))) void lds_void_t;
+        typedef const __attribute__((address_space(1))) void gbl_void_t;
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(Kg + (long)(c0 + row) * 128 + chunk * 16), (lds_void_t*)(Ks + blk * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(Vg + (long)(c0 + row) * 128 + chunk * 16), (lds_void_t*)(Vs + blk * 1024), 16, 0, 0);
+    }
     sync_dma();
 
     if (act0) {
@@ -322,7 +326,7 @@ __global__ __launch_bounds__(512) void attention_res_kernel(const char* __restri
         for (int b = 0; b < nt; ++b) {
             const char* kt_base = Ks + b * 8192;
             const char* vt_base = Vs + b * 8192;
-            const int kv0 = b * 64;
+            const int kv0 = c0 + b * 64;
             // ---- S^T = K Q^T for both row groups: every K fragment read feeds two MFMAs
             f32x16_t s[NG][2];
 #pragma unroll
@@ -407,6 +411,7 @@ __global__ __launch_bounds__(512) void attention_res_kernel(const char* __restri
                 }
         }
     }
+    }  // key chunks
     // ---- O[q][d] = O^T[d][q] / l
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
@@ -434,10 +439,10 @@ extern "C" int tcdiff_attention(int dtype, const void* Q, const void* K, const v
     if (dtype != TC_DTYPE_BF16 && dtype != TC_DTYPE_F32) return TC_ERR_ARG;
     if (Lp_q % 128 != 0 || Lp_k % 64 != 0 || Lp_q < Lq || Lp_k < Lk || ldo < H * 64 || ldo % 4 != 0) return TC_ERR_ARG;
     if (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O) & 15) return TC_ERR_ALIGN;
-    if (dtype == TC_DTYPE_BF16 && Lk <= 64 * ATT_RES_MAXT && Lq <= 512 && Lp_q >= 512) {
-        // K/V-resident kernel: one workgroup per (sequence, head), every wave 64 query rows (Q image padded to >= 512 rows)
-        const int nt = (Lk + 63) / 64;
-        const int smem_bytes = 2 * nt * 8192;
+    if (dtype == TC_DTYPE_BF16 && Lp_q >= 512) {
+        // K/V-resident kernel (Q image padded to >= 512 rows); keys beyond 512 come in LDS-resident chunks
+        const int ntm = (Lk + 63) / 64 < ATT_RES_MAXT ? (Lk + 63) / 64 : ATT_RES_MAXT;
+        const int smem_bytes = 2 * ntm * 8192;
         // 32 query rows per wave (two workgroups per 450-token sequence) while that still fits one round over the CUs,
         // 64 rows per wave (K / V fragment reads shared by two row groups) beyond
         static const int force_ng = [] { const char* v = getenv("TCDIFF_ATT_NG"); return v ? atoi(v) : 0; }();
