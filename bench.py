@@ -5,16 +5,22 @@
 
 One "step" = one full `GaussianDiffusion.p_sample_loop` (hoisted music encoder + 1000 guided denoising steps +
 the result all-gather) over a batch of 16 synthetic clips per GPU, bf16 MFMA operands.  Inputs (weights, music
-features, x_T) are resident in HBM before the timed region.  For N > 1 the driver launches one process per GPU
-(torch.distributed.run); clips are sharded by global index, no collective inside the loop, one RCCL all-gather
-at the end; the timed region is bracketed by barrier + synchronize and the MAX over ranks is reported.
+features, x_T) are resident in HBM before the timed region.
 
-Rank 0 prints ONE JSON line with the whole-job throughput, a `roofline` object for the dominant kernel
-(algorithmic FLOPs / measured HIP-event duration, against the 2.5 PFLOP/s dense bf16 MFMA peak) and, at N=1,
-a `cpu_baseline` object (the CPU oracle -- a port of the reference's PyTorch path -- timed on the host cores on a
-bounded sample of the same workload).
+Ranks.  `--gpus N` with no WORLD_SIZE in the environment makes THIS process a launcher: it never touches the GPU,
+starts N fresh child interpreters (tcdiff_amd/launch.py: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, one GPU
+each), waits, relays rank 0's JSON line and exits non-zero if any rank failed.  Under `torch.distributed.run`
+(WORLD_SIZE already set) the process is a rank; `--gpus` must then equal WORLD_SIZE.  Clips are sharded by global
+index, no collective inside the loop, one RCCL all-gather at the end; the timed region is bracketed by barrier +
+synchronize and the MAX over ranks is reported.
+
+Rank 0 prints ONE JSON line: whole-job throughput, `roofline` for the kernel with the largest share of GPU time
+(algorithmic FLOPs / its average duration INSIDE the running sampler, against the 2.5 PFLOP/s dense bf16 MFMA peak;
+the HBM figure is secondary), `parity_mode` (the f32 mode that carries the <= 1e-3 claim, timed here too) and, at
+N = 1, `cpu_baseline` (the CPU oracle -- a port of the reference's PyTorch path -- on the host cores).
 """
 import argparse
+import importlib.util
 import json
 import os
 import sys
@@ -23,16 +29,13 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-import torch.nn.functional as F  # noqa: E402
-
 GFLOP_PER_CLIP_STEP = {(3, 150): 55.81, (2, 60): 13.73, (5, 300): 240.60}  # SURVEY.md Appendix B (algorithmic)
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBPS = 8000.0      # HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
 
 
-def parse():
+def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=2)
@@ -43,129 +46,201 @@ def parse():
     p.add_argument("--ddpm-steps", type=int, default=1000)
     p.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-parity-mode", action="store_true", help="skip the f32-mode timing")
+    p.add_argument("--no-kernel-profile", action="store_true", help="skip the in-sampler per-kernel timing pass")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
-    return p.parse_args()
+    p.add_argument("--stub", action="store_true",
+                   help="rank plumbing only (process group, shard ranges, all-reduce, JSON relay); no GPU work: "
+                        "what tests/test_launch_cpu.py runs over gloo")
+    return p.parse_args(argv)
 
 
-def event_time_ms(fn, iters=20, warm=3):
-    """Average duration of fn() measured with HIP events on the stream the kernels are launched on."""
-    for _ in range(warm):
-        fn()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    s.record()
-    for _ in range(iters):
-        fn()
-    e.record()
-    e.synchronize()
-    return s.elapsed_time(e) / iters
+# ----------------------------------------------------------------------------------------------------------------
+# launcher (parent process: no torch, no GPU)
+# ----------------------------------------------------------------------------------------------------------------
+def _load_launch():
+    """tcdiff_amd/launch.py by path: importing the package would import torch, which the parent does not need."""
+    spec = importlib.util.spec_from_file_location("_tcdiff_launch", os.path.join(ROOT, "tcdiff_amd", "launch.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
 
 
-def kernel_roofline(eng, B, dtype, streams=1):
-    """Per-kernel achieved rate at the shapes the sampler LAUNCHES: with `streams` free-running sub-batches of B clips
-    each (tcdiff_amd/diffusion.py, dual_parts) one launch covers R = 2*B*L rows and every kernel is launched `streams`
-    times per DDPM step, two launches of different kernels running side by side.  Returns (dominant, all)."""
-    from tcdiff_amd import _lib as L
-    from tcdiff_amd import kernels as K
-    dt, w, b = eng.dt, eng.w, eng.b
-    Lq, S, H = eng.Lseq, eng.S, eng.H
+def launch_ranks(argv, world, timeout=None):
+    """Start `world` ranks of this script; relay rank 0's last JSON line.  Returns the exit code."""
+    rc, out0, errs = _load_launch().spawn_ranks([os.path.abspath(__file__), *argv], world, timeout=timeout)
+    line = None
+    for ln in out0.splitlines():
+        if ln.startswith("{") and ln.rstrip().endswith("}"):
+            line = ln
+    if rc != 0 or line is None:
+        for r, e in enumerate(errs):
+            if e.strip():
+                sys.stderr.write(f"---- rank {r} stderr (tail) ----\n{e}\n")
+        if rc == 0:
+            sys.stderr.write("bench.py: rank 0 printed no JSON line\n")
+            rc = 1
+        return rc
+    print(line, flush=True)
+    return 0
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# per-kernel accounting
+# ----------------------------------------------------------------------------------------------------------------
+def family_flops_per_step(B, dn, S, NL=8, H=8, nf=151, ff=1024):
+    """ALGORITHMIC FLOPs of one two-branch DDPM step of B clips, per kernel family (2 FLOP per MAC; the shapes are
+    SURVEY.md 2.3 / Appendix B, layer-0 self-attention evaluated once for both branches as the engine does)."""
+    Lq = dn * S
+    Rs, R = B * Lq, 2 * B * Lq
+    M = S + 2
+    rowln = 2.0 * B * S * 1024 * 512 * dn                      # last fusion-projection linear
+    tile = 2.0 * Rs * nf * 512 + 2.0 * B * S * 1024 * 512 * dn + 2.0 * B * S * 1024 * 1024   # input proj, f1, f2
+    tile += 2.0 * 2 * B * 512 * (NL * 3 * 1024)               # FiLM stack
+    att = 0.0
+    for l in range(NL):
+        rows_sa = Rs if l == 0 else R
+        nseq_sa = B if l == 0 else 2 * B
+        tile += 2.0 * rows_sa * 1536 * 512 + 2.0 * R * 512 * 512 + 2.0 * R * ff * 512     # qkv, cross-q, linear1
+        rowln += 3 * 2.0 * R * 512 * 512 + 2.0 * R * 512 * ff                             # fc, fc, linear3, linear2
+        att += 4.0 * nseq_sa * H * Lq * Lq * 64 + 4.0 * 2 * B * H * Lq * M * 64
+    tile += 2.0 * R * nf * 512                                 # final layer
+    return {"gemm_rowln": rowln, "gemm_tile": tile, "attention": att}
+
+
+def family_bytes_per_step(B, dn, S, es, NL=8, H=8, ff=1024):
+    """ALGORITHMIC HBM bytes of one two-branch DDPM step per family at kernel granularity: every operand of a launch
+    read once, every result written once (what the op-by-op decomposition must move; SURVEY.md 8(d)'s 110 MB is the
+    figure if no intermediate ever left the chip)."""
+    Lq = dn * S
     R = 2 * B * Lq
-    NLy = eng.NL
-    fld = NLy * 3 * 1024
-    rope = w["rope"]
-    specs = {
-        "gemm_tile[qkv 1536x512]": (NLy, 2.0 * R * 1536 * 512, lambda: K.gemm_tile(
-            dt, b["rot"], w["l1.qkv.w"], R, 1536, 512, A2=b["h"], split_n=1024, mode=L.EPI_QKV_HEADS, out=b["Q"],
-            out_k=b["K"], out_v=b["V"], scale_q=0.125, Lseq=Lq, Lp=eng.Lp, H=H, n_q=512, n_k=512)),
-        "gemm_tile[ffn1 1024x512]": (NLy, 2.0 * R * 1024 * 512, lambda: K.gemm_tile(
-            dt, b["h"], w["l1.ff1.w"], R, 1024, 512, bias=w["l1.ff1.b"], act=L.ACT_GELU, out=b["h1"], ldc=1024)),
-        "gemm_tile[q 512x512]": (NLy, 2.0 * R * 512 * 512, lambda: K.gemm_tile(
-            dt, b["rot"], w["l1.cq.w"], R, 512, 512, mode=L.EPI_QKV_HEADS, out=b["Q"], scale_q=0.125, Lseq=Lq,
-            Lp=eng.Lp, H=H, n_q=512, n_k=0)),
-        "gemm_rowln[K=512, ln+film+res+ln]": (3 * NLy, 2.0 * R * 512 * 512, lambda: K.gemm_rowln(
-            dt, b["O"], w["l1.sfc.w"], R, 512,
-            flags=L.ROW_LN_POST | L.ROW_FILM | L.ROW_STORE_X | L.ROW_NEXT_LN | L.ROW_STORE_ROT, ln_g=w["l1.sln.g"],
-            ln_b=w["l1.sln.b"], ln_eps=1e-6, film=b["film"], film_ld=fld, xres=b["xa"], xout=b["xa"], Lseq=Lq,
-            nln_g=w["l1.norm2.g"], nln_b=w["l1.norm2.b"], nln_eps=1e-5, rout=b["rot"], rope=rope)),
-        "gemm_rowln[K=1024, film+res+ln]": (NLy, 2.0 * R * 512 * 1024, lambda: K.gemm_rowln(
-            dt, b["h1"], w["l1.ff2.w"], R, 1024, flags=L.ROW_BIAS | L.ROW_FILM | L.ROW_NEXT_LN | L.ROW_STORE_H,
-            bias=w["l1.ff2.b"], film=b["film"], film_ld=fld, xres=b["xa"], Lseq=Lq, nln_g=w["l1.norm4.g"],
-            nln_b=w["l1.norm4.b"], nln_eps=1e-5, hout=b["h"])),
-        "attention[self L=%d]" % Lq: (NLy, 4.0 * 2 * B * H * Lq * Lq * 64, lambda: K.attention(
-            dt, b["Q"], b["K"], b["V"], b["O"], 2 * B, H, Lq, Lq, eng.Lp, eng.Lp, 512)),
-        "attention[cross M=%d]" % (S + 2): (NLy, 4.0 * 2 * B * H * Lq * (S + 2) * 64, lambda: K.attention(
-            dt, b["Q"], b["Kc"][1], b["Vc"][1], b["O"], 2 * B, H, Lq, S + 2, eng.Lp, eng.Lpc, 512, n_shared=B)),
-    }
+    act = lambda cols, e=es: R * cols * e
+    x32 = R * 512 * 4
+    rowln = NL * (2 * (act(512) + 512 * 512 * es + 2 * x32 + act(512))          # fc + LN + FiLM + res (+ next LN)
+                  + (act(ff) + 512 * ff * es + x32 + act(512))                 # linear2 + FiLM + res + LN4
+                  + (act(512) + 512 * 512 * es + x32 + 2 * act(512)))          # linear3 + next norm1 + rotary
+    tile = NL * ((2 * act(512) + 1536 * 512 * es + 3 * act(512)) + (act(512) + 512 * 512 * es + act(512))
+                 + (act(512) + ff * 512 * es + act(ff)))
+    lpc = (S + 2 + 127) // 128 * 128                                            # padded memory length of the K/V caches
+    att = NL * ((3 * act(512) + act(512)) + (act(512) + 2 * (B + 1) * H * lpc * 64 * es + act(512)))
+    return {"gemm_rowln": rowln, "gemm_tile": tile, "attention": att}
+
+
+FAMILIES = {"gemm_rowln": ("gemm_rowln_kernel", "chain_kernel"), "gemm_tile": ("gemm_tile_kernel",),
+            "attention": ("attention_res_kernel", "attention_kernel")}
+
+
+def insampler_kernel_times(diff, shape, cond, xT, n_steps=40):
+    """Per-kernel device time INSIDE the running sampler (both free-running streams, graph replay), measured live with
+    torch.profiler (roctracer activity records) over `n_steps` two-branch DDPM steps.  Returns
+    {kernel name: (launches, total_us)}, steps profiled."""
+    import torch
+    from torch.profiler import ProfilerActivity, profile
+    from tcdiff_amd import _lib as L
+    T = diff.n_timestep
+    tseq = list(range(T - 1, T - 1 - n_steps, -1))
+    run = lambda: diff._run(L.SAMPLER_DDPM, tuple(shape), cond, xT.float(), tseq, diff._ddpm_params(tseq), seed=7)
+    run()                                  # graphs of this key are captured by the timed jobs already; settle
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        run()
+        torch.cuda.synchronize()
+    out = {}
+    for ev in prof.key_averages():
+        dt = getattr(ev, "self_device_time_total", None)
+        if dt is None:
+            dt = getattr(ev, "self_cuda_time_total", 0.0)
+        if dt and ev.count:
+            out[ev.key] = (int(ev.count), float(dt))
+    return out, n_steps
+
+
+def kernel_roofline(times, n_steps, B_launch, streams, dn, S, dtype):
+    """Fold profiler records into families; the dominant family's achieved rate = its algorithmic FLOPs per DDPM step /
+    its device time per DDPM step."""
     peak = PEAK_BF16_TFLOPS if dtype == "bf16" else PEAK_F32_TFLOPS
     es = 2 if dtype == "bf16" else 4
-    act = lambda cols, e=es: R * cols * e            # one [R, cols] activation matrix
-    x32 = R * 512 * 4                                # fp32 residual stream
-    qkv_img = 2 * B * H * eng.Lp * 64 * es           # one padded head-major image
-    # ALGORITHMIC HBM bytes per launch: every operand read once, every result written once (weights included)
-    algo_bytes = {
-        "gemm_tile[qkv 1536x512]": 2 * act(512) + 1536 * 512 * es + 3 * act(512),
-        "gemm_tile[ffn1 1024x512]": act(512) + 1024 * 512 * es + act(1024),
-        "gemm_tile[q 512x512]": act(512) + 512 * 512 * es + act(512),
-        "gemm_rowln[K=512, ln+film+res+ln]": act(512) + 512 * 512 * es + x32 + x32 + act(512),
-        "gemm_rowln[K=1024, film+res+ln]": act(1024) + 512 * 1024 * es + x32 + act(512),
-        "attention[self L=%d]" % Lq: 3 * qkv_img + act(512),
-        "attention[cross M=%d]" % (S + 2): qkv_img + 2 * (B + 1) * H * eng.Lpc * 64 * es + act(512),
-    }
+    B = B_launch * streams
+    flops = family_flops_per_step(B, dn, S)
+    nbytes = family_bytes_per_step(B, dn, S, es)
+    fam = {}
+    total_us = sum(t for _, t in times.values())
+    for name, (cnt, us) in times.items():
+        for f, pats in FAMILIES.items():
+            if any(p in name for p in pats):
+                c0, u0 = fam.get(f, (0, 0.0))
+                fam[f] = (c0 + cnt, u0 + us)
     rows = {}
-    for name, (count, flops, fn) in specs.items():
-        ms = event_time_ms(fn)
-        nbytes = algo_bytes[name]
-        count *= streams
-        rows[name] = dict(launches_per_step=count, ms=round(ms, 5), tflops=round(flops / ms / 1e9, 2),
-                          frac=round(flops / ms / 1e9 / peak, 4), step_share_ms=round(count * ms, 4),
-                          algo_mb=round(nbytes / 1e6, 1), gbps=round(nbytes / ms / 1e6, 1),
-                          hbm_frac=round(nbytes / ms / 1e6 / PEAK_HBM_GBPS, 4),
-                          flop_per_byte=round(flops / nbytes, 1))
-    dom = max(rows, key=lambda k: rows[k]["step_share_ms"])
+    for f, (cnt, us) in fam.items():
+        per_step_us = us / n_steps
+        rows[f] = dict(launches_per_ddpm_step=round(cnt / n_steps, 1), avg_launch_ms=round(us / cnt / 1e3, 5),
+                       device_ms_per_ddpm_step=round(per_step_us / 1e3, 4),
+                       share_of_gpu_time=round(us / total_us, 4),
+                       tflops=round(flops[f] / per_step_us / 1e6, 1), mfma_frac=round(flops[f] / per_step_us / 1e6 / peak, 4),
+                       algo_gbps=round(nbytes[f] / per_step_us / 1e3, 1),
+                       hbm_frac=round(nbytes[f] / per_step_us / 1e3 / PEAK_HBM_GBPS, 4))
+    if not rows:
+        return None, rows
+    dom = max(rows, key=lambda k: rows[k]["device_ms_per_ddpm_step"])
     d = rows[dom]
-    # the roofline that bounds a kernel: HBM when its arithmetic intensity is below the machine balance
-    balance = peak * 1e3 / PEAK_HBM_GBPS   # FLOP per byte
-    # measured beside this line, from the committed rocprofv3 runs of the same command (profiles/README.md): HBM-side
-    # bytes per launch (PMC) and the kernel's average duration INSIDE the sampler, where two free-running streams contend
-    traffic, in_step_ms = None, None
-    fam = dom.split("[")[0]
-    try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
-        traffic = pm[fam]["bytes_per_launch"]
-    except Exception:
-        pass
-    try:
-        import csv
-        sym = {"gemm_rowln": "gemm_rowln_kernel", "gemm_tile": "gemm_tile_kernel", "attention": "attention"}[fam]
-        tot = calls = 0
-        for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r01_kernel_stats_bench_200steps.csv"))):
-            if sym in r["Name"]:
-                tot += float(r["TotalDurationNs"]); calls += int(r["Calls"])
-        in_step_ms = round(tot / calls / 1e6, 5) if calls else None
-    except Exception:
-        pass
-    if d["flop_per_byte"] < balance:
-        roof = dict(bound="hbm", kernel=dom, achieved=d["gbps"], peak=PEAK_HBM_GBPS, unit="GB/s", frac=d["hbm_frac"],
-                    traffic=traffic, algorithmic_bytes_per_launch=algo_bytes[dom], avg_launch_ms=d["ms"],
-                    launches_per_ddpm_step=d["launches_per_step"], mfma_tflops=d["tflops"], mfma_frac=d["frac"],
-                    rows_per_launch=R, concurrent_streams=streams, rocprof_in_step_avg_launch_ms=in_step_ms)
-    else:
-        roof = dict(bound="mfma", kernel=dom, achieved=d["tflops"], peak=peak, unit="TFLOP/s", frac=d["frac"],
-                    traffic=traffic, avg_launch_ms=d["ms"], launches_per_ddpm_step=d["launches_per_step"],
-                    rows_per_launch=R, concurrent_streams=streams, rocprof_in_step_avg_launch_ms=in_step_ms)
+    roof = dict(bound="mfma", kernel=dom, achieved=d["tflops"], peak=peak, unit="TFLOP/s", frac=d["mfma_frac"],
+                traffic=None, avg_launch_ms=d["avg_launch_ms"], launches_per_ddpm_step=d["launches_per_ddpm_step"],
+                share_of_gpu_time=d["share_of_gpu_time"],
+                timing=f"torch.profiler device durations inside the running sampler, {n_steps} two-branch DDPM steps, "
+                       f"{streams} free-running stream(s) of {B_launch} clips",
+                algorithmic_gflop_per_ddpm_step=round(flops[dom] / 1e9, 2),
+                hbm=dict(algorithmic_gbps=d["algo_gbps"], peak=PEAK_HBM_GBPS, frac=d["hbm_frac"],
+                         algorithmic_mb_per_ddpm_step=round(nbytes[dom] / 1e6, 1)))
+    # HBM-side bytes from the committed rocprofv3 PMC passes of this command (never measured by this run: labelled)
+    for pm_name in ("r02_pmc.json", "r01_pmc.json"):
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", pm_name)))
+            roof["traffic"] = pm[dom]["bytes_per_launch"]
+            roof["traffic_from"] = f"profiles/{pm_name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, committed)"
+            if "bytes_per_ddpm_step" in pm:
+                roof["traffic_per_ddpm_step"] = dict(bytes=pm["bytes_per_ddpm_step"],
+                                                     algorithmic_min_bytes=110e6, **{"from": f"profiles/{pm_name}"})
+            break
+        except Exception:
+            continue
     return roof, rows
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# CPU baseline
+# ----------------------------------------------------------------------------------------------------------------
+def host_cpu():
+    model, cores = "unknown", set()
+    try:
+        phys = core = None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name") and model == "unknown":
+                model = ln.split(":", 1)[1].strip()
+            elif ln.startswith("physical id"):
+                phys = ln.split(":", 1)[1].strip()
+            elif ln.startswith("core id"):
+                core = ln.split(":", 1)[1].strip()
+            elif not ln.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
+    return model, len(cores) or None, os.cpu_count()
 
 
 def cpu_baseline(dn, S, T, seconds):
     """The CPU oracle (port of the reference's PyTorch path) on the host cores: guided DDPM steps of ONE clip,
     run for ~`seconds`, extrapolated to T steps."""
+    import torch
     from oracle import tcdiff_oracle as O
     sd = O.synth_state_dict(dn=dn, seq_len=S)
     cond = torch.stack([O.synth_cond(0, S)])
     x = torch.stack([O.synth_xT(0, dn * S)])
     tab = O.make_tables(T)
+    model, phys, logical = host_cpu()
     # pick the intra-op thread count that is fastest on this host (all logical CPUs oversubscribes badly)
-    ncpu = os.cpu_count() or 1
+    ncpu = logical or 1
     best = (None, 1e30)
     with torch.no_grad():
         for th in sorted({min(ncpu, c) for c in (8, 16, 32, 64)}):
@@ -188,12 +263,50 @@ def cpu_baseline(dn, S, T, seconds):
                 break
     dt = time.time() - t0
     return dict(value=round(1.0 / (dt / n * T), 6), unit="clips/s", cores=torch.get_num_threads(), kind="port",
+                cpu_model=model, physical_cores=phys, logical_cpus=logical,
                 sample=f"{n} of {T} guided DDPM steps of 1 clip ({dn} dancers x {S} frames) on the CPU oracle "
                        f"(torch CPU fp32, {torch.get_num_threads()} threads), {dt:.1f} s, extrapolated x{T}/{n}")
 
 
-def main():
-    a = parse()
+# ----------------------------------------------------------------------------------------------------------------
+# rank body
+# ----------------------------------------------------------------------------------------------------------------
+def rank_facts(D, n_total, rank, world, dev):
+    """(ranks_seen, [[lo, hi] per rank]): one all-reduce and one all-gather over the job's process group (RCCL on GPUs)."""
+    import torch
+    import torch.distributed as dist
+    lo, hi = D.shard_range(n_total, rank, world)
+    if world == 1:
+        return 1, [[lo, hi]]
+    one = torch.ones(1, device=dev, dtype=torch.int32)
+    dist.all_reduce(one)
+    mine = torch.tensor([lo, hi], device=dev, dtype=torch.int32)
+    allr = torch.empty(world * 2, device=dev, dtype=torch.int32)
+    dist.all_gather_into_tensor(allr, mine)
+    return int(one.item()), allr.view(world, 2).tolist()
+
+
+def stub_rank(a):
+    """Rank plumbing without GPU work (CPU test of the launcher, gloo)."""
+    import torch
+    from tcdiff_amd import dist as D
+    rank, world, local = D.init_from_env("gloo" if not torch.cuda.is_available() else None)
+    n_total = a.batch * world
+    seen, ranges = rank_facts(D, n_total, rank, world, "cpu")
+    t = D.max_over_ranks(0.001 * (rank + 1), "cpu")
+    D.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "stub", "n_gpus": world, "ranks_seen": seen, "clip_ranges": ranges,
+                          "local_rank": local, "max_time": t}), flush=True)
+    else:
+        print(json.dumps({"rank": rank, "local_rank": local}), flush=True)   # not relayed: only rank 0's stdout is
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+def rank_main(a):
+    import torch
+    import torch.nn.functional as F
     from tcdiff_amd import dist as D
     rank, world, local = D.init_from_env()
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
@@ -204,18 +317,23 @@ def main():
 
     dn, S, T, B = a.dancers, a.frames, a.ddpm_steps, a.batch
     Lq = dn * S
-    model = DanceDecoder(nfeats=151, seq_len=S, latent_dim=512, ff_size=1024, num_layers=8, num_heads=8, dropout=0.1,
-                         cond_feature_dim=438, activation=F.gelu, required_dancer_num=dn, compute_dtype=a.dtype)
-    model.load_state_dict(W.synth_state_dict_like(model))
-    model.eval()
-    diff = GaussianDiffusion(model, S, 151, None, schedule="cosine", n_timestep=T, predict_epsilon=False,
-                             loss_type="l2", use_p2=False, cond_drop_prob=0.25, guidance_weight=2, seq_len=S)
-    diff.to(dev).eval()
 
+    def build(compute):
+        model = DanceDecoder(nfeats=151, seq_len=S, latent_dim=512, ff_size=1024, num_layers=8, num_heads=8,
+                             dropout=0.1, cond_feature_dim=438, activation=F.gelu, required_dancer_num=dn,
+                             compute_dtype=compute)
+        model.load_state_dict(W.synth_state_dict_like(model))
+        model.eval()
+        diff = GaussianDiffusion(model, S, 151, None, schedule="cosine", n_timestep=T, predict_epsilon=False,
+                                 loss_type="l2", use_p2=False, cond_drop_prob=0.25, guidance_weight=2, seq_len=S)
+        return diff.to(dev).eval()
+
+    diff = build(a.dtype)
     n_total = B * world
     lo, hi = D.shard_range(n_total, rank, world)
     cond = torch.stack([W.synth_cond(c, S) for c in range(lo, hi)]).to(dev)
     xT = torch.stack([W.synth_xT(c, Lq) for c in range(lo, hi)]).to(dev)
+    ranks_seen, clip_ranges = rank_facts(D, n_total, rank, world, dev)
 
     def one_job():
         x = diff.p_sample_loop((hi - lo, Lq, 151), cond, noise=xT, seed=1234, clip_offset=lo)
@@ -236,12 +354,10 @@ def main():
     if rank == 0:
         clips_per_s = n_total * a.steps / dt
         gf = GFLOP_PER_CLIP_STEP.get((dn, S))
-        # the sampler splits the rank's clips over `streams` sub-batches (tcdiff_amd/diffusion.py); measure those launches
         nb = hi - lo
         streams = diff.dual_parts if diff.dual_stream else 1
         while streams > 1 and nb // streams < 2:
             streams -= 1
-        roof, rows = kernel_roofline(model.engine(nb // streams), nb // streams, a.dtype, streams)
         res = {
             "metric": "sampled clips/sec (3 dancers x 150 frames, 1000 DDPM steps)",
             "value": round(clips_per_s, 4), "unit": "clips/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -250,20 +366,59 @@ def main():
             "config": {"workload": f"batch={B} clips/GPU, {dn} dancers x {S} frames, {T} DDPM steps (p_sample_loop, "
                                    f"CFG w=2, cosine schedule), {a.dtype}, {world}xMI355X",
                        "clips_per_gpu": B, "ddpm_steps": T, "tokens_per_clip": Lq},
-            "roofline": roof,
+            "ranks_seen": ranks_seen, "clip_ranges": clip_ranges,
+            "ms_per_ddpm_step": round(dt / a.steps / T * 1e3, 4),
         }
         if gf is not None:
             res["whole_path"] = {"algorithmic_gflop_per_clip_step": gf,
                                  "achieved_tflops_per_gpu": round(clips_per_s / world * gf * T / 1e3, 2),
                                  "mfma_frac_per_gpu": round(clips_per_s / world * gf * T / 1e3 /
                                                             (PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS), 4)}
+        roof, rows = None, {}
+        if not a.no_kernel_profile and T >= 200:
+            try:
+                times, n_prof = insampler_kernel_times(diff, (nb, Lq, 151), cond, xT)
+                roof, rows = kernel_roofline(times, n_prof, nb // streams, streams, dn, S, a.dtype)
+            except Exception as e:   # the throughput line must not depend on the profiler
+                res["kernel_profile_error"] = repr(e)[:300]
+        res["roofline"] = roof
         res["kernels"] = rows
+        if world == 1 and not a.no_parity_mode and a.dtype == "bf16" and T >= 200:
+            # the f32 mode (v_mfma_f32_32x32x2_f32) is the one held to <= 1e-3 against the reference: time it here too
+            d32 = build("f32")
+            d32.p_sample_loop((nb, Lq, 151), cond, noise=xT, seed=1234, start_point=int(0.1 * T) + 4)   # warm + capture
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            d32.p_sample_loop((nb, Lq, 151), cond, noise=xT, seed=1234)
+            torch.cuda.synchronize()
+            d1 = time.perf_counter() - t1
+            res["parity_mode"] = {"dtype": "f32", "value": round(nb / d1, 4), "unit": "clips/s",
+                                  "ms_per_step": round(d1 * 1e3, 1), "sample": f"one full job of {nb} clips x {T} steps",
+                                  "tolerance": "max-abs <= 1e-3 vs the reference on fp32 (tests/test_parity_gpu.py)",
+                                  "mfma_frac_f32_peak": round(nb / d1 * gf * T / 1e3 / PEAK_F32_TFLOPS, 4) if gf else None}
+            del d32
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(dn, S, T, a.cpu_seconds)
         print(json.dumps(res), flush=True)
     D.barrier()
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
+
+
+def main():
+    a = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and a.gpus > 1:
+        sys.exit(launch_ranks(sys.argv[1:], a.gpus))          # parent: spawns, relays, never touches the GPU
+    world = int(env_world) if env_world is not None else 1
+    if world != a.gpus:
+        sys.stderr.write(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch with "
+                         f"`python bench.py --gpus {a.gpus}` (it starts the ranks itself) or make them agree\n")
+        sys.exit(2)
+    if a.stub:
+        stub_rank(a)
+    else:
+        rank_main(a)
 
 
 if __name__ == "__main__":

@@ -118,9 +118,11 @@ int tcdiff_gemm_rowln(int dtype, const void* A, const void* W, int M, int K, int
  * K,V: T[n_kv ][H][Lp_k][64]   natural [key][feature] rows (written by TC_EPI_QKV_HEADS / tcdiff_scatter_time_kv)
  * kv = seq < n_shared ? 0 : seq - n_shared + (n_shared > 0)   (the unconditional CFG branch shares one K/V)
  * Lp_q % 128 == 0, Lp_k % 64 == 0, pad rows of Q/K/V must be finite (zero).  Keys >= Lk are masked.
+ * ng: query rows per wave of the K/V-resident bf16 kernel in units of 32 (1 or 2); 0 = chosen from the launch size
+ * and the device's CU count.  Results do not depend on ng beyond fp32 summation order inside a row.
  * Replaces model/model.py:97-102 (SBI_MSA core) and nn.MultiheadAttention's core (model/model.py:228-236). */
 int tcdiff_attention(int dtype, const void* Q, const void* K, const void* V, void* O, int n_seq, int H, int Lq,
-                     int Lk, int Lp_q, int Lp_k, int ldo, int n_shared, hipStream_t stream);
+                     int Lk, int Lp_q, int Lp_k, int ldo, int n_shared, int ng, hipStream_t stream);
 
 /* ---- LayerNorm (+ rotary) prologue: one wave per 512-wide row ---------------------------------------
  * u = LayerNorm_eps(x[row]) * g + b; optional outputs: h = T(u); rot = T(rotary(u, pos)); y32 = u (fp32).

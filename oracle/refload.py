@@ -1,6 +1,6 @@
 """Import the REAL reference (Da1yuqin/TCDiff) from /root/reference -- build container only.
 
-Test infrastructure: used by oracle/validate_against_reference.py and tests/golden/make_golden.py to
+Test infrastructure: used by tests/golden/make_golden*.py to
 pin the oracle and to generate golden vectors.  /root/reference does not exist on the GPU box, so nothing
 in ``-m gpu`` tests, smoke() or bench.py may call this.
 

@@ -7,11 +7,10 @@ measured as the product: only ``tests/``, ``__graft_entry__.smoke()`` and the
 ``cpu_baseline`` leg of ``bench.py`` may import it (as the checker / the
 reported CPU baseline).  The product path (``tcdiff_amd``) never imports it.
 
-Parity status: PINNED.  ``oracle/validate_against_reference.py`` imports the real
-reference from /root/reference (in the build container only) and checks every
-function below against it; ``tests/golden/*.npz`` (made by
-``tests/golden/make_golden.py`` from the real reference) are checked in
-``tests/test_oracle_golden.py`` on any box.
+Parity status: PINNED.  ``tests/golden/make_golden*.py`` import the real reference
+from /root/reference (in the build container only, through ``oracle/refload.py``)
+and store its outputs as ``tests/golden/*.npz``; ``tests/test_oracle_golden.py``
+holds every function below to those vectors on any box.
 
 All citations are file:line in the reference repo (Da1yuqin/TCDiff @ 2025-10-17).
 Weights are passed as a flat ``state_dict`` (name -> tensor) with the reference's

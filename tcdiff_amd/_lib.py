@@ -35,7 +35,7 @@ class RowEpi(C.Structure):
 _SIGS = {
     "tcdiff_gemm_tile": [_i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, C.POINTER(TileEpi), _vp],
     "tcdiff_gemm_rowln": [_i, _vp, _vp, _i, _i, _i, _i, _i, C.POINTER(RowEpi), _vp],
-    "tcdiff_attention": [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "tcdiff_attention": [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "tcdiff_ln_rot": [_i, _vp, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "tcdiff_rope_table": [_vp, _vp, _i, _vp],
     "tcdiff_convert_pad": [_i, _vp, _vp, _i, _i, _i, _i, _l, _l, _vp],

@@ -14,7 +14,6 @@
 //     XOR-swizzled 16-byte chunks), KB = 64 keys (bf16) / 32 keys (f32); online softmax across tiles (fp32 m, l).
 //   * the PV A operand is V^T: bf16 reads it with the hardware transpose read ds_read_b64_tr_b16 (two reads per
 //     fragment, in the key order the P^T registers are in); f32 reads one dword per MFMA (lanes = consecutive d).
-#include <cstdlib>
 #include "common.h"
 #include "tcdiff_hip.h"
 
@@ -434,9 +433,10 @@ __global__ __launch_bounds__(512) void attention_res_kernel(const char* __restri
 }
 
 extern "C" int tcdiff_attention(int dtype, const void* Q, const void* K, const void* V, void* O, int n_seq, int H,
-                                int Lq, int Lk, int Lp_q, int Lp_k, int ldo, int n_shared, hipStream_t stream) {
+                                int Lq, int Lk, int Lp_q, int Lp_k, int ldo, int n_shared, int ng, hipStream_t stream) {
     if (!Q || !K || !V || !O || n_seq <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return TC_ERR_ARG;
     if (dtype != TC_DTYPE_BF16 && dtype != TC_DTYPE_F32) return TC_ERR_ARG;
+    if (ng < 0 || ng > 2) return TC_ERR_ARG;
     if (Lp_q % 128 != 0 || Lp_k % 64 != 0 || Lp_q < Lq || Lp_k < Lk || ldo < H * 64 || ldo % 4 != 0) return TC_ERR_ARG;
     if (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O) & 15) return TC_ERR_ALIGN;
     if (dtype == TC_DTYPE_BF16 && Lp_q >= 512) {
@@ -445,25 +445,16 @@ extern "C" int tcdiff_attention(int dtype, const void* Q, const void* K, const v
         const int smem_bytes = 2 * ntm * 8192;
         // 32 query rows per wave (two workgroups per 450-token sequence) while that still fits one round over the CUs,
         // 64 rows per wave (K / V fragment reads shared by two row groups) beyond
-        static const int force_ng = [] { const char* v = getenv("TCDIFF_ATT_NG"); return v ? atoi(v) : 0; }();
-        static int n_cu = 0;
-        if (n_cu == 0) {
-            int dev = 0, v = 0;
-            if (hipGetDevice(&dev) != hipSuccess ||
-                hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
-                v = 256;
-            n_cu = v;
-        }
-        int ng = ((Lq + 255) / 256) * H * n_seq <= n_cu ? 1 : 2;
-        if (force_ng == 1 || force_ng == 2) ng = force_ng;
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_res_kernel<1>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_RES_MAXT * 8192);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_res_kernel<2>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_RES_MAXT * 8192);
-            attr_set = true;
-        }
+        static tc_dev_state dev_state;
+        const int n_cu = tc_device_once(dev_state, [](int) {
+            hipError_t a = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_res_kernel<1>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_RES_MAXT * 8192);
+            hipError_t b = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_res_kernel<2>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_RES_MAXT * 8192);
+            return a != hipSuccess ? a : b;
+        });
+        if (n_cu < 0) return n_cu;
+        if (ng == 0) ng = ((Lq + 255) / 256) * H * n_seq <= n_cu ? 1 : 2;
         const int nqb = (Lq + 256 * ng - 1) / (256 * ng);
         if (ng == 1)
             hipLaunchKernelGGL(attention_res_kernel<1>, dim3(nqb * H * n_seq), dim3(512), smem_bytes, stream,

@@ -214,6 +214,35 @@ DEVINL void sync_dma() {
 #define TC_ERR_LAUNCH (-3)
 #define TC_ERR_UNSUPPORTED (-4)
 
+// Per-device, thread-safe launcher state: the dynamic-LDS limit of a kernel has to be raised on EVERY device that
+// launches it, and the CU count is a property of the device (not of the process).
+#ifdef __cplusplus
+#include <mutex>
+#define TC_MAX_DEVICES 64
+struct tc_dev_state {
+    std::mutex mu;
+    bool ready[TC_MAX_DEVICES] = {};
+    int n_cu[TC_MAX_DEVICES] = {};
+};
+// Runs `setup(dev)` (returns hipSuccess on success) once per device; returns the device's CU count or a negative
+// TC_ERR_* code.
+template <class F>
+static inline int tc_device_once(tc_dev_state& st, F setup) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= TC_MAX_DEVICES) return TC_ERR_UNSUPPORTED;
+    std::lock_guard<std::mutex> lock(st.mu);
+    if (!st.ready[dev]) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+            return TC_ERR_UNSUPPORTED;
+        if (setup(dev) != hipSuccess) return TC_ERR_UNSUPPORTED;
+        st.n_cu[dev] = v;
+        st.ready[dev] = true;
+    }
+    return st.n_cu[dev];
+}
+#endif
+
 #define TC_CHECK_LAUNCH()                                   \
     do {                                                    \
         hipError_t e_ = hipGetLastError();                  \

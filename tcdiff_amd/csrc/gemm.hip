@@ -563,14 +563,15 @@ extern "C" int tcdiff_gemm_rowln(int dtype, const void* A, const void* W, int M,
     tcdiff_row_epi e = *epi;
     if (e.out_mul <= 0) e.out_mul = 1;
     if (e.groups <= 0) e.groups = 1;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rowln_kernel<MmaBF16>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, ROWLN_SMEM);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rowln_kernel<MmaF32>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, ROWLN_SMEM);
-        attr_set = true;
-    }
+    static tc_dev_state dev_state;
+    const int n_cu = tc_device_once(dev_state, [](int) {
+        hipError_t a = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rowln_kernel<MmaBF16>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, ROWLN_SMEM);
+        hipError_t b = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rowln_kernel<MmaF32>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, ROWLN_SMEM);
+        return a != hipSuccess ? a : b;
+    });
+    if (n_cu < 0) return n_cu;
     dim3 grid(((M + 63) / 64) * e.groups);
     if (dtype == TC_DTYPE_BF16)
         hipLaunchKernelGGL(gemm_rowln_kernel<MmaBF16>, grid, dim3(512), ROWLN_SMEM, stream, (const char*)A,

@@ -248,6 +248,12 @@ class GaussianDiffusion(nn.Module):
                     p["st"]["eps"].copy_(eps[p["lo"]:p["hi"]].reshape(p["B"] * Lq, nf))
             gkey = (mode, branches, step_noise is not None, traj is not None, clip_offset, B, len(parts), gens, id(self.model),
                     skewed)
+            # Anything that is not a replay of the free-running per-part graphs launches work for EVERY part on the main
+            # stream: join the side streams first, or their queued replays race with it on the parts' buffers.
+            if side_started and not (use_graph and gkey in graphs):
+                for sk in sides:
+                    torch.cuda.current_stream().wait_stream(sk)
+                side_started = False
             if not use_graph:
                 step(branches, False)
             elif gkey in graphs:
@@ -269,10 +275,6 @@ class GaussianDiffusion(nn.Module):
                 step(branches, False)           # first visit: eager (loads code objects, sets kernel attributes)
                 graphs[("warm", gkey)] = True
             else:                               # second visit: capture the step once, replay from now on
-                if side_started:
-                    for sk in sides:
-                        torch.cuda.current_stream().wait_stream(sk)
-                    side_started = False
                 for k in [k for k in graphs if isinstance(k, tuple) and len(k) == 10 and k[8] == id(self.model) and k[7] != gens]:
                     del graphs[k]               # graphs of engines whose buffers have moved
                 if not skewed:

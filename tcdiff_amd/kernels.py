@@ -55,8 +55,8 @@ def gemm_rowln(dt, A, W, M, K, *, flags, lda=None, ldw=None, a_mod=0, bias=None,
     L.check(rc, "tcdiff_gemm_rowln")
 
 
-def attention(dt, Q, K, V, O, n_seq, H, Lq, Lk, Lp_q, Lp_k, ldo, n_shared=0):
-    rc = L.load().tcdiff_attention(dt, _p(Q), _p(K), _p(V), _p(O), n_seq, H, Lq, Lk, Lp_q, Lp_k, ldo, n_shared,
+def attention(dt, Q, K, V, O, n_seq, H, Lq, Lk, Lp_q, Lp_k, ldo, n_shared=0, ng=0):
+    rc = L.load().tcdiff_attention(dt, _p(Q), _p(K), _p(V), _p(O), n_seq, H, Lq, Lk, Lp_q, Lp_k, ldo, n_shared, ng,
                                    stream())
     L.check(rc, "tcdiff_attention")
 

@@ -306,6 +306,37 @@ def test_attention(dt, Lq, Lk, nseq, n_shared):
     assert err < tol(dt, 2e-5, 2e-2), err
 
 
+@pytest.mark.parametrize("ng", [1, 2])
+@pytest.mark.parametrize("Lq,Lk,nseq,n_shared", [(450, 450, 3, 0), (450, 152, 4, 2), (1500, 1500, 2, 0), (1500, 302, 3, 1),
+                                                 (513, 1025, 1, 0)])
+def test_attention_resident_kernel_both_row_groupings(ng, Lq, Lk, nseq, n_shared):
+    """the K/V-resident bf16 kernel with 32 (ng=1) and 64 (ng=2) query rows per wave FORCED, including the multi-chunk
+    key loop (L = 1500 > 512 keys per LDS-resident chunk): the launcher picks ng from the launch size, so the
+    benchmarked B = 16 shape (ng = 1) and config 4 at B >= 3 (ng = 2 with chunks) both need explicit coverage."""
+    dt, H = L.DT_BF16, 8
+    Lpq, Lpk = K.round_up(Lq, 128), K.round_up(Lk, 128)
+    if Lpq < 512:
+        pytest.skip("resident kernel needs a Q image padded to >= 512 rows")
+    n_kv = nseq if n_shared == 0 else nseq - n_shared + 1
+    q = (rnd(nseq, H, Lq, 64, seed=46) * 0.5).to(T(dt))
+    k = rnd(n_kv, H, Lk, 64, seed=47).to(T(dt))
+    v = rnd(n_kv, H, Lk, 64, seed=48).to(T(dt))
+    Q = torch.zeros(nseq, H, Lpq, 64, device=DEV, dtype=T(dt))
+    Kk = torch.zeros(n_kv, H, Lpk, 64, device=DEV, dtype=T(dt))
+    Vv = torch.zeros_like(Kk)
+    Q[:, :, :Lq], Kk[:, :, :Lk], Vv[:, :, :Lk] = q, k, v
+    O = torch.full((nseq * Lq, 512), 7.0, device=DEV, dtype=T(dt))
+    K.attention(dt, Q, Kk, Vv, O, nseq, H, Lq, Lk, Lpq, Lpk, 512, n_shared=n_shared, ng=ng)
+    kv = torch.tensor([0 if s < n_shared else s - n_shared + (1 if n_shared > 0 else 0) for s in range(nseq)], device=DEV)
+    ref = attn_ref(q, k[kv], v[kv]).permute(0, 2, 1, 3).reshape(nseq * Lq, 512)
+    err = float((O.double() - ref).abs().max())
+    assert err < 2e-2, err
+    # the two groupings only differ in which wave owns a row: same per-row arithmetic
+    O2 = torch.zeros_like(O)
+    K.attention(dt, Q, Kk, Vv, O2, nseq, H, Lq, Lk, Lpq, Lpk, 512, n_shared=n_shared, ng=3 - ng)
+    assert float((O.float() - O2.float()).abs().max()) < 4e-3
+
+
 def test_attention_large_logits_online_softmax():
     """force the running-max rescale branch: one key far above the rest, placed in a late tile"""
     dt, H, Lq, Lk = L.DT_F32, 8, 128, 200
