@@ -39,7 +39,7 @@ def test_argument_validation_without_gpu(lib):
     assert lib.tcdiff_gemm_tile(L.DT_BF16, None, None, 0, None, 1, 1, 64, 64, 64, 0, ctypes.byref(e), None) == -1
     r = L.RowEpi()
     assert lib.tcdiff_gemm_rowln(L.DT_F32, None, None, 1, 32, 32, 32, 0, ctypes.byref(r), None) == -1
-    assert lib.tcdiff_attention(L.DT_F32, None, None, None, None, 1, 8, 1, 1, 128, 128, 512, 0, None) == -1
+    assert lib.tcdiff_attention(L.DT_F32, None, None, None, None, 1, 8, 1, 1, 128, 128, 512, 0, 0, None) == -1
     assert lib.tcdiff_ln_rot(L.DT_F32, None, 1, None, None, 1e-5, None, None, None, None, 0, 0, None) == -1
     assert lib.tcdiff_step_end(None, None) == -1
     with pytest.raises(L.TcdiffError):
