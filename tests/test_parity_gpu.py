@@ -406,7 +406,7 @@ def test_c2_full_batch_16_clip0_vs_reference_golden(golden_dir, compute, bound):
     assert e < (2e-4 if compute == "f32" else BF16_EVAL_BOUND)
 
 
-BF16_DRIFT_BOUND = 1e-1
+BF16_DRIFT_BOUND = 3e-2      # observed on MI355X: max-abs 8.3e-3, mean-abs 1.7e-3
 
 
 def test_c2_bf16_vs_f32_drift_over_the_full_1000_steps():
