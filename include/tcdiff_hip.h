@@ -112,6 +112,57 @@ typedef struct {
 int tcdiff_gemm_rowln(int dtype, const void* A, const void* W, int M, int K, int lda, int ldw, int a_mod,
                       const tcdiff_row_epi* epi, hipStream_t stream);
 
+/* ---- row-block chains (bf16): everything between the two attentions of a decoder layer in ONE launch -------------
+ * A block of 64 token rows stays on a CU; only weights stream (tcdiff_amd/csrc/chain.hip).
+ *   TC_CHAIN_A      : O_self --fc, LayerNorm(1e-6), FiLM, +x--> x ; norm2, rotary ; w_qs --> Q image (cross-attention)
+ *                     replaces model/model.py:103-106,327 and :332,387,78 (+ the 1/sqrt(d_k) of :97)
+ *   TC_CHAIN_B      : O_cross --fc, LN, FiLM, +x--> x ; norm3 ; linear1, GELU ; linear2, FiLM, +x ; norm4 ; linear3 --> x' ;
+ *                     next layer's norm1 (+rotary) ; w_qs / w_ks / w_vs --> Q, K, V images
+ *                     replaces model/model.py:103-106,334,338-339,344,399-401 and the next layer's :326,374-383,78-80
+ *   TC_CHAIN_B_LAST : the same up to linear3, whose bf16 rows feed the final projection (model/model.py:623)
+ * `wstream`: the chain's weights as ONE linear stream per wave in consumption order, [8 waves][n_stages][2048 B]; a
+ * stage is the LDS fragment image of the 64 (512-wide GEMMs: [half][64 weight rows][16 B] of one 16-deep k-step) or
+ * 32 (linear1 chunk: [k-step 2][half][32 rows][16 B]) weight rows wave w consumes; order: fc (32 stages), then for
+ * chain A w_qs (32); for chain B four times {linear1 rows 256c+32w.. (16 stages), linear2 k-slice 256c.. (16)}, then
+ * linear3 (32), w_qs, w_ks, w_vs of the NEXT layer (32 each).  n_stages = 64 / 288 / 192.  tcdiff_amd/engine.py packs it.
+ * Rows: M token rows, L tokens per sequence; FiLM row = m / L, rotary position = m % L; head-major images as
+ * TC_EPI_QKV_HEADS (H must be 8).  a_mod / xres_mod > 0: input / residual row = m % mod (layer 0 shares them between
+ * the CFG branches). */
+#define TC_CHAIN_A 0
+#define TC_CHAIN_B 1
+#define TC_CHAIN_B_LAST 2
+
+typedef struct {
+    int mode, n_stages;
+    int M, L, a_mod, xres_mod, H, Lp;
+    const void* A;        /* bf16 [*,512]: attention output rows */
+    const void* wstream;
+    const float* ln_g;    /* SBI_MSA.layer_norm (eps ln_eps) */
+    const float* ln_b;
+    const float* film;    /* FiLM of the attention block: film[seq * film_ld + n] scale, +512 shift */
+    const float* xres;    /* fp32 [*,512] residual in */
+    float* xout;          /* fp32 [M,512] residual out (chain B: holds x between the blocks, then x') */
+    const float* n2_g;    /* the norm that follows: norm2 (chain A) / norm3 (chain B) */
+    const float* n2_b;
+    const float* rope;    /* [Lmax][512] cos/sin table (tcdiff_rope_table) */
+    void* q_out;          /* Q image T[n_seq][8][Lp][64] (chain A: cross-attention Q; chain B: next layer's) */
+    const float* b1;      /* linear1 bias [1024] */
+    const float* b2;      /* linear2 bias [512]  */
+    const float* film3;   /* FiLM of the feed-forward block */
+    const float* n4_g;
+    const float* n4_b;
+    const float* b3;      /* linear3 bias */
+    const float* nn_g;    /* next layer's norm1 */
+    const float* nn_b;
+    void* k_out;
+    void* v_out;
+    void* h_out;          /* TC_CHAIN_B_LAST: bf16 [M,512] */
+    int film_ld;
+    float ln_eps, n2_eps, n4_eps, nn_eps, scale_q;
+} tcdiff_chain_args;
+
+int tcdiff_chain(const tcdiff_chain_args* args, hipStream_t stream);
+
 /* ---- fused attention ------------------------------------------------------------------------------
  * O[(seq*Lq + q)*ldo + head*64 + d] = softmax_k(Q[seq][head][q] . K[kv][head][k]) V[kv][head][k][d]
  * Q  : T[n_seq][H][Lp_q][64]   (already scaled by 1/sqrt(64))

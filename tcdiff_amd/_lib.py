@@ -15,6 +15,7 @@ EPI_STORE_T, EPI_STORE_F32, EPI_QKV_HEADS = 0, 1, 2
 ROW_BIAS, ROW_LN_POST, ROW_FILM, ROW_RES, ROW_STORE_X, ROW_NEXT_LN, ROW_STORE_H, ROW_STORE_ROT = \
     1, 2, 4, 8, 16, 32, 64, 128
 SAMPLER_DDPM, SAMPLER_DDIM = 0, 1
+CHAIN_A, CHAIN_B, CHAIN_B_LAST = 0, 1, 2
 
 _vp, _i, _f, _l = C.c_void_p, C.c_int, C.c_float, C.c_long
 
@@ -32,10 +33,20 @@ class RowEpi(C.Structure):
                 ("out_add", _i), ("groups", _i)]
 
 
+class ChainArgs(C.Structure):
+    _fields_ = [("mode", _i), ("n_stages", _i), ("M", _i), ("L", _i), ("a_mod", _i), ("xres_mod", _i), ("H", _i),
+                ("Lp", _i), ("A", _vp), ("wstream", _vp), ("ln_g", _vp), ("ln_b", _vp), ("film", _vp), ("xres", _vp),
+                ("xout", _vp), ("n2_g", _vp), ("n2_b", _vp), ("rope", _vp), ("q_out", _vp), ("b1", _vp), ("b2", _vp),
+                ("film3", _vp), ("n4_g", _vp), ("n4_b", _vp), ("b3", _vp), ("nn_g", _vp), ("nn_b", _vp),
+                ("k_out", _vp), ("v_out", _vp), ("h_out", _vp), ("film_ld", _i), ("ln_eps", _f), ("n2_eps", _f),
+                ("n4_eps", _f), ("nn_eps", _f), ("scale_q", _f)]
+
+
 _SIGS = {
     "tcdiff_gemm_tile": [_i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, C.POINTER(TileEpi), _vp],
     "tcdiff_gemm_rowln": [_i, _vp, _vp, _i, _i, _i, _i, _i, C.POINTER(RowEpi), _vp],
     "tcdiff_attention": [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "tcdiff_chain": [C.POINTER(ChainArgs), _vp],
     "tcdiff_ln_rot": [_i, _vp, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "tcdiff_rope_table": [_vp, _vp, _i, _vp],
     "tcdiff_convert_pad": [_i, _vp, _vp, _i, _i, _i, _i, _l, _l, _vp],

@@ -37,44 +37,6 @@
 #include "common.h"
 #include "tcdiff_hip.h"
 
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef const __attribute__((address_space(1))) void gbl_void_t;
-
-// One LDS-DMA instruction in its SGPR-base form: global_load_lds_dwordx4 voffset, s[base:base+1] with M0 = the LDS
-// destination (one address VGPR instead of two; the main loops got 3-13 % shorter).  Written in asm because hipcc picks
-// the 64-bit VGPR address form whenever the base moves inside a loop.  M0 is compiler-reserved, so it is saved and
-// restored inside the statement (cdna_hip_programming.md section 5.7); completion is waited for by sync_dma().
-DEVINL void glds16(const char* base, unsigned voff, const char* lds_dst) {
-    const uintptr_t b = reinterpret_cast<uintptr_t>(base);
-    const uint64_t sb = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) |
-                        (uint32_t)__builtin_amdgcn_readfirstlane((int)(b & 0xffffffffu));
-    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)reinterpret_cast<uintptr_t>(lds_dst));
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(sb), "s"(dst) : "memory");
-}
-
-// Issue the global->LDS DMA of a [ROWS][128 B] tile.  `wave` must be wave-uniform.
-// rows >= row_limit are clamped to row_limit-1 (their results are never stored).
-template <int ROWS, int NWAVES>
-DEVINL void stage_glds(char* lds_tile, const char* src, long ld_bytes, int row0, int row_limit, int row_mod, int wave,
-                       int lane) {
-    constexpr int PER = ROWS / 8 / NWAVES;
-    static_assert(ROWS % (8 * NWAVES) == 0, "tile rows must divide over the waves");
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int blk = wave * PER + i;           // 1-KiB block = 8 tile rows
-        const int row = blk * 8 + (lane >> 3);
-        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-        int gr = row0 + row;
-        gr = gr < row_limit ? gr : row_limit - 1;
-        if (row_mod > 0) gr = gr % row_mod;
-        // 32-bit per-lane offset from the wave-uniform base (the launchers check that an operand spans < 4 GB)
-        const unsigned off = (unsigned)gr * (unsigned)ld_bytes + (unsigned)(chunk * 16);
-        glds16(src, off, lds_tile + blk * 1024);
-    }
-}
-
 #ifdef TC_STAMP
 // diagnostic build (-DTC_STAMP, tools/microbench3.py): per-block timestamps (100 MHz realtime counter) written to a
 // side buffer that nothing else reads; never compiled into the product library.
@@ -88,10 +50,6 @@ extern "C" int tcdiff_debug_stamp_buffer(void* p) {
 #define TC_STAMP_AT(i) do { } while (0)
 #define TC_STAMP_W(i) do { } while (0)
 #endif
-
-DEVINL u32x4 lds_frag(const char* tile, int row, int chunk) {
-    return *reinterpret_cast<const u32x4*>(tile + tile_off(row, chunk));
-}
 
 // =================================================================================================
 // gemm_tile: 128 x 128 x (128 B of K) tiles, 256 threads

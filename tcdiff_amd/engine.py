@@ -19,6 +19,7 @@ out of the DDPM loop; results are identical to recomputing it every step (SURVEY
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, Optional
 
 import torch
@@ -53,6 +54,9 @@ class DenoiserEngine:
         self.plan_B = 0
         self.tables_key = None
         self._sampler_state = None
+        # row-block chain kernels (csrc/chain.hip): bf16 only; the f32 parity mode keeps the op-by-op kernels
+        self.use_chain = self.dt == L.DT_BF16 and os.environ.get("TCDIFF_CHAIN", "1") != "0" and self.ff == 1024 \
+            and self.H == 8
         self.reset_graphs()
 
     def reset_graphs(self):
@@ -86,6 +90,40 @@ class DenoiserEngine:
         out = torch.zeros(n, kp, device=self.dev, dtype=self.T)
         out[:, :k] = w.to(device=self.dev, dtype=self.T)
         return out.contiguous()
+
+    # ---- weight streams of the chain kernels (include/tcdiff_hip.h, tcdiff_chain_args.wstream) -------------------
+    @staticmethod
+    def _stages_n512(W: torch.Tensor) -> torch.Tensor:
+        """[512, K] -> [8 waves][K/16 stages][1024]: stage = [half][64 weight rows][8 k] of one 16-deep k-step."""
+        K_ = W.shape[1]
+        return W.reshape(8, 64, K_ // 16, 2, 8).permute(0, 2, 3, 1, 4).reshape(8, K_ // 16, 1024)
+
+    @staticmethod
+    def _stages_ff1(W1: torch.Tensor) -> torch.Tensor:
+        """[1024, 512] -> [4 chunks][8 waves][16 stages][1024]: stage = [k-step 2][half][32 rows][8 k]."""
+        return W1.reshape(4, 8, 32, 16, 2, 2, 8).permute(0, 1, 3, 4, 5, 2, 6).reshape(4, 8, 16, 1024)
+
+    @staticmethod
+    def _stages_ff2(W2: torch.Tensor) -> torch.Tensor:
+        """[512, 1024] -> [4 chunks][8 waves][16 stages][1024]: the k-slice [256 c, 256 c + 256) of every row."""
+        return W2.reshape(8, 64, 4, 16, 2, 8).permute(2, 0, 3, 4, 1, 5).reshape(4, 8, 16, 1024)
+
+    def _build_chain_streams(self):
+        w = self.w
+        for l in range(self.NL):
+            p = f"l{l}."
+            w[p + "chainA"] = torch.cat([self._stages_n512(w[p + "sfc.w"]), self._stages_n512(w[p + "cq.w"])],
+                                        1).contiguous()
+            f1, f2 = self._stages_ff1(w[p + "ff1.w"]), self._stages_ff2(w[p + "ff2.w"])
+            parts = [self._stages_n512(w[p + "cfc.w"])]
+            for c in range(4):
+                parts += [f1[c], f2[c]]
+            parts.append(self._stages_n512(w[p + "l3.w"]))
+            if l + 1 < self.NL:
+                qkv = w[f"l{l + 1}.qkv.w"]
+                parts += [self._stages_n512(qkv[0:512]), self._stages_n512(qkv[512:1024]),
+                          self._stages_n512(qkv[1024:1536])]
+            w[p + "chainB"] = torch.cat(parts, 1).contiguous()
 
     def _f32(self, t: torch.Tensor) -> torch.Tensor:
         return t.detach().to(device=self.dev, dtype=torch.float32).contiguous()
@@ -146,6 +184,8 @@ class DenoiserEngine:
         w["rope"] = torch.empty(n_pos, 512, device=self.dev, dtype=torch.float32)
         K.rope_table(f(g("rotary.freqs")), w["rope"], n_pos)
         self.w = w
+        if self.use_chain:
+            self._build_chain_streams()
         self.weights_version = version
         self.tables_key = None
         self.reset_graphs()
@@ -316,6 +356,9 @@ class DenoiserEngine:
             p = f"l{l}."
             rows_sa = Rs if l == 0 else R          # layer-0 self-attention is branch-independent
             nseq_sa = B if l == 0 else nseq
+            if self.use_chain:
+                self._layer_chained(l, B, branches, Kc0, Vc0, film0, fld, n_shared)
+                continue
             # ---- self-attention block (model/model.py:326-327,374-383,71-107)
             K.gemm_tile(dt, b["rot"], w[p + "qkv.w"], rows_sa, 1536, 512, A2=b["h"], split_n=1024, mode=L.EPI_QKV_HEADS,
                         out=b["Q"], out_k=b["K"], out_v=b["V"], scale_q=0.125, Lseq=Lq, Lp=self.Lp, H=H, n_q=512,
@@ -354,3 +397,34 @@ class DenoiserEngine:
         # final layer (model/model.py:623)
         K.gemm_tile(dt, b["h"], w["fin.w"], R, self.nf, 512, bias=w["fin.b"], mode=L.EPI_STORE_F32, out=b["out"], ldc=152)
         return b["out"]
+
+    def _layer_chained(self, l: int, B: int, branches: int, Kc0, Vc0, film0, fld: int, n_shared: int):
+        """One decoder layer as attention / chain A / attention / chain B (csrc/chain.hip): the Q, K, V images of
+        this layer's self-attention were written by the previous layer's chain B (layer 0: by the QKV GEMM below)."""
+        dt, w, b = self.dt, self.w, self.b
+        Lq, S, H, NL = self.Lseq, self.S, self.H, self.NL
+        Rs, R = B * Lq, branches * B * Lq
+        nseq = branches * B
+        p = f"l{l}."
+        rope = w["rope"]
+        if l == 0:
+            K.gemm_tile(dt, b["rot"], w[p + "qkv.w"], Rs, 1536, 512, A2=b["h"], split_n=1024, mode=L.EPI_QKV_HEADS,
+                        out=b["Q"], out_k=b["K"], out_v=b["V"], scale_q=0.125, Lseq=Lq, Lp=self.Lp, H=H, n_q=512,
+                        n_k=512)
+        K.attention(dt, b["Q"], b["K"], b["V"], b["O"], B if l == 0 else nseq, H, Lq, Lq, self.Lp, self.Lp, 512)
+        K.chain(L.CHAIN_A, 64, R, Lq, b["O"], w[p + "chainA"], a_mod=Rs if l == 0 else 0,
+                ln_g=w[p + "sln.g"], ln_b=w[p + "sln.b"], ln_eps=1e-6, film=film0[:, (l * 3 + 0) * 1024:], film_ld=fld,
+                xres=b["xs"] if l == 0 else b["xa"], xres_mod=Rs if l == 0 else 0, xout=b["xa"],
+                n2_g=w[p + "norm2.g"], n2_b=w[p + "norm2.b"], n2_eps=1e-5, rope=rope, q_out=b["Q"], scale_q=0.125,
+                Lp=self.Lp, H=H)
+        K.attention(dt, b["Q"], Kc0[l], Vc0[l], b["O"], nseq, H, Lq, S + 2, self.Lp, self.Lpc, 512, n_shared=n_shared)
+        last = l + 1 == NL
+        nn = f"l{l + 1}.norm1." if not last else None
+        K.chain(L.CHAIN_B_LAST if last else L.CHAIN_B, 192 if last else 288, R, Lq, b["O"], w[p + "chainB"],
+                ln_g=w[p + "cln.g"], ln_b=w[p + "cln.b"], ln_eps=1e-6, film=film0[:, (l * 3 + 1) * 1024:], film_ld=fld,
+                xres=b["xa"], xout=b["xa"], n2_g=w[p + "norm3.g"], n2_b=w[p + "norm3.b"], n2_eps=1e-5, rope=rope,
+                b1=w[p + "ff1.b"], b2=w[p + "ff2.b"], film3=film0[:, (l * 3 + 2) * 1024:], n4_g=w[p + "norm4.g"],
+                n4_b=w[p + "norm4.b"], n4_eps=1e-5, b3=w[p + "l3.b"],
+                nn_g=None if last else w[nn + "g"], nn_b=None if last else w[nn + "b"], nn_eps=1e-5,
+                q_out=None if last else b["Q"], k_out=None if last else b["K"], v_out=None if last else b["V"],
+                h_out=b["h"] if last else None, scale_q=0.125, Lp=self.Lp, H=H)

@@ -1,0 +1,173 @@
+"""Row-block chain kernels (csrc/chain.hip, bf16) against the op-by-op kernels they replace (gemm_rowln / gemm_tile, which
+are held to the reference by tests/test_kernels_gpu.py and tests/test_parity_gpu.py): same MFMA k order, so the GEMM
+accumulators agree bit for bit and only LayerNorm summation order differs (then a bf16 rounding may flip)."""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import tcdiff_oracle as O  # noqa: E402  (synthetic inputs only)
+from tcdiff_amd import _lib as L  # noqa: E402
+from tcdiff_amd import kernels as K  # noqa: E402
+from tcdiff_amd.engine import DenoiserEngine  # noqa: E402
+from tcdiff_amd.model import DanceDecoder  # noqa: E402
+
+DEV = "cuda"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+def model_with(chain: bool, dn, S):
+    os.environ["TCDIFF_CHAIN"] = "1" if chain else "0"
+    try:
+        m = DanceDecoder(nfeats=151, seq_len=S, latent_dim=512, ff_size=1024, num_layers=8, num_heads=8, dropout=0.1,
+                         cond_feature_dim=438, activation=F.gelu, required_dancer_num=dn, compute_dtype="bf16")
+        m.load_state_dict(O.synth_state_dict(dn=dn, seq_len=S))
+        m.to(DEV).eval()
+        m.engine(1)                       # the engine reads the switch when it is built
+        assert m._engines[0].use_chain == chain
+        return m
+    finally:
+        os.environ.pop("TCDIFF_CHAIN", None)
+
+
+@pytest.mark.parametrize("dn,S,B", [(2, 60, 1), (2, 60, 3), (3, 150, 2), (3, 150, 5)])
+def test_chained_network_matches_op_by_op_network(dn, S, B):
+    """whole denoiser, both CFG branches (layer-0 rows shared between the branches, ragged last row block)"""
+    Lq = dn * S
+    cond = torch.stack([O.synth_cond(c, S) for c in range(B)]).to(DEV)
+    x = torch.stack([O.synth_xT(c, Lq) for c in range(B)]).to(DEV)
+    outs = []
+    for chain in (False, True):
+        m = model_with(chain, dn, S)
+        tt = torch.full((B,), 640, dtype=torch.long, device=DEV)
+        g = m.guided_forward(x, cond, tt, 2.0)
+        f = m(x, cond, torch.arange(B, device=DEV) * 37 + 5, cond_drop_prob=0.0)
+        outs.append((g, f))
+    for a, b in zip(*outs):
+        d, mean = float((a - b).abs().max()), float((a - b).abs().mean())
+        print(f"chain vs op-by-op ({dn}x{S}, B={B}): max-abs {d:.2e}, mean-abs {mean:.2e}, |out| max {float(a.abs().max()):.2f}")
+        assert torch.isfinite(b).all()
+        # the two paths agree per kernel to a few flipped bf16 roundings (tests below).  A flipped element of a GEMM
+        # operand moves the whole output row by ~1e-4, which flips ~2 % of the next roundings: within two layers the
+        # two paths' rounding errors are independent, and their distance settles at ~sqrt(2) x the bf16-vs-fp32
+        # deviation of either (max ~2e-2, mean ~2e-3: tests/test_parity_gpu.py), not beyond it.  Measured on MI355X:
+        # max 1.1e-2, mean 2.1e-3.
+        assert d < 3e-2 and mean < 4e-3
+
+
+def test_chain_a_kernel_against_rowln_plus_tile():
+    """chain A alone on random data: x (fp32) and the Q image, incl. a_mod / xres_mod and a ragged tail block"""
+    dt = L.DT_BF16
+    Lq, nseq, H = 120, 3, 8
+    M, Rs = nseq * Lq, 2 * Lq            # rows m and m % Rs share the input / residual rows for m >= Rs? (a_mod semantics)
+    Lp = K.round_up(Lq, 128)
+    Oa = rnd(Rs, 512, seed=1, scale=0.5).to(torch.bfloat16)
+    Wfc = rnd(512, 512, seed=2, scale=512 ** -0.5).to(torch.bfloat16)
+    Wq = rnd(512, 512, seed=3, scale=512 ** -0.5).to(torch.bfloat16)
+    g1, b1 = 1 + 0.1 * rnd(512, seed=4), 0.1 * rnd(512, seed=5)
+    g2, b2 = 1 + 0.1 * rnd(512, seed=6), 0.1 * rnd(512, seed=7)
+    film = 0.3 * rnd(nseq, 2048, seed=8)
+    xres = rnd(Rs, 512, seed=9)
+    freqs = 1.0 / (10000 ** (torch.arange(0, 512, 2).float() / 512))
+    rope = torch.empty(Lq, 512, device=DEV)
+    K.rope_table(freqs.to(DEV), rope, Lq)
+    # op-by-op
+    x1 = torch.zeros(M, 512, device=DEV)
+    rot = torch.zeros(M, 512, device=DEV, dtype=torch.bfloat16)
+    K.gemm_rowln(dt, Oa, Wfc, M, 512, a_mod=Rs, flags=L.ROW_LN_POST | L.ROW_FILM | L.ROW_STORE_X | L.ROW_NEXT_LN | L.ROW_STORE_ROT,
+                 ln_g=g1, ln_b=b1, ln_eps=1e-6, film=film, film_ld=2048, xres=xres, xres_mod=Rs, xout=x1, Lseq=Lq,
+                 nln_g=g2, nln_b=b2, nln_eps=1e-5, rout=rot, rope=rope)
+    Q1 = torch.zeros(nseq, H, Lp, 64, device=DEV, dtype=torch.bfloat16)
+    K.gemm_tile(dt, rot, Wq, M, 512, 512, mode=L.EPI_QKV_HEADS, out=Q1, scale_q=0.125, Lseq=Lq, Lp=Lp, H=H, n_q=512, n_k=0)
+    # chain
+    ws = torch.cat([DenoiserEngine._stages_n512(Wfc), DenoiserEngine._stages_n512(Wq)], 1).contiguous()
+    x2 = torch.zeros(M, 512, device=DEV)
+    Q2 = torch.zeros_like(Q1)
+    K.chain(L.CHAIN_A, 64, M, Lq, Oa, ws, a_mod=Rs, ln_g=g1, ln_b=b1, ln_eps=1e-6, film=film, film_ld=2048, xres=xres,
+            xres_mod=Rs, xout=x2, n2_g=g2, n2_b=b2, n2_eps=1e-5, rope=rope, q_out=Q2, scale_q=0.125, Lp=Lp, H=H)
+    torch.cuda.synchronize()
+    dx = float((x1 - x2).abs().max())
+    dq = float((Q1.float() - Q2.float()).abs().max())
+    print(f"chain A: x max-abs diff {dx:.2e} (|x| max {float(x1.abs().max()):.2f}), Q max-abs diff {dq:.2e}")
+    assert dx < 1e-5
+    assert dq < 2e-2 and float((Q1.float() - Q2.float()).abs().mean()) < 1e-4     # isolated bf16 rounding flips only
+    assert float(Q2[:, :, Lq:].abs().max()) == 0.0                                   # padding rows untouched
+
+
+@pytest.mark.parametrize("last", [False, True])
+def test_chain_b_kernel_against_op_by_op_sequence(last):
+    """chain B alone on random data against gemm_rowln / gemm_tile launched in the engine's op-by-op order"""
+    dt = L.DT_BF16
+    Lq, nseq, H = 120, 3, 8
+    M = nseq * Lq - 7                     # ragged: the last sequence is short and the last block has a tail
+    Lp = K.round_up(Lq, 128)
+    bf = torch.bfloat16
+    Oa = rnd(M, 512, seed=11, scale=0.5).to(bf)
+    W = {n: rnd(*s, seed=20 + i, scale=s[1] ** -0.5).to(bf) for i, (n, s) in enumerate(
+        [("cfc", (512, 512)), ("ff1", (1024, 512)), ("ff2", (512, 1024)), ("l3", (512, 512)), ("qkv", (1536, 512))])}
+    vec = lambda seed, base=0.0, amp=0.1: base + amp * rnd(512, seed=seed)
+    g1, b1, g3, b3n, g4, b4, gn, bn = vec(30, 1), vec(31), vec(32, 1), vec(33), vec(34, 1), vec(35), vec(36, 1), vec(37)
+    bias1, bias2, bias3 = 0.05 * rnd(1024, seed=38), vec(39), vec(40)
+    film = 0.3 * rnd(nseq, 4096, seed=41)
+    xres = rnd(M, 512, seed=42)
+    freqs = 1.0 / (10000 ** (torch.arange(0, 512, 2).float() / 512))
+    rope = torch.empty(Lq, 512, device=DEV)
+    K.rope_table(freqs.to(DEV), rope, Lq)
+    z = lambda *s, dtype=bf: torch.zeros(*s, device=DEV, dtype=dtype)
+    # ---- op-by-op (engine.network order)
+    xa = xres.clone()
+    h, h1, rot = z(M, 512), z(M, 1024), z(M, 512)
+    K.gemm_rowln(dt, Oa, W["cfc"], M, 512, flags=L.ROW_LN_POST | L.ROW_FILM | L.ROW_STORE_X | L.ROW_NEXT_LN | L.ROW_STORE_H,
+                 ln_g=g1, ln_b=b1, ln_eps=1e-6, film=film, film_ld=4096, xres=xa, xout=xa, Lseq=Lq, nln_g=g3, nln_b=b3n,
+                 nln_eps=1e-5, hout=h)
+    K.gemm_tile(dt, h, W["ff1"], M, 1024, 512, bias=bias1, act=L.ACT_GELU, out=h1, ldc=1024)
+    K.gemm_rowln(dt, h1, W["ff2"], M, 1024, flags=L.ROW_BIAS | L.ROW_FILM | L.ROW_NEXT_LN | L.ROW_STORE_H, bias=bias2,
+                 film=film[:, 2048:], film_ld=4096, xres=xa, Lseq=Lq, nln_g=g4, nln_b=b4, nln_eps=1e-5, hout=h)
+    Q1, K1, V1 = z(nseq, H, Lp, 64), z(nseq, H, Lp, 64), z(nseq, H, Lp, 64)
+    hl1 = z(M, 512)
+    if last:
+        K.gemm_rowln(dt, h, W["l3"], M, 512, bias=bias3, Lseq=Lq, flags=L.ROW_BIAS | L.ROW_STORE_H, hout=hl1)
+    else:
+        K.gemm_rowln(dt, h, W["l3"], M, 512, bias=bias3, xout=xa, Lseq=Lq,
+                     flags=L.ROW_BIAS | L.ROW_STORE_X | L.ROW_NEXT_LN | L.ROW_STORE_H | L.ROW_STORE_ROT, nln_g=gn,
+                     nln_b=bn, nln_eps=1e-5, hout=h, rout=rot, rope=rope)
+        K.gemm_tile(dt, rot, W["qkv"], M, 1536, 512, A2=h, split_n=1024, mode=L.EPI_QKV_HEADS, out=Q1, out_k=K1,
+                    out_v=V1, scale_q=0.125, Lseq=Lq, Lp=Lp, H=H, n_q=512, n_k=512)
+    # ---- chain
+    E = DenoiserEngine
+    f1, f2 = E._stages_ff1(W["ff1"]), E._stages_ff2(W["ff2"])
+    parts = [E._stages_n512(W["cfc"])]
+    for c in range(4):
+        parts += [f1[c], f2[c]]
+    parts.append(E._stages_n512(W["l3"]))
+    if not last:
+        parts += [E._stages_n512(W["qkv"][i * 512:(i + 1) * 512]) for i in range(3)]
+    ws = torch.cat(parts, 1).contiguous()
+    xb = xres.clone()
+    Q2, K2, V2, hl2 = z(nseq, H, Lp, 64), z(nseq, H, Lp, 64), z(nseq, H, Lp, 64), z(M, 512)
+    K.chain(L.CHAIN_B_LAST if last else L.CHAIN_B, ws.shape[1], M, Lq, Oa, ws, ln_g=g1, ln_b=b1, ln_eps=1e-6, film=film,
+            film_ld=4096, xres=xb, xout=xb, n2_g=g3, n2_b=b3n, n2_eps=1e-5, rope=rope, b1=bias1, b2=bias2,
+            film3=film[:, 2048:], n4_g=g4, n4_b=b4, n4_eps=1e-5, b3=bias3, nn_g=None if last else gn,
+            nn_b=None if last else bn, nn_eps=1e-5, q_out=None if last else Q2, k_out=None if last else K2,
+            v_out=None if last else V2, h_out=hl2 if last else None, scale_q=0.125, Lp=Lp, H=H)
+    torch.cuda.synchronize()
+    md = lambda a, b: (float((a.float() - b.float()).abs().max()), float((a.float() - b.float()).abs().mean()))
+    if last:
+        d = md(hl1, hl2)
+        print(f"chain B (last): linear3 rows max/mean diff {d[0]:.2e}/{d[1]:.2e} (|h| max {float(hl1.float().abs().max()):.2f})")
+        assert d[0] < 6e-2 and d[1] < 2e-3
+    else:
+        dx = md(xa, xb)
+        print(f"chain B: x' max/mean diff {dx[0]:.2e}/{dx[1]:.2e} (|x| max {float(xa.abs().max()):.2f})")
+        for nm, a, b in (("Q", Q1, Q2), ("K", K1, K2), ("V", V1, V2)):
+            d = md(a, b)
+            print(f"chain B: {nm} image max/mean diff {d[0]:.2e}/{d[1]:.2e} (max |.| {float(a.float().abs().max()):.2f})")
+            assert d[0] < 1e-1 and d[1] < 3e-3
+        assert dx[0] < 6e-2 and dx[1] < 2e-3
