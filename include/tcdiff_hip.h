@@ -121,8 +121,8 @@ int tcdiff_gemm_rowln(int dtype, const void* A, const void* W, int M, int K, int
  *                     replaces model/model.py:103-106,334,338-339,344,399-401 and the next layer's :326,374-383,78-80
  *   TC_CHAIN_B_LAST : the same up to linear3, whose bf16 rows feed the final projection (model/model.py:623)
  * `wstream`: the chain's weights as ONE linear stream per wave in consumption order, [8 waves][n_stages][2048 B]; a
- * stage is the LDS fragment image of the 64 (512-wide GEMMs: [half][64 weight rows][16 B] of one 16-deep k-step) or
- * 32 (linear1 chunk: [k-step 2][half][32 rows][16 B]) weight rows wave w consumes; order: fc (32 stages), then for
+ * stage is the MFMA fragment image of the 64 (512-wide GEMMs: [n-tile 2][half][32 weight rows][16 B] of one 16-deep
+ * k-step) or 32 (linear1 chunk: [k-step 2][half][32 rows][16 B]) weight rows wave w consumes; order: fc (32 stages), then for
  * chain A w_qs (32); for chain B four times {linear1 rows 256c+32w.. (16 stages), linear2 k-slice 256c.. (16)}, then
  * linear3 (32), w_qs, w_ks, w_vs of the NEXT layer (32 each).  n_stages = 64 / 288 / 192.  tcdiff_amd/engine.py packs it.
  * Rows: M token rows, L tokens per sequence; FiLM row = m / L, rotary position = m % L; head-major images as

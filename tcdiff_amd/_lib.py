@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libtcdiff_gfx950.so")
+LIB_PATH = os.environ.get("TCDIFF_LIB_PATH") or os.path.join(HERE, "libtcdiff_gfx950.so")   # override: diagnostic builds
 
 DT_F32, DT_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_MISH, ACT_SILU = 0, 1, 2, 3, 4

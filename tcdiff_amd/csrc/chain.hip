@@ -18,50 +18,65 @@
 //     consecutive columns of ONE row per register quad: LayerNorm statistics are in-register sums + one cross-half
 //     swap + an 8-wave exchange through LDS, and FiLM / residual / rotary / bf16 packing need no transposition.
 //   * the weights of a chain are packed ON THE HOST (engine.py, once per checkpoint) into one linear stream per wave in
-//     consumption order, in 2-KB stages that are already the LDS fragment image ([half][row][16 B]): a stage is two
-//     1-KB global_load_lds pieces, each wave feeds a PRIVATE ring of 4 stages and consumes only what it loaded, so the
-//     GEMM loops have NO workgroup barrier: one counted s_waitcnt vmcnt per stage.  The stream runs ahead across GEMM
-//     and epilogue boundaries (the next GEMM's first stages land during the LayerNorm in front of it).
+//     consumption order, in 2-KB stages that are already the MFMA fragment image ([n-tile][half][row][16 B]).  A wave
+//     consumes only fragments of its OWN columns, so weights never touch LDS: a stage is two coalesced 1-KB global
+//     loads straight into registers, 8 stages (16 KB per wave, 128 KB per CU) are in flight in a register ring whose
+//     slots are compile-time indices, and the GEMM loops have NO workgroup barrier and no hand-written waits.  The
+//     stream runs ahead across GEMM and epilogue boundaries (the next GEMM's first stages land during the LayerNorm in
+//     front of it).  (First version: LDS-DMA into per-wave LDS rings of 4 stages: 36 GB/s per CU, bound by the 48 KB
+//     the LDS budget left in flight against ~1.1 us of loaded L2 latency.)
 //   * activations live in LDS as [k-tile][64 rows][128 B] with the XOR chunk swizzle of common.h (tile_off).
 // Barriers: one pair per LayerNorm (statistics exchange) and one per activation hand-off.
 #include "common.h"
 #include "tcdiff_hip.h"
 
-#define CH_ABUF 0            // 64 KB  activation block [8 k-tiles][64][128 B]
-#define CH_H1C 65536         // 32 KB  GELU(linear1) chunk [4 k-tiles][64][128 B]; epilogue scratch aliases it
-#define CH_RING 98304        // 64 KB  8 private rings of 4 stages
-#define CH_SMEM 163840
-#define CH_NSLOT 4
+// LDS map.  The small constant areas come first so that their reads are `base VGPR + 16-bit immediate`.
+#define CH_FILM 0            //  8 KB  FiLM (scale | shift) rows of the <= 2 sequences this block touches, for the next epilogue
+#define CH_VEC 8192          // 12 KB  six 512-float vectors (LayerNorm weights, biases) of the next epilogue(s)
+#define CH_SCR 20480         //  8 KB  LayerNorm statistics exchange: 2 x [2][8 waves][64 rows] floats
+#define CH_ABUF 28672        // 64 KB  activation block [8 k-tiles][64][128 B]
+#define CH_H1C 94208         // 32 KB  GELU(linear1) chunk [4 k-tiles][64][128 B]
+#define CH_ABUF2 94208       // 64 KB  second activation block (un-rotated norm1 image for V); overlays the dead h1 chunk
+#define CH_SMEM 159744
+#define CH_D 4               // weight stages in flight per wave (registers): 4 x 2 KB x 8 waves = 64 KB per CU (tools/probe: 113 GB/s)
 #define CH_STAGE 2048
 
 typedef const float* fptr;
 
+// A wave's weight stream.  The fragments of a stage are private to the wave (it owns the output columns they produce),
+// so they never need LDS: a stage is two coalesced 1-KB global loads straight into the registers the MFMAs read, and
+// the ring of CH_D stages in flight is a register array indexed at compile time (every loop over it is unrolled).
+// The compiler counts vmcnt for these loads itself.  Past the end of the stream the last stage is re-read (never used).
 struct WStream {
-    const char* src;   // this wave's stream (wave-uniform)
-    char* ring;        // this wave's ring
-    unsigned issued;   // stages issued
-    unsigned cons;     // stages consumed
-    unsigned last;     // index of the last stage of the stream
+    const u32x4* p;    // stream base + lane
+    unsigned pos;      // stages consumed so far (wave-uniform)
+    unsigned last;     // index of the last stage
+    u32x4 a[CH_D], b[CH_D];
 };
-
-// issue the next stage; past the end the last stage is re-read into a slot nobody reads again, which keeps the number
-// of pieces in flight -- and with it the vmcnt arithmetic of ws_wait -- constant to the end of the stream
-DEVINL void ws_issue(WStream& ws, int lane) {
-    const unsigned st = ws.issued < ws.last ? ws.issued : ws.last;
-    const unsigned off = st * CH_STAGE + (unsigned)lane * 16u;
-    char* dst = ws.ring + (ws.issued % CH_NSLOT) * CH_STAGE;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slot's fragment reads have returned
-    glds16(ws.src, off, dst);
-    glds16(ws.src, off + 1024u, dst + 1024);
-    ws.issued++;
+DEVINL void ws_load(WStream& ws, int slot, unsigned stage) {
+    const unsigned st = stage < ws.last ? stage : ws.last;
+    ws.a[slot] = ws.p[st * 128u];
+    ws.b[slot] = ws.p[st * 128u + 64u];
 }
-// the oldest stage in flight has landed: all but the 2 x (CH_NSLOT - 1) youngest vector-memory operations are done
-// (any other younger operation, e.g. an epilogue store, only makes the wait stricter)
-DEVINL const char* ws_wait(const WStream& ws) {
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    return ws.ring + (ws.cons % CH_NSLOT) * CH_STAGE;
-}
+#define CH_MMA(acc, w, a) MmaBF16::mma(acc, w, a)
+#define CH_FRAG(at, row, ch) lds_frag(at, row, ch)
+// IR-level fence for memory operations + machine-scheduler fence for everything: keeps an unrolled epilogue loop one
+// iteration at a time (see the fc epilogue)
+#define CH_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 DEVINL void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Fresh copies of the lane / wave index that the compiler cannot relate to earlier ones: every phase derives its LDS
+// and global addresses from its own copy, so address arithmetic is recomputed per phase (a few VALU ops) instead of
+// being hoisted to the top of the kernel and kept alive across it -- which, with 64 accumulator + 32 ring registers
+// resident, spilled ~150 VGPRs, and every scratch reload in an epilogue is a full memory round trip.
+DEVINL int fresh_v(int x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+DEVINL int fresh_s(int x) {
+    asm volatile("" : "+s"(x));
+    return x;
+}
 
 DEVINL f32x4_t ld4(const float* p) { return *reinterpret_cast<const f32x4_t*>(p); }
 DEVINL void zero(f32x16_t& v) {
@@ -69,50 +84,60 @@ DEVINL void zero(f32x16_t& v) {
     v = z;
 }
 
-// acc[mi][ni] (rows 32 mi + r, columns 64 wave + 32 ni + ..) += act[64 x 16 nst] (k-steps kstep0.. of `abuf`) * W stage
-DEVINL void phase_n512(f32x16_t (&acc)[2][2], const char* abuf, int kstep0, int nst, WStream& ws, int lane) {
+// acc[mi][ni] (rows 32 mi + r, columns 64 wave + 32 ni + ..) += act[64 x 16 nst] (k-steps 0.. of `abuf`) * W stages;
+// a stage = one 16-deep k-step of the wave's 64 weight rows: fragment ni = weight rows 32 ni + r.  nst % CH_D == 0.
+DEVINL void phase_n512(f32x16_t (&acc)[2][2], const char* abuf, int nst, WStream& ws, int lane) {
+    lane = fresh_v(lane);
     const int r = lane & 31, h = lane >> 5;
-#pragma unroll 2
-    for (int s = 0; s < nst; ++s) {
-        const char* slot = ws_wait(ws);
-        const int ks = kstep0 + s;
-        const char* at = abuf + (ks >> 2) * 8192;
-        const int ch = 2 * (ks & 3) + h;
-        const u32x4 a0 = lds_frag(at, r, ch), a1 = lds_frag(at, 32 + r, ch);
-        const u32x4 w0 = *reinterpret_cast<const u32x4*>(slot + h * 1024 + r * 16);
-        const u32x4 w1 = *reinterpret_cast<const u32x4*>(slot + h * 1024 + (32 + r) * 16);
-        MmaBF16::mma(acc[0][0], w0, a0);
-        MmaBF16::mma(acc[0][1], w1, a0);
-        MmaBF16::mma(acc[1][0], w0, a1);
-        MmaBF16::mma(acc[1][1], w1, a1);
-        ws_issue(ws, lane);
-        ws.cons++;
-    }
-}
-// linear1 chunk: acc[mi] (columns 32 wave + ..) += act[64 x 512] * W1 chunk; a stage = 2 k-steps of 32 weight rows
-DEVINL void phase_ff1(f32x16_t (&acc)[2], const char* abuf, WStream& ws, int lane) {
-    const int r = lane & 31, h = lane >> 5;
-#pragma unroll 2
-    for (int s = 0; s < 16; ++s) {
-        const char* slot = ws_wait(ws);
+#pragma unroll 1
+    for (int s0 = 0; s0 < nst; s0 += CH_D) {
 #pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2) {
-            const int ks = 2 * s + k2;
+        for (int i = 0; i < CH_D; ++i) {
+            const u32x4 w0 = ws.a[i], w1 = ws.b[i];
+            ws_load(ws, i, ws.pos + CH_D);
+            ws.pos++;
+            const int ks = s0 + i;
             const char* at = abuf + (ks >> 2) * 8192;
             const int ch = 2 * (ks & 3) + h;
-            const u32x4 a0 = lds_frag(at, r, ch), a1 = lds_frag(at, 32 + r, ch);
-            const u32x4 w = *reinterpret_cast<const u32x4*>(slot + k2 * 1024 + h * 512 + r * 16);
-            MmaBF16::mma(acc[0], w, a0);
-            MmaBF16::mma(acc[1], w, a1);
+            const u32x4 a0 = CH_FRAG(at, r, ch), a1 = CH_FRAG(at, 32 + r, ch);
+            CH_MMA(acc[0][0], w0, a0);
+            CH_MMA(acc[0][1], w1, a0);
+            CH_MMA(acc[1][0], w0, a1);
+            CH_MMA(acc[1][1], w1, a1);
+            asm volatile("" ::: "memory");   // keep the refill in its own iteration: the stream must never drain
         }
-        ws_issue(ws, lane);
-        ws.cons++;
+    }
+}
+// linear1 chunk: acc[mi] (columns 32 wave + ..) += act[64 x 512] * W1 chunk; a stage = 2 k-steps of the wave's 32 rows
+DEVINL void phase_ff1(f32x16_t (&acc)[2], const char* abuf, WStream& ws, int lane) {
+    lane = fresh_v(lane);
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll 1
+    for (int s0 = 0; s0 < 16; s0 += CH_D) {
+#pragma unroll
+        for (int i = 0; i < CH_D; ++i) {
+            const u32x4 wk[2] = {ws.a[i], ws.b[i]};
+            ws_load(ws, i, ws.pos + CH_D);
+            ws.pos++;
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                const int ks = 2 * (s0 + i) + k2;
+                const char* at = abuf + (ks >> 2) * 8192;
+                const int ch = 2 * (ks & 3) + h;
+                const u32x4 a0 = CH_FRAG(at, r, ch), a1 = CH_FRAG(at, 32 + r, ch);
+                CH_MMA(acc[0], wk[k2], a0);
+                CH_MMA(acc[1], wk[k2], a1);
+            }
+            asm volatile("" ::: "memory");
+        }
     }
 }
 
 // LayerNorm statistics of the 64 rows over all 512 columns (two-pass, fp32): this lane's rows are 32 mi + r
 DEVINL void row_stats(const f32x16_t (&acc)[2][2], float* scr, int wave, int lane, float eps, float (&mean)[2],
                       float (&rstd)[2]) {
+    lane = fresh_v(lane);
+    wave = fresh_s(wave);
     const int r = lane & 31;
     float s[2];
 #pragma unroll
@@ -162,48 +187,73 @@ DEVINL void row_stats(const f32x16_t (&acc)[2][2], float* scr, int wave, int lan
     }
 }
 
-// u = LayerNorm(acc) (optionally rotated) -> bf16 -> activation block in LDS (k = column)
+// constants of an epilogue come from LDS (staged by stage_consts): no long-latency loads, no long-lived registers
+DEVINL f32x4_t lds4(const char* base, int float_index) {
+    return *reinterpret_cast<const f32x4_t*>(base + float_index * 4);
+}
+
+// This lane's two rows of a [*, 512] fp32 matrix (residual stream, rotary table), 8 column groups each: a register
+// pipeline 4 groups deep (32 VGPRs; all 16 float4 at once would not fit beside accumulators and weight ring).
+struct RowPipe {
+    const float* p[2];     // row base + this lane's first column
+    f32x4_t q[4][2];       // [group & 3][row tile]
+};
+DEVINL void rp_issue(RowPipe& rp, int it) {
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) rp.q[it & 3][mi] = ld4(rp.p[mi] + 32 * (it >> 2) + 8 * (it & 3));
+}
+DEVINL void rp_start(RowPipe& rp, const float* base, const int (&row)[2], int wave, int h) {
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) rp.p[mi] = base + (long)row[mi] * 512 + 64 * wave + 4 * h;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) rp_issue(rp, it);
+}
+
+// u = LayerNorm(acc) (optionally rotated) -> bf16 -> activation block in LDS (k = column); g, b: LDS vectors;
+// rp: the rotary rows (cos0 sin0 cos1 sin1 per column quad), started by the caller before the statistics exchange
 template <bool ROT>
-DEVINL void norm_to_lds(const f32x16_t (&acc)[2][2], const float (&mean)[2], const float (&rstd)[2], fptr g, fptr b,
-                        fptr rope, int L, int m0, int M, char* abuf, int wave, int lane, uint2 (*keep)[2][4]) {
+DEVINL void norm_to_lds(const f32x16_t (&acc)[2][2], const float (&mean)[2], const float (&rstd)[2], const char* g,
+                        const char* b, RowPipe& rp, char* abuf, int wave, int lane, char* plain) {
+    lane = fresh_v(lane);
+    wave = fresh_s(wave);
     const int r = lane & 31, h = lane >> 5;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-        int m = m0 + 32 * mi + r;
-        m = m < M ? m : M - 1;
-        const int pos = m % L;
+    for (int it = 0; it < 8; ++it) {
+        const int ni = it >> 2, gq = it & 3;
+        const int n = 64 * wave + 32 * ni + 8 * gq + 4 * h;
+        const f32x4_t g4 = lds4(g, n), b4 = lds4(b, n);
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int mi = 0; mi < 2; ++mi) {
+            float u[4];
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const int n = 64 * wave + 32 * ni + 8 * gq + 4 * h;
-                const f32x4_t g4 = ld4(g + n), b4 = ld4(b + n);
-                float u[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) u[t] = (acc[mi][ni][4 * gq + t] - mean[mi]) * rstd[mi] * g4[t] + b4[t];
-                if (keep) {   // the un-rotated image is needed later (V = norm1(x) W_v): keep it packed in registers
-                    uint2 pk;
-                    pk.x = pack_bf2(u[0], u[1]);
-                    pk.y = pack_bf2(u[2], u[3]);
-                    keep[mi][ni][gq] = pk;
-                }
-                if (ROT) {
-                    const f32x4_t cs = ld4(rope + (long)pos * 512 + n);   // cos0 sin0 cos1 sin1
-                    const float y0 = u[0] * cs[0] - u[1] * cs[1], y1 = u[1] * cs[0] + u[0] * cs[1];
-                    const float y2 = u[2] * cs[2] - u[3] * cs[3], y3 = u[3] * cs[2] + u[2] * cs[3];
-                    u[0] = y0; u[1] = y1; u[2] = y2; u[3] = y3;
-                }
+            for (int t = 0; t < 4; ++t) u[t] = (acc[mi][ni][4 * gq + t] - mean[mi]) * rstd[mi] * g4[t] + b4[t];
+            if (plain) {   // the un-rotated image too (V = norm1(x) W_v)
                 uint2 pk;
                 pk.x = pack_bf2(u[0], u[1]);
                 pk.y = pack_bf2(u[2], u[3]);
-                *reinterpret_cast<uint2*>(abuf + wave * 8192 + tile_off(32 * mi + r, 4 * ni + gq) + 8 * h) = pk;
+                *reinterpret_cast<uint2*>(plain + wave * 8192 + tile_off(32 * mi + r, 4 * ni + gq) + 8 * h) = pk;
             }
+            if (ROT) {
+                const f32x4_t q = rp.q[it & 3][mi];   // cos0 sin0 cos1 sin1
+                const float y0 = u[0] * q[0] - u[1] * q[1], y1 = u[1] * q[0] + u[0] * q[1];
+                const float y2 = u[2] * q[2] - u[3] * q[3], y3 = u[3] * q[2] + u[2] * q[3];
+                u[0] = y0; u[1] = y1; u[2] = y2; u[3] = y3;
+            }
+            uint2 pk;
+            pk.x = pack_bf2(u[0], u[1]);
+            pk.y = pack_bf2(u[2], u[3]);
+            *reinterpret_cast<uint2*>(abuf + wave * 8192 + tile_off(32 * mi + r, 4 * ni + gq) + 8 * h) = pk;
+        }
+        if (ROT && it + 4 < 8) rp_issue(rp, it + 4);
+        CH_FENCE();   // one column group at a time (see the fc epilogue)
     }
 }
 
 // head-major scatter of a 512-wide projection (wave = head): model/model.py:78-80,92-95
 DEVINL void store_heads(const f32x16_t (&acc)[2][2], void* base, float scale, int L, int Lp, int H, int m0, int M,
                         int wave, int lane) {
+    lane = fresh_v(lane);
+    wave = fresh_s(wave);
     const int r = lane & 31, h = lane >> 5;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
@@ -223,6 +273,13 @@ DEVINL void store_heads(const f32x16_t (&acc)[2][2], void* base, float scale, in
     }
 }
 
+#ifdef CH_STAMP   // diagnostic build: per-phase timestamps of block 0 / wave 0 into the (otherwise unused) h_out buffer
+#define CH_T(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && MODE == TC_CHAIN_B) \
+        reinterpret_cast<unsigned long long*>(a.h_out)[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define CH_T(i) do { } while (0)
+#endif
+
 template <int MODE>
 __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -230,27 +287,67 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int m0 = xcd_remap(blockIdx.x, gridDim.x) * 64;
+    CH_T(0);
     const int M = a.M, L = a.L;
     char* abuf = smem + CH_ABUF;
     char* h1c = smem + CH_H1C;
-    float* scr = reinterpret_cast<float*>(smem + CH_H1C);
+    float* scr = reinterpret_cast<float*>(smem + CH_SCR);
+    char* cfilm = smem + CH_FILM;      // [2 sequences][scale 512 | shift 512] floats
+    char* cvec = smem + CH_VEC;        // six vectors of 512 floats
 
-    WStream ws;
-    ws.src = reinterpret_cast<const char*>(a.wstream) + (long)wave * a.n_stages * CH_STAGE;
-    ws.ring = smem + CH_RING + wave * (CH_NSLOT * CH_STAGE);
-    ws.issued = 0;
-    ws.cons = 0;
-    ws.last = (unsigned)a.n_stages - 1;
-
-    // ---- the block's input rows (attention output) -> LDS, then the first weight stages
+    // rows of this lane (both row tiles), clamped: rows past M recompute row M - 1 and are never stored
+    int mc[2], sidx[2];
+    bool ok[2];
+    const int seq0 = (m0 < M ? m0 : M - 1) / L;
+    const int seq_last = (M - 1) / L;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int m = m0 + 32 * mi + r;
+        ok[mi] = m < M;
+        mc[mi] = ok[mi] ? m : M - 1;
+        sidx[mi] = mc[mi] / L - seq0;          // 0 or 1: L >= 64 rows per sequence (checked by the launcher)
+    }
+    // Epilogue constants go through LDS.  Thread t carries one float4 of the FiLM rows and up to two of the vectors
+    // from global memory to LDS; they are fetched early (latency hidden behind a GEMM) and stored once the previous
+    // epilogue no longer reads the area.
+    struct Consts { f32x4_t f, v0, v1; };
+    auto fetch_consts = [&](const float* film, const float* const (&vec)[6]) {
+        Consts k;
+        int sq = seq0 + (tid >> 8);
+        sq = sq < seq_last ? sq : seq_last;
+        k.f = film ? ld4(film + (long)sq * a.film_ld + (tid & 255) * 4) : f32x4_t{0, 0, 0, 0};
+        const float* p0 = vec[tid >> 7];
+        const float* p1 = tid < 256 ? vec[4 + (tid >> 7)] : nullptr;
+        k.v0 = p0 ? ld4(p0 + (tid & 127) * 4) : f32x4_t{0, 0, 0, 0};
+        k.v1 = p1 ? ld4(p1 + (tid & 127) * 4) : f32x4_t{0, 0, 0, 0};
+        return k;
+    };
+    auto store_consts = [&](const Consts& k) {
+        *reinterpret_cast<f32x4_t*>(cfilm + tid * 16) = k.f;
+        *reinterpret_cast<f32x4_t*>(cvec + tid * 16) = k.v0;
+        if (tid < 256) *reinterpret_cast<f32x4_t*>(cvec + 8192 + tid * 16) = k.v1;
+    };
+    auto vecp = [&](int slot) { return cvec + slot * 2048; };
+    // ---- the block's input rows (attention output) -> LDS, the first CH_D weight stages -> registers, constants -> LDS
 #pragma unroll
     for (int kt = 0; kt < 8; ++kt)
         stage_glds<64, 8>(abuf + kt * 8192, reinterpret_cast<const char*>(a.A) + kt * TC_ROWB, 1024, m0, M, a.a_mod, wave,
                           lane);
+    WStream ws;
+    ws.p = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(a.wstream) + (long)wave * a.n_stages * CH_STAGE) + lane;
+    ws.pos = 0;
+    ws.last = (unsigned)a.n_stages - 1;
 #pragma unroll
-    for (int i = 0; i < CH_NSLOT; ++i) ws_issue(ws, lane);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // the 8 activation pieces are older than the 8 weight pieces
-    lds_barrier();
+    for (int i = 0; i < CH_D; ++i) ws_load(ws, i, (unsigned)i);
+    {
+        const float* const v[6] = {a.ln_g, a.ln_b, a.n2_g, a.n2_b, nullptr, nullptr};
+        store_consts(fetch_consts(a.film, v));
+    }
+    // a wait the compiler can SEE (an asm s_waitcnt is invisible to its vmcnt bookkeeping: it would then treat the
+    // prologue loads as still pending at the loop header and wait vmcnt(0) on every trip): vmcnt(0), others untouched
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    CH_T(1);
 
     f32x16_t acc[2][2];
     auto clear = [&]() {
@@ -260,53 +357,71 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
             for (int ni = 0; ni < 2; ++ni) zero(acc[mi][ni]);
     };
     float mean[2], rstd[2];
+    RowPipe rp;                        // residual rows, later rotary rows, of this lane
+    int pos[2] = {mc[0] % L, mc[1] % L};
 
     // ================= fc: LayerNorm(1e-6), FiLM, residual (model/model.py:103-106,171-173,327 / 334)
     clear();
-    phase_n512(acc, abuf, 0, 32, ws, lane);
-    lds_barrier();                     // every wave is out of the GEMM: scratch (and later the activation block) are free
+    phase_n512(acc, abuf, 32, ws, lane);
+    CH_T(2);
+    {
+        int rr[2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) rr[mi] = a.xres_mod > 0 ? mc[mi] % a.xres_mod : mc[mi];
+        rp_start(rp, a.xres, rr, wave, h);   // in flight during the statistics exchange
+    }
+    lds_barrier();                     // every wave is out of the GEMM: the activation block may be overwritten
     row_stats(acc, scr, wave, lane, a.ln_eps, mean, rstd);
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-        const int m = m0 + 32 * mi + r;
-        const int mc = m < M ? m : M - 1;
-        const int mr = a.xres_mod > 0 ? mc % a.xres_mod : mc;
-        const float* fp = a.film + (long)(mc / L) * a.film_ld;
-        const float* xr = a.xres + (long)mr * 512;
-        float* xo = a.xout + (long)mc * 512;
+    for (int it = 0; it < 8; ++it) {
+        const int ni = it >> 2, gq = it & 3;
+        const int n = 64 * wave + 32 * ni + 8 * gq + 4 * h;
+        const f32x4_t g4 = lds4(vecp(0), n), b4 = lds4(vecp(1), n);
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int mi = 0; mi < 2; ++mi) {
+            const f32x4_t sc = lds4(cfilm, sidx[mi] * 1024 + n), sh = lds4(cfilm, sidx[mi] * 1024 + 512 + n);
+            const f32x4_t x4 = rp.q[it & 3][mi];
+            f32x4_t o;
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const int n = 64 * wave + 32 * ni + 8 * gq + 4 * h;
-                const f32x4_t g4 = ld4(a.ln_g + n), b4 = ld4(a.ln_b + n), sc = ld4(fp + n), sh = ld4(fp + 512 + n);
-                const f32x4_t x4 = ld4(xr + n);
-                f32x4_t o;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    float v = (acc[mi][ni][4 * gq + t] - mean[mi]) * rstd[mi] * g4[t] + b4[t];
-                    v = (sc[t] + 1.0f) * v + sh[t];
-                    v = x4[t] + v;
-                    acc[mi][ni][4 * gq + t] = v;
-                    o[t] = v;
-                }
-                if (m < M) *reinterpret_cast<f32x4_t*>(xo + n) = o;
+            for (int t = 0; t < 4; ++t) {
+                float v = (acc[mi][ni][4 * gq + t] - mean[mi]) * rstd[mi] * g4[t] + b4[t];
+                v = (sc[t] + 1.0f) * v + sh[t];
+                v = x4[t] + v;
+                acc[mi][ni][4 * gq + t] = v;
+                o[t] = v;
             }
+            // unguarded: rows past M rewrite row M - 1 with the SAME values (same inputs; every load of this column
+            // group, in place or not, was issued before this store)
+            *reinterpret_cast<f32x4_t*>(a.xout + (long)mc[mi] * 512 + n) = o;
+        }
+        if (it + 4 < 8) rp_issue(rp, it + 4);
+        // one column group at a time: without a scheduling barrier hipcc hoists the loads of ALL eight groups (row
+        // pipeline refills and LDS constants) above the arithmetic, needs ~100 more registers and spills them
+        CH_FENCE();
     }
+    CH_T(3);
+    if (MODE == TC_CHAIN_A) rp_start(rp, a.rope, pos, wave, h);
     row_stats(acc, scr + 1024, wave, lane, a.n2_eps, mean, rstd);
+    CH_T(4);
     if (MODE == TC_CHAIN_A) {
         // norm2 + rotary (model/model.py:332,387) -> LDS -> Q = rot W_q^T / 8 (model/model.py:78,97)
-        norm_to_lds<true>(acc, mean, rstd, a.n2_g, a.n2_b, a.rope, L, m0, M, abuf, wave, lane, nullptr);
+        norm_to_lds<true>(acc, mean, rstd, vecp(2), vecp(3), rp, abuf, wave, lane, nullptr);
         lds_barrier();
         clear();
-        phase_n512(acc, abuf, 0, 32, ws, lane);
+        phase_n512(acc, abuf, 32, ws, lane);
         store_heads(acc, a.q_out, a.scale_q, L, a.Lp, a.H, m0, M, wave, lane);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         return;
     }
     // ================= feed-forward (model/model.py:338-339,399-401): norm3 -> LDS
-    norm_to_lds<false>(acc, mean, rstd, a.n2_g, a.n2_b, nullptr, L, m0, M, abuf, wave, lane, nullptr);
-    lds_barrier();
+    Consts nxt;
+    {
+        const float* const v[6] = {a.b1, a.b1 + 512, a.b2, a.n4_g, a.n4_b, nullptr};
+        nxt = fetch_consts(a.film3, v);
+    }
+    norm_to_lds<false>(acc, mean, rstd, vecp(2), vecp(3), rp, abuf, wave, lane, nullptr);
+    lds_barrier();                     // nobody reads the fc constants any more
+    store_consts(nxt);                 // visible to everybody after the next barrier (in front of the first GELU)
+    CH_T(5);
     clear();   // acc = linear2 accumulator
 #pragma unroll 1
     for (int c = 0; c < 4; ++c) {
@@ -314,14 +429,16 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
         zero(a1[0]);
         zero(a1[1]);
         phase_ff1(a1, abuf, ws, lane);
-        lds_barrier();                 // the previous chunk's linear2 reads of h1c (and the scratch reads) are done
+        CH_T(6 + 4 * c);
+        lds_barrier();                 // the previous chunk's linear2 reads of h1c are done
+        CH_T(7 + 4 * c);
         {
             const int nb = 256 * c + 32 * wave;
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int gq = 0; gq < 4; ++gq) {
+                const f32x4_t b4 = lds4(cvec, nb + 8 * gq + 4 * h);      // b1 occupies vector slots 0 and 1
 #pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    const f32x4_t b4 = ld4(a.b1 + nb + 8 * gq + 4 * h);
+                for (int mi = 0; mi < 2; ++mi) {
                     float v[4];
 #pragma unroll
                     for (int t = 0; t < 4; ++t) v[t] = a1[mi][4 * gq + t] + b4[t];
@@ -333,102 +450,110 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
                     *reinterpret_cast<uint2*>(h1c + (wave >> 1) * 8192 + tile_off(32 * mi + r, 4 * (wave & 1) + gq) +
                                               8 * h) = pk;
                 }
+            }
         }
         lds_barrier();
-        phase_n512(acc, h1c, 0, 16, ws, lane);
+        CH_T(8 + 4 * c);
+        phase_n512(acc, h1c, 16, ws, lane);
+        CH_T(9 + 4 * c);
     }
-    lds_barrier();                     // h1c is free: scratch
     // linear2 bias, FiLM, residual (the x this lane stored above), norm4 -> LDS
+    rp_start(rp, a.xout, mc, wave, h);
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-        const int m = m0 + 32 * mi + r;
-        const int mc = m < M ? m : M - 1;
-        const float* fp = a.film3 + (long)(mc / L) * a.film_ld;
-        const float* xr = a.xout + (long)mc * 512;
+    for (int it = 0; it < 8; ++it) {
+        const int ni = it >> 2, gq = it & 3;
+        const int n = 64 * wave + 32 * ni + 8 * gq + 4 * h;
+        const f32x4_t b4 = lds4(vecp(2), n);
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int mi = 0; mi < 2; ++mi) {
+            const f32x4_t sc = lds4(cfilm, sidx[mi] * 1024 + n), sh = lds4(cfilm, sidx[mi] * 1024 + 512 + n);
+            const f32x4_t x4 = rp.q[it & 3][mi];
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const int n = 64 * wave + 32 * ni + 8 * gq + 4 * h;
-                const f32x4_t b4 = ld4(a.b2 + n), sc = ld4(fp + n), sh = ld4(fp + 512 + n), x4 = ld4(xr + n);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    float v = acc[mi][ni][4 * gq + t] + b4[t];
-                    v = (sc[t] + 1.0f) * v + sh[t];
-                    acc[mi][ni][4 * gq + t] = x4[t] + v;
-                }
+            for (int t = 0; t < 4; ++t) {
+                float v = acc[mi][ni][4 * gq + t] + b4[t];
+                v = (sc[t] + 1.0f) * v + sh[t];
+                acc[mi][ni][4 * gq + t] = x4[t] + v;
             }
+            // nothing in this iteration touches memory after its loads, so the arithmetic is free to sink below the
+            // loads of all later iterations (whose operands then all have to be kept): pin it to this iteration
+            asm volatile("" ::"v"(acc[mi][ni][4 * gq + 0]), "v"(acc[mi][ni][4 * gq + 1]), "v"(acc[mi][ni][4 * gq + 2]),
+                         "v"(acc[mi][ni][4 * gq + 3]));
+        }
+        if (it + 4 < 8) rp_issue(rp, it + 4);
+        CH_FENCE();
     }
+    CH_T(22);
+    {
+        const float* const v[6] = {a.b3, a.nn_g, a.nn_b, nullptr, nullptr, nullptr};
+        nxt = fetch_consts(nullptr, v);
+    }
+    lds_barrier();                     // every wave is out of the last linear2 chunk (and of its constants' first use)
     row_stats(acc, scr, wave, lane, a.n4_eps, mean, rstd);
-    norm_to_lds<false>(acc, mean, rstd, a.n4_g, a.n4_b, nullptr, L, m0, M, abuf, wave, lane, nullptr);
+    CH_T(23);
+    norm_to_lds<false>(acc, mean, rstd, vecp(3), vecp(4), rp, abuf, wave, lane, nullptr);
     lds_barrier();
+    store_consts(nxt);                 // b3, norm1': read after the barrier that follows linear3
     // ================= x' = linear3(norm4(x)) + b3, no residual (model/model.py:344)
+    CH_T(24);
     clear();
-    phase_n512(acc, abuf, 0, 32, ws, lane);
+    phase_n512(acc, abuf, 32, ws, lane);
+    CH_T(25);
     lds_barrier();
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-        const int m = m0 + 32 * mi + r;
-        const int mc = m < M ? m : M - 1;
+    for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int gq = 0; gq < 4; ++gq) {
+            const int n = 64 * wave + 32 * ni + 8 * gq + 4 * h;
+            const f32x4_t b4 = lds4(vecp(0), n);
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const int n = 64 * wave + 32 * ni + 8 * gq + 4 * h;
-                const f32x4_t b4 = ld4(a.b3 + n);
+            for (int mi = 0; mi < 2; ++mi) {
                 f32x4_t o;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     acc[mi][ni][4 * gq + t] += b4[t];
                     o[t] = acc[mi][ni][4 * gq + t];
                 }
-                if (m < M) {
-                    if (MODE == TC_CHAIN_B_LAST) {   // the final projection reads bf16 rows (model/model.py:623)
-                        uint2 pk;
-                        pk.x = pack_bf2(o[0], o[1]);
-                        pk.y = pack_bf2(o[2], o[3]);
-                        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.h_out) + (long)mc * 512 + n) = pk;
-                    } else {
-                        *reinterpret_cast<f32x4_t*>(a.xout + (long)mc * 512 + n) = o;
-                    }
+                if (MODE == TC_CHAIN_B_LAST) {   // the final projection reads bf16 rows (model/model.py:623)
+                    uint2 pk;
+                    pk.x = pack_bf2(o[0], o[1]);
+                    pk.y = pack_bf2(o[2], o[3]);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.h_out) + (long)mc[mi] * 512 + n) = pk;
+                } else {
+                    *reinterpret_cast<f32x4_t*>(a.xout + (long)mc[mi] * 512 + n) = o;
                 }
             }
-    }
-    if (MODE == TC_CHAIN_B_LAST) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        return;
-    }
+            CH_FENCE();
+        }
+    if (MODE == TC_CHAIN_B_LAST) return;
     // ================= next layer: norm1 + rotary -> Q, K ; norm1 -> V (model/model.py:326,374-383,78-80)
+    CH_T(26);
+    rp_start(rp, a.rope, pos, wave, h);
     row_stats(acc, scr, wave, lane, a.nn_eps, mean, rstd);
-    uint2 keep[2][2][4];
-    norm_to_lds<true>(acc, mean, rstd, a.nn_g, a.nn_b, a.rope, L, m0, M, abuf, wave, lane, keep);
+    CH_T(27);
+    norm_to_lds<true>(acc, mean, rstd, vecp(1), vecp(2), rp, abuf, wave, lane, smem + CH_ABUF2);
     lds_barrier();
+    CH_T(28);
     clear();
-    phase_n512(acc, abuf, 0, 32, ws, lane);
+    phase_n512(acc, abuf, 32, ws, lane);
+    CH_T(29);
     store_heads(acc, a.q_out, a.scale_q, L, a.Lp, a.H, m0, M, wave, lane);
     clear();
-    phase_n512(acc, abuf, 0, 32, ws, lane);
+    phase_n512(acc, abuf, 32, ws, lane);
+    CH_T(30);
     store_heads(acc, a.k_out, 1.0f, L, a.Lp, a.H, m0, M, wave, lane);
-    lds_barrier();                     // every wave is done with the rotated image
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq)
-                *reinterpret_cast<uint2*>(abuf + wave * 8192 + tile_off(32 * mi + r, 4 * ni + gq) + 8 * h) =
-                    keep[mi][ni][gq];
-    lds_barrier();
+    CH_T(31);
     clear();
-    phase_n512(acc, abuf, 0, 32, ws, lane);
+    phase_n512(acc, smem + CH_ABUF2, 32, ws, lane);
+    CH_T(32);
     store_heads(acc, a.v_out, 1.0f, L, a.Lp, a.H, m0, M, wave, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    CH_T(33);
 }
 
 static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 extern "C" int tcdiff_chain(const tcdiff_chain_args* a, hipStream_t stream) {
     if (!a || a->M <= 0 || a->L <= 0 || !a->A || !a->wstream) return TC_ERR_ARG;
+    if (a->L < 64) return TC_ERR_UNSUPPORTED;   // a 64-row block must touch at most two sequences
     const int want = a->mode == TC_CHAIN_A ? 64 : (a->mode == TC_CHAIN_B ? 288 : (a->mode == TC_CHAIN_B_LAST ? 192 : -1));
     if (want < 0 || a->n_stages != want) return TC_ERR_ARG;
     if (!a->ln_g || !a->ln_b || !a->film || a->film_ld % 4 || !a->xres || !a->xout || !a->n2_g || !a->n2_b) return TC_ERR_ARG;

@@ -164,7 +164,9 @@ class GaussianDiffusion(nn.Module):
     # Every kernel of the step alternates between a DMA/MFMA-bound main loop and an HBM-bound epilogue; two
     # independent half-size launch chains let one half's memory-bound phases overlap the other's compute phases.
     # Clips are independent (and the noise is keyed by the global clip index), so the samples are bit-identical.
-    dual_stream = os.environ.get("TCDIFF_DUAL", "1") != "0"
+    # Default OFF since the row-block chain kernels (one workgroup per CU for a whole 16-clip launch): 9.2 clips/s single
+    # stream against 9.06 with two half-batch streams (profiles/README.md); the op-by-op f32 mode still gains ~4 % from it.
+    dual_stream = os.environ.get("TCDIFF_DUAL", "0") != "0"
     dual_parts = int(os.environ.get("TCDIFF_DUAL_PARTS", "2"))
     dual_skew_us = float(os.environ.get("TCDIFF_DUAL_SKEW_US", "40"))   # < 0: lock-step halves inside one graph
 

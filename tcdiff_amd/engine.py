@@ -94,9 +94,10 @@ class DenoiserEngine:
     # ---- weight streams of the chain kernels (include/tcdiff_hip.h, tcdiff_chain_args.wstream) -------------------
     @staticmethod
     def _stages_n512(W: torch.Tensor) -> torch.Tensor:
-        """[512, K] -> [8 waves][K/16 stages][1024]: stage = [half][64 weight rows][8 k] of one 16-deep k-step."""
+        """[512, K] -> [8 waves][K/16 stages][1024]: stage = [n-tile 2][half][32 weight rows][8 k] of one 16-deep k-step
+        (the order in which the 64 lanes of the wave's two 1-KB loads pick up their MFMA fragments)."""
         K_ = W.shape[1]
-        return W.reshape(8, 64, K_ // 16, 2, 8).permute(0, 2, 3, 1, 4).reshape(8, K_ // 16, 1024)
+        return W.reshape(8, 2, 32, K_ // 16, 2, 8).permute(0, 3, 1, 4, 2, 5).reshape(8, K_ // 16, 1024)
 
     @staticmethod
     def _stages_ff1(W1: torch.Tensor) -> torch.Tensor:
@@ -106,7 +107,7 @@ class DenoiserEngine:
     @staticmethod
     def _stages_ff2(W2: torch.Tensor) -> torch.Tensor:
         """[512, 1024] -> [4 chunks][8 waves][16 stages][1024]: the k-slice [256 c, 256 c + 256) of every row."""
-        return W2.reshape(8, 64, 4, 16, 2, 8).permute(2, 0, 3, 4, 1, 5).reshape(4, 8, 16, 1024)
+        return W2.reshape(8, 2, 32, 4, 16, 2, 8).permute(3, 0, 4, 1, 5, 2, 6).reshape(4, 8, 16, 1024)
 
     def _build_chain_streams(self):
         w = self.w
