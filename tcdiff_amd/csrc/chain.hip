@@ -38,7 +38,9 @@
 #define CH_H1C 94208         // 32 KB  GELU(linear1) chunk [4 k-tiles][64][128 B]
 #define CH_ABUF2 94208       // 64 KB  second activation block (un-rotated norm1 image for V); overlays the dead h1 chunk
 #define CH_SMEM 159744
-#define CH_D 4               // weight stages in flight per wave (registers): 4 x 2 KB x 8 waves = 64 KB per CU (tools/probe: 113 GB/s)
+#ifndef CH_D
+#define CH_D 8               // weight stages in flight per wave (registers): 8 x 2 KB x 8 waves = 128 KB per CU
+#endif
 #define CH_STAGE 2048
 
 typedef const float* fptr;
@@ -133,57 +135,46 @@ DEVINL void phase_ff1(f32x16_t (&acc)[2], const char* abuf, WStream& ws, int lan
     }
 }
 
-// LayerNorm statistics of the 64 rows over all 512 columns (two-pass, fp32): this lane's rows are 32 mi + r
+// LayerNorm statistics of the 64 rows over all 512 columns: this lane's rows are 32 mi + r.  One exchange: every wave
+// publishes (sum, sum of squares) of its 64 columns, var = E[v^2] - mean^2 in fp32 (|mean| is of the order of the
+// standard deviation for these activations: the cancellation costs ~1e-7 relative, far below the bf16 operands).
 DEVINL void row_stats(const f32x16_t (&acc)[2][2], float* scr, int wave, int lane, float eps, float (&mean)[2],
                       float (&rstd)[2]) {
     lane = fresh_v(lane);
     wave = fresh_s(wave);
     const int r = lane & 31;
-    float s[2];
+    float s[2], s2[2];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
-        float t = 0.0f;
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) t += acc[mi][ni][q];
-        s[mi] = t + other_half(t);
-    }
-    if (lane < 32) {
-        scr[wave * 64 + r] = s[0];
-        scr[wave * 64 + 32 + r] = s[1];
-    }
-    lds_barrier();
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-        float t = 0.0f;
-#pragma unroll
-        for (int w = 0; w < 8; ++w) t += scr[w * 64 + 32 * mi + r];
-        mean[mi] = t * (1.0f / 512.0f);
-    }
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-        float t = 0.0f;
+        float t = 0.0f, t2 = 0.0f;
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                const float d = acc[mi][ni][q] - mean[mi];
-                t += d * d;
+                t += acc[mi][ni][q];
+                t2 = fmaf(acc[mi][ni][q], acc[mi][ni][q], t2);
             }
         s[mi] = t + other_half(t);
+        s2[mi] = t2 + other_half(t2);
     }
     if (lane < 32) {
-        scr[512 + wave * 64 + r] = s[0];
-        scr[512 + wave * 64 + 32 + r] = s[1];
+        scr[wave * 64 + r] = s[0];
+        scr[wave * 64 + 32 + r] = s[1];
+        scr[512 + wave * 64 + r] = s2[0];
+        scr[512 + wave * 64 + 32 + r] = s2[1];
     }
     lds_barrier();
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
-        float t = 0.0f;
+        float t = 0.0f, t2 = 0.0f;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) t += scr[512 + w * 64 + 32 * mi + r];
-        rstd[mi] = rsqrtf(t * (1.0f / 512.0f) + eps);
+        for (int w = 0; w < 8; ++w) {
+            t += scr[w * 64 + 32 * mi + r];
+            t2 += scr[512 + w * 64 + 32 * mi + r];
+        }
+        mean[mi] = t * (1.0f / 512.0f);
+        const float var = fmaxf(t2 * (1.0f / 512.0f) - mean[mi] * mean[mi], 0.0f);
+        rstd[mi] = rsqrtf(var + eps);
     }
 }
 
@@ -420,7 +411,8 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     }
     norm_to_lds<false>(acc, mean, rstd, vecp(2), vecp(3), rp, abuf, wave, lane, nullptr);
     lds_barrier();                     // nobody reads the fc constants any more
-    store_consts(nxt);                 // visible to everybody after the next barrier (in front of the first GELU)
+    store_consts(nxt);
+    lds_barrier();                     // ... and everybody sees the feed-forward constants
     CH_T(5);
     clear();   // acc = linear2 accumulator
 #pragma unroll 1
@@ -430,7 +422,8 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
         zero(a1[1]);
         phase_ff1(a1, abuf, ws, lane);
         CH_T(6 + 4 * c);
-        lds_barrier();                 // the previous chunk's linear2 reads of h1c are done
+        // two h1 buffers: chunk c - 2's linear2 reads of this one finished before the barrier of chunk c - 1
+        char* hb = h1c + (c & 1) * 32768;
         CH_T(7 + 4 * c);
         {
             const int nb = 256 * c + 32 * wave;
@@ -447,14 +440,14 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
                     pk.x = pack_bf2(v[0], v[1]);
                     pk.y = pack_bf2(v[2], v[3]);
                     // chunk column 32 wave + 8 gq + 4 h: k-tile wave / 2, 16-byte chunk 4 (wave & 1) + gq
-                    *reinterpret_cast<uint2*>(h1c + (wave >> 1) * 8192 + tile_off(32 * mi + r, 4 * (wave & 1) + gq) +
+                    *reinterpret_cast<uint2*>(hb + (wave >> 1) * 8192 + tile_off(32 * mi + r, 4 * (wave & 1) + gq) +
                                               8 * h) = pk;
                 }
             }
         }
         lds_barrier();
         CH_T(8 + 4 * c);
-        phase_n512(acc, h1c, 16, ws, lane);
+        phase_n512(acc, hb, 16, ws, lane);
         CH_T(9 + 4 * c);
     }
     // linear2 bias, FiLM, residual (the x this lane stored above), norm4 -> LDS
