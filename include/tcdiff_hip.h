@@ -112,6 +112,52 @@ typedef struct {
 int tcdiff_gemm_rowln(int dtype, const void* A, const void* W, int M, int K, int lda, int ldw, int a_mod,
                       const tcdiff_row_epi* epi, hipStream_t stream);
 
+/* ---- training-side rows (forward pieces; csrc/train.hip) -----------------------------------------------------------
+ * x_noisy[b][s*dn + d][c] = sqrt_ac[t_b] * x_start[b][d][s][c] + sqrt_1mac[t_b] * noise[b][s][d][c], channels 4 and 5
+ * (trajectory) copied from x_start: q_sample + the restore + the (b, dn, S, C) -> (b, S*dn, C) permute of
+ * model/diffusion.py:625-634,640-651.  t: int64 [b] on the device. */
+int tcdiff_q_sample_traj(const float* x_start, const float* noise, const long* t, const float* sqrt_ac,
+                         const float* sqrt_1mac, float* x_noisy, int b, int dn, int S, int C, hipStream_t stream);
+
+/* axis_angle[i * per_row + j][0..2] = matrix_to_axis_angle(rotation_6d_to_matrix(rot6d + i * row_stride + 6 j))
+ * (dataset/quaternion.py:28-32; pytorch3d 0.7.1 definitions restated, see oracle/tcdiff_oracle.py): per_row rotations
+ * packed in every row of a matrix with `row_stride` floats per row (the 24 x 6 tail of a 151-wide motion row). */
+int tcdiff_ax_from_6v(const float* rot6d, long n_rows, int per_row, long row_stride, float* axis_angle,
+                      hipStream_t stream);
+
+/* SMPLSkeleton.forward (vis.py:358-406): axis_angle [n][24][3], root [n][3] -> joints [n][24][3].  parents (HOST int[24],
+ * a parent precedes its children) and offsets (HOST float[24][3]) are vis.py:48-101's constants or a caller's skeleton. */
+int tcdiff_smpl_fk(const float* axis_angle, const float* root, long n, const int* parents, const float* offsets,
+                   float* joints, hipStream_t stream);
+
+/* out[b][4] = per-clip means of the reconstruction, velocity, FK and foot-skate terms of model/diffusion.py:668-733
+ * (the first three times p2_weight[t_b]); model_out [b][S*dn][C], x_start in the dataset layout [b][dn][S][C],
+ * joints_* [b*S*dn][24][3]; l1 != 0 selects F.l1_loss, else F.mse_loss. */
+int tcdiff_loss_terms(const float* model_out, const float* x_start, const float* joints_model,
+                      const float* joints_target, const float* p2_weight, const long* t, float* out, int b, int dn,
+                      int S, int C, int l1, hipStream_t stream);
+
+/* Adan.step (model/adan.py:33-123) over all parameter tensors in one launch: chunks of <= 65536 elements. */
+typedef struct {
+    float* p;          /* parameter */
+    const float* g;    /* gradient */
+    float* m;
+    float* v;
+    float* n_;
+    float* pg;         /* prev_grad */
+    long n;
+} tcdiff_adan_chunk;
+
+typedef struct {       /* Python-side doubles of adan.py rounded to fp32 where they meet a tensor */
+    float b1, omb1, b2, omb2, b3, omb3;   /* betas and 1 - beta */
+    float cm, cv, cn;                     /* bias corrections 1 / (1 - (1 - beta)^step) */
+    float eps, lr, denom;                 /* denom = 1 + weight_decay * lr */
+    int first;                            /* step == 0 before the call: m, v, n are left untouched (adan.py:71) */
+} tcdiff_adan_scalars;
+
+int tcdiff_adan_step(const tcdiff_adan_chunk* chunks, int n_chunks, const tcdiff_adan_scalars* scalars,
+                     hipStream_t stream);
+
 /* ---- row-block chains (bf16): everything between the two attentions of a decoder layer in ONE launch -------------
  * A block of 64 token rows stays on a CU; only weights stream (tcdiff_amd/csrc/chain.hip).
  *   TC_CHAIN_A      : O_self --fc, LayerNorm(1e-6), FiLM, +x--> x ; norm2, rotary ; w_qs --> Q image (cross-attention)

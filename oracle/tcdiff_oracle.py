@@ -645,3 +645,203 @@ def batch_step_noise(clip_ids, L: int, nfeats: int = 151) -> NoiseFn:
     def fn(i, shape):
         return torch.stack([synth_step_eps(c, i, L, nfeats) for c in clip_ids])
     return fn
+
+
+# ======================================================================================================================
+# Training-side rows: q_sample + p_losses terms, SMPL forward kinematics, Adan.
+#
+# Parity status of THIS block:
+#   * q_sample, the reconstruction and velocity terms of p_losses and the Adan update are PINNED: golden vectors made
+#     by tests/golden/make_golden_train.py from the real reference (model/diffusion.py:625-682, model/adan.py:33-123).
+#   * the rotation conversions and SMPL forward kinematics are "parity unpinned": their arithmetic lives in
+#     pytorch3d==0.7.1 (requirements.txt:70), which is neither installed here nor vendored in the reference.  The five
+#     functions below restate pytorch3d's published definitions (real-first wxyz quaternions; Gram-Schmidt 6-D -> matrix
+#     with ROWS b1, b2, b3; small-angle Taylor 0.5 - angle^2 / 48) and are cross-checked against
+#     scipy.spatial.transform.Rotation in tests/test_train_cpu.py.  The reference call sites they serve:
+#     dataset/quaternion.py:28-32 (ax_from_6v), vis.py:358-406 (SMPLSkeleton.forward), model/diffusion.py:693-733.
+# ======================================================================================================================
+SMPL_PARENTS = [-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 20, 21]   # vis.py:48-73
+SMPL_OFFSETS = [                                                                                      # vis.py:76-101
+    [0.0, 0.0, 0.0], [0.05858135, -0.08228004, -0.01766408], [-0.06030973, -0.09051332, -0.01354254],
+    [0.00443945, 0.12440352, -0.03838522], [0.04345142, -0.38646945, 0.008037],
+    [-0.04325663, -0.38368791, -0.00484304], [0.00448844, 0.1379564, 0.02682033],
+    [-0.01479032, -0.42687458, -0.037428], [0.01905555, -0.4200455, -0.03456167],
+    [-0.00226458, 0.05603239, 0.00285505], [0.04105436, -0.06028581, 0.12204243],
+    [-0.03483987, -0.06210566, 0.13032329], [-0.0133902, 0.21163553, -0.03346758],
+    [0.07170245, 0.11399969, -0.01889817], [-0.08295366, 0.11247234, -0.02370739],
+    [0.01011321, 0.08893734, 0.05040987], [0.12292141, 0.04520509, -0.019046],
+    [-0.11322832, 0.04685326, -0.00847207], [0.2553319, -0.01564902, -0.02294649],
+    [-0.26012748, -0.01436928, -0.03126873], [0.26570925, 0.01269811, -0.00737473],
+    [-0.26910836, 0.00679372, -0.00602676], [0.08669055, -0.01063603, -0.01559429],
+    [-0.0887537, -0.00865157, -0.01010708]]
+FOOT_IDX = [7, 8, 10, 11]            # model/diffusion.py:720
+
+
+def rotation_6d_to_matrix(d6: torch.Tensor) -> torch.Tensor:
+    """pytorch3d.transforms.rotation_6d_to_matrix (Zhou et al. 2019): Gram-Schmidt, rows b1, b2, b3."""
+    a1, a2 = d6[..., :3], d6[..., 3:]
+    b1 = F.normalize(a1, dim=-1)
+    b2 = a2 - (b1 * a2).sum(-1, keepdim=True) * b1
+    b2 = F.normalize(b2, dim=-1)
+    b3 = torch.cross(b1, b2, dim=-1)
+    return torch.stack((b1, b2, b3), dim=-2)
+
+
+def _sqrt_positive_part(x: torch.Tensor) -> torch.Tensor:
+    return torch.where(x > 0, torch.sqrt(torch.clamp(x, min=0)), torch.zeros_like(x))
+
+
+def matrix_to_quaternion(matrix: torch.Tensor) -> torch.Tensor:
+    """pytorch3d.transforms.matrix_to_quaternion (0.7.x): the candidate with the largest |component| is selected."""
+    batch = matrix.shape[:-2]
+    m00, m01, m02, m10, m11, m12, m20, m21, m22 = torch.unbind(matrix.reshape(batch + (9,)), dim=-1)
+    q_abs = _sqrt_positive_part(torch.stack([1.0 + m00 + m11 + m22, 1.0 + m00 - m11 - m22, 1.0 - m00 + m11 - m22,
+                                             1.0 - m00 - m11 + m22], dim=-1))
+    cand = torch.stack([
+        torch.stack([q_abs[..., 0] ** 2, m21 - m12, m02 - m20, m10 - m01], dim=-1),
+        torch.stack([m21 - m12, q_abs[..., 1] ** 2, m10 + m01, m02 + m20], dim=-1),
+        torch.stack([m02 - m20, m10 + m01, q_abs[..., 2] ** 2, m12 + m21], dim=-1),
+        torch.stack([m10 - m01, m20 + m02, m21 + m12, q_abs[..., 3] ** 2], dim=-1)], dim=-2)
+    cand = cand / (2.0 * q_abs[..., None].clamp(min=0.1))
+    idx = q_abs.argmax(dim=-1)
+    return torch.gather(cand, -2, idx[..., None, None].expand(batch + (1, 4))).squeeze(-2)
+
+
+def quaternion_to_axis_angle(q: torch.Tensor) -> torch.Tensor:
+    norms = torch.norm(q[..., 1:], p=2, dim=-1, keepdim=True)
+    half = torch.atan2(norms, q[..., :1])
+    ang = 2 * half
+    small = ang.abs() < 1e-6
+    safe = torch.where(small, torch.ones_like(ang), ang)
+    k = torch.where(small, 0.5 - (ang * ang) / 48, torch.sin(half) / safe)
+    return q[..., 1:] / k
+
+
+def matrix_to_axis_angle(matrix: torch.Tensor) -> torch.Tensor:
+    return quaternion_to_axis_angle(matrix_to_quaternion(matrix))
+
+
+def ax_from_6v(q: torch.Tensor) -> torch.Tensor:
+    """dataset/quaternion.py:28-32."""
+    return matrix_to_axis_angle(rotation_6d_to_matrix(q))
+
+
+def axis_angle_to_quaternion(aa: torch.Tensor) -> torch.Tensor:
+    ang = torch.norm(aa, p=2, dim=-1, keepdim=True)
+    half = ang * 0.5
+    small = ang.abs() < 1e-6
+    safe = torch.where(small, torch.ones_like(ang), ang)
+    k = torch.where(small, 0.5 - (ang * ang) / 48, torch.sin(half) / safe)
+    return torch.cat([torch.cos(half), aa * k], dim=-1)
+
+
+def quaternion_raw_multiply(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    aw, ax, ay, az = torch.unbind(a, -1)
+    bw, bx, by, bz = torch.unbind(b, -1)
+    return torch.stack((aw * bw - ax * bx - ay * by - az * bz, aw * bx + ax * bw + ay * bz - az * by,
+                        aw * by - ax * bz + ay * bw + az * bx, aw * bz + ax * by - ay * bx + az * bw), -1)
+
+
+def quaternion_multiply(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    ab = quaternion_raw_multiply(a, b)
+    return torch.where(ab[..., 0:1] < 0, -ab, ab)          # standardize: non-negative real part
+
+
+def quaternion_apply(q: torch.Tensor, point: torch.Tensor) -> torch.Tensor:
+    p = torch.cat((point.new_zeros(point.shape[:-1] + (1,)), point), -1)
+    inv = q * q.new_tensor([1, -1, -1, -1])
+    return quaternion_raw_multiply(quaternion_raw_multiply(q, p), inv)[..., 1:]
+
+
+def smpl_fk(rotations: torch.Tensor, root_positions: torch.Tensor) -> torch.Tensor:
+    """SMPLSkeleton.forward (vis.py:358-406): rotations (N, L, 24, 3) axis-angle, root (N, L, 3) -> joints (N, L, 24, 3)."""
+    q = axis_angle_to_quaternion(rotations)
+    off = torch.tensor(SMPL_OFFSETS, dtype=rotations.dtype)
+    has_children = [False] * 24
+    for p in SMPL_PARENTS:
+        if p != -1:
+            has_children[p] = True
+    pos, rot = [], []
+    for i, p in enumerate(SMPL_PARENTS):
+        if p == -1:
+            pos.append(root_positions)
+            rot.append(q[:, :, 0])
+        else:
+            pos.append(quaternion_apply(rot[p], off[i].expand(q.shape[0], q.shape[1], 3)) + pos[p])
+            rot.append(quaternion_multiply(rot[p], q[:, :, i]) if has_children[i] else None)
+    return torch.stack(pos, dim=3).permute(0, 1, 3, 2)
+
+
+def p_losses(sd: SD, tab, x_start: torch.Tensor, cond: torch.Tensor, t: torch.Tensor, noise: torch.Tensor,
+             keep_mask: torch.Tensor, loss_type: str = "l2", with_fk: bool = True):
+    """model/diffusion.py:636-741 with the random draws injected: x_start (b, dn, S, C) dataset layout, noise in the
+    PERMUTED layout (b, S, dn, C) as the reference draws it, keep_mask (b,) bool = prob_mask_like's result (eval mode:
+    Dropout is the identity).  Returns (total, (recon, velocity, fk, foot)) with the reference's weights."""
+    lf = (lambda a, b: (a - b) ** 2) if loss_type == "l2" else (lambda a, b: (a - b).abs())
+    bs, dn, sq, c = x_start.shape
+    xs = x_start.permute(0, 2, 1, 3)
+    x_noisy = q_sample(tab, xs, t, noise).clone()
+    x_noisy[:, :, :, [4, 5]] = xs[:, :, :, [4, 5]]
+    x_noisy = x_noisy.reshape(bs, sq * dn, c)
+    out = decoder_forward(sd, x_noisy, cond, t, keep_mask=keep_mask)
+    w = tab["p2_loss_weight"][t]
+    mo, tg = out.reshape(bs, sq, dn, c), xs.reshape(bs, sq, dn, c)
+    loss = lf(mo, tg).reshape(bs, -1).mean(1) * w
+    mc, mo = mo[..., :4], mo[..., 4:]
+    tg = tg[..., 4:]
+    v_loss = lf(mo[:, 1:] - mo[:, :-1], tg[:, 1:] - tg[:, :-1]).reshape(bs, -1).mean(1) * w
+    if not with_fk:
+        z = torch.zeros(())
+        return 0.636 * loss.mean() + 2.964 * v_loss.mean(), (0.636 * loss.mean(), 2.964 * v_loss.mean(), z, z)
+    mq = ax_from_6v(mo[..., 3:].reshape(bs, sq * dn, -1, 6))
+    tq = ax_from_6v(tg[..., 3:].reshape(bs, sq * dn, -1, 6))
+    mxp = smpl_fk(mq, mo[..., :3].reshape(bs, sq * dn, 3))
+    txp = smpl_fk(tq, tg[..., :3].reshape(bs, sq * dn, 3))
+    fk_loss = lf(mxp[:, :, 1:] - mxp[:, :, 0:1], txp[:, :, 1:] - txp[:, :, 0:1]).reshape(bs, -1).mean(1) * w
+    static = mc > 0.95
+    feet = mxp.reshape(bs, sq, dn, 24, 3)[:, :, :, FOOT_IDX]
+    fv = torch.zeros_like(feet)
+    fv[:, :-1] = feet[:, 1:] - feet[:, :-1]
+    fv = torch.where(static[..., None], fv, torch.zeros_like(fv))
+    foot_loss = lf(fv, torch.zeros_like(fv)).reshape(bs, -1).mean(1)
+    losses = (0.636 * loss.mean(), 2.964 * v_loss.mean(), 0.646 * fk_loss.mean(), 10.942 * foot_loss.mean())
+    return sum(losses), losses
+
+
+def _f32(x) -> np.float32:
+    return np.float32(x)
+
+
+def _fma32(a, b, c):
+    """round32(a * b + c) with one rounding (the product of two float32 is exact in float64; the float64 sum is then
+    rounded once more, which differs from a true fused multiply-add only in ~2^-29 of the cases)."""
+    return (np.asarray(a, np.float32).astype(np.float64) * np.asarray(b, np.float32).astype(np.float64)
+            + np.asarray(c, np.float32).astype(np.float64)).astype(np.float32)
+
+
+def adan_step(p, g, state, lr=1e-3, betas=(0.02, 0.08, 0.01), eps=1e-8, weight_decay=0.0):
+    """One Adan.step for one tensor (model/adan.py:33-123) on float32 numpy arrays, with torch's rounding points
+    (established against torch 2.10 CPU, tests/golden/make_golden_train.py): `t.mul_(s)` / `s * t` round once;
+    `t.add_(o, alpha=s)` and `t.addcmul_(a, b, value=s)` are fused multiply-adds (`fma(o, s, t)`, `fma(s * a, b, t)`);
+    `lr / t` is reciprocal-then-multiply (Tensor.__rtruediv__); `x ** 2` is x * x; sqrt, reciprocal and division are
+    IEEE correctly rounded (torch's CPU sqrt goes through MKL VML for large tensors and is 1 ulp off in ~0.7 % of the
+    elements: the golden comparison allows for exactly that); Python scalars are cast to float32 when they meet a
+    float32 tensor.  state: dict(step, m, v, n, prev_grad) (zeros at step 0).  First step: m, v, n stay zero
+    (adan.py:71), so only the weight decay acts."""
+    b1, b2, b3 = betas
+    m, v, n, pg = state["m"], state["v"], state["n"], state["prev_grad"]
+    step = state["step"]
+    if step > 0:
+        m = _fma32(g, _f32(b1), m * _f32(1 - b1))
+        gd = g - pg
+        v = _fma32(gd, _f32(b2), v * _f32(1 - b2))
+        nn = g + _f32(1 - b2) * gd
+        nn = nn * nn
+        n = _fma32(nn, _f32(b3), n * _f32(1 - b3))
+    step += 1
+    cm, cv, cn = (1 / (1 - (1 - b) ** step) for b in (b1, b2, b3))
+    wss = (_f32(1.0) / (np.sqrt(n * _f32(cn)) + _f32(eps))) * _f32(lr)
+    upd = m * _f32(cm) + (_f32(1 - b2) * v) * _f32(cv)
+    p = _fma32(_f32(-1.0) * wss, upd, p) / _f32(1 + weight_decay * lr)
+    state.update(step=step, m=m, v=v, n=n, prev_grad=g.copy())
+    return p

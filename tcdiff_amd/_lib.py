@@ -42,10 +42,20 @@ class ChainArgs(C.Structure):
                 ("n4_eps", _f), ("nn_eps", _f), ("scale_q", _f)]
 
 
+class AdanScalars(C.Structure):
+    _fields_ = [(n, _f) for n in ("b1", "omb1", "b2", "omb2", "b3", "omb3", "cm", "cv", "cn", "eps", "lr", "denom")] + \
+        [("first", _i)]
+
+
 _SIGS = {
     "tcdiff_gemm_tile": [_i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, C.POINTER(TileEpi), _vp],
     "tcdiff_gemm_rowln": [_i, _vp, _vp, _i, _i, _i, _i, _i, C.POINTER(RowEpi), _vp],
     "tcdiff_attention": [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "tcdiff_q_sample_traj": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "tcdiff_ax_from_6v": [_vp, _l, _i, _l, _vp, _vp],
+    "tcdiff_smpl_fk": [_vp, _vp, _l, C.POINTER(_i), C.POINTER(_f), _vp, _vp],
+    "tcdiff_loss_terms": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "tcdiff_adan_step": [_vp, _i, C.POINTER(AdanScalars), _vp],
     "tcdiff_chain": [C.POINTER(ChainArgs), _vp],
     "tcdiff_ln_rot": [_i, _vp, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "tcdiff_rope_table": [_vp, _vp, _i, _vp],

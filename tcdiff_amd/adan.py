@@ -1,0 +1,102 @@
+"""MI355X-native ``Adan`` -- drop-in for the reference's ``model.adan.Adan`` (model/adan.py:11-123; constructed at
+TCDiff.py:110 as ``Adan(model.parameters(), lr=learning_rate, weight_decay=weight_decay)``).
+
+Same constructor, ``param_groups`` / ``state`` layout (``step``, ``prev_grad``, ``m``, ``v``, ``n`` per parameter, so
+``optimizer_state_dict`` checkpoints interchange, TCDiff.py:271) and update rule -- including the first-step quirk: while
+``step == 0`` the moments stay zero, so the first call only applies the weight decay (adan.py:71,96-107).
+
+For fp32 CUDA parameters the whole parameter list is updated by ONE launch of ``tcdiff_adan_step`` (the reference issues
+~15 elementwise kernels per tensor, 435 tensors), with the reference's rounding points (fused multiply-adds where torch's
+``add_(alpha=)`` / ``addcmul_`` fuse, IEEE sqrt / reciprocal / division).  Other parameters (CPU tensors, a
+``restart_cond``) take the reference's tensor arithmetic.
+"""
+from __future__ import annotations
+
+import torch
+from torch.optim import Optimizer
+
+from . import _lib as L
+from . import kernels as K
+
+
+def exists(val):
+    return val is not None
+
+
+class Adan(Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.02, 0.08, 0.01), eps=1e-8, weight_decay=0, restart_cond: callable = None):
+        assert len(betas) == 3
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, restart_cond=restart_cond)
+        super().__init__(params, defaults)
+        self._tables = {}
+
+    def _init_state(self, p):
+        state = self.state[p]
+        if len(state) == 0:
+            state["step"] = 0
+            state["prev_grad"] = torch.zeros_like(p.grad)
+            state["m"] = torch.zeros_like(p.grad)
+            state["v"] = torch.zeros_like(p.grad)
+            state["n"] = torch.zeros_like(p.grad)
+        return state
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if exists(closure):
+            with torch.enable_grad():
+                loss = closure()
+        for gi, group in enumerate(self.param_groups):
+            lr, (beta1, beta2, beta3) = group["lr"], group["betas"]
+            weight_decay, eps, restart_cond = group["weight_decay"], group["eps"], group["restart_cond"]
+            ps = [p for p in group["params"] if exists(p.grad)]
+            if not ps:
+                continue
+            states = [self._init_state(p) for p in ps]
+            step0 = states[0]["step"]
+            fused = not exists(restart_cond) and all(
+                p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous()
+                and not p.grad.is_sparse and s["step"] == step0 for p, s in zip(ps, states))
+            if fused:
+                key = (gi,) + tuple(t.data_ptr() for p, s in zip(ps, states)
+                                    for t in (p.data, p.grad, s["m"], s["v"], s["n"], s["prev_grad"]))
+                if self._tables.get(gi, (None,))[0] != key:
+                    tab = K.adan_chunk_table([p.data for p in ps], [p.grad for p in ps], [s["m"] for s in states],
+                                             [s["v"] for s in states], [s["n"] for s in states],
+                                             [s["prev_grad"] for s in states], ps[0].device)
+                    self._tables[gi] = (key, tab)
+                step = step0 + 1
+                cm, cv, cn = (1 / (1 - (1 - b) ** step) for b in (beta1, beta2, beta3))
+                sc = L.AdanScalars(beta1, 1 - beta1, beta2, 1 - beta2, beta3, 1 - beta3, cm, cv, cn, eps, lr,
+                                   1 + weight_decay * lr, int(step0 == 0))
+                K.adan_step(self._tables[gi][1], sc)
+                for s in states:
+                    s["step"] = step
+                continue
+            for p, state in zip(ps, states):         # the reference's arithmetic (model/adan.py:61-121)
+                data, grad = p.data, p.grad.data
+                assert not grad.is_sparse
+                step, m, v, n, prev_grad = state["step"], state["m"], state["v"], state["n"], state["prev_grad"]
+                if step > 0:
+                    m.mul_(1 - beta1).add_(grad, alpha=beta1)
+                    grad_diff = grad - prev_grad
+                    v.mul_(1 - beta2).add_(grad_diff, alpha=beta2)
+                    next_n = (grad + (1 - beta2) * grad_diff) ** 2
+                    n.mul_(1 - beta3).add_(next_n, alpha=beta3)
+                step += 1
+                correct_m, correct_v, correct_n = map(lambda b: 1 / (1 - (1 - b) ** step), (beta1, beta2, beta3))
+
+                def grad_step_(data, m, v, n):
+                    weighted_step_size = lr / (n * correct_n).sqrt().add_(eps)
+                    denom = 1 + weight_decay * lr
+                    data.addcmul_(weighted_step_size, (m * correct_m + (1 - beta2) * v * correct_v), value=-1.0).div_(denom)
+
+                grad_step_(data, m, v, n)
+                if exists(restart_cond) and restart_cond(state):
+                    m.data.copy_(grad)
+                    v.zero_()
+                    n.data.copy_(grad ** 2)
+                    grad_step_(data, m, v, n)
+                prev_grad.copy_(grad)
+                state["step"] = step
+        return loss

@@ -8,7 +8,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SRC = [os.path.join(HERE, "csrc", f) for f in ("gemm.hip", "attention.hip", "ops.hip", "chain.hip")]
+SRC = [os.path.join(HERE, "csrc", f) for f in ("gemm.hip", "attention.hip", "ops.hip", "chain.hip", "train.hip")]
 HDR = [os.path.join(HERE, "csrc", "common.h"), os.path.join(ROOT, "include", "tcdiff_hip.h")]
 LIB = os.path.join(HERE, "libtcdiff_gfx950.so")
 

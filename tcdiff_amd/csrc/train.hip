@@ -1,0 +1,299 @@
+// Training-side rows of the TCDiff hot path (a15, f1, f2), gfx950: forward pieces only -- the noising
+// step, the rotation conversions + SMPL forward kinematics of the FK / foot-skate terms, the four loss reductions, and
+// the Adan parameter update.  All fp32 and bandwidth- or latency-bound (a few MB per call): plain one-thread-per-item
+// kernels with coalesced rows; nothing here is worth MFMA or LDS tiling.
+//
+//   q_sample + trajectory restore + permute   model/diffusion.py:625-634,640-651
+//   ax_from_6v                                 dataset/quaternion.py:28-32   (pytorch3d rotation_6d_to_matrix, matrix_to_axis_angle)
+//   SMPLSkeleton.forward                       vis.py:358-406                (pytorch3d axis_angle_to_quaternion, quaternion_apply/_multiply)
+//   the four loss terms                        model/diffusion.py:668-741
+//   Adan.step                                  model/adan.py:33-123
+// The pytorch3d arithmetic is restated from its published definitions (oracle/tcdiff_oracle.py, "parity unpinned").
+#include "common.h"
+#include "tcdiff_hip.h"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// x_noisy[b][s*dn + d][c] = a[t_b] * x[b][d][s][c] + s1m[t_b] * noise[b][s][d][c];  channels 4, 5 keep x (trajectory)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void q_sample_traj_kernel(const float* __restrict__ x, const float* __restrict__ noise,
+                                     const long* __restrict__ t, const float* __restrict__ sa,
+                                     const float* __restrict__ s1m, float* __restrict__ out, int b, int dn, int S, int C) {
+#pragma clang fp contract(off)   // two rounded products and a rounded sum, like the reference's tensor expression
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long per = (long)dn * S * C;
+    if (i >= (long)b * per) return;
+    const int bi = (int)(i / per);
+    long rem = i - (long)bi * per;
+    const int c = (int)(rem % C);
+    rem /= C;
+    const int d = (int)(rem % dn), s = (int)(rem / dn);            // output order: frame-major tokens (s, d)
+    const float xv = x[(((long)bi * dn + d) * S + s) * C + c];     // dataset layout (b, dn, S, C)
+    const float a = sa[t[bi]], bb = s1m[t[bi]];
+    const float v = a * xv + bb * noise[i];                        // two roundings and a sum, as the reference's expression
+    out[i] = (c == 4 || c == 5) ? xv : v;
+}
+
+extern "C" int tcdiff_q_sample_traj(const float* x_start, const float* noise, const long* t, const float* sqrt_ac,
+                                    const float* sqrt_1mac, float* x_noisy, int b, int dn, int S, int C,
+                                    hipStream_t stream) {
+    if (!x_start || !noise || !t || !sqrt_ac || !sqrt_1mac || !x_noisy || b <= 0 || dn <= 0 || S <= 0 || C <= 5)
+        return TC_ERR_ARG;
+    const long n = (long)b * dn * S * C;
+    hipLaunchKernelGGL(q_sample_traj_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x_start, noise, t,
+                       sqrt_ac, sqrt_1mac, x_noisy, b, dn, S, C);
+    TC_CHECK_LAUNCH();
+    return TC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// rotation conversions (real-first quaternions)
+// ---------------------------------------------------------------------------------------------------------------------
+struct Q4 { float w, x, y, z; };
+struct V3 { float x, y, z; };
+
+DEVINL V3 normalize3(V3 a) {       // F.normalize: v / max(|v|, 1e-12)
+    const float n = fmaxf(sqrtf(a.x * a.x + a.y * a.y + a.z * a.z), 1e-12f);
+    return V3{a.x / n, a.y / n, a.z / n};
+}
+DEVINL float sqrt_pos(float v) { return v > 0.0f ? sqrtf(v) : 0.0f; }
+
+// 6-D -> rotation matrix rows b1, b2, b3 (Gram-Schmidt) -> quaternion (candidate with the largest |component|)
+DEVINL Q4 quat_from_6d(const float* d6) {
+    const V3 a1{d6[0], d6[1], d6[2]}, a2{d6[3], d6[4], d6[5]};
+    const V3 b1 = normalize3(a1);
+    const float dt = b1.x * a2.x + b1.y * a2.y + b1.z * a2.z;
+    const V3 b2 = normalize3(V3{a2.x - dt * b1.x, a2.y - dt * b1.y, a2.z - dt * b1.z});
+    const V3 b3{b1.y * b2.z - b1.z * b2.y, b1.z * b2.x - b1.x * b2.z, b1.x * b2.y - b1.y * b2.x};
+    const float m00 = b1.x, m01 = b1.y, m02 = b1.z, m10 = b2.x, m11 = b2.y, m12 = b2.z, m20 = b3.x, m21 = b3.y, m22 = b3.z;
+    const float q0 = sqrt_pos(1.0f + m00 + m11 + m22), q1 = sqrt_pos(1.0f + m00 - m11 - m22);
+    const float q2 = sqrt_pos(1.0f - m00 + m11 - m22), q3 = sqrt_pos(1.0f - m00 - m11 + m22);
+    int best = 0;                   // argmax, first maximum wins (torch.argmax)
+    float bm = q0;
+    if (q1 > bm) { bm = q1; best = 1; }
+    if (q2 > bm) { bm = q2; best = 2; }
+    if (q3 > bm) { bm = q3; best = 3; }
+    const float den = 2.0f * fmaxf(bm, 0.1f);
+    Q4 r;
+    if (best == 0) r = Q4{q0 * q0, m21 - m12, m02 - m20, m10 - m01};
+    else if (best == 1) r = Q4{m21 - m12, q1 * q1, m10 + m01, m02 + m20};
+    else if (best == 2) r = Q4{m02 - m20, m10 + m01, q2 * q2, m12 + m21};
+    else r = Q4{m10 - m01, m20 + m02, m21 + m12, q3 * q3};
+    return Q4{r.w / den, r.x / den, r.y / den, r.z / den};
+}
+DEVINL V3 axis_angle_from_quat(Q4 q) {
+    const float nrm = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z);
+    const float half = atan2f(nrm, q.w), ang = 2.0f * half;
+    const float k = fabsf(ang) < 1e-6f ? 0.5f - (ang * ang) / 48.0f : sinf(half) / ang;
+    return V3{q.x / k, q.y / k, q.z / k};
+}
+DEVINL Q4 quat_from_axis_angle(V3 a) {
+    const float ang = sqrtf(a.x * a.x + a.y * a.y + a.z * a.z), half = ang * 0.5f;
+    const float k = fabsf(ang) < 1e-6f ? 0.5f - (ang * ang) / 48.0f : sinf(half) / ang;
+    return Q4{cosf(half), a.x * k, a.y * k, a.z * k};
+}
+DEVINL Q4 qmul_raw(Q4 a, Q4 b) {
+    return Q4{a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+              a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x, a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
+}
+DEVINL Q4 qmul_std(Q4 a, Q4 b) {
+    Q4 r = qmul_raw(a, b);
+    if (r.w < 0.0f) r = Q4{-r.w, -r.x, -r.y, -r.z};
+    return r;
+}
+DEVINL V3 qapply(Q4 q, V3 p) {
+    const Q4 t = qmul_raw(qmul_raw(q, Q4{0.0f, p.x, p.y, p.z}), Q4{q.w, -q.x, -q.y, -q.z});
+    return V3{t.x, t.y, t.z};
+}
+
+// one thread per rotation: rotation j of row i is the 6 floats at in + i * row_stride + 6 j; out [n_rows * per_row][3]
+__global__ void ax_from_6v_kernel(const float* __restrict__ in, long n_rows, int per_row, long row_stride,
+                                  float* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows * per_row) return;
+    const V3 a = axis_angle_from_quat(quat_from_6d(in + (i / per_row) * row_stride + (i % per_row) * 6));
+    out[i * 3 + 0] = a.x;
+    out[i * 3 + 1] = a.y;
+    out[i * 3 + 2] = a.z;
+}
+
+extern "C" int tcdiff_ax_from_6v(const float* rot6d, long n_rows, int per_row, long row_stride, float* axis_angle,
+                                 hipStream_t stream) {
+    if (!rot6d || !axis_angle || n_rows <= 0 || per_row <= 0 || row_stride < 6L * per_row) return TC_ERR_ARG;
+    const long n = n_rows * per_row;
+    hipLaunchKernelGGL(ax_from_6v_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, rot6d, n_rows, per_row,
+                       row_stride, axis_angle);
+    TC_CHECK_LAUNCH();
+    return TC_OK;
+}
+
+// SMPL chain: one thread per pose.  parents / offsets are the SMPL constants of vis.py:48-101 (passed in so that a
+// caller-supplied skeleton works too); joints whose parents precede them (true for SMPL) only.
+#define TC_FK_J 24
+struct tcdiff_fk_skel { int parent[TC_FK_J]; int has_children[TC_FK_J]; float off[TC_FK_J][3]; };
+
+__global__ void smpl_fk_kernel(const float* __restrict__ aa, const float* __restrict__ root, long n, tcdiff_fk_skel sk,
+                               float* __restrict__ joints) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Q4 rw[TC_FK_J];
+    V3 pw[TC_FK_J];
+    const float* a = aa + i * (TC_FK_J * 3);
+#pragma unroll
+    for (int j = 0; j < TC_FK_J; ++j) {
+        const Q4 q = quat_from_axis_angle(V3{a[3 * j], a[3 * j + 1], a[3 * j + 2]});
+        const int p = sk.parent[j];
+        if (p < 0) {
+            pw[j] = V3{root[i * 3], root[i * 3 + 1], root[i * 3 + 2]};
+            rw[j] = q;
+        } else {
+            const V3 o = qapply(rw[p], V3{sk.off[j][0], sk.off[j][1], sk.off[j][2]});
+            pw[j] = V3{o.x + pw[p].x, o.y + pw[p].y, o.z + pw[p].z};
+            rw[j] = sk.has_children[j] ? qmul_std(rw[p], q) : q;
+        }
+        joints[(i * TC_FK_J + j) * 3 + 0] = pw[j].x;
+        joints[(i * TC_FK_J + j) * 3 + 1] = pw[j].y;
+        joints[(i * TC_FK_J + j) * 3 + 2] = pw[j].z;
+    }
+}
+
+extern "C" int tcdiff_smpl_fk(const float* axis_angle, const float* root, long n, const int* parents,
+                              const float* offsets, float* joints, hipStream_t stream) {
+    if (!axis_angle || !root || !parents || !offsets || !joints || n <= 0) return TC_ERR_ARG;
+    tcdiff_fk_skel sk;
+    for (int j = 0; j < TC_FK_J; ++j) sk.has_children[j] = 0;
+    for (int j = 0; j < TC_FK_J; ++j) {
+        sk.parent[j] = parents[j];
+        if (parents[j] >= j) return TC_ERR_ARG;          // a parent must precede its children
+        if (parents[j] >= 0) sk.has_children[parents[j]] = 1;
+        for (int k = 0; k < 3; ++k) sk.off[j][k] = offsets[3 * j + k];
+    }
+    hipLaunchKernelGGL(smpl_fk_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, stream, axis_angle, root, n, sk,
+                       joints);
+    TC_CHECK_LAUNCH();
+    return TC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// loss terms: out[b][k], k = recon, velocity, fk, foot: per-clip means (times p2 weight for the first three)
+// ---------------------------------------------------------------------------------------------------------------------
+DEVINL float lossf(float a, float b, int l1) {
+    const float d = a - b;
+    return l1 ? fabsf(d) : d * d;
+}
+
+__global__ __launch_bounds__(256) void loss_terms_kernel(const float* __restrict__ mo, const float* __restrict__ xs,
+                                                         const float* __restrict__ jm, const float* __restrict__ jt,
+                                                         const float* __restrict__ w, const long* __restrict__ t,
+                                                         float* __restrict__ out, int dn, int S, int C, int l1) {
+    const int bi = blockIdx.x, term = blockIdx.y, tid = threadIdx.x;
+    const long Lq = (long)S * dn;
+    auto model = [&](int s, int d, int c) { return mo[((long)bi * Lq + (long)s * dn + d) * C + c]; };
+    auto target = [&](int s, int d, int c) { return xs[(((long)bi * dn + d) * S + s) * C + c]; };   // dataset layout
+    double acc = 0.0;          // per-thread partial in fp64: the reduction order must not matter at 1e-6
+    long count = 1;
+    if (term == 0) {
+        count = Lq * C;
+        for (long i = tid; i < count; i += 256) {
+            const int c = (int)(i % C);
+            const long sd = i / C;
+            const int d = (int)(sd % dn), s = (int)(sd / dn);
+            acc += lossf(model(s, d, c), target(s, d, c), l1);
+        }
+    } else if (term == 1) {
+        const int C4 = C - 4;
+        count = (long)(S - 1) * dn * C4;
+        for (long i = tid; i < count; i += 256) {
+            const int c = 4 + (int)(i % C4);
+            const long sd = i / C4;
+            const int d = (int)(sd % dn), s = (int)(sd / dn);
+            acc += lossf(model(s + 1, d, c) - model(s, d, c), target(s + 1, d, c) - target(s, d, c), l1);
+        }
+    } else if (term == 2) {
+        count = Lq * 23 * 3;
+        for (long i = tid; i < count; i += 256) {
+            const int k = (int)(i % 3);
+            const long r2 = i / 3;
+            const int j = 1 + (int)(r2 % 23);
+            const long row = (long)bi * Lq + r2 / 23;
+            acc += lossf(jm[(row * 24 + j) * 3 + k] - jm[(row * 24) * 3 + k], jt[(row * 24 + j) * 3 + k] - jt[(row * 24) * 3 + k], l1);
+        }
+    } else {
+        const int foot[4] = {7, 8, 10, 11};
+        count = Lq * 4 * 3;
+        for (long i = tid; i < count; i += 256) {
+            const int k = (int)(i % 3);
+            const long r2 = i / 3;
+            const int f = (int)(r2 % 4);
+            const long sd = r2 / 4;
+            const int d = (int)(sd % dn), s = (int)(sd / dn);
+            float v = 0.0f;
+            if (s + 1 < S && model(s, d, f) > 0.95f) {
+                const long r0 = (long)bi * Lq + (long)s * dn + d, r1 = r0 + dn;
+                v = jm[(r1 * 24 + foot[f]) * 3 + k] - jm[(r0 * 24 + foot[f]) * 3 + k];
+            }
+            acc += lossf(v, 0.0f, l1);
+        }
+    }
+    __shared__ double red[256];
+    red[tid] = acc;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+        if (tid < s2) red[tid] += red[tid + s2];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const float mean = (float)(red[0] / (double)count);
+        out[bi * 4 + term] = term < 3 ? mean * w[t[bi]] : mean;
+    }
+}
+
+extern "C" int tcdiff_loss_terms(const float* model_out, const float* x_start, const float* joints_model,
+                                 const float* joints_target, const float* p2_weight, const long* t, float* out, int b,
+                                 int dn, int S, int C, int l1, hipStream_t stream) {
+    if (!model_out || !x_start || !joints_model || !joints_target || !p2_weight || !t || !out || b <= 0 || dn <= 0 ||
+        S < 2 || C <= 7)
+        return TC_ERR_ARG;
+    hipLaunchKernelGGL(loss_terms_kernel, dim3(b, 4), dim3(256), 0, stream, model_out, x_start, joints_model,
+                       joints_target, p2_weight, t, out, dn, S, C, l1);
+    TC_CHECK_LAUNCH();
+    return TC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Adan (model/adan.py:33-123), all parameter tensors in one launch; the reference's rounding points (oracle adan_step):
+//   m = fma(g, b1, m * (1 - b1)); gd = g - pg; v = fma(gd, b2, v * (1 - b2)); nn = g + (1 - b2) * gd; nn = nn * nn;
+//   n = fma(nn, b3, n * (1 - b3))                                             [skipped on the first step, adan.py:71]
+//   wss = (1 / (sqrt(n * cn) + eps)) * lr;  upd = m * cm + ((1 - b2) * v) * cv;  p = fma(-wss, upd, p) / (1 + wd * lr)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adan_step_kernel(const tcdiff_adan_chunk* __restrict__ chunks, tcdiff_adan_scalars k) {
+#pragma clang fp contract(off)
+    const tcdiff_adan_chunk c = chunks[blockIdx.x];
+    for (long i = threadIdx.x; i < c.n; i += 256) {
+        const float g = c.g[i];
+        float m = c.m[i], v = c.v[i], n = c.n_[i];
+        if (!k.first) {
+            const float pg = c.pg[i];
+            m = __builtin_fmaf(g, k.b1, m * k.omb1);
+            const float gd = g - pg;
+            v = __builtin_fmaf(gd, k.b2, v * k.omb2);
+            float nn = g + k.omb2 * gd;
+            nn = nn * nn;
+            n = __builtin_fmaf(nn, k.b3, n * k.omb3);
+            c.m[i] = m;
+            c.v[i] = v;
+            c.n_[i] = n;
+        }
+        const float wss = __frcp_rn(__fsqrt_rn(n * k.cn) + k.eps) * k.lr;
+        const float upd = m * k.cm + (k.omb2 * v) * k.cv;
+        c.p[i] = __fdiv_rn(__builtin_fmaf(-1.0f * wss, upd, c.p[i]), k.denom);
+        c.pg[i] = g;
+    }
+}
+
+extern "C" int tcdiff_adan_step(const tcdiff_adan_chunk* chunks, int n_chunks, const tcdiff_adan_scalars* scalars,
+                                hipStream_t stream) {
+    if (!chunks || !scalars || n_chunks <= 0) return TC_ERR_ARG;
+    hipLaunchKernelGGL(adan_step_kernel, dim3(n_chunks), dim3(256), 0, stream, chunks, *scalars);
+    TC_CHECK_LAUNCH();
+    return TC_OK;
+}

@@ -6,7 +6,7 @@ then ONE fused kernel doing CFG combine + clamp + the DDPM / DDIM update (+ traj
 step scalars read from device memory so that a single captured hipGraph is replayed for every step.
 
 Out of scope here: the stick-figure renderer behind ``render_sample`` (this class returns
-the samples instead), and the training loss ``p_losses`` (next row, needs backward kernels + SMPL FK).
+the samples instead) and the backward pass of the training loss (``p_losses`` is forward-only).
 """
 from __future__ import annotations
 
@@ -567,16 +567,67 @@ class GaussianDiffusion(nn.Module):
     def partial_denoise(self, x, cond, t):
         return self.p_sample_loop(x.shape, cond, noise=self.noise_to_t(x, t), start_point=t)
 
-    # ---- training (next row) -----------------------------------------------------------
-    def p_losses(self, x_start, cond, t, trj_dist=None):
-        raise NotImplementedError("training loss (p_losses: backward kernels + SMPL FK) is the next row of the "
-                                  "hot-path scope table (SURVEY.md 8(f)); this build covers the samplers")
+    # ---- training loss, forward (reference model/diffusion.py:636-753) ---------------------------------------------------
+    @torch.no_grad()
+    def p_losses(self, x_start, cond, t, trj_dist=None, *, noise=None, keep_mask=None):
+        """The four-term training loss (reference model/diffusion.py:636-741), FORWARD ONLY: q_sample with the
+        trajectory channels restored, one conditional evaluation of the denoiser (keep mask ~ 1 - cond_drop_prob), then
+        reconstruction, velocity, SMPL-FK and foot-skate terms -- each a HIP kernel (csrc/train.hip).  Returns
+        ``(total, (recon, velocity, fk, foot))`` like the reference.  No autograd graph is recorded: the backward pass
+        (and with it a full training step) is the next row of the scope table, so Dropout is the identity here
+        (the reference's eval-mode arithmetic).  Keyword-only extras inject the random draws (parity tests):
+        ``noise`` in the permuted (b, S, dn, C) layout the reference draws it in, ``keep_mask`` (b,) bool."""
+        if trj_dist is not None:
+            raise L.TcdiffError("trj_dist is not supported (never passed by the reference's callers, TCDiff.py:227-229)")
+        dev = self._device()
+        if dev.type != "cuda":
+            raise L.TcdiffError("p_losses runs on MI355X only (no CPU fallback)")
+        x_start = x_start.to(dev).float().contiguous()
+        bs, dn, sq, c = x_start.shape
+        t = t.to(dev).long().contiguous()
+        if noise is None:
+            noise = torch.randn(bs, sq, dn, c, device=dev)
+        noise = noise.to(dev).float().contiguous()
+        x_noisy = torch.empty(bs, sq * dn, c, device=dev)
+        K.q_sample_traj(x_start, noise, t, self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod, x_noisy, bs, dn,
+                        sq, c)
+        out = self.model(x_noisy, cond, t, cond_drop_prob=self.cond_drop_prob, keep_mask=keep_mask).contiguous()
+        # FK of prediction and target: 6-D rotations are channels 7.. of the 151 (4 contact, 3 root, 24 x 6)
+        from .fk import SMPLSkeleton
+        smpl = self.smpl
+        if smpl is None or not hasattr(smpl, "_parents"):
+            smpl = self.__dict__.setdefault("_smpl_hip", SMPLSkeleton(dev))
+        parents = [int(p) for p in smpl._parents]
+        offsets = smpl._offsets.detach().cpu().tolist()
+        xs_rows = x_start.permute(0, 2, 1, 3).reshape(bs * sq * dn, c).contiguous()      # target rows, token order
+        joints = []
+        for rows in (out.reshape(bs * sq * dn, c), xs_rows):
+            n = rows.shape[0]
+            aa = torch.empty(n, 24, 3, device=dev)
+            if rows.stride(0) != c or rows.stride(1) != 1:
+                raise L.TcdiffError("internal: motion rows must be contiguous")
+            K.ax_from_6v(rows[:, 7:], n, 24, c, aa)
+            jt = torch.empty(n, 24, 3, device=dev)
+            K.smpl_fk(aa, rows[:, 4:7].contiguous(), n, parents, offsets, jt)
+            joints.append(jt)
+        terms = torch.empty(bs, 4, device=dev)
+        K.loss_terms(out, x_start, joints[0], joints[1], self.p2_loss_weight, t, terms, bs, dn, sq, c,
+                     l1=self.loss_type == "l1")
+        m = terms.mean(0)
+        losses = (0.636 * m[0], 2.964 * m[1], 0.646 * m[2], 10.942 * m[3])
+        return sum(losses), losses
 
     def loss(self, x, cond, t_override=None, trj_dist=None):
-        return self.p_losses(x, cond, None, trj_dist)
+        batch_size = len(x)
+        dev = self._device()
+        if t_override is None:
+            t = torch.randint(0, self.n_timestep, (batch_size,), device=dev).long()
+        else:
+            t = torch.full((batch_size,), t_override, device=dev).long()
+        return self.p_losses(x, cond, t, trj_dist=trj_dist)
 
     def forward(self, x, cond, t_override=None, trj_dist=None):
-        return self.loss(x, cond, t_override, trj_dist)
+        return self.loss(x, cond, t_override, trj_dist=trj_dist)
 
     # ---- render_sample: sampling only ---------------------------------------------------------------------
     @torch.no_grad()

@@ -146,3 +146,40 @@ def ema_update(table, beta):
     L.check(L.load().tcdiff_ema_update(_p(table), table.shape[0], float(beta), float(1.0 - beta), stream()),
             "tcdiff_ema_update")
 
+
+
+# ---- training-side rows ------------------------------------------------------------------------------------------------
+def q_sample_traj(x_start, noise, t, sqrt_ac, sqrt_1mac, x_noisy, b, dn, S, Cn):
+    L.check(L.load().tcdiff_q_sample_traj(_p(x_start), _p(noise), _p(t), _p(sqrt_ac), _p(sqrt_1mac), _p(x_noisy), b, dn,
+                                          S, Cn, stream()), "tcdiff_q_sample_traj")
+
+
+def ax_from_6v(rot6d, n_rows, per_row, row_stride, out):
+    L.check(L.load().tcdiff_ax_from_6v(_p(rot6d), n_rows, per_row, row_stride, _p(out), stream()), "tcdiff_ax_from_6v")
+
+
+def smpl_fk(axis_angle, root, n, parents, offsets, joints):
+    par = (C.c_int * 24)(*[int(p) for p in parents])
+    off = (C.c_float * 72)(*[float(v) for row in offsets for v in row])
+    L.check(L.load().tcdiff_smpl_fk(_p(axis_angle), _p(root), n, par, off, _p(joints), stream()), "tcdiff_smpl_fk")
+
+
+def loss_terms(model_out, x_start, joints_model, joints_target, p2_weight, t, out, b, dn, S, Cn, l1):
+    L.check(L.load().tcdiff_loss_terms(_p(model_out), _p(x_start), _p(joints_model), _p(joints_target), _p(p2_weight),
+                                       _p(t), _p(out), b, dn, S, Cn, int(l1), stream()), "tcdiff_loss_terms")
+
+
+def adan_chunk_table(params, grads, ms, vs, ns, pgs, device):
+    """int64 [n_chunks, 7] device table of (p, g, m, v, n, prev_grad pointers, count) for tcdiff_adan_step."""
+    rows = []
+    for p, g, m, v, n, pg in zip(params, grads, ms, vs, ns, pgs):
+        cnt = p.numel()
+        for lo in range(0, cnt, 65536):
+            o = 4 * lo
+            rows.append((p.data_ptr() + o, g.data_ptr() + o, m.data_ptr() + o, v.data_ptr() + o, n.data_ptr() + o,
+                         pg.data_ptr() + o, min(65536, cnt - lo)))
+    return torch.tensor(rows, dtype=torch.int64, device=device).reshape(-1, 7)
+
+
+def adan_step(table, scalars):
+    L.check(L.load().tcdiff_adan_step(_p(table), table.shape[0], C.byref(scalars), stream()), "tcdiff_adan_step")

@@ -234,7 +234,8 @@ class DanceDecoder(nn.Module):
             K.cfg_combine(out, out[B * Lq:], 152, float(guidance_weight), y, B * Lq, self.nfeats)
             return y
 
-    def forward(self, x: Tensor, cond_embed: Tensor, times: Tensor, cond_drop_prob: float = 0.0, trj_dist=None):
+    def forward(self, x: Tensor, cond_embed: Tensor, times: Tensor, cond_drop_prob: float = 0.0, trj_dist=None, *,
+                keep_mask: Optional[Tensor] = None):
         """One denoiser evaluation (model/model.py:548-624), inference only (no autograd graph is recorded).
 
         ``trj_dist`` is accepted for signature parity; the reference never passes it (TCDiff.py:227-229)."""
@@ -251,7 +252,9 @@ class DanceDecoder(nn.Module):
             dev = x.device
             # keep mask (model/utils.py:52-58): no RNG when the probability is 0 or 1
             p_keep = 1 - cond_drop_prob
-            if p_keep == 1:
+            if keep_mask is not None:           # injected draw (parity tests of the training loss)
+                keep = keep_mask.to(device=dev, dtype=torch.bool).reshape(B)
+            elif p_keep == 1:
                 keep = torch.ones(B, dtype=torch.bool, device=dev)
             elif p_keep == 0:
                 keep = torch.zeros(B, dtype=torch.bool, device=dev)

@@ -100,7 +100,7 @@ def test_no_cpu_fallback(small):
         model(torch.zeros(1, 450, 151), torch.zeros(1, 301, 438), torch.zeros(1, dtype=torch.long))
     with pytest.raises(L.TcdiffError):
         diff.p_sample_loop((1, 450, 151), torch.zeros(1, 301, 438))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(L.TcdiffError):           # the training loss (forward) is HIP-only too
         diff(torch.zeros(1, 3, 150, 151), torch.zeros(1, 301, 438))
 
 
