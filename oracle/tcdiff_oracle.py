@@ -773,7 +773,7 @@ def smpl_fk(rotations: torch.Tensor, root_positions: torch.Tensor) -> torch.Tens
 
 
 def p_losses(sd: SD, tab, x_start: torch.Tensor, cond: torch.Tensor, t: torch.Tensor, noise: torch.Tensor,
-             keep_mask: torch.Tensor, loss_type: str = "l2", with_fk: bool = True):
+             keep_mask: torch.Tensor, loss_type: str = "l2", with_fk: bool = True, model_out: Optional[torch.Tensor] = None):
     """model/diffusion.py:636-741 with the random draws injected: x_start (b, dn, S, C) dataset layout, noise in the
     PERMUTED layout (b, S, dn, C) as the reference draws it, keep_mask (b,) bool = prob_mask_like's result (eval mode:
     Dropout is the identity).  Returns (total, (recon, velocity, fk, foot)) with the reference's weights."""
@@ -783,7 +783,7 @@ def p_losses(sd: SD, tab, x_start: torch.Tensor, cond: torch.Tensor, t: torch.Te
     x_noisy = q_sample(tab, xs, t, noise).clone()
     x_noisy[:, :, :, [4, 5]] = xs[:, :, :, [4, 5]]
     x_noisy = x_noisy.reshape(bs, sq * dn, c)
-    out = decoder_forward(sd, x_noisy, cond, t, keep_mask=keep_mask)
+    out = decoder_forward(sd, x_noisy, cond, t, keep_mask=keep_mask) if model_out is None else model_out
     w = tab["p2_loss_weight"][t]
     mo, tg = out.reshape(bs, sq, dn, c), xs.reshape(bs, sq, dn, c)
     loss = lf(mo, tg).reshape(bs, -1).mean(1) * w

@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void adan_step_kernel(const tcdiff_adan_chunk*
             c.v[i] = v;
             c.n_[i] = n;
         }
-        const float wss = __frcp_rn(__fsqrt_rn(n * k.cn) + k.eps) * k.lr;
+        const float wss = __frcp_rn(sqrtf(n * k.cn) + k.eps) * k.lr;
         const float upd = m * k.cm + (k.omb2 * v) * k.cv;
         c.p[i] = __fdiv_rn(__builtin_fmaf(-1.0f * wss, upd, c.p[i]), k.denom);
         c.pg[i] = g;

@@ -71,7 +71,14 @@ def test_l1_loss_type_and_q_sample_kernel_exact(golden_dir):
     xn = torch.empty(b, S * dn, 151, device=DEV)
     K.q_sample_traj(x_start.to(DEV), noise.to(DEV), t.to(DEV), diff.sqrt_alphas_cumprod, diff.sqrt_one_minus_alphas_cumprod,
                     xn, b, dn, S, 151)
-    assert np.array_equal(xn.cpu().numpy(), ref["x_noisy"])          # the reference's own noised input, bit for bit
+    # bit for bit the reference's expression (model/diffusion.py:629-632,649) evaluated with THIS box's schedule tables
+    # (torch's CPU sqrt / cumprod differ by an ulp between hosts, so the committed golden is held to 1e-6 instead)
+    xs = x_start.permute(0, 2, 1, 3)
+    sa, s1 = diff.sqrt_alphas_cumprod.cpu()[t].reshape(-1, 1, 1, 1), diff.sqrt_one_minus_alphas_cumprod.cpu()[t].reshape(-1, 1, 1, 1)
+    want = sa * xs + s1 * noise
+    want[:, :, :, [4, 5]] = xs[:, :, :, [4, 5]]
+    assert torch.equal(xn.cpu(), want.reshape(b, S * dn, 151))
+    assert np.abs(xn.cpu().numpy() - ref["x_noisy"]).max() < 1e-6
     _, losses = diff.p_losses(x_start.to(DEV), cond.to(DEV), t.to(DEV), noise=noise.to(DEV), keep_mask=keep.to(DEV))
     with torch.no_grad():
         _, ol = O.p_losses(sd, O.make_tables(T), x_start, cond, t, noise, keep, loss_type="l1")
@@ -149,3 +156,34 @@ def test_adan_drives_the_full_parameter_list_in_one_launch():
         grads = [torch.randn(q.shape, device=DEV, generator=g2) * 0.01 for q in model.parameters()]
         ref_p = O.adan_step(ref_p, grads[idx].cpu().numpy(), st, lr=5e-5, weight_decay=0.02)
     assert np.array_equal(ref_p, p.detach().cpu().numpy())
+
+
+@pytest.mark.parametrize("l1", [False, True])
+def test_loss_term_kernels_with_active_foot_contacts(l1):
+    """the four reductions alone on a synthetic model output whose contact channels cross 0.95 (random-weight networks
+    never do): foot-skate masking, the zero velocity of the last frame, p2 weighting"""
+    from tcdiff_amd import kernels as K
+    dn, S, T, b = 3, 20, 100, 2
+    g = torch.Generator().manual_seed(21)
+    x_start = torch.rand(b, dn, S, 151, generator=g) * 2 - 1
+    mo = torch.rand(b, S * dn, 151, generator=g) * 2 - 1
+    mo[:, :, :4] = torch.rand(b, S * dn, 4, generator=g) * 1.2          # ~20 % of the contacts above 0.95
+    t = torch.tensor([7, 93])
+    tab = O.make_tables(T)
+    _, want = O.p_losses({}, tab, x_start, None, t, torch.zeros(b, S, dn, 151), None, loss_type="l1" if l1 else "l2",
+                         model_out=mo)
+    assert float(want[3]) > 0
+    from tcdiff_amd import SMPLSkeleton, ax_from_6v
+    sk = SMPLSkeleton(DEV)
+    rows_t = x_start.permute(0, 2, 1, 3).reshape(b * S * dn, 151)
+    joints = []
+    for rows in (mo.reshape(b * S * dn, 151), rows_t):
+        aa = ax_from_6v(rows[:, 7:].reshape(-1, 24, 6).to(DEV))
+        joints.append(sk.forward(aa[None], rows[None, :, 4:7].to(DEV))[0].contiguous())
+    out = torch.empty(b, 4, device=DEV)
+    K.loss_terms(mo.to(DEV), x_start.to(DEV), joints[0], joints[1], tab["p2_loss_weight"].to(DEV), t.to(DEV), out, b, dn,
+                 S, 151, l1)
+    m = out.mean(0).cpu()
+    got = (0.636 * m[0], 2.964 * m[1], 0.646 * m[2], 10.942 * m[3])
+    for a, o in zip(got, want):
+        assert abs(float(a) - float(o)) < 2e-5 * abs(float(o)) + 1e-7, (float(a), float(o))
