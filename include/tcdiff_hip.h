@@ -274,6 +274,20 @@ int tcdiff_sampler_update(int mode, const float* out_unc, const float* out_cond,
                           const int* counter, const float* params, const int* tseq, uint64_t seed, int clip0,
                           hipStream_t stream);
 
+/* Constraints re-imposed after a sampler step, as a launch of the captured step (no host callback between steps).
+ *   kind 1: x = mask ? value : x unless this is the last step        (ddim_sample_Footwork, model/diffusion.py:341-356)
+ *   kind 2: x = (p4 * value + p5 * noise) * mask + (1 - mask) * x    (inpaint_loop's q_sample(value, t-1) blend, :545-551)
+ * Bit 1 of (int)params[step][7] enables the step (the host writes "not last" / "t > 0"); columns 4, 5 hold sqrt_ac[t-1],
+ * sqrt(1 - ac[t-1]) for kind 2 (DDPM steps, whose own scalars are columns 0..3).  mask: fp32 [mask_rows][nfeat] (row % mask_rows: one [L][nfeat] mask may serve every
+ * clip); value, q_eps: fp32 [n_rows][nfeat]; q_eps NULL -> Philox normal (stream word 1, same keying as the step). */
+int tcdiff_sampler_constrain(int kind, float* x, const float* mask, int mask_rows, const float* value,
+                             const float* q_eps, int n_rows, int nfeat, int L, const int* counter, const float* params,
+                             const int* tseq, uint64_t seed, int clip0, hipStream_t stream);
+
+/* tcdiff_window_couple gated by bit 0 of (int)params[step][7] (the reference does not couple after the last step). */
+int tcdiff_window_couple_step(float* x, int b, int seq_len, int row_elems, const int* counter, const float* params,
+                              hipStream_t stream);
+
 /* y[row][c] = unc + (cond - unc) * w, c < nfeat  (DanceDecoder.guided_forward, model/model.py:546) */
 int tcdiff_cfg_combine(const float* out_unc, const float* out_cond, int ldo, float w, float* y, int n_rows,
                        int nfeat, hipStream_t stream);

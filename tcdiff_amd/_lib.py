@@ -68,6 +68,8 @@ _SIGS = {
     "tcdiff_step_end": [_vp, _vp],
     "tcdiff_sampler_update": [_i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, C.c_uint64, _i, _vp],
     "tcdiff_window_couple": [_vp, _i, _i, _i, _vp],
+    "tcdiff_window_couple_step": [_vp, _i, _i, _i, _vp, _vp, _vp],
+    "tcdiff_sampler_constrain": [_i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, C.c_uint64, _i, _vp],
     "tcdiff_ema_update": [_vp, _i, _f, _f, _vp],
     "tcdiff_cfg_combine": [_vp, _vp, _i, _f, _vp, _i, _i, _vp],
 }

@@ -390,6 +390,87 @@ extern "C" int tcdiff_window_couple(float* x, int b, int seq_len, int row_elems,
     return TC_OK;
 }
 
+// ---- in-painting constraints and window coupling INSIDE the captured step (no per-step host callback) ---------------
+// kind 1: x = mask ? value : x while the step is not the last one (ddim_sample_Footwork, model/diffusion.py:341-356)
+// kind 2: x = q_sample(value, t - 1) * mask + (1 - mask) * x for t > 0 (inpaint_loop, model/diffusion.py:545-551);
+//         q_sample = params[4] * value + params[5] * noise, noise injected (q_eps) or Philox (stream word 1)
+__global__ void sampler_constrain_kernel(int kind, float* __restrict__ x, const float* __restrict__ mask, int mask_rows,
+                                         const float* __restrict__ value, const float* __restrict__ q_eps, int n_rows,
+                                         int nfeat, int L, const int* __restrict__ counter,
+                                         const float* __restrict__ params, const int* __restrict__ tseq, uint64_t seed,
+                                         int clip0) {
+    const int quads = (nfeat + 3) / 4;
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)n_rows * quads) return;
+    const int row = (int)(i / quads), qd = (int)(i % quads);
+    const int step = counter[0];
+    const float* pr = params + (long)step * 8;
+    if ((((int)pr[7]) & 2) == 0) return;           // column 7 bit 1: constraint enabled for this step (host-side schedule)
+    float z[4] = {0.f, 0.f, 0.f, 0.f};
+    if (kind == 2 && !q_eps) {
+        const int clip = clip0 + row / L, tok = row % L;
+        uint32_t c[4] = {(uint32_t)(tok * quads + qd), (uint32_t)tseq[step], (uint32_t)clip, 1u};
+        philox4(c, (uint32_t)seed ^ (uint32_t)counter[1], (uint32_t)(seed >> 32) ^ (uint32_t)counter[2]);
+        const float u0 = u01(c[0]), u1 = u01(c[1]), u2 = u01(c[2]), u3 = u01(c[3]);
+        const float r0 = sqrtf(-2.0f * logf(u0)), r1 = sqrtf(-2.0f * logf(u2));
+        float s0, c0, s1, c1;
+        sincosf(6.283185307179586f * u1, &s0, &c0);
+        sincosf(6.283185307179586f * u3, &s1, &c1);
+        z[0] = r0 * c0; z[1] = r0 * s0; z[2] = r1 * c1; z[3] = r1 * s1;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = qd * 4 + j;
+        if (c >= nfeat) break;
+        const long xi = (long)row * nfeat + c;
+        const float m = mask[(long)(row % mask_rows) * nfeat + c];
+        const float v = value[xi];
+        if (kind == 1) {
+            if (m != 0.0f) x[xi] = v;
+        } else {
+            const float e = q_eps ? q_eps[xi] : z[j];
+            const float qs = pr[4] * v + pr[5] * e;
+            x[xi] = qs * m + (1.0f - m) * x[xi];
+        }
+    }
+}
+
+extern "C" int tcdiff_sampler_constrain(int kind, float* x, const float* mask, int mask_rows, const float* value,
+                                        const float* q_eps, int n_rows, int nfeat, int L, const int* counter,
+                                        const float* params, const int* tseq, uint64_t seed, int clip0,
+                                        hipStream_t stream) {
+    if ((kind != 1 && kind != 2) || !x || !mask || !value || !counter || !params || !tseq || n_rows <= 0 || nfeat <= 0 ||
+        L <= 0 || mask_rows <= 0)
+        return TC_ERR_ARG;
+    long n = (long)n_rows * ((nfeat + 3) / 4);
+    hipLaunchKernelGGL(sampler_constrain_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, kind, x, mask,
+                       mask_rows, value, q_eps, n_rows, nfeat, L, counter, params, tseq, seed, clip0);
+    TC_CHECK_LAUNCH();
+    return TC_OK;
+}
+
+// window coupling gated by the step's flag column 7 (the reference skips it after the last step)
+__global__ void window_couple_step_kernel(float* __restrict__ x, int b, long half_elems, const int* __restrict__ counter,
+                                          const float* __restrict__ params) {
+    if ((((int)params[(long)counter[0] * 8 + 7]) & 1) == 0) return;   // column 7 bit 0: couple after this step
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)(b - 1) * half_elems) return;
+    long clip = 1 + i / half_elems, e = i % half_elems;
+    x[clip * 2 * half_elems + e] = x[(clip - 1) * 2 * half_elems + half_elems + e];
+}
+
+extern "C" int tcdiff_window_couple_step(float* x, int b, int seq_len, int row_elems, const int* counter,
+                                         const float* params, hipStream_t stream) {
+    if (!x || !counter || !params || b <= 0 || seq_len <= 0 || (seq_len & 1) || row_elems <= 0) return TC_ERR_ARG;
+    if (b == 1) return TC_OK;
+    long half = (long)(seq_len / 2) * row_elems;
+    long n = (long)(b - 1) * half;
+    hipLaunchKernelGGL(window_couple_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, b, half,
+                       counter, params);
+    TC_CHECK_LAUNCH();
+    return TC_OK;
+}
+
 __global__ void cfg_combine_kernel(const float* __restrict__ ou, const float* __restrict__ oc, int ldo, float w,
                                    float* __restrict__ y, int n_rows, int nfeat) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -172,11 +172,17 @@ class GaussianDiffusion(nn.Module):
 
     def _run(self, mode: int, shape, cond, x: torch.Tensor, tseq, params: torch.Tensor, *, traj=None,
              step_noise: Optional[Callable] = None, seed: Optional[int] = None, clip_offset: int = 0,
-             after_step: Optional[Callable] = None, use_graph: bool = True, collect=None):
-        """Run len(tseq) sampler steps on x (fp32 [B, L, nfeat]); returns the updated tensor."""
+             after_step: Optional[Callable] = None, use_graph: bool = True, collect=None, constrain=None, couple=None):
+        """Run len(tseq) sampler steps on x (fp32 [B, L, nfeat]); returns the updated tensor.
+
+        constrain = dict(kind, mask [L or B*L, nfeat] float, value [B, L, nfeat], q_noise=None | callable(t, shape)) and
+        couple = (seq_len, row_elems) put the in-painting constraint / window coupling INSIDE the captured step
+        (tcdiff_sampler_constrain / tcdiff_window_couple_step, enabled per step by params[:, 7] bits 1 / 0), so those
+        samplers replay one graph per step like the plain ones; `after_step` remains for callers' own hooks."""
         B, Lq, nf = shape
         n = len(tseq)
-        nparts = self.dual_parts if (self.dual_stream and use_graph and after_step is None and n > 2) else 1
+        nparts = self.dual_parts if (self.dual_stream and use_graph and after_step is None and couple is None
+                                     and n > 2) else 1
         while nparts > 1 and B // nparts < 2:
             nparts -= 1
         cuts = [(k * B) // nparts for k in range(nparts + 1)]        # near-equal contiguous sub-batches
@@ -197,9 +203,15 @@ class GaussianDiffusion(nn.Module):
             st["params"][:n] = params.to(torch.float32)
             if traj is not None:
                 st["traj"].copy_(traj.reshape(B, Lq, 3)[lo:hi].reshape(Bp * Lq, 3))
+            cm = 0
+            if constrain is not None:
+                st["cval"].copy_(constrain["value"].reshape(B, Lq, nf)[lo:hi].reshape(Bp * Lq, nf))
+                m = constrain["mask"].to(st["x"].device, torch.float32).reshape(-1, nf)
+                cm = Lq if m.shape[0] == Lq else Bp * Lq      # one [L, nfeat] mask for every clip, or a full one
+                st["cmask"][:cm].copy_(m if m.shape[0] == Lq else m.reshape(B, Lq, nf)[lo:hi].reshape(Bp * Lq, nf))
             # the seed lives in device memory (counter[1..2]) so that a captured graph can be re-seeded
             st["counter"][1:3] = torch.tensor([seed & 0x7FFFFFFF, (seed >> 31) & 0x7FFFFFFF], dtype=torch.int32)
-            parts.append(dict(eng=eng, st=st, B=Bp, lo=lo, hi=hi))
+            parts.append(dict(eng=eng, st=st, B=Bp, lo=lo, hi=hi, mask_rows=cm))
 
         def step_part(p, branches: int):
             eng, st, Bp = p["eng"], p["st"], p["B"]
@@ -215,6 +227,12 @@ class GaussianDiffusion(nn.Module):
             K.sampler_update(mode, unc, con, 152, st["x"], st["eps"] if step_noise is not None else None,
                              st["traj"] if traj is not None else None, None, Bp * Lq, nf, Lq, st["counter"],
                              st["params"], st["tseq"], seed=0, clip0=clip_offset + p["lo"])
+            if constrain is not None:
+                K.sampler_constrain(constrain["kind"], st["x"], st["cmask"], p["mask_rows"], st["cval"],
+                                    st["qeps"] if constrain.get("q_noise") is not None else None, Bp * Lq, nf, Lq,
+                                    st["counter"], st["params"], st["tseq"], seed=0, clip0=clip_offset + p["lo"])
+            if couple is not None:
+                K.window_couple_step(st["x"], Bp, couple[0], couple[1], st["counter"], st["params"])
             K.step_end(st["counter"])
 
         def step(branches: int, parallel: bool):
@@ -239,7 +257,8 @@ class GaussianDiffusion(nn.Module):
         # Free-running halves: each half replays its own step graph on its own stream with no per-step join, the second
         # one started `dual_skew_us` late, so that the two launch chains stay out of phase (one half's HBM-bound
         # epilogues beside the other's MFMA-bound main loops) instead of running the same kernel side by side.
-        skewed = len(parts) > 1 and self.dual_skew_us >= 0 and step_noise is None and collect is None
+        q_noise = constrain.get("q_noise") if constrain is not None else None
+        skewed = len(parts) > 1 and self.dual_skew_us >= 0 and step_noise is None and collect is None and q_noise is None
         sides = [self._side_stream(x.device, k) for k in range(1, len(parts))]
         side_started = False
         for i, t in enumerate(tseq):
@@ -248,8 +267,14 @@ class GaussianDiffusion(nn.Module):
                 eps = step_noise(int(t), (B, Lq, nf))
                 for p in parts:
                     p["st"]["eps"].copy_(eps[p["lo"]:p["hi"]].reshape(p["B"] * Lq, nf))
+            if q_noise is not None:
+                qe = q_noise(int(t), (B, Lq, nf))
+                for p in parts:
+                    p["st"]["qeps"].copy_(qe[p["lo"]:p["hi"]].reshape(p["B"] * Lq, nf))
+            ckey = None if constrain is None else (constrain["kind"], q_noise is not None,
+                                                   tuple(p["mask_rows"] for p in parts))
             gkey = (mode, branches, step_noise is not None, traj is not None, clip_offset, B, len(parts), gens, id(self.model),
-                    skewed)
+                    skewed, ckey, couple)
             # Anything that is not a replay of the free-running per-part graphs launches work for EVERY part on the main
             # stream: join the side streams first, or their queued replays race with it on the parts' buffers.
             if side_started and not (use_graph and gkey in graphs):
@@ -277,7 +302,7 @@ class GaussianDiffusion(nn.Module):
                 step(branches, False)           # first visit: eager (loads code objects, sets kernel attributes)
                 graphs[("warm", gkey)] = True
             else:                               # second visit: capture the step once, replay from now on
-                for k in [k for k in graphs if isinstance(k, tuple) and len(k) == 10 and k[8] == id(self.model) and k[7] != gens]:
+                for k in [k for k in graphs if isinstance(k, tuple) and len(k) == 12 and k[8] == id(self.model) and k[7] != gens]:
                     del graphs[k]               # graphs of engines whose buffers have moved
                 if not skewed:
                     graph = torch.cuda.CUDAGraph()
@@ -446,14 +471,11 @@ class GaussianDiffusion(nn.Module):
         weights = np.clip(np.linspace(0, self.guidance_weight * 2, 50), None, self.guidance_weight)
         params = self._ddim_params(pairs, weights)
         row = (Lq // self.seq_len) * nf
-
-        def couple(i, t, xv):
-            if pairs[i][1] >= 0 and t > 0:
-                K.window_couple(xv, B, self.seq_len, row)
-
+        for i, (time, time_next) in enumerate(pairs):       # x[1:, :half] = x[:-1, half:] after every step but the last
+            params[i, 7] = 1.0 if (time_next >= 0 and time > 0) else 0.0
         return self._run(L.SAMPLER_DDIM, (B, Lq, nf), cond, x, [a for a, _ in pairs], params, traj=traj,
                          step_noise=kwargs.get("step_noise"), seed=kwargs.get("seed"),
-                         clip_offset=kwargs.get("clip_offset", 0), after_step=couple)
+                         clip_offset=kwargs.get("clip_offset", 0), couple=(self.seq_len, row))
 
     def _footwork_mask(self, Lq, nf, dn, device):
         m = torch.zeros(self.seq_len, dn, nf, dtype=torch.bool, device=device)
@@ -473,7 +495,7 @@ class GaussianDiffusion(nn.Module):
         x = torch.randn(shape, device=device) if init is None else init.to(device).float().clone()
         pairs = self._ddim_pairs()
         params = self._ddim_params(pairs, [self.guidance_weight] * len(pairs))
-        traj, after = None, None
+        traj, constrain = None, None
         if x_0 is not None:
             x_0 = x_0.to(device).float().reshape(B, Lq, nf)
             mask = self._footwork_mask(Lq, nf, dn, device)
@@ -481,13 +503,12 @@ class GaussianDiffusion(nn.Module):
             traj[:, :, 0:2] = x_0[:, :, 0:2]        # the reference copies x_0[...,[0,1]] of the 151-d x_0 into x[...,[4,5]] (:303)
             x[:, :, 4:6] = x_0[:, :, 0:2]
             x = torch.where(mask[None], x_0, x)
-
-            def after(i, t, xv):
-                if pairs[i][1] >= 0:
-                    xv.copy_(torch.where(mask[None], x_0, xv))
+            constrain = dict(kind=1, mask=mask.float(), value=x_0)     # re-imposed inside every captured step but the last
+            for i, (_, time_next) in enumerate(pairs):
+                params[i, 7] = 2.0 if time_next >= 0 else 0.0
         x = self._run(L.SAMPLER_DDIM, (B, Lq, nf), cond, x, [a for a, _ in pairs], params, traj=traj,
                       step_noise=kwargs.get("step_noise"), seed=kwargs.get("seed"),
-                      clip_offset=kwargs.get("clip_offset", 0), after_step=after)
+                      clip_offset=kwargs.get("clip_offset", 0), constrain=constrain)
         if x_0 is not None:
             xv = x.view(B, self.seq_len, dn, nf)
             x0v = x_0.view(B, self.seq_len, dn, nf)
@@ -515,15 +536,15 @@ class GaussianDiffusion(nn.Module):
         chain = [x] if return_diffusion else None
 
         q_noise = kw.get("q_noise")      # optional callable(t, shape): the randn_like q_sample draws in step t
-
-        def after(i, t, xv):
-            if t > 0:
-                tt = torch.full((shape[0],), t - 1, device=device, dtype=torch.long)
-                qn = None if q_noise is None else q_noise(t, tuple(value.shape)).to(device)
-                xv.copy_(self.q_sample(value, tt, qn) * mask + (1.0 - mask) * xv)
-
-        out = self._run(L.SAMPLER_DDPM, tuple(shape), cond, x.float(), tseq, self._ddpm_params(tseq),
-                        step_noise=kw.get("step_noise"), seed=kw.get("seed"), after_step=after, collect=chain)
+        params = self._ddpm_params(tseq)
+        sa, s1 = self.sqrt_alphas_cumprod.cpu(), self.sqrt_one_minus_alphas_cumprod.cpu()
+        for i, tt in enumerate(tseq):    # x = q_sample(value, t - 1) * mask + (1 - mask) * x after every step with t > 0
+            if tt > 0:
+                params[i, 4], params[i, 5], params[i, 7] = sa[tt - 1], s1[tt - 1], 2.0
+        constrain = dict(kind=2, mask=mask.float().expand(shape).reshape(-1, shape[-1]), value=value.float().expand(shape),
+                         q_noise=(lambda tt, sh: q_noise(tt, sh).to(device)) if q_noise is not None else None)
+        out = self._run(L.SAMPLER_DDPM, tuple(shape), cond, x.float(), tseq, params, step_noise=kw.get("step_noise"),
+                        seed=kw.get("seed"), collect=chain, constrain=constrain)
         return (out, chain) if return_diffusion else out
 
     @torch.no_grad()
@@ -541,12 +562,11 @@ class GaussianDiffusion(nn.Module):
         tseq = list(reversed(range(0, start_point)))
         chain = [x] if return_diffusion else None
 
-        def after(i, t, xv):
-            if t > 0:
-                K.window_couple(xv, B, Lq, nf)
-
-        out = self._run(L.SAMPLER_DDPM, (B, Lq, nf), cond, x.float(), tseq, self._ddpm_params(tseq),
-                        step_noise=kw.get("step_noise"), seed=kw.get("seed"), after_step=after, collect=chain)
+        params = self._ddpm_params(tseq)
+        for i, tt in enumerate(tseq):
+            params[i, 7] = 1.0 if tt > 0 else 0.0
+        out = self._run(L.SAMPLER_DDPM, (B, Lq, nf), cond, x.float(), tseq, params, step_noise=kw.get("step_noise"),
+                        seed=kw.get("seed"), collect=chain, couple=(Lq, nf))
         return (out, chain) if return_diffusion else out
 
     @torch.no_grad()

@@ -73,6 +73,8 @@ class DenoiserEngine:
             dev = self.dev
             st = dict(cap=cap,
                       x=torch.zeros(rows, nfeat, device=dev), eps=torch.zeros(rows, nfeat, device=dev),
+                      cval=torch.zeros(rows, nfeat, device=dev), qeps=torch.zeros(rows, nfeat, device=dev),
+                      cmask=torch.zeros(rows, nfeat, device=dev),
                       traj=torch.zeros(rows, 3, device=dev), counter=torch.zeros(4, device=dev, dtype=torch.int32),
                       rows=torch.zeros(cap, device=dev, dtype=torch.int32),
                       tseq=torch.zeros(cap, device=dev, dtype=torch.int32),

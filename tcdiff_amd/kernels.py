@@ -127,6 +127,17 @@ def window_couple(x, b, seq_len, row_elems):
     L.check(L.load().tcdiff_window_couple(_p(x), b, seq_len, row_elems, stream()), "tcdiff_window_couple")
 
 
+def sampler_constrain(kind, x, mask, mask_rows, value, q_eps, n_rows, nfeat, Lseq, counter, params, tseq, seed=0, clip0=0):
+    rc = L.load().tcdiff_sampler_constrain(kind, _p(x), _p(mask), mask_rows, _p(value), _p(q_eps), n_rows, nfeat, Lseq,
+                                           _p(counter), _p(params), _p(tseq), seed, clip0, stream())
+    L.check(rc, "tcdiff_sampler_constrain")
+
+
+def window_couple_step(x, b, seq_len, row_elems, counter, params):
+    L.check(L.load().tcdiff_window_couple_step(_p(x), b, seq_len, row_elems, _p(counter), _p(params), stream()),
+            "tcdiff_window_couple_step")
+
+
 def cfg_combine(out_unc, out_cond, ldo, w, y, n_rows, nfeat):
     L.check(L.load().tcdiff_cfg_combine(_p(out_unc), _p(out_cond), ldo, float(w), _p(y), n_rows, nfeat, stream()),
             "tcdiff_cfg_combine")
