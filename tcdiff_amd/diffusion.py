@@ -455,7 +455,8 @@ class GaussianDiffusion(nn.Module):
     def long_ddim_sample(self, shape, cond, x_0, **kwargs):
         """Half-overlapping windows generated as one batch, coupled every step (reference model/diffusion.py:446-515)."""
         B, Lq, nf = shape
-        if B == 1:
+        halo = kwargs.get("halo_exchange")      # callable(x_view): cross-rank boundary copy (tcdiff_amd/stitch.py); the
+        if B == 1 and halo is None:              # windows of one song sharded over ranks stay "long" with one per rank
             return self.ddim_sample(shape, cond, **{k: v for k, v in kwargs.items()
                                                     if k in ("init_noise", "step_noise", "seed", "clip_offset")})
         device = self._device()
@@ -465,7 +466,7 @@ class GaussianDiffusion(nn.Module):
         if x_0 is not None:
             traj = x_0.to(device).float().reshape(B, Lq, 3)
             x.view(B, Lq, nf)[:, :, 4:6] = traj[:, :, 0:2]
-        assert B > 1
+        assert B > 1 or halo is not None
         assert self.seq_len % 2 == 0
         pairs = self._ddim_pairs()
         weights = np.clip(np.linspace(0, self.guidance_weight * 2, 50), None, self.guidance_weight)
@@ -473,9 +474,14 @@ class GaussianDiffusion(nn.Module):
         row = (Lq // self.seq_len) * nf
         for i, (time, time_next) in enumerate(pairs):       # x[1:, :half] = x[:-1, half:] after every step but the last
             params[i, 7] = 1.0 if (time_next >= 0 and time > 0) else 0.0
+        after = None
+        if halo is not None:
+            def after(i, t, xv):
+                if pairs[i][1] >= 0 and t > 0:
+                    halo(xv)
         return self._run(L.SAMPLER_DDIM, (B, Lq, nf), cond, x, [a for a, _ in pairs], params, traj=traj,
                          step_noise=kwargs.get("step_noise"), seed=kwargs.get("seed"),
-                         clip_offset=kwargs.get("clip_offset", 0), couple=(self.seq_len, row))
+                         clip_offset=kwargs.get("clip_offset", 0), couple=(self.seq_len, row), after_step=after)
 
     def _footwork_mask(self, Lq, nf, dn, device):
         m = torch.zeros(self.seq_len, dn, nf, dtype=torch.bool, device=device)

@@ -66,3 +66,19 @@ def max_over_ranks(seconds: float, device) -> float:
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()
+
+
+def long_ddim_sample_sharded(diff, n_windows: int, Lq: int, nfeat: int, cond_local: torch.Tensor, x0_local, **kw):
+    """`GaussianDiffusion.long_ddim_sample` over the windows of one song sharded in contiguous blocks: the coupling
+    inside a rank is part of the captured step, the one boundary per rank pair crosses RCCL point-to-point after every
+    step (tcdiff_amd/stitch.py halo_exchange), and the result is all-gathered.  Noise is keyed by the GLOBAL window
+    index, so the windows equal the single-GPU ones (reference model/diffusion.py:446-515 has no multi-GPU path)."""
+    from .stitch import halo_exchange
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    lo, hi = shard_range(n_windows, rank, world)
+    row = (Lq // diff.seq_len) * nfeat
+    out = diff.long_ddim_sample((hi - lo, Lq, nfeat), cond_local, x0_local, clip_offset=lo,
+                                halo_exchange=(lambda xv: halo_exchange(xv, diff.seq_len, row)) if world > 1 else None,
+                                **kw)
+    return gather_samples(out, n_windows)
