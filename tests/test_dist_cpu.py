@@ -68,3 +68,35 @@ def test_shard_range_covers_everything():
             spans = [D.shard_range(n, r, w) for r in range(w)]
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    D.init_from_env("gloo")
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.zeros(s)) for s in ((300, 7), (5,), (1000,), (64, 64), (3,))]
+    for i, p in enumerate(ps):
+        if i != 1:                                    # parameter 1 is "dead": no gradient on any rank
+            p.grad = torch.full(p.shape, float(rank + 1) * (i + 1))
+    red = D.GradientAllReducer(ps, bucket_bytes=8192)
+    n = red.reduce()
+    ok = ps[1].grad is None and all(torch.allclose(p.grad, torch.full(p.shape, 1.5 * (i + 1)))
+                                    for i, p in enumerate(ps) if i != 1)
+    q.put((rank, ok, n, len(red.buckets)))
+    torch.distributed.destroy_process_group()
+
+
+def test_bucketed_gradient_allreduce_averages_over_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res)
+    assert res[0][2] == res[1][2] and res[0][3] >= 3          # several buckets, the same collectives on both ranks
