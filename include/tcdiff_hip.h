@@ -173,10 +173,17 @@ int tcdiff_adan_step(const tcdiff_adan_chunk* chunks, int n_chunks, const tcdiff
  * linear3 (32), w_qs, w_ks, w_vs of the NEXT layer (32 each).  n_stages = 64 / 288 / 192.  tcdiff_amd/engine.py packs it.
  * Rows: M token rows, L tokens per sequence; FiLM row = m / L, rotary position = m % L; head-major images as
  * TC_EPI_QKV_HEADS (H must be 8).  a_mod / xres_mod > 0: input / residual row = m % mod (layer 0 shares them between
- * the CFG branches). */
+ * the CFG branches).
+ *   TC_CHAIN_FULL / TC_CHAIN_FULL_LAST : chain A, then the CROSS-ATTENTION itself (head w on wave w, K / V from the
+ *                     fragment-ordered cache images written by tcdiff_pack_kv_frags), then chain B / B_LAST, in one launch:
+ *                     per layer the step is  self-attention -> one chain launch.  Stream: chain A's stages followed by
+ *                     chain B's (352 / 256 stages); the first fc block uses ln_g.., film, n2_*, the second lnb_*, filmb,
+ *                     n3_*; xres / xres_mod feed the first, xout carries x in between. */
 #define TC_CHAIN_A 0
 #define TC_CHAIN_B 1
 #define TC_CHAIN_B_LAST 2
+#define TC_CHAIN_FULL 3
+#define TC_CHAIN_FULL_LAST 4
 
 typedef struct {
     int mode, n_stages;
@@ -205,9 +212,28 @@ typedef struct {
     void* h_out;          /* TC_CHAIN_B_LAST: bf16 [M,512] */
     int film_ld;
     float ln_eps, n2_eps, n4_eps, nn_eps, scale_q;
+    /* TC_CHAIN_FULL*: the cross-attention block */
+    const float* lnb_g;   /* multihead_attn.layer_norm */
+    const float* lnb_b;
+    const float* filmb;   /* FiLM of the cross-attention block */
+    const float* n3_g;    /* norm3 */
+    const float* n3_b;
+    const void* kf;       /* fragment-ordered K cache of this layer: T[n_kv][8 heads][nkt][4][64 lanes][8] */
+    const void* vf;       /* fragment-ordered V cache                                                      */
+    int n_shared, nkt, Lk; /* kv slot = seq < n_shared ? 0 : seq - n_shared + (n_shared > 0); nkt = ceil(Lk / 32) tiles */
 } tcdiff_chain_args;
 
 int tcdiff_chain(const tcdiff_chain_args* args, hipStream_t stream);
+
+/* Fragment-ordered images of the cross-attention K / V caches for TC_CHAIN_FULL (bf16): for keys key_lo <= key < key_hi
+ * of every (slot, head) of Kc / Vc (T[n_slots][H][Lp][64], natural [key][d] rows),
+ *   Kf[slot][head][key / 32][d / 16][half * 32 + key % 32][j]  with d % 16 = 8 (j / 4) + 4 half + j % 4
+ *   Vf[slot][head][key / 32][(key % 32) / 16][d / 32][half * 32 + d % 32][j]  with key % 16 = 8 (j / 4) + 4 half + j % 4
+ * i.e. each 1-KB piece is the 64 lanes' 16-byte MFMA A-operand fragments of one (key tile, k-step).  Keys >= Lk inside
+ * the last tile must hold finite values (zero).  Run once over [0, Lk) when a cache slot is filled and over the two
+ * time-token keys every step. */
+int tcdiff_pack_kv_frags(const void* Kc, const void* Vc, void* Kf, void* Vf, int n_slots, int H, int Lp, int nkt,
+                         int key_lo, int key_hi, hipStream_t stream);
 
 /* ---- fused attention ------------------------------------------------------------------------------
  * O[(seq*Lq + q)*ldo + head*64 + d] = softmax_k(Q[seq][head][q] . K[kv][head][k]) V[kv][head][k][d]

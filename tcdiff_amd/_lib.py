@@ -15,7 +15,7 @@ EPI_STORE_T, EPI_STORE_F32, EPI_QKV_HEADS = 0, 1, 2
 ROW_BIAS, ROW_LN_POST, ROW_FILM, ROW_RES, ROW_STORE_X, ROW_NEXT_LN, ROW_STORE_H, ROW_STORE_ROT = \
     1, 2, 4, 8, 16, 32, 64, 128
 SAMPLER_DDPM, SAMPLER_DDIM = 0, 1
-CHAIN_A, CHAIN_B, CHAIN_B_LAST = 0, 1, 2
+CHAIN_A, CHAIN_B, CHAIN_B_LAST, CHAIN_FULL, CHAIN_FULL_LAST = 0, 1, 2, 3, 4
 
 _vp, _i, _f, _l = C.c_void_p, C.c_int, C.c_float, C.c_long
 
@@ -39,7 +39,8 @@ class ChainArgs(C.Structure):
                 ("xout", _vp), ("n2_g", _vp), ("n2_b", _vp), ("rope", _vp), ("q_out", _vp), ("b1", _vp), ("b2", _vp),
                 ("film3", _vp), ("n4_g", _vp), ("n4_b", _vp), ("b3", _vp), ("nn_g", _vp), ("nn_b", _vp),
                 ("k_out", _vp), ("v_out", _vp), ("h_out", _vp), ("film_ld", _i), ("ln_eps", _f), ("n2_eps", _f),
-                ("n4_eps", _f), ("nn_eps", _f), ("scale_q", _f)]
+                ("n4_eps", _f), ("nn_eps", _f), ("scale_q", _f), ("lnb_g", _vp), ("lnb_b", _vp), ("filmb", _vp),
+                ("n3_g", _vp), ("n3_b", _vp), ("kf", _vp), ("vf", _vp), ("n_shared", _i), ("nkt", _i), ("Lk", _i)]
 
 
 class AdanScalars(C.Structure):
@@ -56,6 +57,7 @@ _SIGS = {
     "tcdiff_smpl_fk": [_vp, _vp, _l, C.POINTER(_i), C.POINTER(_f), _vp, _vp],
     "tcdiff_loss_terms": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "tcdiff_adan_step": [_vp, _i, C.POINTER(AdanScalars), _vp],
+    "tcdiff_pack_kv_frags": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "tcdiff_chain": [C.POINTER(ChainArgs), _vp],
     "tcdiff_ln_rot": [_i, _vp, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "tcdiff_rope_table": [_vp, _vp, _i, _vp],

@@ -264,8 +264,121 @@ DEVINL void store_heads(const f32x16_t (&acc)[2][2], void* base, float scale, in
     }
 }
 
+// Cross-attention of this wave's head inside the chain (model/model.py:386-396,97-102 with cached K / V): the wave owns
+// head `wave` of all 64 rows.  qacc = (rot W_q^T)^T tiles straight from the projection GEMM (lane = row, registers = d):
+// scaled and packed they ARE the B operand of S^T = K Q^T, with d in the order the accumulator holds it -- the K / V
+// caches are kept in a second, fragment-ordered image (tcdiff_pack_kv_frags) whose 1-KB pieces load straight into the
+// A operands.  Online softmax over 32-key tiles exactly as csrc/attention.hip; O^T = V^T P^T with P^T fed from the S^T
+// accumulator registers.  A 32-row tile that straddles two sequences runs once per sequence and every lane keeps the
+// result of its own row's sequence.  Output: bf16 O rows into the activation block (columns 64 wave ..).
+DEVINL void cross_attention(const f32x16_t (&qacc)[2][2], const tcdiff_chain_args& a, int m0, char* abuf, int wave,
+                            int lane) {
+    lane = fresh_v(lane);
+    wave = fresh_s(wave);
+    const int r = lane & 31, h = lane >> 5;
+    const int M = a.M, L = a.L, nkt = a.nkt;
+    u32x4 qf[2][4];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int s16 = 0; s16 < 4; ++s16) {
+            const int ni = s16 >> 1, o8 = 8 * (s16 & 1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                qf[mi][s16][j] = pack_bf2(qacc[mi][ni][o8 + 2 * j] * a.scale_q, qacc[mi][ni][o8 + 2 * j + 1] * a.scale_q);
+        }
+    constexpr float LOG2E = 1.4426950408889634f;
+    const long head_bytes = (long)nkt * 4096;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        int ra = m0 + 32 * mi, rb = ra + 31;
+        ra = ra < M ? ra : M - 1;
+        rb = rb < M ? rb : M - 1;
+        const int sa = ra / L, sb = rb / L;                 // wave-uniform
+        int mrow = m0 + 32 * mi + r;
+        mrow = mrow < M ? mrow : M - 1;
+        const int my_seq = mrow / L;
+#pragma unroll 1
+        for (int seq = sa; seq <= sb; ++seq) {
+            const int kv = seq < a.n_shared ? 0 : seq - a.n_shared + (a.n_shared > 0 ? 1 : 0);
+            const u32x4* Kp = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(a.kf) +
+                                                              ((long)kv * a.H + wave) * head_bytes) + lane;
+            const u32x4* Vp = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(a.vf) +
+                                                              ((long)kv * a.H + wave) * head_bytes) + lane;
+            f32x16_t o[2];
+            zero(o[0]);
+            zero(o[1]);
+            float m_run = -INFINITY, l_run = 0.0f;
+            u32x4 kn[4];                                           // K fragments run one tile ahead
+#pragma unroll
+            for (int i = 0; i < 4; ++i) kn[i] = Kp[i * 64];
+#pragma unroll 1
+            for (int kt = 0; kt < nkt; ++kt) {
+                u32x4 kc[4], vc[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    kc[i] = kn[i];
+                    vc[i] = Vp[(kt * 4 + i) * 64];                 // V of this tile: in flight under QK^T and the softmax
+                }
+                const int nx = kt + 1 < nkt ? kt + 1 : kt;       // the last iteration re-reads its own tile (unused)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) kn[i] = Kp[(nx * 4 + i) * 64];
+                f32x16_t s;
+                zero(s);
+#pragma unroll
+                for (int s16 = 0; s16 < 4; ++s16) MmaBF16::mma(s, kc[s16], qf[mi][s16]);
+                if (kt * 32 + 32 > a.Lk) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)
+                        if (kt * 32 + acc_row(q, h) >= a.Lk) s[q] = -INFINITY;
+                }
+                float mx = s[0];
+#pragma unroll
+                for (int q = 1; q < 16; ++q) mx = fmaxf(mx, s[q]);
+                mx = fmaxf(mx, other_half(mx)) * LOG2E;
+                const float m_new = fmaxf(m_run, mx);
+                float rs = 0.0f;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const float p = __builtin_amdgcn_exp2f(fmaf(s[q], LOG2E, -m_new));
+                    s[q] = p;
+                    rs += p;
+                }
+                rs += other_half(rs);
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // first tile: exp2(-inf) = 0, o is 0
+                l_run = l_run * alpha + rs;
+                m_run = m_new;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) o[dt][q] *= alpha;
+#pragma unroll
+                for (int sp = 0; sp < 2; ++sp) {
+                    u32x4 pf;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) pf[j] = pack_bf2(s[8 * sp + 2 * j], s[8 * sp + 2 * j + 1]);
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) MmaBF16::mma(o[dt], vc[sp * 2 + dt], pf);
+                }
+            }
+            if (my_seq == seq) {
+                const float inv = 1.0f / l_run;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        uint2 pk;
+                        pk.x = pack_bf2(o[dt][4 * gq + 0] * inv, o[dt][4 * gq + 1] * inv);
+                        pk.y = pack_bf2(o[dt][4 * gq + 2] * inv, o[dt][4 * gq + 3] * inv);
+                        *reinterpret_cast<uint2*>(abuf + wave * 8192 + tile_off(32 * mi + r, 4 * dt + gq) + 8 * h) = pk;
+                    }
+            }
+        }
+    }
+}
+
 #ifdef CH_STAMP   // diagnostic build: per-phase timestamps of block 0 / wave 0 into the (otherwise unused) h_out buffer
-#define CH_T(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && MODE == TC_CHAIN_B) \
+#define CH_T(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && (MODE == TC_CHAIN_B || MODE == TC_CHAIN_FULL)) \
         reinterpret_cast<unsigned long long*>(a.h_out)[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define CH_T(i) do { } while (0)
@@ -273,6 +386,9 @@ DEVINL void store_heads(const f32x16_t (&acc)[2][2], void* base, float scale, in
 
 template <int MODE>
 __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
+    constexpr bool HAS_A = MODE == TC_CHAIN_A || MODE == TC_CHAIN_FULL || MODE == TC_CHAIN_FULL_LAST;   // fc + norm2 + w_qs
+    constexpr bool FULL = MODE == TC_CHAIN_FULL || MODE == TC_CHAIN_FULL_LAST;                          // + cross-attention
+    constexpr bool LAST = MODE == TC_CHAIN_B_LAST || MODE == TC_CHAIN_FULL_LAST;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -286,16 +402,14 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     char* cfilm = smem + CH_FILM;      // [2 sequences][scale 512 | shift 512] floats
     char* cvec = smem + CH_VEC;        // six vectors of 512 floats
 
-    // rows of this lane (both row tiles), clamped: rows past M recompute row M - 1 and are never stored
+    // rows of this lane (both row tiles), clamped: rows past M recompute row M - 1 (their inputs are clamped to it)
     int mc[2], sidx[2];
-    bool ok[2];
     const int seq0 = (m0 < M ? m0 : M - 1) / L;
     const int seq_last = (M - 1) / L;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
         const int m = m0 + 32 * mi + r;
-        ok[mi] = m < M;
-        mc[mi] = ok[mi] ? m : M - 1;
+        mc[mi] = m < M ? m : M - 1;
         sidx[mi] = mc[mi] / L - seq0;          // 0 or 1: L >= 64 rows per sequence (checked by the launcher)
     }
     // Epilogue constants go through LDS.  Thread t carries one float4 of the FiLM rows and up to two of the vectors
@@ -319,6 +433,13 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
         if (tid < 256) *reinterpret_cast<f32x4_t*>(cvec + 8192 + tid * 16) = k.v1;
     };
     auto vecp = [&](int slot) { return cvec + slot * 2048; };
+    // constants of the fc block that opens chain B: its own set when chain A ran in front of it in this launch
+    const float* fcb_g = FULL ? a.lnb_g : a.ln_g;
+    const float* fcb_b = FULL ? a.lnb_b : a.ln_b;
+    const float* fcb_film = FULL ? a.filmb : a.film;
+    const float* n3_g = FULL ? a.n3_g : a.n2_g;
+    const float* n3_b = FULL ? a.n3_b : a.n2_b;
+
     // ---- the block's input rows (attention output) -> LDS, the first CH_D weight stages -> registers, constants -> LDS
 #pragma unroll
     for (int kt = 0; kt < 8; ++kt)
@@ -350,61 +471,94 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     float mean[2], rstd[2];
     RowPipe rp;                        // residual rows, later rotary rows, of this lane
     int pos[2] = {mc[0] % L, mc[1] % L};
+    Consts nxt;
 
-    // ================= fc: LayerNorm(1e-6), FiLM, residual (model/model.py:103-106,171-173,327 / 334)
-    clear();
-    phase_n512(acc, abuf, 32, ws, lane);
-    CH_T(2);
-    {
-        int rr[2];
+    // fc epilogue: LayerNorm(eps), FiLM, residual -> x in the accumulators and in xout (model/model.py:103-106,171-173,
+    // 327 / 334); constants in vector slots 0, 1 and the FiLM area; the residual rows were started by the caller
+    auto fc_epilogue = [&](float eps) {
+        lds_barrier();                 // every wave is out of the GEMM: the activation block may be overwritten
+        row_stats(acc, scr, wave, lane, eps, mean, rstd);
+        // fresh copies: the two inlined instances of this epilogue must not share (and keep alive) their addresses
+        const int hh = fresh_v(h), wv = fresh_s(wave);
+        const int mcl[2] = {fresh_v(mc[0]), fresh_v(mc[1])}, sx[2] = {fresh_v(sidx[0]), fresh_v(sidx[1])};
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) rr[mi] = a.xres_mod > 0 ? mc[mi] % a.xres_mod : mc[mi];
-        rp_start(rp, a.xres, rr, wave, h);   // in flight during the statistics exchange
-    }
-    lds_barrier();                     // every wave is out of the GEMM: the activation block may be overwritten
-    row_stats(acc, scr, wave, lane, a.ln_eps, mean, rstd);
+        for (int it = 0; it < 8; ++it) {
+            const int ni = it >> 2, gq = it & 3;
+            const int n = 64 * wv + 32 * ni + 8 * gq + 4 * hh;
+            const f32x4_t g4 = lds4(vecp(0), n), b4 = lds4(vecp(1), n);
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const int ni = it >> 2, gq = it & 3;
-        const int n = 64 * wave + 32 * ni + 8 * gq + 4 * h;
-        const f32x4_t g4 = lds4(vecp(0), n), b4 = lds4(vecp(1), n);
+            for (int mi = 0; mi < 2; ++mi) {
+                const f32x4_t sc = lds4(cfilm, sx[mi] * 1024 + n), sh = lds4(cfilm, sx[mi] * 1024 + 512 + n);
+                const f32x4_t x4 = rp.q[it & 3][mi];
+                f32x4_t o;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-            const f32x4_t sc = lds4(cfilm, sidx[mi] * 1024 + n), sh = lds4(cfilm, sidx[mi] * 1024 + 512 + n);
-            const f32x4_t x4 = rp.q[it & 3][mi];
-            f32x4_t o;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                float v = (acc[mi][ni][4 * gq + t] - mean[mi]) * rstd[mi] * g4[t] + b4[t];
-                v = (sc[t] + 1.0f) * v + sh[t];
-                v = x4[t] + v;
-                acc[mi][ni][4 * gq + t] = v;
-                o[t] = v;
+                for (int t = 0; t < 4; ++t) {
+                    float v = (acc[mi][ni][4 * gq + t] - mean[mi]) * rstd[mi] * g4[t] + b4[t];
+                    v = (sc[t] + 1.0f) * v + sh[t];
+                    v = x4[t] + v;
+                    acc[mi][ni][4 * gq + t] = v;
+                    o[t] = v;
+                }
+                // unguarded: rows past M rewrite row M - 1 with the SAME values (same inputs; every load of this column
+                // group, in place or not, was issued before this store)
+                *reinterpret_cast<f32x4_t*>(a.xout + (long)mcl[mi] * 512 + n) = o;
             }
-            // unguarded: rows past M rewrite row M - 1 with the SAME values (same inputs; every load of this column
-            // group, in place or not, was issued before this store)
-            *reinterpret_cast<f32x4_t*>(a.xout + (long)mc[mi] * 512 + n) = o;
+            if (it + 4 < 8) rp_issue(rp, it + 4);
+            // one column group at a time: without a fence hipcc hoists the loads of ALL eight groups (row pipeline
+            // refills and LDS constants) above the arithmetic, needs ~100 more registers and spills them
+            CH_FENCE();
         }
-        if (it + 4 < 8) rp_issue(rp, it + 4);
-        // one column group at a time: without a scheduling barrier hipcc hoists the loads of ALL eight groups (row
-        // pipeline refills and LDS constants) above the arithmetic, needs ~100 more registers and spills them
-        CH_FENCE();
-    }
-    CH_T(3);
-    if (MODE == TC_CHAIN_A) rp_start(rp, a.rope, pos, wave, h);
-    row_stats(acc, scr + 1024, wave, lane, a.n2_eps, mean, rstd);
-    CH_T(4);
-    if (MODE == TC_CHAIN_A) {
+    };
+
+    if (HAS_A) {
+        // ================= self-attention block tail: fc + LayerNorm(1e-6) + FiLM + residual, norm2 + rotary, w_qs
+        clear();
+        phase_n512(acc, abuf, 32, ws, lane);
+        CH_T(2);
+        {
+            int rr[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) rr[mi] = a.xres_mod > 0 ? mc[mi] % a.xres_mod : mc[mi];
+            rp_start(rp, a.xres, rr, wave, h);   // in flight during the statistics exchange
+        }
+        fc_epilogue(a.ln_eps);
+        CH_T(3);
+        if (FULL) {
+            const float* const v[6] = {fcb_g, fcb_b, n3_g, n3_b, nullptr, nullptr};
+            nxt = fetch_consts(fcb_film, v);
+        }
+        rp_start(rp, a.rope, pos, wave, h);
+        row_stats(acc, scr + 1024, wave, lane, a.n2_eps, mean, rstd);
+        CH_T(4);
         // norm2 + rotary (model/model.py:332,387) -> LDS -> Q = rot W_q^T / 8 (model/model.py:78,97)
         norm_to_lds<true>(acc, mean, rstd, vecp(2), vecp(3), rp, abuf, wave, lane, nullptr);
         lds_barrier();
+        if (FULL) store_consts(nxt);   // the cross-attention fc block's constants: read two barriers from here
         clear();
         phase_n512(acc, abuf, 32, ws, lane);
-        store_heads(acc, a.q_out, a.scale_q, L, a.Lp, a.H, m0, M, wave, lane);
-        return;
+        if (!FULL) {
+            store_heads(acc, a.q_out, a.scale_q, L, a.Lp, a.H, m0, M, wave, lane);
+            return;
+        }
+        // ================= cross-attention in place (the Q image never leaves the registers)
+        lds_barrier();                 // every wave is out of the w_qs GEMM: the activation block becomes O
+        cross_attention(acc, a, m0, abuf, wave, lane);
+        lds_barrier();
     }
+    // ================= cross-attention block tail: fc + LayerNorm(1e-6) + FiLM + residual (model/model.py:334)
+    clear();
+    phase_n512(acc, abuf, 32, ws, lane);
+    if (FULL) {
+        rp_start(rp, a.xout, mc, wave, h);       // the x this lane stored in the first fc epilogue
+    } else {
+        int rr[2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) rr[mi] = a.xres_mod > 0 ? mc[mi] % a.xres_mod : mc[mi];
+        rp_start(rp, a.xres, rr, wave, h);
+    }
+    fc_epilogue(a.ln_eps);
+    row_stats(acc, scr + 1024, wave, lane, a.n2_eps, mean, rstd);
     // ================= feed-forward (model/model.py:338-339,399-401): norm3 -> LDS
-    Consts nxt;
     {
         const float* const v[6] = {a.b1, a.b1 + 512, a.b2, a.n4_g, a.n4_b, nullptr};
         nxt = fetch_consts(a.film3, v);
@@ -506,7 +660,7 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
                     acc[mi][ni][4 * gq + t] += b4[t];
                     o[t] = acc[mi][ni][4 * gq + t];
                 }
-                if (MODE == TC_CHAIN_B_LAST) {   // the final projection reads bf16 rows (model/model.py:623)
+                if (LAST) {   // the final projection reads bf16 rows (model/model.py:623)
                     uint2 pk;
                     pk.x = pack_bf2(o[0], o[1]);
                     pk.y = pack_bf2(o[2], o[3]);
@@ -517,7 +671,7 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
             }
             CH_FENCE();
         }
-    if (MODE == TC_CHAIN_B_LAST) return;
+    if (LAST) return;
     // ================= next layer: norm1 + rotary -> Q, K ; norm1 -> V (model/model.py:326,374-383,78-80)
     CH_T(26);
     rp_start(rp, a.rope, pos, wave, h);
@@ -547,42 +701,52 @@ static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 extern "C" int tcdiff_chain(const tcdiff_chain_args* a, hipStream_t stream) {
     if (!a || a->M <= 0 || a->L <= 0 || !a->A || !a->wstream) return TC_ERR_ARG;
     if (a->L < 64) return TC_ERR_UNSUPPORTED;   // a 64-row block must touch at most two sequences
-    const int want = a->mode == TC_CHAIN_A ? 64 : (a->mode == TC_CHAIN_B ? 288 : (a->mode == TC_CHAIN_B_LAST ? 192 : -1));
+    const int want = a->mode == TC_CHAIN_A ? 64 : a->mode == TC_CHAIN_B ? 288 : a->mode == TC_CHAIN_B_LAST ? 192 :
+                     a->mode == TC_CHAIN_FULL ? 352 : a->mode == TC_CHAIN_FULL_LAST ? 256 : -1;
     if (want < 0 || a->n_stages != want) return TC_ERR_ARG;
     if (!a->ln_g || !a->ln_b || !a->film || a->film_ld % 4 || !a->xres || !a->xout || !a->n2_g || !a->n2_b) return TC_ERR_ARG;
     if ((long)(a->a_mod > 0 ? a->a_mod : a->M) * 1024 >= (1L << 32)) return TC_ERR_ARG;
     const void* ptrs[] = {a->A, a->wstream, a->ln_g, a->ln_b, a->film, a->xres, a->xout, a->n2_g, a->n2_b, a->rope,
                           a->q_out, a->b1, a->b2, a->film3, a->n4_g, a->n4_b, a->b3, a->nn_g, a->nn_b, a->k_out,
-                          a->v_out, a->h_out};
+                          a->v_out, a->h_out, a->lnb_g, a->lnb_b, a->filmb, a->n3_g, a->n3_b, a->kf, a->vf};
     for (const void* p : ptrs)
         if (p && !al16(p)) return TC_ERR_ALIGN;
-    if (a->mode == TC_CHAIN_A) {
-        if (!a->rope || !a->q_out || a->H != 8 || a->Lp <= 0) return TC_ERR_ARG;
-    } else {
-        if (!a->b1 || !a->b2 || !a->film3 || !a->n4_g || !a->n4_b || !a->b3) return TC_ERR_ARG;
-        if (a->mode == TC_CHAIN_B &&
-            (!a->rope || !a->nn_g || !a->nn_b || !a->q_out || !a->k_out || !a->v_out || a->H != 8 || a->Lp <= 0))
-            return TC_ERR_ARG;
-        if (a->mode == TC_CHAIN_B_LAST && !a->h_out) return TC_ERR_ARG;
-    }
+    const bool has_a = a->mode == TC_CHAIN_A || a->mode >= TC_CHAIN_FULL;
+    const bool has_b = a->mode != TC_CHAIN_A;
+    const bool full = a->mode >= TC_CHAIN_FULL;
+    const bool last = a->mode == TC_CHAIN_B_LAST || a->mode == TC_CHAIN_FULL_LAST;
+    if (has_a && (!a->rope || a->H != 8)) return TC_ERR_ARG;
+    if (a->mode == TC_CHAIN_A && (!a->q_out || a->Lp <= 0)) return TC_ERR_ARG;
+    if (has_b && (!a->b1 || !a->b2 || !a->film3 || !a->n4_g || !a->n4_b || !a->b3)) return TC_ERR_ARG;
+    if (has_b && !last &&
+        (!a->rope || !a->nn_g || !a->nn_b || !a->q_out || !a->k_out || !a->v_out || a->H != 8 || a->Lp <= 0))
+        return TC_ERR_ARG;
+    if (last && !a->h_out) return TC_ERR_ARG;
+    if (full && (!a->lnb_g || !a->lnb_b || !a->filmb || !a->n3_g || !a->n3_b || !a->kf || !a->vf || a->nkt <= 0 ||
+                 a->Lk <= 0 || a->Lk > 32 * a->nkt || a->n_shared < 0))
+        return TC_ERR_ARG;
     static tc_dev_state dev_state;
     const int n_cu = tc_device_once(dev_state, [](int) {
-        hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel<TC_CHAIN_A>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, CH_SMEM);
-        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel<TC_CHAIN_B>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, CH_SMEM);
-        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel<TC_CHAIN_B_LAST>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, CH_SMEM);
-        return e0 != hipSuccess ? e0 : (e1 != hipSuccess ? e1 : e2);
+        const void* fns[5] = {reinterpret_cast<const void*>(chain_kernel<TC_CHAIN_A>),
+                              reinterpret_cast<const void*>(chain_kernel<TC_CHAIN_B>),
+                              reinterpret_cast<const void*>(chain_kernel<TC_CHAIN_B_LAST>),
+                              reinterpret_cast<const void*>(chain_kernel<TC_CHAIN_FULL>),
+                              reinterpret_cast<const void*>(chain_kernel<TC_CHAIN_FULL_LAST>)};
+        for (const void* f : fns) {
+            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, CH_SMEM);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
     });
     if (n_cu < 0) return n_cu;
     dim3 grid((a->M + 63) / 64);
-    if (a->mode == TC_CHAIN_A)
-        hipLaunchKernelGGL(chain_kernel<TC_CHAIN_A>, grid, dim3(512), CH_SMEM, stream, *a);
-    else if (a->mode == TC_CHAIN_B)
-        hipLaunchKernelGGL(chain_kernel<TC_CHAIN_B>, grid, dim3(512), CH_SMEM, stream, *a);
-    else
-        hipLaunchKernelGGL(chain_kernel<TC_CHAIN_B_LAST>, grid, dim3(512), CH_SMEM, stream, *a);
+    switch (a->mode) {
+        case TC_CHAIN_A: hipLaunchKernelGGL(chain_kernel<TC_CHAIN_A>, grid, dim3(512), CH_SMEM, stream, *a); break;
+        case TC_CHAIN_B: hipLaunchKernelGGL(chain_kernel<TC_CHAIN_B>, grid, dim3(512), CH_SMEM, stream, *a); break;
+        case TC_CHAIN_B_LAST: hipLaunchKernelGGL(chain_kernel<TC_CHAIN_B_LAST>, grid, dim3(512), CH_SMEM, stream, *a); break;
+        case TC_CHAIN_FULL: hipLaunchKernelGGL(chain_kernel<TC_CHAIN_FULL>, grid, dim3(512), CH_SMEM, stream, *a); break;
+        default: hipLaunchKernelGGL(chain_kernel<TC_CHAIN_FULL_LAST>, grid, dim3(512), CH_SMEM, stream, *a); break;
+    }
     TC_CHECK_LAUNCH();
     return TC_OK;
 }

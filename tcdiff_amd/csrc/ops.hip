@@ -390,6 +390,42 @@ extern "C" int tcdiff_window_couple(float* x, int b, int seq_len, int row_elems,
     return TC_OK;
 }
 
+// ---- fragment-ordered K / V cache images for the in-chain cross-attention (csrc/chain.hip cross_attention) -----------
+__global__ void pack_kv_frags_kernel(const uint16_t* __restrict__ Kc, const uint16_t* __restrict__ Vc,
+                                     uint16_t* __restrict__ Kf, uint16_t* __restrict__ Vf, long n_sh, int Lp, int nkt,
+                                     int key_lo, int nkeys) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;          // (slot*head, key, d)
+    if (i >= n_sh * nkeys * 64) return;
+    const int d = (int)(i & 63);
+    const long r2 = i >> 6;
+    const int key = key_lo + (int)(r2 % nkeys);
+    const long sh = r2 / nkeys;
+    const long src = (sh * Lp + key) * 64 + d;
+    const long base = sh * (long)nkt * 2048;                              // elements per (slot, head) image
+    const int kt = key >> 5, k32 = key & 31;
+    {   // K: [kt][d / 16][half][key % 32][j],  d % 16 = 8 (j / 4) + 4 half + j % 4
+        const int s16 = d >> 4, dd = d & 15, hh = (dd & 7) >> 2, j = 4 * (dd >> 3) + (dd & 3);
+        Kf[base + ((long)(kt * 4 + s16) * 64 + hh * 32 + k32) * 8 + j] = Kc[src];
+    }
+    {   // V: [kt][(key % 32) / 16][d / 32][half][d % 32][j],  key % 16 = 8 (j / 4) + 4 half + j % 4
+        const int sp = k32 >> 4, kk = k32 & 15, hh = (kk & 7) >> 2, j = 4 * (kk >> 3) + (kk & 3);
+        Vf[base + ((long)((kt * 2 + sp) * 2 + (d >> 5)) * 64 + hh * 32 + (d & 31)) * 8 + j] = Vc[src];
+    }
+}
+
+extern "C" int tcdiff_pack_kv_frags(const void* Kc, const void* Vc, void* Kf, void* Vf, int n_slots, int H, int Lp,
+                                    int nkt, int key_lo, int key_hi, hipStream_t stream) {
+    if (!Kc || !Vc || !Kf || !Vf || n_slots <= 0 || H <= 0 || Lp <= 0 || nkt <= 0 || key_lo < 0 || key_hi <= key_lo ||
+        key_hi > 32 * nkt || key_hi > Lp)
+        return TC_ERR_ARG;
+    const long n = (long)n_slots * H * (key_hi - key_lo) * 64;
+    hipLaunchKernelGGL(pack_kv_frags_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                       (const uint16_t*)Kc, (const uint16_t*)Vc, (uint16_t*)Kf, (uint16_t*)Vf, (long)n_slots * H, Lp, nkt,
+                       key_lo, key_hi - key_lo);
+    TC_CHECK_LAUNCH();
+    return TC_OK;
+}
+
 // ---- in-painting constraints and window coupling INSIDE the captured step (no per-step host callback) ---------------
 // kind 1: x = mask ? value : x while the step is not the last one (ddim_sample_Footwork, model/diffusion.py:341-356)
 // kind 2: x = q_sample(value, t - 1) * mask + (1 - mask) * x for t > 0 (inpaint_loop, model/diffusion.py:545-551);

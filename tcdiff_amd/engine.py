@@ -57,6 +57,9 @@ class DenoiserEngine:
         # row-block chain kernels (csrc/chain.hip): bf16 only; the f32 parity mode keeps the op-by-op kernels
         self.use_chain = self.dt == L.DT_BF16 and os.environ.get("TCDIFF_CHAIN", "1") != "0" and self.ff == 1024 \
             and self.H == 8
+        # TCDIFF_CHAIN=2 (default): cross-attention inside the chain too: per layer self-attention + ONE chain launch
+        self.use_full = self.use_chain and os.environ.get("TCDIFF_CHAIN", "2") == "2"
+        self.nkt = (self.S + 2 + 31) // 32          # 32-key tiles of the cross-attention memory
         self.reset_graphs()
 
     def reset_graphs(self):
@@ -127,6 +130,8 @@ class DenoiserEngine:
                 parts += [self._stages_n512(qkv[0:512]), self._stages_n512(qkv[512:1024]),
                           self._stages_n512(qkv[1024:1536])]
             w[p + "chainB"] = torch.cat(parts, 1).contiguous()
+            if self.use_full:
+                w[p + "chainF"] = torch.cat([w[p + "chainA"], w[p + "chainB"]], 1).contiguous()
 
     def _f32(self, t: torch.Tensor) -> torch.Tensor:
         return t.detach().to(device=self.dev, dtype=torch.float32).contiguous()
@@ -218,6 +223,9 @@ class DenoiserEngine:
         b["film_in"] = z(2 * B, 512)
         b["Kc"] = z(NL, 2 * B, H, self.Lpc, 64)      # slots: sampler uses 0..B, generic forward up to 2B
         b["Vc"] = z(NL, 2 * B, H, self.Lpc, 64)
+        if self.use_full:                            # fragment-ordered images of the same caches (csrc/chain.hip)
+            b["Kf"] = z(NL, 2 * B, H, self.nkt * 2048)
+            b["Vf"] = z(NL, 2 * B, H, self.nkt * 2048)
         b["hidden_all"] = z(2 * B, 512, dtype=torch.float32)
         b["tidx"] = torch.zeros(2 * B, device=dev, dtype=torch.int32)
         # music encoder (setup only)
@@ -287,6 +295,8 @@ class DenoiserEngine:
             K.gemm_tile(dt, b["mrot"], w[f"l{l}.ckv.w"], M, 1024, 512, A2=b["mh"], split_n=512, mode=L.EPI_QKV_HEADS,
                         out=None, out_k=b["Kc"][l], out_v=b["Vc"][l], Lseq=S, Lp=self.Lpc, H=self.H, n_q=0, n_k=512,
                         seq_off=slot0)
+        if self.use_full:
+            K.pack_kv_frags(b["Kc"], b["Vc"], b["Kf"], b["Vf"], self.NL * b["Kc"].shape[1], self.H, self.Lpc, self.nkt, 0, S)
 
     def build_time_tables(self, times_i32: torch.Tensor):
         """time path for a set of timesteps (model/model.py:601-605,615-616 rows S,S+1, and their K/V rows):
@@ -324,6 +334,9 @@ class DenoiserEngine:
         dt, w, b = self.dt, self.w, self.b
         K.scatter_time_kv(dt, self.kv_tab, self.n_t, b["tidx"], b["Kc"], b["Vc"], self.NL, b["Kc"].shape[1], self.H,
                           self.Lpc, self.S)
+        if self.use_full:
+            K.pack_kv_frags(b["Kc"], b["Vc"], b["Kf"], b["Vf"], self.NL * b["Kc"].shape[1], self.H, self.Lpc, self.nkt,
+                            self.S, self.S + 2)
         K.add_act(dt, self.t_base, b["tidx"], b["hidden_all"], n_rows_seq, L.ACT_MISH, out=b["film_in"])
         nfilm = self.NL * NL_FILM * 1024
         K.gemm_tile(dt, b["film_in"], w["film.w"], n_rows_seq, nfilm, 512, bias=w["film.b"], mode=L.EPI_STORE_F32,
@@ -360,7 +373,7 @@ class DenoiserEngine:
             rows_sa = Rs if l == 0 else R          # layer-0 self-attention is branch-independent
             nseq_sa = B if l == 0 else nseq
             if self.use_chain:
-                self._layer_chained(l, B, branches, Kc0, Vc0, film0, fld, n_shared)
+                self._layer_chained(l, B, branches, Kc0, Vc0, film0, fld, n_shared, kv_slot0)
                 continue
             # ---- self-attention block (model/model.py:326-327,374-383,71-107)
             K.gemm_tile(dt, b["rot"], w[p + "qkv.w"], rows_sa, 1536, 512, A2=b["h"], split_n=1024, mode=L.EPI_QKV_HEADS,
@@ -401,7 +414,7 @@ class DenoiserEngine:
         K.gemm_tile(dt, b["h"], w["fin.w"], R, self.nf, 512, bias=w["fin.b"], mode=L.EPI_STORE_F32, out=b["out"], ldc=152)
         return b["out"]
 
-    def _layer_chained(self, l: int, B: int, branches: int, Kc0, Vc0, film0, fld: int, n_shared: int):
+    def _layer_chained(self, l: int, B: int, branches: int, Kc0, Vc0, film0, fld: int, n_shared: int, kv_slot0: int):
         """One decoder layer as attention / chain A / attention / chain B (csrc/chain.hip): the Q, K, V images of
         this layer's self-attention were written by the previous layer's chain B (layer 0: by the QKV GEMM below)."""
         dt, w, b = self.dt, self.w, self.b
@@ -415,19 +428,26 @@ class DenoiserEngine:
                         out=b["Q"], out_k=b["K"], out_v=b["V"], scale_q=0.125, Lseq=Lq, Lp=self.Lp, H=H, n_q=512,
                         n_k=512)
         K.attention(dt, b["Q"], b["K"], b["V"], b["O"], B if l == 0 else nseq, H, Lq, Lq, self.Lp, self.Lp, 512)
-        K.chain(L.CHAIN_A, 64, R, Lq, b["O"], w[p + "chainA"], a_mod=Rs if l == 0 else 0,
-                ln_g=w[p + "sln.g"], ln_b=w[p + "sln.b"], ln_eps=1e-6, film=film0[:, (l * 3 + 0) * 1024:], film_ld=fld,
-                xres=b["xs"] if l == 0 else b["xa"], xres_mod=Rs if l == 0 else 0, xout=b["xa"],
-                n2_g=w[p + "norm2.g"], n2_b=w[p + "norm2.b"], n2_eps=1e-5, rope=rope, q_out=b["Q"], scale_q=0.125,
-                Lp=self.Lp, H=H)
-        K.attention(dt, b["Q"], Kc0[l], Vc0[l], b["O"], nseq, H, Lq, S + 2, self.Lp, self.Lpc, 512, n_shared=n_shared)
         last = l + 1 == NL
         nn = f"l{l + 1}.norm1." if not last else None
+        tail = dict(b1=w[p + "ff1.b"], b2=w[p + "ff2.b"], film3=film0[:, (l * 3 + 2) * 1024:], n4_g=w[p + "norm4.g"],
+                    n4_b=w[p + "norm4.b"], n4_eps=1e-5, b3=w[p + "l3.b"],
+                    nn_g=None if last else w[nn + "g"], nn_b=None if last else w[nn + "b"], nn_eps=1e-5,
+                    q_out=None if last else b["Q"], k_out=None if last else b["K"], v_out=None if last else b["V"],
+                    h_out=b["h"] if last else None, scale_q=0.125, Lp=self.Lp, H=H)
+        head = dict(a_mod=Rs if l == 0 else 0, ln_g=w[p + "sln.g"], ln_b=w[p + "sln.b"], ln_eps=1e-6,
+                    film=film0[:, (l * 3 + 0) * 1024:], film_ld=fld, xres=b["xs"] if l == 0 else b["xa"],
+                    xres_mod=Rs if l == 0 else 0, xout=b["xa"], n2_g=w[p + "norm2.g"], n2_b=w[p + "norm2.b"], n2_eps=1e-5,
+                    rope=rope)
+        if self.use_full:
+            # self-attention tail, cross-attention (K / V from the fragment-ordered caches) and feed-forward in ONE launch
+            K.chain(L.CHAIN_FULL_LAST if last else L.CHAIN_FULL, 256 if last else 352, R, Lq, b["O"], w[p + "chainF"],
+                    lnb_g=w[p + "cln.g"], lnb_b=w[p + "cln.b"], filmb=film0[:, (l * 3 + 1) * 1024:], n3_g=w[p + "norm3.g"],
+                    n3_b=w[p + "norm3.b"], kf=b["Kf"][l, kv_slot0:], vf=b["Vf"][l, kv_slot0:], n_shared=n_shared,
+                    nkt=self.nkt, Lk=S + 2, **head, **tail)
+            return
+        K.chain(L.CHAIN_A, 64, R, Lq, b["O"], w[p + "chainA"], **head, q_out=b["Q"], scale_q=0.125, Lp=self.Lp, H=H)
+        K.attention(dt, b["Q"], Kc0[l], Vc0[l], b["O"], nseq, H, Lq, S + 2, self.Lp, self.Lpc, 512, n_shared=n_shared)
         K.chain(L.CHAIN_B_LAST if last else L.CHAIN_B, 192 if last else 288, R, Lq, b["O"], w[p + "chainB"],
                 ln_g=w[p + "cln.g"], ln_b=w[p + "cln.b"], ln_eps=1e-6, film=film0[:, (l * 3 + 1) * 1024:], film_ld=fld,
-                xres=b["xa"], xout=b["xa"], n2_g=w[p + "norm3.g"], n2_b=w[p + "norm3.b"], n2_eps=1e-5, rope=rope,
-                b1=w[p + "ff1.b"], b2=w[p + "ff2.b"], film3=film0[:, (l * 3 + 2) * 1024:], n4_g=w[p + "norm4.g"],
-                n4_b=w[p + "norm4.b"], n4_eps=1e-5, b3=w[p + "l3.b"],
-                nn_g=None if last else w[nn + "g"], nn_b=None if last else w[nn + "b"], nn_eps=1e-5,
-                q_out=None if last else b["Q"], k_out=None if last else b["K"], v_out=None if last else b["V"],
-                h_out=b["h"] if last else None, scale_q=0.125, Lp=self.Lp, H=H)
+                xres=b["xa"], xout=b["xa"], n2_g=w[p + "norm3.g"], n2_b=w[p + "norm3.b"], n2_eps=1e-5, rope=rope, **tail)

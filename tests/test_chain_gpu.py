@@ -23,15 +23,16 @@ def rnd(*shape, seed=0, scale=1.0):
     return (torch.randn(*shape, generator=g) * scale).to(DEV)
 
 
-def model_with(chain: bool, dn, S):
-    os.environ["TCDIFF_CHAIN"] = "1" if chain else "0"
+def model_with(chain: int, dn, S):
+    """chain: 0 = op-by-op kernels, 1 = chain A / cross-attention / chain B, 2 = the whole layer tail in one launch"""
+    os.environ["TCDIFF_CHAIN"] = str(int(chain))
     try:
         m = DanceDecoder(nfeats=151, seq_len=S, latent_dim=512, ff_size=1024, num_layers=8, num_heads=8, dropout=0.1,
                          cond_feature_dim=438, activation=F.gelu, required_dancer_num=dn, compute_dtype="bf16")
         m.load_state_dict(O.synth_state_dict(dn=dn, seq_len=S))
         m.to(DEV).eval()
         m.engine(1)                       # the engine reads the switch when it is built
-        assert m._engines[0].use_chain == chain
+        assert m._engines[0].use_chain == (chain > 0) and m._engines[0].use_full == (chain == 2)
         return m
     finally:
         os.environ.pop("TCDIFF_CHAIN", None)
@@ -44,15 +45,16 @@ def test_chained_network_matches_op_by_op_network(dn, S, B):
     cond = torch.stack([O.synth_cond(c, S) for c in range(B)]).to(DEV)
     x = torch.stack([O.synth_xT(c, Lq) for c in range(B)]).to(DEV)
     outs = []
-    for chain in (False, True):
+    for chain in (0, 1, 2):
         m = model_with(chain, dn, S)
         tt = torch.full((B,), 640, dtype=torch.long, device=DEV)
         g = m.guided_forward(x, cond, tt, 2.0)
         f = m(x, cond, torch.arange(B, device=DEV) * 37 + 5, cond_drop_prob=0.0)
         outs.append((g, f))
-    for a, b in zip(*outs):
+    for which, other in (("chain", outs[1]), ("full chain", outs[2])):
+      for a, b in zip(outs[0], other):
         d, mean = float((a - b).abs().max()), float((a - b).abs().mean())
-        print(f"chain vs op-by-op ({dn}x{S}, B={B}): max-abs {d:.2e}, mean-abs {mean:.2e}, |out| max {float(a.abs().max()):.2f}")
+        print(f"{which} vs op-by-op ({dn}x{S}, B={B}): max-abs {d:.2e}, mean-abs {mean:.2e}, |out| max {float(a.abs().max()):.2f}")
         assert torch.isfinite(b).all()
         # the two paths agree per kernel to a few flipped bf16 roundings (tests below).  A flipped element of a GEMM
         # operand moves the whole output row by ~1e-4, which flips ~2 % of the next roundings: within two layers the
