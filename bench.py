@@ -90,43 +90,47 @@ def launch_ranks(argv, world, timeout=None):
 # ----------------------------------------------------------------------------------------------------------------
 def family_flops_per_step(B, dn, S, NL=8, H=8, nf=151, ff=1024):
     """ALGORITHMIC FLOPs of one two-branch DDPM step of B clips, per kernel family (2 FLOP per MAC; the shapes are
-    SURVEY.md 2.3 / Appendix B, layer-0 self-attention evaluated once for both branches as the engine does)."""
+    SURVEY.md 2.3 / Appendix B, layer-0 self-attention evaluated once for both branches as the engine does).
+    `chain` = the row-block chain launches (csrc/chain.hip): every projection of a layer behind the self-attention
+    (fc, w_qs, cross-attention, fc, linear1/2/3, next w_qs/w_ks/w_vs); `attention` = self-attention;
+    `gemm_tile` / `gemm_rowln` = what is left outside the layers (input + fusion projection, FiLM stack, layer-0 QKV, final)."""
     Lq = dn * S
     Rs, R = B * Lq, 2 * B * Lq
     M = S + 2
     rowln = 2.0 * B * S * 1024 * 512 * dn                      # last fusion-projection linear
     tile = 2.0 * Rs * nf * 512 + 2.0 * B * S * 1024 * 512 * dn + 2.0 * B * S * 1024 * 1024   # input proj, f1, f2
     tile += 2.0 * 2 * B * 512 * (NL * 3 * 1024)               # FiLM stack
-    att = 0.0
-    for l in range(NL):
-        rows_sa = Rs if l == 0 else R
-        nseq_sa = B if l == 0 else 2 * B
-        tile += 2.0 * rows_sa * 1536 * 512 + 2.0 * R * 512 * 512 + 2.0 * R * ff * 512     # qkv, cross-q, linear1
-        rowln += 3 * 2.0 * R * 512 * 512 + 2.0 * R * 512 * ff                             # fc, fc, linear3, linear2
-        att += 4.0 * nseq_sa * H * Lq * Lq * 64 + 4.0 * 2 * B * H * Lq * M * 64
+    tile += 2.0 * Rs * 1536 * 512                              # layer-0 QKV
     tile += 2.0 * R * nf * 512                                 # final layer
-    return {"gemm_rowln": rowln, "gemm_tile": tile, "attention": att}
+    att, chain = 0.0, 0.0
+    for l in range(NL):
+        nseq_sa = B if l == 0 else 2 * B
+        att += 4.0 * nseq_sa * H * Lq * Lq * 64
+        chain += 3 * 2.0 * R * 512 * 512 + 2.0 * R * 512 * ff          # fc, fc, linear3, linear2
+        chain += 2.0 * R * 512 * 512 + 2.0 * R * ff * 512              # cross-attention w_qs, linear1
+        chain += 4.0 * 2 * B * H * Lq * M * 64                         # cross-attention
+        if l + 1 < NL:
+            chain += 2.0 * R * 1536 * 512                              # next layer's w_qs / w_ks / w_vs
+    return {"chain": chain, "gemm_rowln": rowln, "gemm_tile": tile, "attention": att}
 
 
 def family_bytes_per_step(B, dn, S, es, NL=8, H=8, ff=1024):
-    """ALGORITHMIC HBM bytes of one two-branch DDPM step per family at kernel granularity: every operand of a launch
-    read once, every result written once (what the op-by-op decomposition must move; SURVEY.md 8(d)'s 110 MB is the
-    figure if no intermediate ever left the chip)."""
+    """ALGORITHMIC HBM bytes of one two-branch DDPM step per family at launch granularity: every operand of a launch
+    read once, every result written once (SURVEY.md 8(d)'s 110 MB is the figure if no intermediate ever left the chip).
+    Chain launch: O in, x in / out (fp32), Q / K / V images out, the layer's weights and K / V caches once."""
     Lq = dn * S
     R = 2 * B * Lq
     act = lambda cols, e=es: R * cols * e
     x32 = R * 512 * 4
-    rowln = NL * (2 * (act(512) + 512 * 512 * es + 2 * x32 + act(512))          # fc + LN + FiLM + res (+ next LN)
-                  + (act(ff) + 512 * ff * es + x32 + act(512))                 # linear2 + FiLM + res + LN4
-                  + (act(512) + 512 * 512 * es + x32 + 2 * act(512)))          # linear3 + next norm1 + rotary
-    tile = NL * ((2 * act(512) + 1536 * 512 * es + 3 * act(512)) + (act(512) + 512 * 512 * es + act(512))
-                 + (act(512) + ff * 512 * es + act(ff)))
-    lpc = (S + 2 + 127) // 128 * 128                                            # padded memory length of the K/V caches
-    att = NL * ((3 * act(512) + act(512)) + (act(512) + 2 * (B + 1) * H * lpc * 64 * es + act(512)))
-    return {"gemm_rowln": rowln, "gemm_tile": tile, "attention": att}
+    lpc = (S + 2 + 31) // 32 * 32
+    wl = (5 * 512 * 512 + 2 * 512 * ff + 1536 * 512) * es                 # weights of one chain launch
+    chain = NL * (act(512) + 2 * x32 + 3 * act(512) + wl + 2 * (B + 1) * H * lpc * 64 * es)
+    att = NL * (3 * act(512) + act(512))
+    tile = (act(512) + 1536 * 512 * es + 3 * act(512)) // 2
+    return {"chain": chain, "gemm_rowln": 0.0, "gemm_tile": tile, "attention": att}
 
 
-FAMILIES = {"gemm_rowln": ("gemm_rowln_kernel", "chain_kernel"), "gemm_tile": ("gemm_tile_kernel",),
+FAMILIES = {"chain": ("chain_kernel",), "gemm_rowln": ("gemm_rowln_kernel",), "gemm_tile": ("gemm_tile_kernel",),
             "attention": ("attention_res_kernel", "attention_kernel")}
 
 

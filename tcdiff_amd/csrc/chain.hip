@@ -533,6 +533,7 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
         // norm2 + rotary (model/model.py:332,387) -> LDS -> Q = rot W_q^T / 8 (model/model.py:78,97)
         norm_to_lds<true>(acc, mean, rstd, vecp(2), vecp(3), rp, abuf, wave, lane, nullptr);
         lds_barrier();
+        CH_T(34);
         if (FULL) store_consts(nxt);   // the cross-attention fc block's constants: read two barriers from here
         clear();
         phase_n512(acc, abuf, 32, ws, lane);
@@ -541,8 +542,10 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
             return;
         }
         // ================= cross-attention in place (the Q image never leaves the registers)
+        CH_T(35);
         lds_barrier();                 // every wave is out of the w_qs GEMM: the activation block becomes O
         cross_attention(acc, a, m0, abuf, wave, lane);
+        CH_T(36);
         lds_barrier();
     }
     // ================= cross-attention block tail: fc + LayerNorm(1e-6) + FiLM + residual (model/model.py:334)
@@ -556,8 +559,11 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
         for (int mi = 0; mi < 2; ++mi) rr[mi] = a.xres_mod > 0 ? mc[mi] % a.xres_mod : mc[mi];
         rp_start(rp, a.xres, rr, wave, h);
     }
+    CH_T(37);
     fc_epilogue(a.ln_eps);
+    CH_T(38);
     row_stats(acc, scr + 1024, wave, lane, a.n2_eps, mean, rstd);
+    CH_T(39);
     // ================= feed-forward (model/model.py:338-339,399-401): norm3 -> LDS
     {
         const float* const v[6] = {a.b1, a.b1 + 512, a.b2, a.n4_g, a.n4_b, nullptr};

@@ -1,28 +1,35 @@
-"""Diagnostic: per-phase time line of chain B (block 0, wave 0) from a -DCH_STAMP build (tools/chain_ablate.sh)."""
+"""Diagnostic: per-phase time line of the fused layer chain (block 0, wave 0) from a -DCH_STAMP build."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("TCDIFF_LIB_PATH", "tools/probe/libtc_STAMP.so")
 import torch
 exec(open(os.path.join(os.path.dirname(__file__), "chain_bench.py")).read().split("def run(")[0])
-names = {0: "start", 1: "A block + first stages landed", 2: "fc GEMM", 3: "fc epilogue: stats + LN/FiLM/res/store", 4: "norm3 stats", 5: "norm3 -> LDS + barrier",
-         22: "linear2 epilogue (loads)", 23: "norm4 stats", 24: "norm4 -> LDS + barrier", 25: "linear3 GEMM", 26: "linear3 epilogue", 27: "norm1' stats",
-         28: "norm1' + rotary -> LDS", 29: "Q GEMM", 30: "Q store + K GEMM", 31: "K store", 32: "V GEMM", 33: "V store + drain"}
+S_, nkt = 150, 5
+order = [(0, "start"), (1, "A block + first stages landed"), (2, "self fc GEMM"), (3, "self fc epilogue (stats, LN, FiLM, res, store)"),
+         (4, "norm2 stats"), (34, "norm2 + rotary -> LDS + barrier"), (35, "w_qs GEMM"), (36, "cross-attention (incl. barrier)"),
+         (37, "cross fc GEMM (incl. barrier)"), (38, "cross fc epilogue"), (39, "norm3 stats"), (5, "norm3 -> LDS, consts, 2 barriers")]
 for c in range(4):
-    names[6 + 4 * c] = f"linear1 chunk {c} GEMM"; names[7 + 4 * c] = "  barrier"; names[8 + 4 * c] = "  GELU -> LDS + barrier"; names[9 + 4 * c] = f"linear2 chunk {c} GEMM"
+    order += [(6 + 4 * c, f"linear1 chunk {c} GEMM"), (8 + 4 * c, "  GELU -> LDS + barrier"), (9 + 4 * c, f"linear2 chunk {c} GEMM")]
+order += [(22, "linear2 epilogue"), (23, "norm4 stats (incl. barrier)"), (24, "norm4 -> LDS + barrier"), (25, "linear3 GEMM"),
+          (26, "linear3 epilogue (incl. barrier)"), (27, "norm1' stats"), (28, "norm1' + rotary -> LDS + barrier"), (29, "Q GEMM"),
+          (30, "Q store + K GEMM"), (31, "K store"), (32, "V GEMM"), (33, "V store")]
+wsF = torch.cat([wsA, wsB], 1).contiguous()
 for nblk in (1, 225):
     M = nblk * 64
     nseq = (M + Lq - 1) // Lq
-    Oa = rnd(M, 512, scale=0.5).to(bf); film = 0.3 * rnd(nseq, 4096); x = rnd(M, 512)
+    Oa = rnd(M, 512, scale=0.5).to(bf); film = 0.3 * rnd(nseq, 6144); x = rnd(M, 512)
     Q, Kk, V = (torch.zeros(nseq, H, Lp, 64, device=dev, dtype=bf) for _ in range(3))
+    kf = rnd(nseq + 1, H, nkt * 2048, scale=0.5).to(bf); vf = rnd(nseq + 1, H, nkt * 2048, scale=0.5).to(bf)
     st = torch.zeros(64, device=dev, dtype=torch.int64)
     for _ in range(5):
-        K.chain(L.CHAIN_B, 288, M, Lq, Oa, wsB, ln_g=g[0], ln_b=g[1], ln_eps=1e-6, film=film, film_ld=4096, xres=x, xout=x,
-                n2_g=g[2], n2_b=g[3], rope=rope, b1=b1, b2=b2, film3=film[:, 2048:], n4_g=g[4], n4_b=g[5], b3=b3, nn_g=g[6],
-                nn_b=g[7], q_out=Q, k_out=Kk, v_out=V, h_out=st, Lp=Lp, H=H)
+        K.chain(L.CHAIN_FULL, 352, M, Lq, Oa, wsF, ln_g=g[0], ln_b=g[1], ln_eps=1e-6, film=film, film_ld=6144, xres=x, xout=x,
+                n2_g=g[2], n2_b=g[3], rope=rope, b1=b1, b2=b2, film3=film[:, 4096:], n4_g=g[4], n4_b=g[5], b3=b3, nn_g=g[6],
+                nn_b=g[7], q_out=Q, k_out=Kk, v_out=V, h_out=st, Lp=Lp, H=H, lnb_g=g[0], lnb_b=g[1], filmb=film[:, 2048:],
+                n3_g=g[2], n3_b=g[3], kf=kf, vf=vf, n_shared=nseq // 2, nkt=nkt, Lk=S_ + 2)
     torch.cuda.synchronize()
     t = st.cpu().tolist()
-    print(f"---- chain B, {nblk} block(s): total {(t[33] - t[0]) / 100:.1f} us (100 MHz counter)")
+    print(f"---- fused layer chain, {nblk} block(s): total {(t[33] - t[0]) / 100:.1f} us (100 MHz counter)")
     prev = t[0]
-    for i in range(1, 34):
-        print(f"  {names.get(i, str(i)):45s} {(t[i] - prev) / 100:6.2f} us")
+    for i, name in order[1:]:
+        print(f"  {name:50s} {(t[i] - prev) / 100:6.2f} us")
         prev = t[i]
