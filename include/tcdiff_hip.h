@@ -284,6 +284,30 @@ int tcdiff_scatter_time_kv(int dtype, const void* tab, int n_t, const int* tidx,
 int tcdiff_step_begin(const int* counter, const int* tseq, int* tidx, int n, hipStream_t stream);
 int tcdiff_step_end(int* counter, hipStream_t stream);
 
+/* tcdiff_step_prologue: step_begin + add_act(mish) + scatter_time_kv (+ its pack_kv_frags image) + convert_pad of x_t
+ * + the counter bump of step_end in ONE launch (model/model.py:606-612 conditioning of a step; model/diffusion.py:245
+ * loop variable).  counter is int[4] = {current step, seed0, seed1, next step}; the launch reads counter[3] and writes
+ * counter[0] = that step; tcdiff_sampler_update(mode | TC_SAMPLER_ADVANCE) later writes counter[3] = counter[0] + 1,
+ * so that no tcdiff_step_end launch is needed.
+ * Kc/Vc (row-major caches) or Kf/Vf (fragment images, bf16 only) may be NULL, not both; x may be NULL (no copy). */
+typedef struct tcdiff_step_prologue_args {
+    int* counter;
+    const int* tseq;
+    int* tidx;            /* [n_seq] <- timestep (kept for the op-by-op kernels) */
+    const float* t_base;  /* [n_t][512] time-embedding MLP output per timestep */
+    const float* hidden;  /* [n_seq][512] cond hidden rows */
+    void* film_in;        /* [n_seq][512] model dtype */
+    int n_seq;
+    const void* tab;      /* [NL][n_t][2][1024] time-token K|V rows, model dtype */
+    int n_t;
+    void *Kc, *Vc, *Kf, *Vf;
+    int NL, n_kv, H, Lp, nkt, tok0;
+    const float* x;       /* [rows][nfeat] fp32 x_t or NULL */
+    void* xin;            /* [rows][ld_xin] model dtype, zero padded */
+    int rows, nfeat, ld_xin;
+} tcdiff_step_prologue_args;
+int tcdiff_step_prologue(int dtype, const tcdiff_step_prologue_args* a, hipStream_t stream);
+
 /* DDPM: params = {w, coef1, coef2, sigma}  (model/diffusion.py:217-252, model/model.py:546)
  *   x0 = clamp(unc + (cond - unc) * w, -1, 1);  x <- coef1*x0 + coef2*x + sigma*eps
  * DDIM: params = {w, sqrt_recip_ac, sqrt_recipm1_ac, sqrt_ac_next, c, sigma, last}  (model/diffusion.py:195-204,407-431)
@@ -295,6 +319,7 @@ int tcdiff_step_end(int* counter, hipStream_t stream);
  * (model/diffusion.py:427-431).  x is updated in place; x0_out (optional) receives x0. */
 #define TC_SAMPLER_DDPM 0
 #define TC_SAMPLER_DDIM 1
+#define TC_SAMPLER_ADVANCE 0x100 /* OR into mode: also write counter[3] = counter[0] + 1 (pairs with tcdiff_step_prologue) */
 int tcdiff_sampler_update(int mode, const float* out_unc, const float* out_cond, int ldo, float* x,
                           const float* eps, const float* traj, float* x0_out, int n_rows, int nfeat, int L,
                           const int* counter, const float* params, const int* tseq, uint64_t seed, int clip0,

@@ -15,6 +15,7 @@ EPI_STORE_T, EPI_STORE_F32, EPI_QKV_HEADS = 0, 1, 2
 ROW_BIAS, ROW_LN_POST, ROW_FILM, ROW_RES, ROW_STORE_X, ROW_NEXT_LN, ROW_STORE_H, ROW_STORE_ROT = \
     1, 2, 4, 8, 16, 32, 64, 128
 SAMPLER_DDPM, SAMPLER_DDIM = 0, 1
+SAMPLER_ADVANCE = 0x100          # OR into the mode: sampler_update also advances counter[3] (step_prologue protocol)
 CHAIN_A, CHAIN_B, CHAIN_B_LAST, CHAIN_FULL, CHAIN_FULL_LAST = 0, 1, 2, 3, 4
 
 _vp, _i, _f, _l = C.c_void_p, C.c_int, C.c_float, C.c_long
@@ -43,6 +44,13 @@ class ChainArgs(C.Structure):
                 ("n3_g", _vp), ("n3_b", _vp), ("kf", _vp), ("vf", _vp), ("n_shared", _i), ("nkt", _i), ("Lk", _i)]
 
 
+class StepPrologueArgs(C.Structure):
+    _fields_ = [("counter", _vp), ("tseq", _vp), ("tidx", _vp), ("t_base", _vp), ("hidden", _vp), ("film_in", _vp),
+                ("n_seq", _i), ("tab", _vp), ("n_t", _i), ("Kc", _vp), ("Vc", _vp), ("Kf", _vp), ("Vf", _vp),
+                ("NL", _i), ("n_kv", _i), ("H", _i), ("Lp", _i), ("nkt", _i), ("tok0", _i), ("x", _vp), ("xin", _vp),
+                ("rows", _i), ("nfeat", _i), ("ld_xin", _i)]
+
+
 class AdanScalars(C.Structure):
     _fields_ = [(n, _f) for n in ("b1", "omb1", "b2", "omb2", "b3", "omb3", "cm", "cv", "cn", "eps", "lr", "denom")] + \
         [("first", _i)]
@@ -68,6 +76,7 @@ _SIGS = {
     "tcdiff_scatter_time_kv": [_i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "tcdiff_step_begin": [_vp, _vp, _vp, _i, _vp],
     "tcdiff_step_end": [_vp, _vp],
+    "tcdiff_step_prologue": [_i, _vp, _vp],
     "tcdiff_sampler_update": [_i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, C.c_uint64, _i, _vp],
     "tcdiff_window_couple": [_vp, _i, _i, _i, _vp],
     "tcdiff_window_couple_step": [_vp, _i, _i, _i, _vp, _vp, _vp],

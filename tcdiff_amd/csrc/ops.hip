@@ -280,6 +280,76 @@ extern "C" int tcdiff_step_end(int* counter, hipStream_t stream) {
     return TC_OK;
 }
 
+// One launch for everything a sampler step does before the network: timestep lookup, FiLM generator input
+// (mish(time_base[t] + hidden[row])), the two time-token K / V rows of every layer (row-major cache and / or the
+// fragment-ordered images chain.hip reads), the model-dtype copy of x_t, and the step counter bump.
+// counter = {current step (written here), seed0, seed1, next step}: this launch only READS counter[3] and only WRITES
+// counter[0]; sampler_update (mode | TC_SAMPLER_ADVANCE) only reads counter[0] and writes counter[3] = step + 1.  The
+// kernel boundary between the two orders everything: no atomics, no device-scope fence (on gfx950 an agent-scope
+// release writes the XCD's L2 back; a ticket counter built on one cost 45 us per launch here).
+template <class P>
+__global__ __launch_bounds__(256) void step_prologue_kernel(tcdiff_step_prologue_args a) {
+    typedef typename P::elem_t E;
+    int* counter = a.counter;
+    const int step = counter[3];
+    const int t = a.tseq[step];
+    const long n_film = (long)a.n_seq * 512;
+    const long n_kv = (long)a.NL * a.n_kv * 2 * 1024;
+    const long n_x = a.x ? (long)a.rows * a.ld_xin : 0;
+    const long total = n_film + n_kv + n_x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        if (i < n_film) {
+            const int c = (int)(i & 511);
+            if (c == 0) a.tidx[i >> 9] = t;
+            ((E*)a.film_in)[i] = P::from_f32(mish_f(a.t_base[(long)t * 512 + c] + a.hidden[i]));
+        } else if (i < n_film + n_kv) {
+            const long k = i - n_film;
+            const int c = (int)(k & 1023), rr = (int)((k >> 10) & 1);
+            const long rest = k >> 11;
+            const int kv = (int)(rest % a.n_kv), l = (int)(rest / a.n_kv);
+            const E v = ((const E*)a.tab)[(((long)l * a.n_t + t) * 2 + rr) * 1024 + c];
+            const int tok = a.tok0 + rr, cc = c & 511, head = cc >> 6, d = cc & 63;
+            const long sh = ((long)l * a.n_kv + kv) * a.H + head;
+            if (a.Kc) ((E*)(c < 512 ? a.Kc : a.Vc))[(sh * a.Lp + tok) * 64 + d] = v;
+            if (a.Kf) {  // same element maps as pack_kv_frags_kernel
+                const long base = sh * (long)a.nkt * 2048;
+                const int kt = tok >> 5, k32 = tok & 31;
+                if (c < 512) {
+                    const int s16 = d >> 4, dd = d & 15, hh = (dd & 7) >> 2, j = 4 * (dd >> 3) + (dd & 3);
+                    ((E*)a.Kf)[base + ((long)(kt * 4 + s16) * 64 + hh * 32 + k32) * 8 + j] = v;
+                } else {
+                    const int sp = k32 >> 4, kk = k32 & 15, hh = (kk & 7) >> 2, j = 4 * (kk >> 3) + (kk & 3);
+                    ((E*)a.Vf)[base + ((long)((kt * 2 + sp) * 2 + (d >> 5)) * 64 + hh * 32 + (d & 31)) * 8 + j] = v;
+                }
+            }
+        } else {
+            const long k = i - n_film - n_kv;
+            const int r = (int)(k / a.ld_xin), c = (int)(k % a.ld_xin);
+            ((E*)a.xin)[k] = P::from_f32(c < a.nfeat ? a.x[(long)r * a.nfeat + c] : 0.0f);
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) counter[0] = step;
+}
+
+extern "C" int tcdiff_step_prologue(int dtype, const tcdiff_step_prologue_args* a, hipStream_t stream) {
+    if (!a || !a->counter || !a->tseq || !a->tidx || !a->t_base || !a->hidden || !a->film_in || !a->tab ||
+        a->n_seq <= 0 || a->NL <= 0 || a->n_kv <= 0 || a->H * 64 != 512 || (!a->Kc && !a->Kf) || (!a->Kc != !a->Vc) ||
+        (!a->Kf != !a->Vf) || a->tok0 + 1 >= a->Lp || (a->Kf && a->tok0 + 2 > 32 * a->nkt) ||
+        (a->x && (!a->xin || a->rows <= 0 || a->ld_xin < a->nfeat)))
+        return TC_ERR_ARG;
+    if (a->Kf && dtype != TC_DTYPE_BF16) return TC_ERR_ARG;
+    const long total = (long)a->n_seq * 512 + (long)a->NL * a->n_kv * 2048 + (a->x ? (long)a->rows * a->ld_xin : 0);
+    const unsigned grid = (unsigned)std::min<long>((total + 255) / 256, 2048);
+    if (dtype == TC_DTYPE_BF16)
+        hipLaunchKernelGGL(step_prologue_kernel<MmaBF16>, dim3(grid), dim3(256), 0, stream, *a);
+    else if (dtype == TC_DTYPE_F32)
+        hipLaunchKernelGGL(step_prologue_kernel<MmaF32>, dim3(grid), dim3(256), 0, stream, *a);
+    else
+        return TC_ERR_ARG;
+    TC_CHECK_LAUNCH();
+    return TC_OK;
+}
+
 // Philox4x32-10 (Salmon et al. 2011), counter = (element quad, timestep, clip, 0), key = seed
 DEVINL void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
@@ -301,15 +371,16 @@ DEVINL float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 1677721
 __global__ void sampler_update_kernel(int mode, const float* __restrict__ out_unc, const float* __restrict__ out_cond,
                                       int ldo, float* __restrict__ x, const float* __restrict__ eps,
                                       const float* __restrict__ traj, float* __restrict__ x0_out, int n_rows,
-                                      int nfeat, int L, const int* __restrict__ counter,
+                                      int nfeat, int L, int* counter,
                                       const float* __restrict__ params, const int* __restrict__ tseq, uint64_t seed,
-                                      int clip0) {
+                                      int clip0, int advance) {
     // one thread per 4 consecutive elements of a row (so one Philox call feeds 4 normals)
     const int quads = (nfeat + 3) / 4;
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)n_rows * quads) return;
     const int row = (int)(i / quads), qd = (int)(i % quads);
     const int step = counter[0];
+    if (advance && i == 0) counter[3] = step + 1;                      // see step_prologue_kernel
     const float* pr = params + (long)step * 8;
     const float w = pr[0];
     float z[4] = {0.f, 0.f, 0.f, 0.f};
@@ -363,10 +434,13 @@ extern "C" int tcdiff_sampler_update(int mode, const float* out_unc, const float
                                      hipStream_t stream) {
     if (!out_cond || !x || !counter || !params || !tseq || n_rows <= 0 || nfeat <= 0 || L <= 0 || ldo < nfeat)
         return TC_ERR_ARG;
+    const int advance = (mode & TC_SAMPLER_ADVANCE) != 0;
+    mode &= ~TC_SAMPLER_ADVANCE;
     if (mode != TC_SAMPLER_DDPM && mode != TC_SAMPLER_DDIM) return TC_ERR_ARG;
     long n = (long)n_rows * ((nfeat + 3) / 4);
     hipLaunchKernelGGL(sampler_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, mode, out_unc,
-                       out_cond, ldo, x, eps, traj, x0_out, n_rows, nfeat, L, counter, params, tseq, seed, clip0);
+                       out_cond, ldo, x, eps, traj, x0_out, n_rows, nfeat, L, const_cast<int*>(counter), params, tseq, seed,
+                       clip0, advance);
     TC_CHECK_LAUNCH();
     return TC_OK;
 }

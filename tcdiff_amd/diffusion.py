@@ -216,15 +216,14 @@ class GaussianDiffusion(nn.Module):
         def step_part(p, branches: int):
             eng, st, Bp = p["eng"], p["st"], p["B"]
             b = eng.b
-            K.step_begin(st["counter"], st["rows"], b["tidx"], 2 * Bp)
-            eng.per_step_conditioning(2 * Bp)
+            eng.step_prologue(st, 2 * Bp, st["x"], Bp * Lq)
             if branches == 2:
-                out = eng.network(st["x"], Bp, 2, 0, Bp, 0)
+                out = eng.network(st["x"], Bp, 2, 0, Bp, 0, x_ready=True)
                 unc, con = out, out[Bp * Lq:]
             else:
-                out = eng.network(st["x"], Bp, 1, 1, 0, Bp)
+                out = eng.network(st["x"], Bp, 1, 1, 0, Bp, x_ready=True)
                 unc, con = None, out
-            K.sampler_update(mode, unc, con, 152, st["x"], st["eps"] if step_noise is not None else None,
+            K.sampler_update(mode | L.SAMPLER_ADVANCE, unc, con, 152, st["x"], st["eps"] if step_noise is not None else None,
                              st["traj"] if traj is not None else None, None, Bp * Lq, nf, Lq, st["counter"],
                              st["params"], st["tseq"], seed=0, clip0=clip_offset + p["lo"])
             if constrain is not None:
@@ -233,7 +232,6 @@ class GaussianDiffusion(nn.Module):
                                     st["counter"], st["params"], st["tseq"], seed=0, clip0=clip_offset + p["lo"])
             if couple is not None:
                 K.window_couple_step(st["x"], Bp, couple[0], couple[1], st["counter"], st["params"])
-            K.step_end(st["counter"])
 
         def step(branches: int, parallel: bool):
             if len(parts) == 1 or not parallel:

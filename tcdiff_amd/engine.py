@@ -78,7 +78,7 @@ class DenoiserEngine:
                       x=torch.zeros(rows, nfeat, device=dev), eps=torch.zeros(rows, nfeat, device=dev),
                       cval=torch.zeros(rows, nfeat, device=dev), qeps=torch.zeros(rows, nfeat, device=dev),
                       cmask=torch.zeros(rows, nfeat, device=dev),
-                      traj=torch.zeros(rows, 3, device=dev), counter=torch.zeros(4, device=dev, dtype=torch.int32),
+                      traj=torch.zeros(rows, 3, device=dev), counter=torch.zeros(8, device=dev, dtype=torch.int32),
                       rows=torch.zeros(cap, device=dev, dtype=torch.int32),
                       tseq=torch.zeros(cap, device=dev, dtype=torch.int32),
                       params=torch.zeros(cap, 8, device=dev))
@@ -342,7 +342,22 @@ class DenoiserEngine:
         K.gemm_tile(dt, b["film_in"], w["film.w"], n_rows_seq, nfilm, 512, bias=w["film.b"], mode=L.EPI_STORE_F32,
                     out=b["film"], ldc=nfilm)
 
-    def network(self, x: torch.Tensor, B: int, branches: int, kv_slot0: int, n_shared: int, film_row0: int):
+    def step_prologue(self, st: dict, n_rows_seq: int, x: torch.Tensor, rows: int):
+        """One sampler step's prologue in a single launch (timestep lookup, FiLM input, time-token K/V rows, model
+        dtype copy of x_t, step counter bump), then the FiLM generator GEMM.  Replaces step_begin +
+        per_step_conditioning + network's convert_pad + step_end."""
+        dt, w, b = self.dt, self.w, self.b
+        full = self.use_full
+        K.step_prologue(dt, st["counter"], st["rows"], b["tidx"], self.t_base, b["hidden_all"], b["film_in"],
+                        n_rows_seq, self.kv_tab, self.n_t, None if full else b["Kc"], None if full else b["Vc"],
+                        b["Kf"] if full else None, b["Vf"] if full else None, self.NL, b["Kc"].shape[1], self.H,
+                        self.Lpc, self.nkt if full else 0, self.S, x, b["xin"], rows, self.nf, 192)
+        nfilm = self.NL * NL_FILM * 1024
+        K.gemm_tile(dt, b["film_in"], w["film.w"], n_rows_seq, nfilm, 512, bias=w["film.b"], mode=L.EPI_STORE_F32,
+                    out=b["film"], ldc=nfilm)
+
+    def network(self, x: torch.Tensor, B: int, branches: int, kv_slot0: int, n_shared: int, film_row0: int,
+                x_ready: bool = False):
         """DanceDecoder.forward body after the conditioning prologue (model/model.py:553-561,621-623) for
         `branches` stacked copies of the B clips in x (fp32 [B*L, nfeats]).  Returns b['out'] fp32 [branches*B*L, 152].
 
@@ -356,7 +371,8 @@ class DenoiserEngine:
         film0 = b["film"][film_row0:]
         rope = w["rope"]
         # input projection + fusion projection over per-frame concatenated dancers (model/model.py:560-561)
-        K.convert_pad(dt, x, b["xin"], Rs, self.nf, 192)
+        if not x_ready:                      # the sampler's step_prologue already wrote b["xin"]
+            K.convert_pad(dt, x, b["xin"], Rs, self.nf, 192)
         K.gemm_tile(dt, b["xin"], w["in.w"], Rs, 512, 192, bias=w["in.b"], out=b["xp"], ldc=512)
         K.gemm_tile(dt, b["xp"], w["f1.w"], B * S, 1024, 512 * dn, bias=w["f1.b"], act=L.ACT_RELU, out=b["f1"], ldc=1024)
         K.gemm_tile(dt, b["f1"], w["f2.w"], B * S, 1024, 1024, bias=w["f2.b"], act=L.ACT_RELU, out=b["f2"], ldc=1024)

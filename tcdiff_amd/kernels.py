@@ -122,6 +122,14 @@ def step_end(counter):
     L.check(L.load().tcdiff_step_end(_p(counter), stream()), "tcdiff_step_end")
 
 
+def step_prologue(dt, counter, tseq, tidx, t_base, hidden, film_in, n_seq, tab, n_t, Kc, Vc, Kf, Vf, NL, n_kv, H, Lp, nkt,
+                  tok0, x=None, xin=None, rows=0, nfeat=0, ld_xin=0):
+    a = L.StepPrologueArgs(_p(counter), _p(tseq), _p(tidx), _p(t_base), _p(hidden), _p(film_in), n_seq, _p(tab), n_t,
+                           _p(Kc), _p(Vc), _p(Kf), _p(Vf), NL, n_kv, H, Lp, nkt, tok0, _p(x), _p(xin), rows, nfeat,
+                           ld_xin)
+    L.check(L.load().tcdiff_step_prologue(dt, C.byref(a), stream()), "tcdiff_step_prologue")
+
+
 def sampler_update(mode, out_unc, out_cond, ldo, x, eps, traj, x0_out, n_rows, nfeat, Lseq, counter, params, tseq,
                    seed=0, clip0=0):
     rc = L.load().tcdiff_sampler_update(mode, _p(out_unc), _p(out_cond), ldo, _p(x), _p(eps), _p(traj), _p(x0_out),

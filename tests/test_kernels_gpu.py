@@ -469,6 +469,50 @@ def test_step_counter():
     assert counter[0].item() == 3
 
 
+@pytest.mark.parametrize("dt,frags", [(L.DT_F32, False), (L.DT_BF16, False), (L.DT_BF16, True)])
+def test_step_prologue_equals_the_separate_launches(dt, frags):
+    """tcdiff_step_prologue == step_begin + add_act(mish) + scatter_time_kv (+ pack_kv_frags) + convert_pad + step_end,
+    bit for bit, over three consecutive steps (the counter protocol: counter[0] current, counter[3] next, advanced by sampler_update | SAMPLER_ADVANCE)."""
+    NL, n_kv, H, S, n_t, n_seq, rows, nf = 3, 6, 8, 40, 5, 6, 130, 151
+    Lp, nkt = 128, (S + 2 + 31) // 32
+    tdt = T(dt)
+    tab = rnd(NL, n_t, 2, 1024, seed=1).to(tdt)
+    t_base, hidden = rnd(n_t, 512, seed=2), rnd(n_seq, 512, seed=3)
+    tseq = torch.tensor([4, 2, 0], dtype=torch.int32, device=DEV)
+    x = rnd(rows, nf, seed=4)
+
+    def bufs():
+        g = torch.Generator(device="cpu").manual_seed(9)
+        mk = lambda *sh: torch.randn(*sh, generator=g).to(DEV).to(tdt)      # noqa: E731
+        return dict(Kc=mk(NL, n_kv, H, Lp, 64), Vc=mk(NL, n_kv, H, Lp, 64), Kf=mk(NL, n_kv, H, nkt * 2048),
+                    Vf=mk(NL, n_kv, H, nkt * 2048), film_in=torch.zeros(n_seq, 512, device=DEV, dtype=tdt),
+                    xin=torch.full((rows, 192), 7.0, device=DEV, dtype=tdt),
+                    tidx=torch.zeros(n_seq, dtype=torch.int32, device=DEV),
+                    counter=torch.zeros(8, dtype=torch.int32, device=DEV))
+    a, b = bufs(), bufs()
+    for step in range(3):
+        K.step_begin(a["counter"], tseq, a["tidx"], n_seq)
+        K.add_act(dt, t_base, a["tidx"], hidden, n_seq, L.ACT_MISH, out=a["film_in"])
+        K.scatter_time_kv(dt, tab, n_t, a["tidx"], a["Kc"], a["Vc"], NL, n_kv, H, Lp, S)
+        if frags:
+            K.pack_kv_frags(a["Kc"], a["Vc"], a["Kf"], a["Vf"], NL * n_kv, H, Lp, nkt, S, S + 2)
+        K.convert_pad(dt, x, a["xin"], rows, nf, 192)
+        K.step_end(a["counter"])
+        K.step_prologue(dt, b["counter"], tseq, b["tidx"], t_base, hidden, b["film_in"], n_seq, tab, n_t,
+                        None if frags else b["Kc"], None if frags else b["Vc"], b["Kf"] if frags else None,
+                        b["Vf"] if frags else None, NL, n_kv, H, Lp, nkt if frags else 0, S, x, b["xin"], rows, nf, 192)
+        dummy = torch.zeros(4, 152, device=DEV)
+        K.sampler_update(L.SAMPLER_DDPM | L.SAMPLER_ADVANCE, None, dummy, 152, torch.zeros(4, 151, device=DEV), None, None,
+                         None, 4, 151, 4, b["counter"], torch.zeros(3, 8, device=DEV), tseq)
+        torch.cuda.synchronize()
+        assert b["counter"][0].item() == step and b["counter"][3].item() == step + 1
+        assert a["counter"][0].item() == step + 1
+        names = ["film_in", "xin", "tidx"] + (["Kf", "Vf"] if frags else ["Kc", "Vc"])
+        for n in names:
+            assert torch.equal(a[n], b[n]), (n, step)
+        x = x * 0.5 + 0.1
+
+
 def test_argument_errors():
     a = torch.zeros(64, 64, device=DEV)
     with pytest.raises(L.TcdiffError):
