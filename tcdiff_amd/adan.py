@@ -70,6 +70,7 @@ class Adan(Optimizer):
                 sc = L.AdanScalars(beta1, 1 - beta1, beta2, 1 - beta2, beta3, 1 - beta3, cm, cv, cn, eps, lr,
                                    1 + weight_decay * lr, int(step0 == 0))
                 K.adan_step(self._tables[gi][1], sc)
+                torch.autograd.graph.increment_version(ps)     # written through raw pointers: keep ._version honest
                 for s in states:
                     s["step"] = step
                 continue

@@ -265,27 +265,65 @@ extern "C" int tcdiff_loss_terms(const float* model_out, const float* x_start, c
 //   n = fma(nn, b3, n * (1 - b3))                                             [skipped on the first step, adan.py:71]
 //   wss = (1 / (sqrt(n * cn) + eps)) * lr;  upd = m * cm + ((1 - b2) * v) * cv;  p = fma(-wss, upd, p) / (1 + wd * lr)
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void adan_step_kernel(const tcdiff_adan_chunk* __restrict__ chunks, tcdiff_adan_scalars k) {
+// one element of the update; every rounding point is the reference's (see tcdiff_hip.h)
+DEVINL void adan_element(const tcdiff_adan_scalars& k, float g, float pg, float& p, float& m, float& v, float& n) {
 #pragma clang fp contract(off)
+    if (!k.first) {
+        m = __builtin_fmaf(g, k.b1, m * k.omb1);
+        const float gd = g - pg;
+        v = __builtin_fmaf(gd, k.b2, v * k.omb2);
+        float nn = g + k.omb2 * gd;
+        nn = nn * nn;
+        n = __builtin_fmaf(nn, k.b3, n * k.omb3);
+    }
+    const float wss = __frcp_rn(sqrtf(n * k.cn) + k.eps) * k.lr;
+    const float upd = m * k.cm + (k.omb2 * v) * k.cv;
+    p = __fdiv_rn(__builtin_fmaf(-1.0f * wss, upd, p), k.denom);
+}
+
+__global__ __launch_bounds__(256) void adan_step_kernel(const tcdiff_adan_chunk* __restrict__ chunks, tcdiff_adan_scalars k) {
     const tcdiff_adan_chunk c = chunks[blockIdx.x];
-    for (long i = threadIdx.x; i < c.n; i += 256) {
+    // HBM-bound: 6 streams in, 5 out.  16-byte accesses when all six chunk pointers allow it (torch allocations are
+    // 512-B aligned and chunk offsets are multiples of 4 elements, so only odd-sized tails take the scalar loop).
+    const bool vec = ((reinterpret_cast<uintptr_t>(c.p) | reinterpret_cast<uintptr_t>(c.g) | reinterpret_cast<uintptr_t>(c.m) |
+                       reinterpret_cast<uintptr_t>(c.v) | reinterpret_cast<uintptr_t>(c.n_) |
+                       reinterpret_cast<uintptr_t>(c.pg)) & 15) == 0;
+    long i0 = 0;
+    if (vec) {
+        const long n4 = c.n >> 2;
+        for (long i = threadIdx.x; i < n4; i += 256) {
+            const f32x4_t g = reinterpret_cast<const f32x4_t*>(c.g)[i];
+            f32x4_t p = reinterpret_cast<f32x4_t*>(c.p)[i], m = reinterpret_cast<f32x4_t*>(c.m)[i];
+            f32x4_t v = reinterpret_cast<f32x4_t*>(c.v)[i], n = reinterpret_cast<f32x4_t*>(c.n_)[i];
+            f32x4_t pg = {0.f, 0.f, 0.f, 0.f};
+            if (!k.first) pg = reinterpret_cast<f32x4_t*>(c.pg)[i];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float pe = p[t], me = m[t], ve = v[t], ne = n[t];
+                adan_element(k, g[t], pg[t], pe, me, ve, ne);
+                p[t] = pe; m[t] = me; v[t] = ve; n[t] = ne;
+            }
+            if (!k.first) {
+                reinterpret_cast<f32x4_t*>(c.m)[i] = m;
+                reinterpret_cast<f32x4_t*>(c.v)[i] = v;
+                reinterpret_cast<f32x4_t*>(c.n_)[i] = n;
+            }
+            reinterpret_cast<f32x4_t*>(c.p)[i] = p;
+            reinterpret_cast<f32x4_t*>(c.pg)[i] = g;
+        }
+        i0 = n4 << 2;
+    }
+    for (long i = i0 + threadIdx.x; i < c.n; i += 256) {
         const float g = c.g[i];
-        float m = c.m[i], v = c.v[i], n = c.n_[i];
+        float p = c.p[i], m = c.m[i], v = c.v[i], n = c.n_[i];
+        const float pg = k.first ? 0.0f : c.pg[i];
+        adan_element(k, g, pg, p, m, v, n);
         if (!k.first) {
-            const float pg = c.pg[i];
-            m = __builtin_fmaf(g, k.b1, m * k.omb1);
-            const float gd = g - pg;
-            v = __builtin_fmaf(gd, k.b2, v * k.omb2);
-            float nn = g + k.omb2 * gd;
-            nn = nn * nn;
-            n = __builtin_fmaf(nn, k.b3, n * k.omb3);
             c.m[i] = m;
             c.v[i] = v;
             c.n_[i] = n;
         }
-        const float wss = __frcp_rn(sqrtf(n * k.cn) + k.eps) * k.lr;
-        const float upd = m * k.cm + (k.omb2 * v) * k.cv;
-        c.p[i] = __fdiv_rn(__builtin_fmaf(-1.0f * wss, upd, c.p[i]), k.denom);
+        c.p[i] = p;
         c.pg[i] = g;
     }
 }

@@ -60,18 +60,22 @@ class EMA:
         self._table_key = None
 
     def update_model_average(self, ma_model, current_model):
-        cur = [p.data for p in current_model.parameters()]
-        ma = [p.data for p in ma_model.parameters()]
-        fused = len(cur) > 0 and all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in cur + ma)
-        if not fused:
-            for c, m in zip(current_model.parameters(), ma_model.parameters()):
+        cur_p, ma_p = list(current_model.parameters()), list(ma_model.parameters())
+        key = tuple(p.data_ptr() for p in cur_p) + tuple(p.data_ptr() for p in ma_p)
+        if key != self._table_key:                       # (re)allocation: decide the path and rebuild the chunk table
+            ts = [p.data for p in cur_p + ma_p]
+            fused = len(cur_p) > 0 and all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in ts)
+            self._table = K.ema_chunk_table([p.data for p in ma_p], [p.data for p in cur_p],
+                                            cur_p[0].device) if fused else None
+            self._table_key = key
+        if self._table is None:
+            for c, m in zip(cur_p, ma_p):
                 m.data = self.update_average(m.data, c.data)
             return
-        key = tuple(t.data_ptr() for t in cur + ma)
-        if key != self._table_key:
-            self._table = K.ema_chunk_table(ma, cur, cur[0].device)
-            self._table_key = key
         K.ema_update(self._table, self.beta)
+        # the kernel wrote through raw pointers: bump ._version so DanceDecoder._weights_version sees new weights
+        # (packed bf16 copies, conditioning caches and captured graphs are keyed by it)
+        torch.autograd.graph.increment_version(ma_p)
 
     def update_average(self, old, new):
         return new if old is None else old * self.beta + (1 - self.beta) * new

@@ -442,3 +442,32 @@ def test_first_call_crosses_guidance_boundary_after_many_skewed_replays():
     ref.dual_stream = False
     single = ref.p_sample_loop((4, 450, 151), cond, noise=xT, start_point=400, seed=31)
     assert torch.equal(dual, single)
+
+
+def test_weights_written_by_fused_ema_and_adan_are_seen_by_the_next_forward():
+    """The fused EMA / Adan kernels write parameters through raw pointers; the packed model-dtype weight copies,
+    conditioning caches and captured graphs are keyed by Parameter._version, which those updates must bump
+    (model/diffusion.py:61-76 feeds master_model, which the samplers then run: TCDiff.py:243-245,277-303)."""
+    from tcdiff_amd.adan import Adan
+    from tcdiff_amd.diffusion import EMA
+    _, ma, _ = build(2, 60, 100, compute="bf16")
+    _, cur, _ = build(2, 60, 100, compute="bf16")
+    ma, cur = ma.to(DEV), cur.to(DEV)
+    cond = torch.stack([O.synth_cond(0, 60)]).to(DEV)
+    x = torch.stack([O.synth_xT(0, 120)]).to(DEV)
+    t = torch.full((1,), 50, dtype=torch.long, device=DEV)
+    y0 = ma(x, cond, t).clone()
+    with torch.no_grad():
+        for p in cur.parameters():
+            p.mul_(1.05)
+    y_cur = cur(x, cond, t).clone()
+    assert maxabs(y_cur, y0) > 1e-3
+    v0 = [p._version for p in ma.parameters()]
+    EMA(0.0).update_model_average(ma, cur)                    # beta = 0: ma <- cur exactly
+    assert all(p._version > v for p, v in zip(ma.parameters(), v0))
+    assert torch.equal(ma(x, cond, t), y_cur)                 # not the stale packed weights
+    for p in ma.parameters():
+        p.grad = torch.full_like(p, 1e-3)
+    opt = Adan(ma.parameters(), lr=1e-2, weight_decay=0.02)
+    opt.step(); opt.step()                                    # second step moves the weights (model/adan.py:71)
+    assert maxabs(ma(x, cond, t), y_cur) > 1e-4
