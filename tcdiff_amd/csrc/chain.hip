@@ -86,9 +86,58 @@ DEVINL void zero(f32x16_t& v) {
     v = z;
 }
 
-// acc[mi][ni] (rows 32 mi + r, columns 64 wave + 32 ni + ..) += act[64 x 16 nst] (k-steps 0.. of `abuf`) * W stages;
-// a stage = one 16-deep k-step of the wave's 64 weight rows: fragment ni = weight rows 32 ni + r.  nst % CH_D == 0.
-DEVINL void phase_n512(f32x16_t (&acc)[2][2], const char* abuf, int nst, WStream& ws, int lane) {
+// acc[mi][ni] (rows 32 mi + r, columns 64 wave + 32 ni + ..) += act[64 x 16 NST] (k-steps 0.. of `abuf`) * W stages;
+// a stage = one 16-deep k-step of the wave's 64 weight rows: fragment ni = weight rows 32 ni + r.  NST % CH_D == 0.
+// Fully unrolled (NST <= 32 stage bodies): a rolled loop carries the ring through a phi, and hipcc placed a register
+// copy of the most recently loaded slot at the loop header -- i.e. `s_waitcnt vmcnt(0)`, a full drain of the wave's
+// weight stream, every CH_D stages.  The activation fragments of stage ks + 1 are read before the MFMAs of stage ks.
+// (Tried: the two waves of a SIMD taking turns at issue priority every few stages (s_setprio), because with the
+// default oldest-first arbitration waves 0-3 finish every barrier-free stretch ~2 us before waves 4-7.  It balances
+// them, and the stretch takes exactly as long: the pair is bound by what the CU gets from L2, not by arbitration.)
+// TAIL: the launch's last phase -- its last CH_D stages refill nothing (there is nothing behind them).
+template <int NST, bool TAIL = false>
+DEVINL void phase_n512(f32x16_t (&acc)[2][2], const char* abuf, WStream& ws, int lane) {
+    static_assert(NST % CH_D == 0, "a phase starts at ring slot 0");
+    lane = fresh_v(lane);
+    const int r = lane & 31, h = lane >> 5;
+    u32x4 a0 = CH_FRAG(abuf, r, h), a1 = CH_FRAG(abuf, 32 + r, h);
+#pragma unroll
+    for (int ks = 0; ks < NST; ++ks) {
+        const int i = ks % CH_D;
+        const u32x4 w0 = ws.a[i], w1 = ws.b[i];
+#ifdef CH_NO_TAIL
+        ws_load(ws, i, ws.pos + CH_D);
+#else
+        if (!(TAIL && ks + CH_D >= NST)) ws_load(ws, i, ws.pos + CH_D);
+#endif
+        ws.pos++;
+        u32x4 n0 = a0, n1 = a1;
+        if (ks + 1 < NST) {
+            const char* at = abuf + ((ks + 1) >> 2) * 8192;
+            const int ch = 2 * ((ks + 1) & 3) + h;
+            n0 = CH_FRAG(at, r, ch);
+            n1 = CH_FRAG(at, 32 + r, ch);
+        }
+        // Stage order: the next stage's two LDS reads and the refill are ISSUED, then this stage's MFMAs run (the
+        // ~100 cycles of LDS latency pass under them even when the wave is alone on its SIMD), then the fence.  Left to
+        // itself hipcc schedules read, wait, use, and a wave whose SIMD mate is parked at a barrier exposes the whole
+        // LDS latency in every stage.
+        __builtin_amdgcn_sched_barrier(0);
+        CH_MMA(acc[0][0], w0, a0);
+        CH_MMA(acc[0][1], w1, a0);
+        CH_MMA(acc[1][0], w0, a1);
+        CH_MMA(acc[1][1], w1, a1);
+        __builtin_amdgcn_sched_barrier(0);   // ... and the MFMAs do not sink below the next stage's reads either
+        // Stage fence.  Memory clobber: the refill stays in its own stage, the stream never drains.  The next stage's
+        // fragments pass THROUGH it, so the next stage's MFMAs cannot be pulled up to right behind their reads.
+        asm volatile("" : "+v"(n0), "+v"(n1) : : "memory");
+        a0 = n0;
+        a1 = n1;
+    }
+}
+// The rolled form (one CH_D-stage body, looped): kept for TC_CHAIN_A alone, whose fully unrolled build hipcc spills
+// (277 VGPRs); that mode is the reference the fused launch is tested against, not the production path.
+DEVINL void phase_n512_rolled(f32x16_t (&acc)[2][2], const char* abuf, int nst, WStream& ws, int lane) {
     lane = fresh_v(lane);
     const int r = lane & 31, h = lane >> 5;
 #pragma unroll 1
@@ -106,7 +155,7 @@ DEVINL void phase_n512(f32x16_t (&acc)[2][2], const char* abuf, int nst, WStream
             CH_MMA(acc[0][1], w1, a0);
             CH_MMA(acc[1][0], w0, a1);
             CH_MMA(acc[1][1], w1, a1);
-            asm volatile("" ::: "memory");   // keep the refill in its own iteration: the stream must never drain
+            asm volatile("" ::: "memory");
         }
     }
 }
@@ -114,23 +163,30 @@ DEVINL void phase_n512(f32x16_t (&acc)[2][2], const char* abuf, int nst, WStream
 DEVINL void phase_ff1(f32x16_t (&acc)[2], const char* abuf, WStream& ws, int lane) {
     lane = fresh_v(lane);
     const int r = lane & 31, h = lane >> 5;
-#pragma unroll 1
-    for (int s0 = 0; s0 < 16; s0 += CH_D) {
+    u32x4 a0 = CH_FRAG(abuf, r, h), a1 = CH_FRAG(abuf, 32 + r, h);
 #pragma unroll
-        for (int i = 0; i < CH_D; ++i) {
-            const u32x4 wk[2] = {ws.a[i], ws.b[i]};
-            ws_load(ws, i, ws.pos + CH_D);
-            ws.pos++;
+    for (int st = 0; st < 16; ++st) {
+        const int i = st % CH_D;
+        const u32x4 wk[2] = {ws.a[i], ws.b[i]};
+        ws_load(ws, i, ws.pos + CH_D);
+        ws.pos++;
 #pragma unroll
-            for (int k2 = 0; k2 < 2; ++k2) {
-                const int ks = 2 * (s0 + i) + k2;
-                const char* at = abuf + (ks >> 2) * 8192;
-                const int ch = 2 * (ks & 3) + h;
-                const u32x4 a0 = CH_FRAG(at, r, ch), a1 = CH_FRAG(at, 32 + r, ch);
-                CH_MMA(acc[0], wk[k2], a0);
-                CH_MMA(acc[1], wk[k2], a1);
+        for (int k2 = 0; k2 < 2; ++k2) {
+            const int ks = 2 * st + k2;
+            u32x4 n0 = a0, n1 = a1;
+            if (ks + 1 < 32) {
+                const char* at = abuf + ((ks + 1) >> 2) * 8192;
+                const int ch = 2 * ((ks + 1) & 3) + h;
+                n0 = CH_FRAG(at, r, ch);
+                n1 = CH_FRAG(at, 32 + r, ch);
             }
-            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);   // see phase_n512
+            CH_MMA(acc[0], wk[k2], a0);
+            CH_MMA(acc[1], wk[k2], a1);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" : "+v"(n0), "+v"(n1) : : "memory");
+            a0 = n0;
+            a1 = n1;
         }
     }
 }
@@ -377,10 +433,14 @@ DEVINL void cross_attention(const f32x16_t (&qacc)[2][2], const tcdiff_chain_arg
     }
 }
 
-#ifdef CH_STAMP   // diagnostic build: per-phase timestamps of block 0 / wave 0 into the (otherwise unused) h_out buffer
-#define CH_T(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && (MODE == TC_CHAIN_B || MODE == TC_CHAIN_FULL)) \
-        reinterpret_cast<unsigned long long*>(a.h_out)[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#ifdef CH_STAMP   // diagnostic build: per-phase timestamps of block 0, every wave, into the (otherwise unused) h_out buffer
+#define CH_T(i) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (MODE == TC_CHAIN_B || MODE == TC_CHAIN_FULL)) \
+        reinterpret_cast<unsigned long long*>(a.h_out)[(threadIdx.x >> 6) * 64 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+// the shader-clock counter beside the 100 MHz one: slots 60 / 61 = s_memtime at the first / last stamp
+#define CH_TC(i) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (MODE == TC_CHAIN_B || MODE == TC_CHAIN_FULL)) \
+        reinterpret_cast<unsigned long long*>(a.h_out)[(threadIdx.x >> 6) * 64 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
+#define CH_TC(i) do { } while (0)
 #define CH_T(i) do { } while (0)
 #endif
 
@@ -395,6 +455,7 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     const int r = lane & 31, h = lane >> 5;
     const int m0 = xcd_remap(blockIdx.x, gridDim.x) * 64;
     CH_T(0);
+    CH_TC(60);
     const int M = a.M, L = a.L;
     char* abuf = smem + CH_ABUF;
     char* h1c = smem + CH_H1C;
@@ -475,9 +536,11 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
 
     // fc epilogue: LayerNorm(eps), FiLM, residual -> x in the accumulators and in xout (model/model.py:103-106,171-173,
     // 327 / 334); constants in vector slots 0, 1 and the FiLM area; the residual rows were started by the caller
-    auto fc_epilogue = [&](float eps) {
+    auto fc_epilogue = [&](float eps, int stamp) {
         lds_barrier();                 // every wave is out of the GEMM: the activation block may be overwritten
+        CH_T(stamp);
         row_stats(acc, scr, wave, lane, eps, mean, rstd);
+        CH_T(stamp + 1);
         // fresh copies: the two inlined instances of this epilogue must not share (and keep alive) their addresses
         const int hh = fresh_v(h), wv = fresh_s(wave);
         const int mcl[2] = {fresh_v(mc[0]), fresh_v(mc[1])}, sx[2] = {fresh_v(sidx[0]), fresh_v(sidx[1])};
@@ -513,7 +576,10 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     if (HAS_A) {
         // ================= self-attention block tail: fc + LayerNorm(1e-6) + FiLM + residual, norm2 + rotary, w_qs
         clear();
-        phase_n512(acc, abuf, 32, ws, lane);
+        if (FULL)
+            phase_n512<32>(acc, abuf, ws, lane);
+        else
+            phase_n512_rolled(acc, abuf, 32, ws, lane);
         CH_T(2);
         {
             int rr[2];
@@ -521,7 +587,7 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
             for (int mi = 0; mi < 2; ++mi) rr[mi] = a.xres_mod > 0 ? mc[mi] % a.xres_mod : mc[mi];
             rp_start(rp, a.xres, rr, wave, h);   // in flight during the statistics exchange
         }
-        fc_epilogue(a.ln_eps);
+        fc_epilogue(a.ln_eps, 40);
         CH_T(3);
         if (FULL) {
             const float* const v[6] = {fcb_g, fcb_b, n3_g, n3_b, nullptr, nullptr};
@@ -536,11 +602,12 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
         CH_T(34);
         if (FULL) store_consts(nxt);   // the cross-attention fc block's constants: read two barriers from here
         clear();
-        phase_n512(acc, abuf, 32, ws, lane);
         if (!FULL) {
+            phase_n512_rolled(acc, abuf, 32, ws, lane);
             store_heads(acc, a.q_out, a.scale_q, L, a.Lp, a.H, m0, M, wave, lane);
             return;
         }
+        phase_n512<32>(acc, abuf, ws, lane);
         // ================= cross-attention in place (the Q image never leaves the registers)
         CH_T(35);
         lds_barrier();                 // every wave is out of the w_qs GEMM: the activation block becomes O
@@ -550,7 +617,7 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     }
     // ================= cross-attention block tail: fc + LayerNorm(1e-6) + FiLM + residual (model/model.py:334)
     clear();
-    phase_n512(acc, abuf, 32, ws, lane);
+    phase_n512<32>(acc, abuf, ws, lane);
     if (FULL) {
         rp_start(rp, a.xout, mc, wave, h);       // the x this lane stored in the first fc epilogue
     } else {
@@ -560,7 +627,7 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
         rp_start(rp, a.xres, rr, wave, h);
     }
     CH_T(37);
-    fc_epilogue(a.ln_eps);
+    fc_epilogue(a.ln_eps, 42);
     CH_T(38);
     row_stats(acc, scr + 1024, wave, lane, a.n2_eps, mean, rstd);
     CH_T(39);
@@ -607,7 +674,7 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
         }
         lds_barrier();
         CH_T(8 + 4 * c);
-        phase_n512(acc, hb, 16, ws, lane);
+        phase_n512<16>(acc, hb, ws, lane);
         CH_T(9 + 4 * c);
     }
     // linear2 bias, FiLM, residual (the x this lane stored above), norm4 -> LDS
@@ -649,7 +716,10 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     // ================= x' = linear3(norm4(x)) + b3, no residual (model/model.py:344)
     CH_T(24);
     clear();
-    phase_n512(acc, abuf, 32, ws, lane);
+    if (LAST)
+        phase_n512<32, true>(acc, abuf, ws, lane);
+    else
+        phase_n512<32>(acc, abuf, ws, lane);
     CH_T(25);
     lds_barrier();
 #pragma unroll
@@ -687,19 +757,20 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     lds_barrier();
     CH_T(28);
     clear();
-    phase_n512(acc, abuf, 32, ws, lane);
+    phase_n512<32>(acc, abuf, ws, lane);
     CH_T(29);
     store_heads(acc, a.q_out, a.scale_q, L, a.Lp, a.H, m0, M, wave, lane);
     clear();
-    phase_n512(acc, abuf, 32, ws, lane);
+    phase_n512<32>(acc, abuf, ws, lane);
     CH_T(30);
     store_heads(acc, a.k_out, 1.0f, L, a.Lp, a.H, m0, M, wave, lane);
     CH_T(31);
     clear();
-    phase_n512(acc, smem + CH_ABUF2, 32, ws, lane);
+    phase_n512<32, true>(acc, smem + CH_ABUF2, ws, lane);
     CH_T(32);
     store_heads(acc, a.v_out, 1.0f, L, a.Lp, a.H, m0, M, wave, lane);
     CH_T(33);
+    CH_TC(61);
 }
 
 static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }

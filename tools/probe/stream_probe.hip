@@ -48,11 +48,36 @@ float run(const u32x4* buf, size_t bytes, unsigned* out, int nblk, int nwaves, i
     return ms / iters * 1e3f;
 }
 
+// Same kernel, but every launch streams a DIFFERENT buffer of a set larger than all L2s together (as the sampler does:
+// 8 layers x 5.5 MB per step): is the per-CU rate set by L2 hits or by the fill from the Infinity Cache?
+template <int D>
+float run_cold(u32x4* const* bufs, int nbuf, size_t bytes, unsigned* out, int nblk, int nwaves, int iters) {
+    hipEvent_t s, e;
+    hipEventCreate(&s); hipEventCreate(&e);
+    for (int i = 0; i < nbuf; ++i) probe<D, 0><<<nblk, nwaves * 64>>>(bufs[i], bytes, out, nwaves);
+    hipEventRecord(s);
+    for (int i = 0; i < iters; ++i) probe<D, 0><<<nblk, nwaves * 64>>>(bufs[i % nbuf], bytes, out, nwaves);
+    hipEventRecord(e); hipEventSynchronize(e);
+    float ms; hipEventElapsedTime(&ms, s, e);
+    return ms / iters * 1e3f;
+}
+
 int main() {
     const size_t bytes = 4608 * 1024;   // one chain-B weight stream
     u32x4* buf; unsigned* out;
     hipMalloc(&buf, bytes); hipMalloc(&out, 64);
     hipMemset(buf, 1, bytes); hipMemset(out, 0, 64);
+    {
+        const int NB = 16;
+        u32x4* bufs[NB];
+        for (int i = 0; i < NB; ++i) { hipMalloc(&bufs[i], bytes); hipMemset(bufs[i], 1 + i, bytes); }
+        for (int nb : {28, 225}) {
+            float w = run<8, 0>(bufs[0], bytes, out, nb, 8, 32), c = run_cold<8>(bufs, NB, bytes, out, nb, 8, 32),
+                  c16 = run_cold<16>(bufs, NB, bytes, out, nb, 8, 32);
+            printf("blocks %3d waves 8 contiguous: same buffer every launch D=8 %6.1f | 16 buffers in turn (74 MB) D=8 %6.1f D=16 %6.1f GB/s per CU\n",
+                   nb, bytes / w * 1e-3, bytes / c * 1e-3, bytes / c16 * 1e-3);
+        }
+    }
     const int blks[] = {1, 32, 225};
     for (int nb : blks)
         for (int nw : {4, 8, 16}) {
