@@ -37,7 +37,8 @@
 #define CH_ABUF 28672        // 64 KB  activation block [8 k-tiles][64][128 B]
 #define CH_H1C 94208         // 32 KB  GELU(linear1) chunk [4 k-tiles][64][128 B]
 #define CH_ABUF2 94208       // 64 KB  second activation block (un-rotated norm1 image for V); overlays the dead h1 chunk
-#define CH_SMEM 159744
+#define CH_STG7 159744       //  4 KB  eighth staging slot of store_heads (slots 0-6: the first 28 KB)
+#define CH_SMEM 163840
 #ifndef CH_D
 #define CH_D 8               // weight stages in flight per wave (registers): 8 x 2 KB x 8 waves = 128 KB per CU
 #endif
@@ -296,18 +297,24 @@ DEVINL void norm_to_lds(const f32x16_t (&acc)[2][2], const float (&mean)[2], con
     }
 }
 
-// head-major scatter of a 512-wide projection (wave = head): model/model.py:78-80,92-95
+// head-major scatter of a 512-wide projection (wave = head): model/model.py:78-80,92-95.  The accumulator layout gives a
+// lane 8 bytes of a row at a time; written like that every store instruction makes 32 sixteen-byte write requests, and
+// the three scatters of the next layer's Q, K, V cost 13 us of a 130-us launch.  Instead each 32-row half of the wave's
+// [64 rows][64 columns] tile goes through 4 KB of the (by now idle) constants area -- wave-private, XOR-swizzled by
+// row & 7, no barrier -- and leaves as 16 bytes per lane, 8 lanes per 128-byte row: 8 full lines per instruction.
+DEVINL char* stage_area(char* smem, int wave) { return smem + (wave < 7 ? wave * 4096 : CH_STG7); }
 DEVINL void store_heads(const f32x16_t (&acc)[2][2], void* base, float scale, int L, int Lp, int H, int m0, int M,
-                        int wave, int lane) {
+                        int wave, int lane, char* smem) {
+#ifdef CH_ABLATE_STORES   // timing experiment only: how much of the Q / K / V tail is the head-major scatter?
+    if (M > 0) return;
+#endif
     lane = fresh_v(lane);
     wave = fresh_s(wave);
     const int r = lane & 31, h = lane >> 5;
+    char* stg = stage_area(smem, wave);
+    const int row0 = lane >> 3, ch = lane & 7;      // read side: row row0 + 8 k, 16-byte chunk ch
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
-        const int m = m0 + 32 * mi + r;
-        if (m >= M) continue;
-        const int seq = m / L, tok = m % L;
-        uint16_t* dst = reinterpret_cast<uint16_t*>(base) + (((long)seq * H + wave) * Lp + tok) * 64;
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -315,8 +322,25 @@ DEVINL void store_heads(const f32x16_t (&acc)[2][2], void* base, float scale, in
                 uint2 pk;
                 pk.x = pack_bf2(acc[mi][ni][4 * gq + 0] * scale, acc[mi][ni][4 * gq + 1] * scale);
                 pk.y = pack_bf2(acc[mi][ni][4 * gq + 2] * scale, acc[mi][ni][4 * gq + 3] * scale);
-                *reinterpret_cast<uint2*>(dst + 32 * ni + 8 * gq + 4 * h) = pk;
+                *reinterpret_cast<uint2*>(stg + r * 128 + (((4 * ni + gq) ^ (r & 7)) << 4) + 8 * h) = pk;
             }
+        // the LDS queue of a wave is in order: its reads below see its writes above
+        int m = m0 + 32 * mi + row0;
+        int seq = m / L, tok = m - seq * L;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int row = row0 + 8 * k;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(stg + row * 128 + ((ch ^ (row & 7)) << 4));
+            if (m < M)
+                *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(base) + (((long)seq * H + wave) * Lp + tok) * 64 +
+                                          ch * 8) = v;
+            m += 8;
+            tok += 8;
+            if (tok >= L) {
+                tok -= L;
+                ++seq;
+            }
+        }
     }
 }
 
@@ -604,7 +628,7 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
         clear();
         if (!FULL) {
             phase_n512_rolled(acc, abuf, 32, ws, lane);
-            store_heads(acc, a.q_out, a.scale_q, L, a.Lp, a.H, m0, M, wave, lane);
+            store_heads(acc, a.q_out, a.scale_q, L, a.Lp, a.H, m0, M, wave, lane, smem);
             return;
         }
         phase_n512<32>(acc, abuf, ws, lane);
@@ -759,16 +783,16 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     clear();
     phase_n512<32>(acc, abuf, ws, lane);
     CH_T(29);
-    store_heads(acc, a.q_out, a.scale_q, L, a.Lp, a.H, m0, M, wave, lane);
+    store_heads(acc, a.q_out, a.scale_q, L, a.Lp, a.H, m0, M, wave, lane, smem);
     clear();
     phase_n512<32>(acc, abuf, ws, lane);
     CH_T(30);
-    store_heads(acc, a.k_out, 1.0f, L, a.Lp, a.H, m0, M, wave, lane);
+    store_heads(acc, a.k_out, 1.0f, L, a.Lp, a.H, m0, M, wave, lane, smem);
     CH_T(31);
     clear();
     phase_n512<32, true>(acc, smem + CH_ABUF2, ws, lane);
     CH_T(32);
-    store_heads(acc, a.v_out, 1.0f, L, a.Lp, a.H, m0, M, wave, lane);
+    store_heads(acc, a.v_out, 1.0f, L, a.Lp, a.H, m0, M, wave, lane, smem);
     CH_T(33);
     CH_TC(61);
 }
