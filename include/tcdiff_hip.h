@@ -173,7 +173,7 @@ int tcdiff_adan_step(const tcdiff_adan_chunk* chunks, int n_chunks, const tcdiff
  * linear3 (32), w_qs, w_ks, w_vs of the NEXT layer (32 each).  n_stages = 64 / 288 / 192.  tcdiff_amd/engine.py packs it.
  * Rows: M token rows, L tokens per sequence; FiLM row = m / L, rotary position = m % L; head-major images as
  * TC_EPI_QKV_HEADS (H must be 8).  a_mod / xres_mod > 0: input / residual row = m % mod (layer 0 shares them between
- * the CFG branches).
+ * the CFG branches).  The fp32 residual stream between chain launches is column-blocked (see the struct).
  *   TC_CHAIN_FULL / TC_CHAIN_FULL_LAST : chain A, then the CROSS-ATTENTION itself (head w on wave w, K / V from the
  *                     fragment-ordered cache images written by tcdiff_pack_kv_frags), then chain B / B_LAST, in one launch:
  *                     per layer the step is  self-attention -> one chain launch.  Stream: chain A's stages followed by
@@ -193,11 +193,12 @@ typedef struct {
     const float* ln_g;    /* SBI_MSA.layer_norm (eps ln_eps) */
     const float* ln_b;
     const float* film;    /* FiLM of the attention block: film[seq * film_ld + n] scale, +512 shift */
-    const float* xres;    /* fp32 [*,512] residual in */
-    float* xout;          /* fp32 [M,512] residual out (chain B: holds x between the blocks, then x') */
+    const float* xres;    /* fp32 residual in: column-blocked (below) with M (xres_mod > 0: xres_mod) rows, or, with
+                             xres_rowmajor, plain [*,512] rows (layer 0: written by tcdiff_gemm_rowln) */
+    float* xout;          /* fp32 residual out, column-blocked [64][M][8] (chain B: holds x between the blocks, then x') */
     const float* n2_g;    /* the norm that follows: norm2 (chain A) / norm3 (chain B) */
     const float* n2_b;
-    const float* rope;    /* [Lmax][512] cos/sin table (tcdiff_rope_table) */
+    const float* rope;    /* cos/sin table of tcdiff_rope_table, column-blocked [64][rope_rows][8] */
     void* q_out;          /* Q image T[n_seq][8][Lp][64] (chain A: cross-attention Q; chain B: next layer's) */
     const float* b1;      /* linear1 bias [1024] */
     const float* b2;      /* linear2 bias [512]  */
@@ -221,6 +222,10 @@ typedef struct {
     const void* kf;       /* fragment-ordered K cache of this layer: T[n_kv][8 heads][nkt][4][64 lanes][8] */
     const void* vf;       /* fragment-ordered V cache                                                      */
     int n_shared, nkt, Lk; /* kv slot = seq < n_shared ? 0 : seq - n_shared + (n_shared > 0); nkt = ceil(Lk / 32) tiles */
+    /* COLUMN-BLOCKED fp32 [rows][512] matrix: element (row, c) at ((c / 8) * rows + row) * 8 + c % 8 -- the 32 rows a
+     * wave instruction touches are then one contiguous kilobyte instead of 32 separate 32-byte pieces */
+    int xres_rowmajor;     /* 1: xres is a plain row-major [*,512] matrix */
+    int rope_rows;         /* rows of the column-blocked rotary table (>= L) */
 } tcdiff_chain_args;
 
 int tcdiff_chain(const tcdiff_chain_args* args, hipStream_t stream);

@@ -41,7 +41,8 @@ class ChainArgs(C.Structure):
                 ("film3", _vp), ("n4_g", _vp), ("n4_b", _vp), ("b3", _vp), ("nn_g", _vp), ("nn_b", _vp),
                 ("k_out", _vp), ("v_out", _vp), ("h_out", _vp), ("film_ld", _i), ("ln_eps", _f), ("n2_eps", _f),
                 ("n4_eps", _f), ("nn_eps", _f), ("scale_q", _f), ("lnb_g", _vp), ("lnb_b", _vp), ("filmb", _vp),
-                ("n3_g", _vp), ("n3_b", _vp), ("kf", _vp), ("vf", _vp), ("n_shared", _i), ("nkt", _i), ("Lk", _i)]
+                ("n3_g", _vp), ("n3_b", _vp), ("kf", _vp), ("vf", _vp), ("n_shared", _i), ("nkt", _i), ("Lk", _i),
+                ("xres_rowmajor", _i), ("rope_rows", _i)]
 
 
 class StepPrologueArgs(C.Structure):

@@ -240,19 +240,36 @@ DEVINL f32x4_t lds4(const char* base, int float_index) {
     return *reinterpret_cast<const f32x4_t*>(base + float_index * 4);
 }
 
-// This lane's two rows of a [*, 512] fp32 matrix (residual stream, rotary table), 8 column groups each: a register
+// This lane's two rows of a [rows, 512] fp32 matrix (residual stream, rotary table), 8 column groups each: a register
 // pipeline 4 groups deep (32 VGPRs; all 16 float4 at once would not fit beside accumulators and weight ring).
+// Layouts.  Row-major [row][512]: a load instruction then touches 32 rows x 32 bytes = 32 separate line requests, and
+// five such passes plus three store passes cost ~17 us of a 130-us launch (measured by ablation).  COLUMN-BLOCKED
+// [64 groups of 8 columns][rows][8 floats]: the 32 rows of a lane half are consecutive, so an instruction reads ONE
+// contiguous kilobyte.  The residual stream between chain launches and the rotary table handed to them are
+// column-blocked; only layer 0's input (written by gemm_rowln) is row-major (`xres_rowmajor`).
 struct RowPipe {
-    const float* p[2];     // row base + this lane's first column
+    const float* p[2];     // this lane's first 4 floats of its row in column group 8 wave
+    long its;              // floats between column groups (8 row-major, 8 rows column-blocked)
     f32x4_t q[4][2];       // [group & 3][row tile]
 };
-DEVINL void rp_issue(RowPipe& rp, int it) {
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) rp.q[it & 3][mi] = ld4(rp.p[mi] + 32 * (it >> 2) + 8 * (it & 3));
+DEVINL long cb_off(int wave, int it, long rows, int row, int h) {   // column-blocked offset of (row, column group 8 wave + it)
+    return ((long)(wave * 8 + it) * rows + row) * 8 + 4 * h;
 }
-DEVINL void rp_start(RowPipe& rp, const float* base, const int (&row)[2], int wave, int h) {
+DEVINL void rp_issue(RowPipe& rp, int it) {
+#ifdef CH_ABLATE_XLOAD
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) rp.p[mi] = base + (long)row[mi] * 512 + 64 * wave + 4 * h;
+    for (int mi = 0; mi < 2; ++mi) rp.q[it & 3][mi] = f32x4_t{0.5f, 0.25f, 0.5f, 0.25f};
+#else
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) rp.q[it & 3][mi] = ld4(rp.p[mi] + it * rp.its);
+#endif
+}
+// rows: row count of the column-blocked matrix, or 0 for a row-major one
+DEVINL void rp_start(RowPipe& rp, const float* base, const int (&row)[2], long rows, int wave, int h) {
+    rp.its = rows > 0 ? rows * 8 : 8;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+        rp.p[mi] = rows > 0 ? base + cb_off(wave, 0, rows, row[mi], h) : base + (long)row[mi] * 512 + 64 * wave + 4 * h;
 #pragma unroll
     for (int it = 0; it < 4; ++it) rp_issue(rp, it);
 }
@@ -588,7 +605,7 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
                 }
                 // unguarded: rows past M rewrite row M - 1 with the SAME values (same inputs; every load of this column
                 // group, in place or not, was issued before this store)
-                *reinterpret_cast<f32x4_t*>(a.xout + (long)mcl[mi] * 512 + n) = o;
+                *reinterpret_cast<f32x4_t*>(a.xout + cb_off(wv, it, M, mcl[mi], hh)) = o;
             }
             if (it + 4 < 8) rp_issue(rp, it + 4);
             // one column group at a time: without a fence hipcc hoists the loads of ALL eight groups (row pipeline
@@ -609,7 +626,7 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
             int rr[2];
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) rr[mi] = a.xres_mod > 0 ? mc[mi] % a.xres_mod : mc[mi];
-            rp_start(rp, a.xres, rr, wave, h);   // in flight during the statistics exchange
+            rp_start(rp, a.xres, rr, a.xres_rowmajor ? 0 : (a.xres_mod > 0 ? a.xres_mod : M), wave, h);   // in flight during the statistics exchange
         }
         fc_epilogue(a.ln_eps, 40);
         CH_T(3);
@@ -617,7 +634,7 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
             const float* const v[6] = {fcb_g, fcb_b, n3_g, n3_b, nullptr, nullptr};
             nxt = fetch_consts(fcb_film, v);
         }
-        rp_start(rp, a.rope, pos, wave, h);
+        rp_start(rp, a.rope, pos, a.rope_rows, wave, h);
         row_stats(acc, scr + 1024, wave, lane, a.n2_eps, mean, rstd);
         CH_T(4);
         // norm2 + rotary (model/model.py:332,387) -> LDS -> Q = rot W_q^T / 8 (model/model.py:78,97)
@@ -643,12 +660,12 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     clear();
     phase_n512<32>(acc, abuf, ws, lane);
     if (FULL) {
-        rp_start(rp, a.xout, mc, wave, h);       // the x this lane stored in the first fc epilogue
+        rp_start(rp, a.xout, mc, M, wave, h);    // the x this lane stored in the first fc epilogue
     } else {
         int rr[2];
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) rr[mi] = a.xres_mod > 0 ? mc[mi] % a.xres_mod : mc[mi];
-        rp_start(rp, a.xres, rr, wave, h);
+        rp_start(rp, a.xres, rr, a.xres_rowmajor ? 0 : (a.xres_mod > 0 ? a.xres_mod : M), wave, h);
     }
     CH_T(37);
     fc_epilogue(a.ln_eps, 42);
@@ -702,7 +719,7 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
         CH_T(9 + 4 * c);
     }
     // linear2 bias, FiLM, residual (the x this lane stored above), norm4 -> LDS
-    rp_start(rp, a.xout, mc, wave, h);
+    rp_start(rp, a.xout, mc, M, wave, h);
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
         const int ni = it >> 2, gq = it & 3;
@@ -766,7 +783,7 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
                     pk.y = pack_bf2(o[2], o[3]);
                     *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.h_out) + (long)mc[mi] * 512 + n) = pk;
                 } else {
-                    *reinterpret_cast<f32x4_t*>(a.xout + (long)mc[mi] * 512 + n) = o;
+                    *reinterpret_cast<f32x4_t*>(a.xout + cb_off(wave, 4 * ni + gq, M, mc[mi], h)) = o;
                 }
             }
             CH_FENCE();
@@ -774,7 +791,7 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     if (LAST) return;
     // ================= next layer: norm1 + rotary -> Q, K ; norm1 -> V (model/model.py:326,374-383,78-80)
     CH_T(26);
-    rp_start(rp, a.rope, pos, wave, h);
+    rp_start(rp, a.rope, pos, a.rope_rows, wave, h);
     row_stats(acc, scr, wave, lane, a.nn_eps, mean, rstd);
     CH_T(27);
     norm_to_lds<true>(acc, mean, rstd, vecp(1), vecp(2), rp, abuf, wave, lane, smem + CH_ABUF2);

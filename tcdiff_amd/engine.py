@@ -191,6 +191,7 @@ class DenoiserEngine:
         n_pos = max(self.Lseq, self.S + 2)
         w["rope"] = torch.empty(n_pos, 512, device=self.dev, dtype=torch.float32)
         K.rope_table(f(g("rotary.freqs")), w["rope"], n_pos)
+        w["rope_cb"] = K.to_cb(w["rope"])                  # the chain kernels read it column-blocked [64][n_pos][8]
         self.w = w
         if self.use_chain:
             self._build_chain_streams()
@@ -438,7 +439,7 @@ class DenoiserEngine:
         Rs, R = B * Lq, branches * B * Lq
         nseq = branches * B
         p = f"l{l}."
-        rope = w["rope"]
+        rope = w["rope_cb"]
         if l == 0:
             K.gemm_tile(dt, b["rot"], w[p + "qkv.w"], Rs, 1536, 512, A2=b["h"], split_n=1024, mode=L.EPI_QKV_HEADS,
                         out=b["Q"], out_k=b["K"], out_v=b["V"], scale_q=0.125, Lseq=Lq, Lp=self.Lp, H=H, n_q=512,
@@ -453,8 +454,8 @@ class DenoiserEngine:
                     h_out=b["h"] if last else None, scale_q=0.125, Lp=self.Lp, H=H)
         head = dict(a_mod=Rs if l == 0 else 0, ln_g=w[p + "sln.g"], ln_b=w[p + "sln.b"], ln_eps=1e-6,
                     film=film0[:, (l * 3 + 0) * 1024:], film_ld=fld, xres=b["xs"] if l == 0 else b["xa"],
-                    xres_mod=Rs if l == 0 else 0, xout=b["xa"], n2_g=w[p + "norm2.g"], n2_b=w[p + "norm2.b"], n2_eps=1e-5,
-                    rope=rope)
+                    xres_mod=Rs if l == 0 else 0, xres_rowmajor=l == 0, xout=b["xa"], n2_g=w[p + "norm2.g"],
+                    n2_b=w[p + "norm2.b"], n2_eps=1e-5, rope=rope)     # b["xa"] is COLUMN-BLOCKED on this path
         if self.use_full:
             # self-attention tail, cross-attention (K / V from the fragment-ordered caches) and feed-forward in ONE launch
             K.chain(L.CHAIN_FULL_LAST if last else L.CHAIN_FULL, 256 if last else 352, R, Lq, b["O"], w[p + "chainF"],

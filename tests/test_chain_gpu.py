@@ -92,9 +92,13 @@ def test_chain_a_kernel_against_rowln_plus_tile():
     ws = torch.cat([DenoiserEngine._stages_n512(Wfc), DenoiserEngine._stages_n512(Wq)], 1).contiguous()
     x2 = torch.zeros(M, 512, device=DEV)
     Q2 = torch.zeros_like(Q1)
+    # the chain kernels take the rotary table and keep the residual stream COLUMN-BLOCKED ([64][rows][8]); layer 0's
+    # residual input (gemm_rowln's output) is row-major
     K.chain(L.CHAIN_A, 64, M, Lq, Oa, ws, a_mod=Rs, ln_g=g1, ln_b=b1, ln_eps=1e-6, film=film, film_ld=2048, xres=xres,
-            xres_mod=Rs, xout=x2, n2_g=g2, n2_b=b2, n2_eps=1e-5, rope=rope, q_out=Q2, scale_q=0.125, Lp=Lp, H=H)
+            xres_mod=Rs, xres_rowmajor=True, xout=x2, n2_g=g2, n2_b=b2, n2_eps=1e-5, rope=K.to_cb(rope), q_out=Q2,
+            scale_q=0.125, Lp=Lp, H=H)
     torch.cuda.synchronize()
+    x2 = K.from_cb(x2, M)
     dx = float((x1 - x2).abs().max())
     dq = float((Q1.float() - Q2.float()).abs().max())
     print(f"chain A: x max-abs diff {dx:.2e} (|x| max {float(x1.abs().max()):.2f}), Q max-abs diff {dq:.2e}")
@@ -152,10 +156,10 @@ def test_chain_b_kernel_against_op_by_op_sequence(last):
     if not last:
         parts += [E._stages_n512(W["qkv"][i * 512:(i + 1) * 512]) for i in range(3)]
     ws = torch.cat(parts, 1).contiguous()
-    xb = xres.clone()
+    xb = K.to_cb(xres)                     # column-blocked residual stream, updated in place
     Q2, K2, V2, hl2 = z(nseq, H, Lp, 64), z(nseq, H, Lp, 64), z(nseq, H, Lp, 64), z(M, 512)
     K.chain(L.CHAIN_B_LAST if last else L.CHAIN_B, ws.shape[1], M, Lq, Oa, ws, ln_g=g1, ln_b=b1, ln_eps=1e-6, film=film,
-            film_ld=4096, xres=xb, xout=xb, n2_g=g3, n2_b=b3n, n2_eps=1e-5, rope=rope, b1=bias1, b2=bias2,
+            film_ld=4096, xres=xb, xout=xb, n2_g=g3, n2_b=b3n, n2_eps=1e-5, rope=K.to_cb(rope), b1=bias1, b2=bias2,
             film3=film[:, 2048:], n4_g=g4, n4_b=b4, n4_eps=1e-5, b3=bias3, nn_g=None if last else gn,
             nn_b=None if last else bn, nn_eps=1e-5, q_out=None if last else Q2, k_out=None if last else K2,
             v_out=None if last else V2, h_out=hl2 if last else None, scale_q=0.125, Lp=Lp, H=H)
@@ -166,7 +170,7 @@ def test_chain_b_kernel_against_op_by_op_sequence(last):
         print(f"chain B (last): linear3 rows max/mean diff {d[0]:.2e}/{d[1]:.2e} (|h| max {float(hl1.float().abs().max()):.2f})")
         assert d[0] < 6e-2 and d[1] < 2e-3
     else:
-        dx = md(xa, xb)
+        dx = md(xa, K.from_cb(xb, M))
         print(f"chain B: x' max/mean diff {dx[0]:.2e}/{dx[1]:.2e} (|x| max {float(xa.abs().max()):.2f})")
         for nm, a, b in (("Q", Q1, Q2), ("K", K1, K2), ("V", V1, V2)):
             d = md(a, b)
@@ -197,6 +201,7 @@ def test_fused_layer_chain_against_chain_a_attention_chain_b(last):
     xres = rnd(M, 512, seed=94)
     rope = torch.empty(Lq, 512, device=DEV)
     K.rope_table((1.0 / (10000 ** (torch.arange(0, 512, 2).float() / 512))).to(DEV), rope, Lq)
+    rope = K.to_cb(rope)                   # column-blocked, like the residual stream x1 / x2 below
     Kc = torch.zeros(n_kv, H, Lpc, 64, device=DEV, dtype=bf)
     Vc = torch.zeros_like(Kc)
     Kc[:, :, :Lk] = rnd(n_kv, H, Lk, 64, seed=95).to(bf)
@@ -216,7 +221,7 @@ def test_fused_layer_chain_against_chain_a_attention_chain_b(last):
     tail = dict(b1=bias1, b2=bias2, film3=film[:, 4096:], n4_g=gs[6], n4_b=gs[7], b3=bias3, nn_g=None if last else gs[8],
                 nn_b=None if last else gs[9], scale_q=0.125, Lp=Lp, H=H)
     # ---- three launches
-    x1 = xres.clone()
+    x1 = K.to_cb(xres)
     Qc, O2 = z(nseq, H, Lp, 64), z(M, 512)
     K.chain(L.CHAIN_A, 64, M, Lq, Oa, wsA, ln_g=gs[0], ln_b=gs[1], ln_eps=1e-6, film=film, film_ld=6144, xres=x1, xout=x1,
             n2_g=gs[2], n2_b=gs[3], rope=rope, q_out=Qc, scale_q=0.125, Lp=Lp, H=H)
@@ -229,7 +234,7 @@ def test_fused_layer_chain_against_chain_a_attention_chain_b(last):
     # ---- one launch
     Kf, Vf = z(n_kv, H, nkt * 2048), z(n_kv, H, nkt * 2048)
     K.pack_kv_frags(Kc, Vc, Kf, Vf, n_kv, H, Lpc, nkt, 0, Lk)
-    x2 = xres.clone()
+    x2 = K.to_cb(xres)
     Q2, K2, V2, h2 = z(nseq, H, Lp, 64), z(nseq, H, Lp, 64), z(nseq, H, Lp, 64), z(M, 512)
     K.chain(L.CHAIN_FULL_LAST if last else L.CHAIN_FULL, wsF.shape[1], M, Lq, Oa, wsF, ln_g=gs[0], ln_b=gs[1], ln_eps=1e-6,
             film=film, film_ld=6144, xres=x2, xout=x2, n2_g=gs[2], n2_b=gs[3], rope=rope, lnb_g=gs[4], lnb_b=gs[5],

@@ -23,6 +23,7 @@ wsB = torch.cat(parts, 1).contiguous()
 wsA = torch.cat([E._stages_n512(W["sfc"]), E._stages_n512(W["cq"])], 1).contiguous()
 rope = torch.empty(Lq, 512, device=dev)
 K.rope_table((1.0 / (10000 ** (torch.arange(0, 512, 2).float() / 512))).to(dev), rope, Lq)
+rope = K.to_cb(rope)          # the chain kernels read the table (and keep x) column-blocked
 g = [vec(1), vec(), vec(1), vec(), vec(1), vec(), vec(1), vec()]
 b1, b2, b3 = 0.05 * rnd(1024), vec(), vec()
 
