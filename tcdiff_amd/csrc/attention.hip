@@ -15,6 +15,7 @@
 //   * the PV A operand is V^T: bf16 reads it with the hardware transpose read ds_read_b64_tr_b16 (two reads per
 //     fragment, in the key order the P^T registers are in); f32 reads one dword per MFMA (lanes = consecutive d).
 #include "common.h"
+#include <type_traits>
 #include "tcdiff_hip.h"
 
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
@@ -321,15 +322,16 @@ __global__ __launch_bounds__(512) void attention_res_kernel(const char* __restri
     sync_dma();
 
     if (act0) {
-#pragma unroll 1
-        for (int b = 0; b < nt; ++b) {
+        // one tile of NS * 32 keys (NS = 2 except for a last tile with <= 32 keys left: 450 keys = 7 tiles + 2 keys)
+        auto tile = [&](auto ns_c, int b) {
+            constexpr int NS = decltype(ns_c)::value;
             const char* kt_base = Ks + b * 8192;
             const char* vt_base = Vs + b * 8192;
             const int kv0 = c0 + b * 64;
             // ---- S^T = K Q^T for both row groups: every K fragment read feeds two MFMAs
             f32x16_t s[NG][2];
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt) {
+            for (int kt = 0; kt < NS; ++kt) {
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     const u32x4 kf = *reinterpret_cast<const u32x4*>(kt_base + tile_off(kt * 32 + r, 2 * ks + h));
@@ -346,7 +348,7 @@ __global__ __launch_bounds__(512) void attention_res_kernel(const char* __restri
 #pragma unroll
                 for (int g = 0; g < NG; ++g)
 #pragma unroll
-                    for (int kt = 0; kt < 2; ++kt)
+                    for (int kt = 0; kt < NS; ++kt)
 #pragma unroll
                         for (int q = 0; q < 16; ++q)
                             if (kv0 + kt * 32 + acc_row(q, h) >= Lk) s[g][kt][q] = -INFINITY;
@@ -357,7 +359,7 @@ __global__ __launch_bounds__(512) void attention_res_kernel(const char* __restri
             for (int g = 0; g < NG; ++g) {
                 float mx = s[g][0][0];
 #pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
+                for (int kt = 0; kt < NS; ++kt)
 #pragma unroll
                     for (int q = 0; q < 16; ++q) mx = fmaxf(mx, s[g][kt][q]);
                 mx = fmaxf(mx, other_half(mx)) * LOG2E;
@@ -366,7 +368,7 @@ __global__ __launch_bounds__(512) void attention_res_kernel(const char* __restri
                 f32x2_t rs2 = {0.0f, 0.0f};
                 const f32x2_t l2 = {LOG2E, LOG2E}, nm = {-m_new, -m_new};
 #pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
+                for (int kt = 0; kt < NS; ++kt)
 #pragma unroll
                     for (int q = 0; q < 16; q += 2) {
                         const f32x2_t x = __builtin_elementwise_fma(f32x2_t{s[g][kt][q], s[g][kt][q + 1]}, l2, nm);
@@ -390,7 +392,7 @@ __global__ __launch_bounds__(512) void attention_res_kernel(const char* __restri
             }
             // ---- O^T += V^T P^T: every V^T fragment (two transposed reads) feeds both groups
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
+            for (int kt = 0; kt < NS; ++kt)
 #pragma unroll
                 for (int st = 0; st < 2; ++st) {
                     u32x4 pf[NG];
@@ -408,26 +410,42 @@ __global__ __launch_bounds__(512) void attention_res_kernel(const char* __restri
                         for (int g = 0; g < NG; ++g) P::mma(o[g][dt], vf, pf[g]);
                     }
                 }
-        }
+        };
+        const int nfull = (Lk - c0 - 64 * (nt - 1)) <= 32 ? nt - 1 : nt;     // tiles that use both 32-key halves
+#pragma unroll 1
+        for (int b = 0; b < nfull; ++b) tile(std::integral_constant<int, 2>{}, b);
+        if (nfull < nt) tile(std::integral_constant<int, 1>{}, nt - 1);
     }
     }  // key chunks
-    // ---- O[q][d] = O^T[d][q] / l
+    // ---- O[q][d] = O^T[d][q] / l.  A lane holds 8 bytes of a row at a time; stored like that an instruction makes 32
+    // sixteen-byte write requests.  Each 32-row group goes through 4 KB of wave-private LDS behind the K / V images
+    // (XOR-swizzled by row & 7; a wave's LDS queue is in order, no barrier) and leaves as 16 bytes per lane, 8 lanes per
+    // 128-byte row: 8 full lines per store instruction.
+    char* stg = smem + 2 * ntm * 8192 + wave * 4096;
+    const int srow0 = lane >> 3, sch = lane & 7;
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-        const int qg = qbase + g * 32 + r;
-        if ((g == 0 ? act0 : act1) && qg < Lq) {
-            const float inv = 1.0f / l_run[g];
-            uint16_t* orow = reinterpret_cast<uint16_t*>(O) + ((long)seq * Lq + qg) * ldo + head * 64;
+        if (!(g == 0 ? act0 : act1)) continue;      // wave-uniform
+        const float inv = 1.0f / l_run[g];
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
+        for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    const int d0 = dt * 32 + 8 * q4 + 4 * h;
-                    uint2 pk;
-                    pk.x = pack_bf2(o[g][dt][4 * q4 + 0] * inv, o[g][dt][4 * q4 + 1] * inv);
-                    pk.y = pack_bf2(o[g][dt][4 * q4 + 2] * inv, o[g][dt][4 * q4 + 3] * inv);
-                    *reinterpret_cast<uint2*>(orow + d0) = pk;
-                }
+            for (int q4 = 0; q4 < 4; ++q4) {
+                uint2 pk;
+                pk.x = pack_bf2(o[g][dt][4 * q4 + 0] * inv, o[g][dt][4 * q4 + 1] * inv);
+                pk.y = pack_bf2(o[g][dt][4 * q4 + 2] * inv, o[g][dt][4 * q4 + 3] * inv);
+                *reinterpret_cast<uint2*>(stg + r * 128 + (((4 * dt + q4) ^ (r & 7)) << 4) + 8 * h) = pk;
+            }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int row = srow0 + 8 * k;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(stg + row * 128 + ((sch ^ (row & 7)) << 4));
+            const int qg = qbase + g * 32 + row;
+#ifdef ATT_ABLATE_OSTORE
+            if (v.x == 0x12345678u)
+#endif
+            if (qg < Lq)
+                *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(O) + ((long)seq * Lq + qg) * ldo + head * 64 + sch * 8) = v;
         }
     }
 }
@@ -440,17 +458,18 @@ extern "C" int tcdiff_attention(int dtype, const void* Q, const void* K, const v
     if (Lp_q % 128 != 0 || Lp_k % 64 != 0 || Lp_q < Lq || Lp_k < Lk || ldo < H * 64 || ldo % 4 != 0) return TC_ERR_ARG;
     if (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O) & 15) return TC_ERR_ALIGN;
     if (dtype == TC_DTYPE_BF16 && Lp_q >= 512) {
+        if (ldo % 8 != 0) return TC_ERR_ALIGN;      // output rows leave as 16-byte pieces
         // K/V-resident kernel (Q image padded to >= 512 rows); keys beyond 512 come in LDS-resident chunks
         const int ntm = (Lk + 63) / 64 < ATT_RES_MAXT ? (Lk + 63) / 64 : ATT_RES_MAXT;
-        const int smem_bytes = 2 * ntm * 8192;
+        const int smem_bytes = 2 * ntm * 8192 + 8 * 4096;      // K, V images + the eight 4-KB output staging areas
         // 32 query rows per wave (two workgroups per 450-token sequence) while that still fits one round over the CUs,
         // 64 rows per wave (K / V fragment reads shared by two row groups) beyond
         static tc_dev_state dev_state;
         const int n_cu = tc_device_once(dev_state, [](int) {
             hipError_t a = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_res_kernel<1>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_RES_MAXT * 8192);
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_RES_MAXT * 8192 + 8 * 4096);
             hipError_t b = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_res_kernel<2>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_RES_MAXT * 8192);
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_RES_MAXT * 8192 + 8 * 4096);
             return a != hipSuccess ? a : b;
         });
         if (n_cu < 0) return n_cu;
