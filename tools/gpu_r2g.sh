@@ -3,6 +3,7 @@
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 python -m pytest tests -q -x -m gpu 2>&1 | tail -4
+python -m pytest tests/test_parity_gpu.py -m gpu -s -q -k "c2 or bf16 or drift" > gpurun_out/r02_parity_at_benchmarked_config.log 2>&1; tail -3 gpurun_out/r02_parity_at_benchmarked_config.log
 python bench.py 2>gpurun_out/bench_default_err.log > gpurun_out/bench_default.json; tail -c 3000 gpurun_out/bench_default.json
 rm -rf gpurun_out/prof_trace
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_trace -- python3 bench.py --steps 1 --warmup 1 --ddpm-steps 200 --no-cpu-baseline --no-kernel-profile --no-parity-mode > gpurun_out/prof_trace.log 2>&1
