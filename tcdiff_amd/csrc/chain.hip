@@ -42,6 +42,10 @@
 #ifndef CH_D
 #define CH_D 8               // weight stages in flight per wave (registers): 8 x 2 KB x 8 waves = 128 KB per CU
 #endif
+#define CH_R 16              // ring slots inside a GEMM phase: a phase tops the CH_D resident stages up to CH_R in flight
+#ifndef CH_QKV_R
+#define CH_QKV_R CH_D        // ring depth of the Q / K / V GEMMs at the end of the launch
+#endif
 #define CH_STAGE 2048
 
 typedef const float* fptr;
@@ -54,7 +58,7 @@ struct WStream {
     const u32x4* p;    // stream base + lane
     unsigned pos;      // stages consumed so far (wave-uniform)
     unsigned last;     // index of the last stage
-    u32x4 a[CH_D], b[CH_D];
+    u32x4 a[CH_R], b[CH_R];   // slots 0 .. CH_D-1 live across phases, the rest only inside a GEMM phase
 };
 DEVINL void ws_load(WStream& ws, int slot, unsigned stage) {
     const unsigned st = stage < ws.last ? stage : ws.last;
@@ -96,22 +100,30 @@ DEVINL void zero(f32x16_t& v) {
 // default oldest-first arbitration waves 0-3 finish every barrier-free stretch ~2 us before waves 4-7.  It balances
 // them, and the stretch takes exactly as long: the pair is bound by what the CU gets from L2, not by arbitration.)
 // TAIL: the launch's last phase -- its last CH_D stages refill nothing (there is nothing behind them).
-template <int NST, bool TAIL = false>
+template <int NST, bool TAIL = false, int R = CH_D>
 DEVINL void phase_n512(f32x16_t (&acc)[2][2], const char* abuf, WStream& ws, int lane) {
-    static_assert(NST % CH_D == 0, "a phase starts at ring slot 0");
+    static_assert(NST % R == 0, "a phase starts and ends at ring slot 0");
     lane = fresh_v(lane);
     const int r = lane & 31, h = lane >> 5;
     u32x4 a0 = CH_FRAG(abuf, r, h), a1 = CH_FRAG(abuf, 32 + r, h);
+    // Between phases CH_D stages are in flight (64 VGPRs, all the epilogues can spare).  Inside a phase the accumulators
+    // and the ring are all that is live, so the phase opens by topping the ring up to CH_R stages: the weight stream of
+    // a CU is latency-bound (bytes in flight / ~1.7 us), and the deeper ring is what the register file allows HERE.
+    // Relative stage j lives in slot j % CH_R; nothing past the next phase's first CH_D stages is loaded, so the phase
+    // ends as it began: stages NST .. NST + CH_D - 1 in slots 0 .. CH_D - 1.
+    const unsigned base = ws.pos;
+#pragma unroll
+    for (int j = CH_D; j < R; ++j)
+        if (!(TAIL && j >= NST)) ws_load(ws, j, base + j);
 #pragma unroll
     for (int ks = 0; ks < NST; ++ks) {
-        const int i = ks % CH_D;
+        const int i = ks % R;
         const u32x4 w0 = ws.a[i], w1 = ws.b[i];
 #ifdef CH_NO_TAIL
-        ws_load(ws, i, ws.pos + CH_D);
+        if (ks + R < NST + CH_D) ws_load(ws, i, base + ks + R);
 #else
-        if (!(TAIL && ks + CH_D >= NST)) ws_load(ws, i, ws.pos + CH_D);
+        if (ks + R < NST + CH_D && !(TAIL && ks + R >= NST)) ws_load(ws, i, base + ks + R);
 #endif
-        ws.pos++;
         u32x4 n0 = a0, n1 = a1;
         if (ks + 1 < NST) {
             const char* at = abuf + ((ks + 1) >> 2) * 8192;
@@ -135,6 +147,7 @@ DEVINL void phase_n512(f32x16_t (&acc)[2][2], const char* abuf, WStream& ws, int
         a0 = n0;
         a1 = n1;
     }
+    ws.pos = base + NST;
 }
 // The rolled form (one CH_D-stage body, looped): kept for TC_CHAIN_A alone, whose fully unrolled build hipcc spills
 // (277 VGPRs); that mode is the reference the fused launch is tested against, not the production path.
@@ -165,12 +178,13 @@ DEVINL void phase_ff1(f32x16_t (&acc)[2], const char* abuf, WStream& ws, int lan
     lane = fresh_v(lane);
     const int r = lane & 31, h = lane >> 5;
     u32x4 a0 = CH_FRAG(abuf, r, h), a1 = CH_FRAG(abuf, 32 + r, h);
+    const unsigned base = ws.pos;
+    // (CH_D deep only: two accumulator sets are live in the feed-forward loop)
 #pragma unroll
     for (int st = 0; st < 16; ++st) {
         const int i = st % CH_D;
         const u32x4 wk[2] = {ws.a[i], ws.b[i]};
-        ws_load(ws, i, ws.pos + CH_D);
-        ws.pos++;
+        ws_load(ws, i, base + st + CH_D);
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
             const int ks = 2 * st + k2;
@@ -190,6 +204,7 @@ DEVINL void phase_ff1(f32x16_t (&acc)[2], const char* abuf, WStream& ws, int lan
             a1 = n1;
         }
     }
+    ws.pos = base + 16;
 }
 
 // LayerNorm statistics of the 64 rows over all 512 columns: this lane's rows are 32 mi + r.  One exchange: every wave
@@ -798,16 +813,16 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     lds_barrier();
     CH_T(28);
     clear();
-    phase_n512<32>(acc, abuf, ws, lane);
+    phase_n512<32, false, CH_QKV_R>(acc, abuf, ws, lane);
     CH_T(29);
     store_heads(acc, a.q_out, a.scale_q, L, a.Lp, a.H, m0, M, wave, lane, smem);
     clear();
-    phase_n512<32>(acc, abuf, ws, lane);
+    phase_n512<32, false, CH_QKV_R>(acc, abuf, ws, lane);
     CH_T(30);
     store_heads(acc, a.k_out, 1.0f, L, a.Lp, a.H, m0, M, wave, lane, smem);
     CH_T(31);
     clear();
-    phase_n512<32, true>(acc, smem + CH_ABUF2, ws, lane);
+    phase_n512<32, true, CH_QKV_R>(acc, smem + CH_ABUF2, ws, lane);
     CH_T(32);
     store_heads(acc, a.v_out, 1.0f, L, a.Lp, a.H, m0, M, wave, lane, smem);
     CH_T(33);

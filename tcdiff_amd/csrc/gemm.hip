@@ -54,13 +54,18 @@ extern "C" int tcdiff_debug_stamp_buffer(void* p) {
 // =================================================================================================
 // gemm_tile: 128 x 128 x (128 B of K) tiles, 256 threads
 // =================================================================================================
-template <class P, int ACT>
+// NS = LDS stages of 32 KB ([A tile | W tile] of one k-tile).  Two stages (64 KB, two workgroups per CU) when the grid
+// has tiles to spare; FOUR (128 KB, one workgroup per CU) when it has about one tile per CU -- the per-step GEMMs
+// outside the decoder layers (FiLM stack, input / fusion / final projection: 152-228 tiles, K up to 1536).  With two
+// stages every k-tile waits out what is left of a ~1.2 us DMA round trip after 0.25 us of MFMA work (25 us for K =
+// 1536); with four the DMA of tile kt + 3 is issued while tile kt is computed.
+template <class P, int ACT, int NS>
 __global__ __launch_bounds__(256) void gemm_tile_kernel(const char* __restrict__ A, const char* __restrict__ A2,
                                                         int split_n, const char* __restrict__ W, int M, int N,
                                                         int K, long lda_b, long ldw_b, int a_mod, tcdiff_tile_epi e) {
     typedef typename P::elem_t T;
     constexpr int ES = sizeof(T);
-    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * 128 * TC_ROWB];  // 64 KB
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // NS x 32 KB (the epilogue restages through 64 KB)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -85,19 +90,28 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(const char* __restrict__
     constexpr int WOFF = 128 * TC_ROWB;
 
     TC_STAMP_AT(0);
-    stage_glds<128, 4>(smem, Ause, lda_b, m0, M, a_mod, wave, lane);
-    stage_glds<128, 4>(smem + WOFF, W, ldw_b, n0, N, 0, wave, lane);
+    // tile t of the k-loop -> slot t % NS; past the end the last tile is re-issued (never read), so that the number of
+    // DMA instructions in flight behind a tile is the same in every trip: 8 per tile and wave
+    auto issue = [&](int t) {
+        const int tt = t < nk ? t : nk - 1;
+        char* dst = smem + (t % NS) * STAGE;
+        stage_glds<128, 4>(dst, Ause + (long)tt * TC_ROWB, lda_b, m0, M, a_mod, wave, lane);
+        stage_glds<128, 4>(dst + WOFF, W + (long)tt * TC_ROWB, ldw_b, n0, N, 0, wave, lane);
+    };
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t) issue(t);
     TC_STAMP_AT(1);
-    sync_dma();
     TC_STAMP_AT(2);
 
     for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) {
-            char* nxt = smem + (cur ^ 1) * STAGE;
-            stage_glds<128, 4>(nxt, Ause + (long)(kt + 1) * TC_ROWB, lda_b, m0, M, a_mod, wave, lane);
-            stage_glds<128, 4>(nxt + WOFF, W + (long)(kt + 1) * TC_ROWB, ldw_b, n0, N, 0, wave, lane);
-        }
+        // tile kt has landed (this wave's part: all but the 8 (NS - 2) younger DMAs; the barrier: everyone's part), and
+        // every wave is out of tile kt - 1, whose slot the next DMA overwrites
+        if (NS == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (NS == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        __syncthreads();
+        issue(kt + NS - 1);
+        const int cur = kt % NS;
         const char* ta = smem + cur * STAGE + (wm * 64) * TC_ROWB;
         const char* tw = smem + cur * STAGE + WOFF + (wn * 64) * TC_ROWB;
 #pragma unroll
@@ -112,8 +126,8 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(const char* __restrict__
 #pragma unroll
                 for (int j = 0; j < 2; ++j) P::mma(acc[i][j], fw[j], fa[i]);
         }
-        sync_dma();  // all waves done with buf[cur]; the DMA of tile kt+1 has landed
     }
+    sync_dma();  // the re-issued tail DMAs have landed and every wave is out of the last tile: smem becomes the output stage
 
     TC_STAMP_AT(3);
     // ---- epilogue --------------------------------------------------------------------------------
@@ -475,9 +489,30 @@ extern "C" int tcdiff_gemm_tile(int dtype, const void* A, const void* A2, int sp
     tcdiff_tile_epi e = *epi;
     const int actk = e.act <= TC_ACT_GELU ? e.act : 3;   // 3 = runtime choice between the setup-only Mish / SiLU
     dim3 grid(((N + 127) / 128) * ((M + 127) / 128));
-#define TC_LAUNCH_TILE(POL, ACTK)                                                                                \
-    hipLaunchKernelGGL((gemm_tile_kernel<POL, ACTK>), grid, dim3(256), 0, stream, (const char*)A, (const char*)A2, \
-                       split_n, (const char*)W, M, N, K, (long)lda * es, (long)ldw * es, a_mod, e)
+    static tc_dev_state dev_state;
+    const int n_cu = tc_device_once(dev_state, [](int) {
+        hipError_t err = hipSuccess;
+#define TC_TILE_ATTR(POL, ACTK)                                                                                    \
+        if (err == hipSuccess)                                                                                     \
+            err = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tile_kernel<POL, ACTK, 4>),              \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 128 * TC_ROWB);
+        TC_TILE_ATTR(MmaBF16, 0) TC_TILE_ATTR(MmaBF16, 1) TC_TILE_ATTR(MmaBF16, 2) TC_TILE_ATTR(MmaBF16, 3)
+        TC_TILE_ATTR(MmaF32, 0) TC_TILE_ATTR(MmaF32, 1) TC_TILE_ATTR(MmaF32, 2) TC_TILE_ATTR(MmaF32, 3)
+#undef TC_TILE_ATTR
+        return err;
+    });
+    if (n_cu < 0) return n_cu;
+    // about one tile per CU and a k-loop long enough to matter: four stages, one workgroup per CU
+    const bool deep = (long)grid.x * 4 <= (long)n_cu * 5 && K / kt >= 3;
+#define TC_LAUNCH_TILE(POL, ACTK)                                                                                       \
+    if (deep)                                                                                                           \
+        hipLaunchKernelGGL((gemm_tile_kernel<POL, ACTK, 4>), grid, dim3(256), 4 * 2 * 128 * TC_ROWB, stream,            \
+                           (const char*)A, (const char*)A2, split_n, (const char*)W, M, N, K, (long)lda * es,           \
+                           (long)ldw * es, a_mod, e);                                                                    \
+    else                                                                                                                \
+        hipLaunchKernelGGL((gemm_tile_kernel<POL, ACTK, 2>), grid, dim3(256), 2 * 2 * 128 * TC_ROWB, stream,            \
+                           (const char*)A, (const char*)A2, split_n, (const char*)W, M, N, K, (long)lda * es,           \
+                           (long)ldw * es, a_mod, e)
 #define TC_DISPATCH_TILE(POL)                                      \
     switch (actk) {                                                \
         case 0: TC_LAUNCH_TILE(POL, 0); break;                     \
