@@ -210,7 +210,9 @@ DEVINL void phase_ff1(f32x16_t (&acc)[2], const char* abuf, WStream& ws, int lan
 // LayerNorm statistics of the 64 rows over all 512 columns: this lane's rows are 32 mi + r.  One exchange: every wave
 // publishes (sum, sum of squares) of its 64 columns, var = E[v^2] - mean^2 in fp32 (|mean| is of the order of the
 // standard deviation for these activations: the cancellation costs ~1e-7 relative, far below the bf16 operands).
-DEVINL void row_stats(const f32x16_t (&acc)[2][2], float* scr, int wave, int lane, float eps, float (&mean)[2],
+// Returns rstd and nmr = -mean * rstd: the normalised value is fma(v, rstd, nmr), one op per element instead of two.
+// The sums run on float2 accumulators (v_pk_add_f32 / v_pk_fma_f32: 64 instructions for the 64 values, not 128).
+DEVINL void row_stats(const f32x16_t (&acc)[2][2], float* scr, int wave, int lane, float eps, float (&nmr)[2],
                       float (&rstd)[2]) {
     lane = fresh_v(lane);
     wave = fresh_s(wave);
@@ -218,16 +220,18 @@ DEVINL void row_stats(const f32x16_t (&acc)[2][2], float* scr, int wave, int lan
     float s[2], s2[2];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
-        float t = 0.0f, t2 = 0.0f;
+        f32x2_t t = {0.0f, 0.0f}, t2 = {0.0f, 0.0f};
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                t += acc[mi][ni][q];
-                t2 = fmaf(acc[mi][ni][q], acc[mi][ni][q], t2);
+            for (int q = 0; q < 16; q += 2) {
+                const f32x2_t v = {acc[mi][ni][q], acc[mi][ni][q + 1]};
+                t += v;
+                t2 = __builtin_elementwise_fma(v, v, t2);
             }
-        s[mi] = t + other_half(t);
-        s2[mi] = t2 + other_half(t2);
+        const float ts = t[0] + t[1], t2s = t2[0] + t2[1];
+        s[mi] = ts + other_half(ts);
+        s2[mi] = t2s + other_half(t2s);
     }
     if (lane < 32) {
         scr[wave * 64 + r] = s[0];
@@ -244,9 +248,10 @@ DEVINL void row_stats(const f32x16_t (&acc)[2][2], float* scr, int wave, int lan
             t += scr[w * 64 + 32 * mi + r];
             t2 += scr[512 + w * 64 + 32 * mi + r];
         }
-        mean[mi] = t * (1.0f / 512.0f);
-        const float var = fmaxf(t2 * (1.0f / 512.0f) - mean[mi] * mean[mi], 0.0f);
+        const float mean = t * (1.0f / 512.0f);
+        const float var = fmaxf(t2 * (1.0f / 512.0f) - mean * mean, 0.0f);
         rstd[mi] = rsqrtf(var + eps);
+        nmr[mi] = -mean * rstd[mi];
     }
 }
 
@@ -292,7 +297,7 @@ DEVINL void rp_start(RowPipe& rp, const float* base, const int (&row)[2], long r
 // u = LayerNorm(acc) (optionally rotated) -> bf16 -> activation block in LDS (k = column); g, b: LDS vectors;
 // rp: the rotary rows (cos0 sin0 cos1 sin1 per column quad), started by the caller before the statistics exchange
 template <bool ROT>
-DEVINL void norm_to_lds(const f32x16_t (&acc)[2][2], const float (&mean)[2], const float (&rstd)[2], const char* g,
+DEVINL void norm_to_lds(const f32x16_t (&acc)[2][2], const float (&nmr)[2], const float (&rstd)[2], const char* g,
                         const char* b, RowPipe& rp, char* abuf, int wave, int lane, char* plain) {
     lane = fresh_v(lane);
     wave = fresh_s(wave);
@@ -306,7 +311,7 @@ DEVINL void norm_to_lds(const f32x16_t (&acc)[2][2], const float (&mean)[2], con
         for (int mi = 0; mi < 2; ++mi) {
             float u[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) u[t] = (acc[mi][ni][4 * gq + t] - mean[mi]) * rstd[mi] * g4[t] + b4[t];
+            for (int t = 0; t < 4; ++t) u[t] = fmaf(fmaf(acc[mi][ni][4 * gq + t], rstd[mi], nmr[mi]), g4[t], b4[t]);
             if (plain) {   // the un-rotated image too (V = norm1(x) W_v)
                 uint2 pk;
                 pk.x = pack_bf2(u[0], u[1]);
@@ -335,6 +340,7 @@ DEVINL void norm_to_lds(const f32x16_t (&acc)[2][2], const float (&mean)[2], con
 // [64 rows][64 columns] tile goes through 4 KB of the (by now idle) constants area -- wave-private, XOR-swizzled by
 // row & 7, no barrier -- and leaves as 16 bytes per lane, 8 lanes per 128-byte row: 8 full lines per instruction.
 DEVINL char* stage_area(char* smem, int wave) { return smem + (wave < 7 ? wave * 4096 : CH_STG7); }
+template <bool SCALE>   // Q carries 1 / sqrt(d_k); K and V are stored as they are
 DEVINL void store_heads(const f32x16_t (&acc)[2][2], void* base, float scale, int L, int Lp, int H, int m0, int M,
                         int wave, int lane, char* smem) {
 #ifdef CH_ABLATE_STORES   // timing experiment only: how much of the Q / K / V tail is the head-major scatter?
@@ -352,8 +358,13 @@ DEVINL void store_heads(const f32x16_t (&acc)[2][2], void* base, float scale, in
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 uint2 pk;
-                pk.x = pack_bf2(acc[mi][ni][4 * gq + 0] * scale, acc[mi][ni][4 * gq + 1] * scale);
-                pk.y = pack_bf2(acc[mi][ni][4 * gq + 2] * scale, acc[mi][ni][4 * gq + 3] * scale);
+                if (SCALE) {
+                    pk.x = pack_bf2(acc[mi][ni][4 * gq + 0] * scale, acc[mi][ni][4 * gq + 1] * scale);
+                    pk.y = pack_bf2(acc[mi][ni][4 * gq + 2] * scale, acc[mi][ni][4 * gq + 3] * scale);
+                } else {
+                    pk.x = pack_bf2(acc[mi][ni][4 * gq + 0], acc[mi][ni][4 * gq + 1]);
+                    pk.y = pack_bf2(acc[mi][ni][4 * gq + 2], acc[mi][ni][4 * gq + 3]);
+                }
                 *reinterpret_cast<uint2*>(stg + r * 128 + (((4 * ni + gq) ^ (r & 7)) << 4) + 8 * h) = pk;
             }
         // the LDS queue of a wave is in order: its reads below see its writes above
@@ -585,7 +596,7 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) zero(acc[mi][ni]);
     };
-    float mean[2], rstd[2];
+    float nmr[2], rstd[2];             // LayerNorm of the current rows: u = fma(v, rstd, nmr)
     RowPipe rp;                        // residual rows, later rotary rows, of this lane
     int pos[2] = {mc[0] % L, mc[1] % L};
     Consts nxt;
@@ -595,7 +606,7 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     auto fc_epilogue = [&](float eps, int stamp) {
         lds_barrier();                 // every wave is out of the GEMM: the activation block may be overwritten
         CH_T(stamp);
-        row_stats(acc, scr, wave, lane, eps, mean, rstd);
+        row_stats(acc, scr, wave, lane, eps, nmr, rstd);
         CH_T(stamp + 1);
         // fresh copies: the two inlined instances of this epilogue must not share (and keep alive) their addresses
         const int hh = fresh_v(h), wv = fresh_s(wave);
@@ -612,7 +623,7 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
                 f32x4_t o;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    float v = (acc[mi][ni][4 * gq + t] - mean[mi]) * rstd[mi] * g4[t] + b4[t];
+                    float v = fmaf(fmaf(acc[mi][ni][4 * gq + t], rstd[mi], nmr[mi]), g4[t], b4[t]);
                     v = (sc[t] + 1.0f) * v + sh[t];
                     v = x4[t] + v;
                     acc[mi][ni][4 * gq + t] = v;
@@ -650,17 +661,17 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
             nxt = fetch_consts(fcb_film, v);
         }
         rp_start(rp, a.rope, pos, a.rope_rows, wave, h);
-        row_stats(acc, scr + 1024, wave, lane, a.n2_eps, mean, rstd);
+        row_stats(acc, scr + 1024, wave, lane, a.n2_eps, nmr, rstd);
         CH_T(4);
         // norm2 + rotary (model/model.py:332,387) -> LDS -> Q = rot W_q^T / 8 (model/model.py:78,97)
-        norm_to_lds<true>(acc, mean, rstd, vecp(2), vecp(3), rp, abuf, wave, lane, nullptr);
+        norm_to_lds<true>(acc, nmr, rstd, vecp(2), vecp(3), rp, abuf, wave, lane, nullptr);
         lds_barrier();
         CH_T(34);
         if (FULL) store_consts(nxt);   // the cross-attention fc block's constants: read two barriers from here
         clear();
         if (!FULL) {
             phase_n512_rolled(acc, abuf, 32, ws, lane);
-            store_heads(acc, a.q_out, a.scale_q, L, a.Lp, a.H, m0, M, wave, lane, smem);
+            store_heads<true>(acc, a.q_out, a.scale_q, L, a.Lp, a.H, m0, M, wave, lane, smem);
             return;
         }
         phase_n512<32>(acc, abuf, ws, lane);
@@ -685,14 +696,14 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     CH_T(37);
     fc_epilogue(a.ln_eps, 42);
     CH_T(38);
-    row_stats(acc, scr + 1024, wave, lane, a.n2_eps, mean, rstd);
+    row_stats(acc, scr + 1024, wave, lane, a.n2_eps, nmr, rstd);
     CH_T(39);
     // ================= feed-forward (model/model.py:338-339,399-401): norm3 -> LDS
     {
         const float* const v[6] = {a.b1, a.b1 + 512, a.b2, a.n4_g, a.n4_b, nullptr};
         nxt = fetch_consts(a.film3, v);
     }
-    norm_to_lds<false>(acc, mean, rstd, vecp(2), vecp(3), rp, abuf, wave, lane, nullptr);
+    norm_to_lds<false>(acc, nmr, rstd, vecp(2), vecp(3), rp, abuf, wave, lane, nullptr);
     lds_barrier();                     // nobody reads the fc constants any more
     store_consts(nxt);
     lds_barrier();                     // ... and everybody sees the feed-forward constants
@@ -764,9 +775,9 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
         nxt = fetch_consts(nullptr, v);
     }
     lds_barrier();                     // every wave is out of the last linear2 chunk (and of its constants' first use)
-    row_stats(acc, scr, wave, lane, a.n4_eps, mean, rstd);
+    row_stats(acc, scr, wave, lane, a.n4_eps, nmr, rstd);
     CH_T(23);
-    norm_to_lds<false>(acc, mean, rstd, vecp(3), vecp(4), rp, abuf, wave, lane, nullptr);
+    norm_to_lds<false>(acc, nmr, rstd, vecp(3), vecp(4), rp, abuf, wave, lane, nullptr);
     lds_barrier();
     store_consts(nxt);                 // b3, norm1': read after the barrier that follows linear3
     // ================= x' = linear3(norm4(x)) + b3, no residual (model/model.py:344)
@@ -807,24 +818,24 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     // ================= next layer: norm1 + rotary -> Q, K ; norm1 -> V (model/model.py:326,374-383,78-80)
     CH_T(26);
     rp_start(rp, a.rope, pos, a.rope_rows, wave, h);
-    row_stats(acc, scr, wave, lane, a.nn_eps, mean, rstd);
+    row_stats(acc, scr, wave, lane, a.nn_eps, nmr, rstd);
     CH_T(27);
-    norm_to_lds<true>(acc, mean, rstd, vecp(1), vecp(2), rp, abuf, wave, lane, smem + CH_ABUF2);
+    norm_to_lds<true>(acc, nmr, rstd, vecp(1), vecp(2), rp, abuf, wave, lane, smem + CH_ABUF2);
     lds_barrier();
     CH_T(28);
     clear();
     phase_n512<32, false, CH_QKV_R>(acc, abuf, ws, lane);
     CH_T(29);
-    store_heads(acc, a.q_out, a.scale_q, L, a.Lp, a.H, m0, M, wave, lane, smem);
+    store_heads<true>(acc, a.q_out, a.scale_q, L, a.Lp, a.H, m0, M, wave, lane, smem);
     clear();
     phase_n512<32, false, CH_QKV_R>(acc, abuf, ws, lane);
     CH_T(30);
-    store_heads(acc, a.k_out, 1.0f, L, a.Lp, a.H, m0, M, wave, lane, smem);
+    store_heads<false>(acc, a.k_out, 1.0f, L, a.Lp, a.H, m0, M, wave, lane, smem);
     CH_T(31);
     clear();
     phase_n512<32, true, CH_QKV_R>(acc, smem + CH_ABUF2, ws, lane);
     CH_T(32);
-    store_heads(acc, a.v_out, 1.0f, L, a.Lp, a.H, m0, M, wave, lane, smem);
+    store_heads<false>(acc, a.v_out, 1.0f, L, a.Lp, a.H, m0, M, wave, lane, smem);
     CH_T(33);
     CH_TC(61);
 }

@@ -106,8 +106,8 @@ DEVINL float gelu_erf(float x) {
 }
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 DEVINL f32x2_t gelu_erf2(f32x2_t x) {
-    f32x2_t z = {fabsf(x[0]), fabsf(x[1])};
-    z = z * 0.70710678118654752440f;
+    const f32x2_t ax = {fabsf(x[0]), fabsf(x[1])};
+    const f32x2_t z = ax * 0.70710678118654752440f;
     f32x2_t p = __builtin_elementwise_fma((f32x2_t)(0.0000430638f), z, (f32x2_t)(0.0002765672f));
     p = __builtin_elementwise_fma(p, z, (f32x2_t)(0.0001520143f));
     p = __builtin_elementwise_fma(p, z, (f32x2_t)(0.0092705272f));
@@ -116,9 +116,9 @@ DEVINL f32x2_t gelu_erf2(f32x2_t x) {
     p = __builtin_elementwise_fma(p, z, (f32x2_t)(1.0f));
     p = p * p; p = p * p; p = p * p; p = p * p;
     const f32x2_t r = {__builtin_amdgcn_rcpf(p[0]), __builtin_amdgcn_rcpf(p[1])};
-    const f32x2_t hr = (x * 0.5f) * r;
-    f32x2_t y = {fmaxf(x[0], 0.0f) - fabsf(hr[0]), fmaxf(x[1], 0.0f) - fabsf(hr[1])};
-    return y;
+    // max(x, 0) - |0.5 x r| = 0.5 (x + |x|) - 0.5 |x| r, all in packed ops (r > 0)
+    const f32x2_t ha = ax * 0.5f;
+    return __builtin_elementwise_fma(-ha, r, __builtin_elementwise_fma(x, (f32x2_t)(0.5f), ha));
 }
 DEVINL float softplus_t(float x) { return x > 20.0f ? x : log1pf(expf(x)); }  // torch threshold 20
 DEVINL float mish_f(float x) { return x * tanhf(softplus_t(x)); }
