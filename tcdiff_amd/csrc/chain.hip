@@ -369,19 +369,23 @@ DEVINL void store_heads(const f32x16_t (&acc)[2][2], void* base, float scale, in
             }
         // the LDS queue of a wave is in order: its reads below see its writes above
         int m = m0 + 32 * mi + row0;
-        int seq = m / L, tok = m - seq * L;
+        const int seq = m / L;
+        int tok = m - seq * L;
+        // destination of (sequence, head = wave, token, chunk): +8 tokens = +1 KB; past the end of a sequence the next
+        // one starts (H * Lp - L) rows further
+        uint16_t* dst = reinterpret_cast<uint16_t*>(base) + (((long)seq * H + wave) * Lp + tok) * 64 + ch * 8;
+        const long wrap = ((long)H * Lp - L) * 64;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int row = row0 + 8 * k;
             const u32x4 v = *reinterpret_cast<const u32x4*>(stg + row * 128 + ((ch ^ (row & 7)) << 4));
-            if (m < M)
-                *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(base) + (((long)seq * H + wave) * Lp + tok) * 64 +
-                                          ch * 8) = v;
+            if (m < M) *reinterpret_cast<u32x4*>(dst) = v;
             m += 8;
             tok += 8;
+            dst += 8 * 64;
             if (tok >= L) {
                 tok -= L;
-                ++seq;
+                dst += wrap;
             }
         }
     }
@@ -460,21 +464,30 @@ DEVINL void cross_attention(const f32x16_t (&qacc)[2][2], const tcdiff_chain_arg
                 for (int q = 1; q < 16; ++q) mx = fmaxf(mx, s[q]);
                 mx = fmaxf(mx, other_half(mx)) * LOG2E;
                 const float m_new = fmaxf(m_run, mx);
-                float rs = 0.0f;
+                // x = s log2(e) - m and the row sum as float2 ops (v_pk_fma_f32 / v_pk_add_f32); exp2 stays scalar
+                f32x2_t rs2 = {0.0f, 0.0f};
+                const f32x2_t l2 = {LOG2E, LOG2E}, nm = {-m_new, -m_new};
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const float p = __builtin_amdgcn_exp2f(fmaf(s[q], LOG2E, -m_new));
-                    s[q] = p;
-                    rs += p;
+                for (int q = 0; q < 16; q += 2) {
+                    const f32x2_t x = __builtin_elementwise_fma(f32x2_t{s[q], s[q + 1]}, l2, nm);
+                    const f32x2_t pp = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+                    s[q] = pp[0];
+                    s[q + 1] = pp[1];
+                    rs2 += pp;
                 }
+                float rs = rs2[0] + rs2[1];
                 rs += other_half(rs);
-                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // first tile: exp2(-inf) = 0, o is 0
-                l_run = l_run * alpha + rs;
-                m_run = m_new;
+                // the running maximum moves in the first tile or two; afterwards the whole wave skips the rescale
+                if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {
+                    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // first tile: exp2(-inf) = 0, o is 0
+                    l_run *= alpha;
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt)
+                    for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) o[dt][q] *= alpha;
+                        for (int q = 0; q < 16; ++q) o[dt][q] *= alpha;
+                    m_run = m_new;
+                }
+                l_run += rs;
 #pragma unroll
                 for (int sp = 0; sp < 2; ++sp) {
                     u32x4 pf;
