@@ -11,6 +11,9 @@
 //   chain B : O_cross --fc--> LN, FiLM, +x --> x (HBM) --norm3--> [LDS] --linear1, GELU--> [LDS, 256-column chunks]
 //             --linear2--> FiLM, +x --norm4--> [LDS] --linear3--> x' (fp32, HBM) --norm1', rotary--> [LDS]
 //             --w_qs / w_ks--> Q, K images ; norm1' --> [LDS] --w_vs--> V image        (last layer: stops after linear3)
+//   FULL    : chain A, then the cross-attention itself (head w on wave w; K / V from fragment-ordered cache images, the
+//             Q^T accumulator tile is the B operand of the score MFMA), then chain B: ONE launch per decoder layer.
+//             This is the production path; A and B alone are the reference it is tested against.
 //
 // Only the weights stream.  Structure:
 //   * 8 waves, wave w owns output columns [64 w, 64 w + 64) of every 512-wide GEMM (= head w of Q / K / V) for all 64
@@ -21,11 +24,14 @@
 //     consumption order, in 2-KB stages that are already the MFMA fragment image ([n-tile][half][row][16 B]).  A wave
 //     consumes only fragments of its OWN columns, so weights never touch LDS: a stage is two coalesced 1-KB global
 //     loads straight into registers, 8 stages (16 KB per wave, 128 KB per CU) are in flight in a register ring whose
-//     slots are compile-time indices, and the GEMM loops have NO workgroup barrier and no hand-written waits.  The
-//     stream runs ahead across GEMM and epilogue boundaries (the next GEMM's first stages land during the LayerNorm in
-//     front of it).  (First version: LDS-DMA into per-wave LDS rings of 4 stages: 36 GB/s per CU, bound by the 48 KB
-//     the LDS budget left in flight against ~1.1 us of loaded L2 latency.)
+//     slots are compile-time indices, and the GEMM phases (fully unrolled) have NO workgroup barrier and no
+//     hand-written waits.  The stream runs ahead across GEMM and epilogue boundaries (the next GEMM's first stages land
+//     during the LayerNorm in front of it).
 //   * activations live in LDS as [k-tile][64 rows][128 B] with the XOR chunk swizzle of common.h (tile_off).
+//   * every global access of an epilogue is a contiguous kilobyte per wave instruction: the fp32 residual stream and the
+//     rotary table are column-blocked (RowPipe below), head-major images leave through wave-private LDS staging
+//     (store_heads).  With the accumulator layout the natural "my 16 bytes of my row" access is 32 separate line
+//     requests per instruction; those passes cost 30 us of a 130-us launch before.
 // Barriers: one pair per LayerNorm (statistics exchange) and one per activation hand-off.
 #include "common.h"
 #include "tcdiff_hip.h"
