@@ -95,6 +95,21 @@ def c2():
     return sd, cond, xT
 
 
+def test_c2_full_loop_first_100_steps(golden_dir, c2):
+    """The benchmark-length golden (tests/golden/make_golden_c2_full.py: the real reference's p_sample_loop, 1 clip,
+    3 x 150, 1000 steps): the oracle is walked through the first 100 steps here (the GPU suite runs all 1000)."""
+    sd, cond, xT = c2
+    ref = g(golden_dir, "c2_p_sample_loop_full")
+    tab = O.make_tables(1000, "cosine")
+    eps = O.batch_step_noise([0], 450)
+    x = xT[:1].clone()
+    for i in reversed(range(900, 1000)):
+        x, _ = O.p_sample(sd, tab, x, cond[:1], i, 1000, 2, eps(i, x.shape))
+        if i == 999:
+            assert maxabs(x, ref["after_step_999"]) < 1e-4
+    assert maxabs(x, ref["after_step_900"]) < 1e-4
+
+
 def test_c2_forward(golden_dir, c2):
     sd, cond, xT = c2
     ref = g(golden_dir, "c2_forward")
