@@ -181,3 +181,20 @@ def test_c1_long_inpaint_loop(golden_dir):
     x = O.long_inpaint_loop(sd, (2, 120, 151), cond, xT, n_timestep=100, step_noise=O.batch_step_noise([0, 1], 120))
     assert maxabs(x, ref["final"]) < 1e-4
 
+
+
+def test_c4_guided_forward_and_steps(golden_dir):
+    """BASELINE config 4 (5 x 300, L = 1500): oracle against the real reference (tests/golden/make_golden_c4.py)."""
+    dn, S, T = 5, 300, 1000
+    ref = g(golden_dir, "c4_steps")
+    sd = O.synth_state_dict(dn=dn, seq_len=S)
+    cond = torch.stack([O.synth_cond(0, S)])
+    xT = torch.stack([O.synth_xT(0, dn * S)])
+    tt = torch.full((1,), 500, dtype=torch.long)
+    assert maxabs(O.guided_forward(sd, xT, cond, tt, 2), ref["guided_w2_t500"]) < 5e-5
+    tab = O.make_tables(T)
+    eps = O.batch_step_noise([0], dn * S)
+    x = xT.clone()
+    for i in (999, 998):
+        x, _ = O.p_sample(sd, tab, x, cond, i, T, 2, eps(i, x.shape))
+        assert maxabs(x, ref[f"after_step_{i}"]) < 1e-4

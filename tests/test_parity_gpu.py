@@ -310,6 +310,27 @@ def test_c4_long_sequence_forward_and_steps_vs_oracle():
     assert e < 5e-4
 
 
+@pytest.mark.parametrize("compute,bound", [("f32", 5e-4), ("bf16", 5e-2)])
+def test_c4_vs_reference_golden(golden_dir, compute, bound):
+    """BASELINE config 4 against the REAL reference (tests/golden/make_golden_c4.py): a guided evaluation at t = 500 and
+    the first two DDPM steps, 5 dancers x 300 frames."""
+    from tcdiff_amd import _lib as L
+    dn, S, T = 5, 300, 1000
+    ref = gold(golden_dir, "c4_steps")
+    _, model, diff = build(dn, S, T, compute=compute)
+    Lq = dn * S
+    cond = torch.stack([O.synth_cond(0, S)])
+    xT = torch.stack([O.synth_xT(0, Lq)])
+    tt = torch.full((1,), 500, dtype=torch.long)
+    e0 = maxabs(model.guided_forward(xT.to(DEV), cond.to(DEV), tt.to(DEV), 2), ref["guided_w2_t500"])
+    chain = []
+    diff._run(L.SAMPLER_DDPM, (1, Lq, 151), cond, xT.to(DEV), [999, 998], diff._ddpm_params([999, 998]),
+              step_noise=dev_noise([0], Lq), collect=chain)
+    e1, e2 = maxabs(chain[-2], ref["after_step_999"]), maxabs(chain[-1], ref["after_step_998"])
+    print(f"C4 ({compute}) vs reference golden: guided t=500 {e0:.2e}, after step 999 {e1:.2e}, after step 998 {e2:.2e}")
+    assert max(e0, e1, e2) < bound
+
+
 def test_c4_bf16_runs_and_is_close():
     dn, S = 5, 300
     sd, model, diff = build(dn, S, 1000, compute="bf16")
