@@ -419,7 +419,7 @@ __global__ __launch_bounds__(512) void attention_res_kernel(const char* __restri
     }  // key chunks
     // ---- O[q][d] = O^T[d][q] / l.  A lane holds 8 bytes of a row at a time; stored like that an instruction makes 32
     // sixteen-byte write requests.  Each 32-row group goes through 4 KB of wave-private LDS behind the K / V images
-    // (XOR-swizzled by row & 7; a wave's LDS queue is in order, no barrier) and leaves as 16 bytes per lane, 8 lanes per
+    // (XOR-swizzled by (row >> 1) & 7: rows alternate between the two 128-byte halves of the 64 banks; a wave's LDS queue is in order, no barrier) and leaves as 16 bytes per lane, 8 lanes per
     // 128-byte row: 8 full lines per store instruction.
     char* stg = smem + 2 * ntm * 8192 + wave * 4096;
     const int srow0 = lane >> 3, sch = lane & 7;
@@ -434,12 +434,12 @@ __global__ __launch_bounds__(512) void attention_res_kernel(const char* __restri
                 uint2 pk;
                 pk.x = pack_bf2(o[g][dt][4 * q4 + 0] * inv, o[g][dt][4 * q4 + 1] * inv);
                 pk.y = pack_bf2(o[g][dt][4 * q4 + 2] * inv, o[g][dt][4 * q4 + 3] * inv);
-                *reinterpret_cast<uint2*>(stg + r * 128 + (((4 * dt + q4) ^ (r & 7)) << 4) + 8 * h) = pk;
+                *reinterpret_cast<uint2*>(stg + r * 128 + (((4 * dt + q4) ^ ((r >> 1) & 7)) << 4) + 8 * h) = pk;
             }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int row = srow0 + 8 * k;
-            const u32x4 v = *reinterpret_cast<const u32x4*>(stg + row * 128 + ((sch ^ (row & 7)) << 4));
+            const u32x4 v = *reinterpret_cast<const u32x4*>(stg + row * 128 + ((sch ^ ((row >> 1) & 7)) << 4));
             const int qg = qbase + g * 32 + row;
 #ifdef ATT_ABLATE_OSTORE
             if (v.x == 0x12345678u)

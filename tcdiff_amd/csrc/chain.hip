@@ -344,7 +344,7 @@ DEVINL void norm_to_lds(const f32x16_t (&acc)[2][2], const float (&nmr)[2], cons
 // lane 8 bytes of a row at a time; written like that every store instruction makes 32 sixteen-byte write requests, and
 // the three scatters of the next layer's Q, K, V cost 13 us of a 130-us launch.  Instead each 32-row half of the wave's
 // [64 rows][64 columns] tile goes through 4 KB of the (by now idle) constants area -- wave-private, XOR-swizzled by
-// row & 7, no barrier -- and leaves as 16 bytes per lane, 8 lanes per 128-byte row: 8 full lines per instruction.
+// (row >> 1) & 7 (the 64 banks hold two 128-byte rows), no barrier -- and leaves as 16 bytes per lane, 8 lanes per 128-byte row: 8 full lines per instruction.
 DEVINL char* stage_area(char* smem, int wave) { return smem + (wave < 7 ? wave * 4096 : CH_STG7); }
 template <bool SCALE>   // Q carries 1 / sqrt(d_k); K and V are stored as they are
 DEVINL void store_heads(const f32x16_t (&acc)[2][2], void* base, float scale, int L, int Lp, int H, int m0, int M,
@@ -371,7 +371,7 @@ DEVINL void store_heads(const f32x16_t (&acc)[2][2], void* base, float scale, in
                     pk.x = pack_bf2(acc[mi][ni][4 * gq + 0], acc[mi][ni][4 * gq + 1]);
                     pk.y = pack_bf2(acc[mi][ni][4 * gq + 2], acc[mi][ni][4 * gq + 3]);
                 }
-                *reinterpret_cast<uint2*>(stg + r * 128 + (((4 * ni + gq) ^ (r & 7)) << 4) + 8 * h) = pk;
+                *reinterpret_cast<uint2*>(stg + r * 128 + (((4 * ni + gq) ^ ((r >> 1) & 7)) << 4) + 8 * h) = pk;
             }
         // the LDS queue of a wave is in order: its reads below see its writes above
         int m = m0 + 32 * mi + row0;
@@ -384,7 +384,7 @@ DEVINL void store_heads(const f32x16_t (&acc)[2][2], void* base, float scale, in
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int row = row0 + 8 * k;
-            const u32x4 v = *reinterpret_cast<const u32x4*>(stg + row * 128 + ((ch ^ (row & 7)) << 4));
+            const u32x4 v = *reinterpret_cast<const u32x4*>(stg + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
             if (m < M) *reinterpret_cast<u32x4*>(dst) = v;
             m += 8;
             tok += 8;
