@@ -61,15 +61,18 @@ typedef const float* fptr;
 // the ring of CH_D stages in flight is a register array indexed at compile time (every loop over it is unrolled).
 // The compiler counts vmcnt for these loads itself.  Past the end of the stream the last stage is re-read (never used).
 struct WStream {
-    const u32x4* p;    // stream base + lane
+    __amdgpu_buffer_rsrc_t rsrc;   // this wave's stream as a raw buffer: a stage address is SGPR descriptor + SGPR stage
+    unsigned voff;                 // offset + this one VGPR (lane * 16); as 64-bit global addresses every stage load
+                                   // cost a v_lshl_add_u64 and a VGPR pair (760 VALU instructions per launch and wave)
     unsigned pos;      // stages consumed so far (wave-uniform)
     unsigned last;     // index of the last stage
     u32x4 a[CH_R], b[CH_R];   // slots 0 .. CH_D-1 live across phases, the rest only inside a GEMM phase
 };
 DEVINL void ws_load(WStream& ws, int slot, unsigned stage) {
     const unsigned st = stage < ws.last ? stage : ws.last;
-    ws.a[slot] = ws.p[st * 128u];
-    ws.b[slot] = ws.p[st * 128u + 64u];
+    const unsigned so = st * CH_STAGE;                       // scalar
+    ws.a[slot] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ws.rsrc, ws.voff, so, 0));
+    ws.b[slot] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ws.rsrc, ws.voff + 1024u, so, 0));
 }
 #define CH_MMA(acc, w, a) MmaBF16::mma(acc, w, a)
 #define CH_FRAG(at, row, ch) lds_frag(at, row, ch)
@@ -593,7 +596,10 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
         stage_glds<64, 8>(abuf + kt * 8192, reinterpret_cast<const char*>(a.A) + kt * TC_ROWB, 1024, m0, M, a.a_mod, wave,
                           lane);
     WStream ws;
-    ws.p = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(a.wstream) + (long)wave * a.n_stages * CH_STAGE) + lane;
+    ws.rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(a.wstream)) + (long)wave * a.n_stages * CH_STAGE, 0,
+        a.n_stages * CH_STAGE, 0x00020000);   // raw buffer (stride 0), bounds = the wave's stream, 32-bit data format
+    ws.voff = (unsigned)lane * 16u;
     ws.pos = 0;
     ws.last = (unsigned)a.n_stages - 1;
 #pragma unroll
