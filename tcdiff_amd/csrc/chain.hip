@@ -277,12 +277,14 @@ DEVINL f32x4_t lds4(const char* base, int float_index) {
 // contiguous kilobyte.  The residual stream between chain launches and the rotary table handed to them are
 // column-blocked; only layer 0's input (written by gemm_rowln) is row-major (`xres_rowmajor`).
 struct RowPipe {
-    const float* p[2];     // this lane's first 4 floats of its row in column group 8 wave
-    long its;              // floats between column groups (8 row-major, 8 rows column-blocked)
-    f32x4_t q[4][2];       // [group & 3][row tile]
+    __amdgpu_buffer_rsrc_t rsrc;   // the matrix as a raw buffer: address = SGPR descriptor + SGPR (column group) + VGPR (row)
+    unsigned voff[2];              // byte offset of this lane's 16 bytes of its row inside a column group
+    unsigned soff, its;            // byte offset of column group 8 wave, bytes between column groups (wave-uniform)
+    f32x4_t q[4][2];               // [group & 3][row tile]
 };
-DEVINL long cb_off(int wave, int it, long rows, int row, int h) {   // column-blocked offset of (row, column group 8 wave + it)
-    return ((long)(wave * 8 + it) * rows + row) * 8 + 4 * h;
+DEVINL __amdgpu_buffer_rsrc_t f32_buffer(const float* base, long n_floats) {
+    const long bytes = n_floats * 4;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes < 0xFFFFFFFFl ? (int)bytes : -1, 0x00020000);
 }
 DEVINL void rp_issue(RowPipe& rp, int it) {
 #ifdef CH_ABLATE_XLOAD
@@ -290,17 +292,26 @@ DEVINL void rp_issue(RowPipe& rp, int it) {
     for (int mi = 0; mi < 2; ++mi) rp.q[it & 3][mi] = f32x4_t{0.5f, 0.25f, 0.5f, 0.25f};
 #else
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) rp.q[it & 3][mi] = ld4(rp.p[mi] + it * rp.its);
+    for (int mi = 0; mi < 2; ++mi)
+        rp.q[it & 3][mi] = __builtin_bit_cast(
+            f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rp.rsrc, rp.voff[mi], rp.soff + (unsigned)it * rp.its, 0));
 #endif
 }
-// rows: row count of the column-blocked matrix, or 0 for a row-major one
-DEVINL void rp_start(RowPipe& rp, const float* base, const int (&row)[2], long rows, int wave, int h) {
-    rp.its = rows > 0 ? rows * 8 : 8;
+// rows: row count of the column-blocked matrix, or 0 for a row-major one (`total_rows` rows of 512 floats)
+DEVINL void rp_start(RowPipe& rp, const float* base, const int (&row)[2], long rows, long total_rows, int wave, int h) {
+    rp.rsrc = f32_buffer(base, total_rows * 512);
+    rp.its = rows > 0 ? (unsigned)rows * 32u : 32u;
+    rp.soff = rows > 0 ? (unsigned)wave * 8u * rp.its : (unsigned)wave * 256u;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
-        rp.p[mi] = rows > 0 ? base + cb_off(wave, 0, rows, row[mi], h) : base + (long)row[mi] * 512 + 64 * wave + 4 * h;
+        rp.voff[mi] = rows > 0 ? (unsigned)row[mi] * 32u + 16u * h : (unsigned)row[mi] * 2048u + 16u * h;
 #pragma unroll
     for (int it = 0; it < 4; ++it) rp_issue(rp, it);
+}
+// store this lane's 16 bytes of column group 8 wave + it of a column-blocked matrix of `rows` rows
+DEVINL void cb_store(__amdgpu_buffer_rsrc_t rsrc, long rows, int wave, int it, int row, int h, f32x4_t v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, (unsigned)row * 32u + 16u * h,
+                                           (unsigned)(wave * 8 + it) * ((unsigned)rows * 32u), 0);
 }
 
 // u = LayerNorm(acc) (optionally rotated) -> bf16 -> activation block in LDS (k = column); g, b: LDS vectors;
@@ -623,6 +634,7 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     };
     float nmr[2], rstd[2];             // LayerNorm of the current rows: u = fma(v, rstd, nmr)
     RowPipe rp;                        // residual rows, later rotary rows, of this lane
+    const __amdgpu_buffer_rsrc_t xo = f32_buffer(a.xout, (long)M * 512);   // the residual stream out
     int pos[2] = {mc[0] % L, mc[1] % L};
     Consts nxt;
 
@@ -656,7 +668,7 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
                 }
                 // unguarded: rows past M rewrite row M - 1 with the SAME values (same inputs; every load of this column
                 // group, in place or not, was issued before this store)
-                *reinterpret_cast<f32x4_t*>(a.xout + cb_off(wv, it, M, mcl[mi], hh)) = o;
+                cb_store(xo, M, wv, it, mcl[mi], hh, o);
             }
             if (it + 4 < 8) rp_issue(rp, it + 4);
             // one column group at a time: without a fence hipcc hoists the loads of ALL eight groups (row pipeline
@@ -677,7 +689,7 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
             int rr[2];
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) rr[mi] = a.xres_mod > 0 ? mc[mi] % a.xres_mod : mc[mi];
-            rp_start(rp, a.xres, rr, a.xres_rowmajor ? 0 : (a.xres_mod > 0 ? a.xres_mod : M), wave, h);   // in flight during the statistics exchange
+            rp_start(rp, a.xres, rr, a.xres_rowmajor ? 0 : (a.xres_mod > 0 ? a.xres_mod : M), a.xres_mod > 0 ? a.xres_mod : M, wave, h);   // in flight during the statistics exchange
         }
         fc_epilogue(a.ln_eps, 40);
         CH_T(3);
@@ -685,7 +697,7 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
             const float* const v[6] = {fcb_g, fcb_b, n3_g, n3_b, nullptr, nullptr};
             nxt = fetch_consts(fcb_film, v);
         }
-        rp_start(rp, a.rope, pos, a.rope_rows, wave, h);
+        rp_start(rp, a.rope, pos, a.rope_rows, a.rope_rows, wave, h);
         row_stats(acc, scr + 1024, wave, lane, a.n2_eps, nmr, rstd);
         CH_T(4);
         // norm2 + rotary (model/model.py:332,387) -> LDS -> Q = rot W_q^T / 8 (model/model.py:78,97)
@@ -711,12 +723,12 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     clear();
     phase_n512<32>(acc, abuf, ws, lane);
     if (FULL) {
-        rp_start(rp, a.xout, mc, M, wave, h);    // the x this lane stored in the first fc epilogue
+        rp_start(rp, a.xout, mc, M, M, wave, h);    // the x this lane stored in the first fc epilogue
     } else {
         int rr[2];
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) rr[mi] = a.xres_mod > 0 ? mc[mi] % a.xres_mod : mc[mi];
-        rp_start(rp, a.xres, rr, a.xres_rowmajor ? 0 : (a.xres_mod > 0 ? a.xres_mod : M), wave, h);
+        rp_start(rp, a.xres, rr, a.xres_rowmajor ? 0 : (a.xres_mod > 0 ? a.xres_mod : M), a.xres_mod > 0 ? a.xres_mod : M, wave, h);
     }
     CH_T(37);
     fc_epilogue(a.ln_eps, 42);
@@ -770,7 +782,7 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
         CH_T(9 + 4 * c);
     }
     // linear2 bias, FiLM, residual (the x this lane stored above), norm4 -> LDS
-    rp_start(rp, a.xout, mc, M, wave, h);
+    rp_start(rp, a.xout, mc, M, M, wave, h);
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
         const int ni = it >> 2, gq = it & 3;
@@ -834,7 +846,7 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
                     pk.y = pack_bf2(o[2], o[3]);
                     *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.h_out) + (long)mc[mi] * 512 + n) = pk;
                 } else {
-                    *reinterpret_cast<f32x4_t*>(a.xout + cb_off(wave, 4 * ni + gq, M, mc[mi], h)) = o;
+                    cb_store(xo, M, wave, 4 * ni + gq, mc[mi], h, o);
                 }
             }
             CH_FENCE();
@@ -842,7 +854,7 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     if (LAST) return;
     // ================= next layer: norm1 + rotary -> Q, K ; norm1 -> V (model/model.py:326,374-383,78-80)
     CH_T(26);
-    rp_start(rp, a.rope, pos, a.rope_rows, wave, h);
+    rp_start(rp, a.rope, pos, a.rope_rows, a.rope_rows, wave, h);
     row_stats(acc, scr, wave, lane, a.nn_eps, nmr, rstd);
     CH_T(27);
     norm_to_lds<true>(acc, nmr, rstd, vecp(1), vecp(2), rp, abuf, wave, lane, smem + CH_ABUF2);
