@@ -60,6 +60,10 @@ class DenoiserEngine:
         # TCDIFF_CHAIN=2 (default): cross-attention inside the chain too: per layer self-attention + ONE chain launch
         self.use_full = self.use_chain and os.environ.get("TCDIFF_CHAIN", "2") == "2"
         self.nkt = (self.S + 2 + 31) // 32          # 32-key tiles of the cross-attention memory
+        # throughput mode: input_projection folded into the first fusion linear (one GEMM, K = dn * nfeats padded);
+        # the f32 parity mode keeps the reference's two GEMMs (and its summation order)
+        self.fold_in = self.dt == L.DT_BF16 and os.environ.get("TCDIFF_FOLD_IN", "1") != "0"
+        self.kin = K.round_up(self.dn * self.nf, 64)
         self.reset_graphs()
 
     def reset_graphs(self):
@@ -144,6 +148,16 @@ class DenoiserEngine:
         for i, j in ((0, "f1"), (2, "f2"), (4, "f3")):
             w[j + ".w"] = p(g(f"relative_projection_layer.{i}.weight"))
             w[j + ".b"] = f(g(f"relative_projection_layer.{i}.bias"))
+        if self.fold_in:
+            # input_projection and the first fusion linear are two linear maps with nothing in between
+            # (model/model.py:560-561): W3 [x_0 W_in^T + b | x_1 .. | ..] + b3 = x_frame [W3_d W_in]_d^T + (sum_d W3_d b_in + b3)
+            # with x_frame the dn * nfeats motion values of one frame, which are contiguous in x.  One GEMM with
+            # K = dn * nfeats (453 -> 512) replaces K = 192 + K = 512 dn; products in fp32, rounded to the model dtype once.
+            W3 = g("relative_projection_layer.0.weight").to(self.dev, torch.float32).reshape(1024, self.dn, 512)
+            Win = g("input_projection.weight").to(self.dev, torch.float32)             # [512, nfeats]
+            bin_ = g("input_projection.bias").to(self.dev, torch.float32)
+            w["f1in.w"] = p(torch.einsum("odk,kn->odn", W3, Win).reshape(1024, self.dn * self.nf), self.kin)
+            w["f1in.b"] = (torch.einsum("odk,k->o", W3, bin_) + w["f1.b"]).contiguous()
         w["t1.w"], w["t1.b"] = p(g("time_mlp.1.weight")), f(g("time_mlp.1.bias"))
         w["tc.w"], w["tc.b"] = p(g("to_time_cond.0.weight")), f(g("to_time_cond.0.bias"))
         w["tt.w"], w["tt.b"] = p(g("to_time_tokens.0.weight")), f(g("to_time_tokens.0.bias"))
@@ -210,7 +224,7 @@ class DenoiserEngine:
         Lq, S, H, NL = self.Lseq, self.S, self.H, self.NL
         R = 2 * B * Lq
         b = {}
-        b["xin"] = z(B * Lq, 192)
+        b["xin"] = z(B * S, self.kin) if self.fold_in else z(B * Lq, 192)    # [frames, dn * nfeats] or [tokens, nfeats]
         b["xp"] = z(B * Lq, 512)
         b["f1"], b["f2"] = z(B * S, 1024), z(B * S, 1024)
         b["xs"] = z(B * Lq, 512, dtype=torch.float32)
@@ -343,6 +357,13 @@ class DenoiserEngine:
         K.gemm_tile(dt, b["film_in"], w["film.w"], n_rows_seq, nfilm, 512, bias=w["film.b"], mode=L.EPI_STORE_F32,
                     out=b["film"], ldc=nfilm)
 
+    def _xin_shape(self, token_rows: int):
+        """(rows, columns, padded pitch) of the model-dtype copy of x_t: one row per token, or -- with the input
+        projection folded into the first fusion linear -- one row per frame (dn tokens, contiguous in x)"""
+        if self.fold_in:
+            return token_rows // self.dn, self.dn * self.nf, self.kin
+        return token_rows, self.nf, 192
+
     def step_prologue(self, st: dict, n_rows_seq: int, x: torch.Tensor, rows: int):
         """One sampler step's prologue in a single launch (timestep lookup, FiLM input, time-token K/V rows, model
         dtype copy of x_t, step counter bump), then the FiLM generator GEMM.  Replaces step_begin +
@@ -352,7 +373,7 @@ class DenoiserEngine:
         K.step_prologue(dt, st["counter"], st["rows"], b["tidx"], self.t_base, b["hidden_all"], b["film_in"],
                         n_rows_seq, self.kv_tab, self.n_t, None if full else b["Kc"], None if full else b["Vc"],
                         b["Kf"] if full else None, b["Vf"] if full else None, self.NL, b["Kc"].shape[1], self.H,
-                        self.Lpc, self.nkt if full else 0, self.S, x, b["xin"], rows, self.nf, 192)
+                        self.Lpc, self.nkt if full else 0, self.S, x, b["xin"], *self._xin_shape(rows))
         nfilm = self.NL * NL_FILM * 1024
         K.gemm_tile(dt, b["film_in"], w["film.w"], n_rows_seq, nfilm, 512, bias=w["film.b"], mode=L.EPI_STORE_F32,
                     out=b["film"], ldc=nfilm)
@@ -373,9 +394,14 @@ class DenoiserEngine:
         rope = w["rope"]
         # input projection + fusion projection over per-frame concatenated dancers (model/model.py:560-561)
         if not x_ready:                      # the sampler's step_prologue already wrote b["xin"]
-            K.convert_pad(dt, x, b["xin"], Rs, self.nf, 192)
-        K.gemm_tile(dt, b["xin"], w["in.w"], Rs, 512, 192, bias=w["in.b"], out=b["xp"], ldc=512)
-        K.gemm_tile(dt, b["xp"], w["f1.w"], B * S, 1024, 512 * dn, bias=w["f1.b"], act=L.ACT_RELU, out=b["f1"], ldc=1024)
+            K.convert_pad(dt, x, b["xin"], *self._xin_shape(Rs))
+        if self.fold_in:
+            K.gemm_tile(dt, b["xin"], w["f1in.w"], B * S, 1024, self.kin, bias=w["f1in.b"], act=L.ACT_RELU, out=b["f1"],
+                        ldc=1024)
+        else:
+            K.gemm_tile(dt, b["xin"], w["in.w"], Rs, 512, 192, bias=w["in.b"], out=b["xp"], ldc=512)
+            K.gemm_tile(dt, b["xp"], w["f1.w"], B * S, 1024, 512 * dn, bias=w["f1.b"], act=L.ACT_RELU, out=b["f1"],
+                        ldc=1024)
         K.gemm_tile(dt, b["f1"], w["f2.w"], B * S, 1024, 1024, bias=w["f2.b"], act=L.ACT_RELU, out=b["f2"], ldc=1024)
         # last fusion linear, one group per dancer in ONE launch: group d writes token rows m*dn + d (de-interleave:
         # frame row m, dancer d -> token m*dn + d); fused with layer-0 norm1 + rotary
