@@ -210,7 +210,7 @@ typedef struct {
     const float* nn_b;
     void* k_out;
     void* v_out;
-    void* h_out;          /* TC_CHAIN_B_LAST: bf16 [M,512] */
+    void* h_out;          /* *_LAST modes: see out_ld */
     int film_ld;
     float ln_eps, n2_eps, n4_eps, nn_eps, scale_q;
     /* TC_CHAIN_FULL*: the cross-attention block */
@@ -226,6 +226,9 @@ typedef struct {
      * wave instruction touches are then one contiguous kilobyte instead of 32 separate 32-byte pieces */
     int xres_rowmajor;     /* 1: xres is a plain row-major [*,512] matrix */
     int rope_rows;         /* rows of the column-blocked rotary table (>= L) */
+    int out_ld;            /* *_LAST modes: 0 -> h_out = bf16 [M,512] rows of linear3; > 0 -> h_out = fp32 [M][out_ld], the
+                              first out_ld columns of linear3 (the caller folded final_layer into its weights and bias:
+                              model/model.py:344,623); out_ld % 4 == 0 */
 } tcdiff_chain_args;
 
 int tcdiff_chain(const tcdiff_chain_args* args, hipStream_t stream);

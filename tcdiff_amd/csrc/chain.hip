@@ -840,7 +840,12 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
                     acc[mi][ni][4 * gq + t] += b4[t];
                     o[t] = acc[mi][ni][4 * gq + t];
                 }
-                if (LAST) {   // the final projection reads bf16 rows (model/model.py:623)
+                if (LAST && a.out_ld > 0) {
+                    // linear3 carries the final projection folded into it (engine.py: W_final W_3, two linear maps
+                    // with nothing in between, model/model.py:344,623): columns [0, out_ld) ARE the network output
+                    if (n < a.out_ld)
+                        *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(a.h_out) + (long)mc[mi] * a.out_ld + n) = o;
+                } else if (LAST) {   // a separate final projection reads bf16 rows (model/model.py:623)
                     uint2 pk;
                     pk.x = pack_bf2(o[0], o[1]);
                     pk.y = pack_bf2(o[2], o[3]);
@@ -886,6 +891,7 @@ extern "C" int tcdiff_chain(const tcdiff_chain_args* a, hipStream_t stream) {
                      a->mode == TC_CHAIN_FULL ? 352 : a->mode == TC_CHAIN_FULL_LAST ? 256 : -1;
     if (want < 0 || a->n_stages != want) return TC_ERR_ARG;
     if (!a->ln_g || !a->ln_b || !a->film || a->film_ld % 4 || !a->xres || !a->xout || !a->n2_g || !a->n2_b) return TC_ERR_ARG;
+    if (a->out_ld < 0 || a->out_ld % 4 || a->out_ld > 512) return TC_ERR_ARG;
     if ((long)(a->a_mod > 0 ? a->a_mod : a->M) * 1024 >= (1L << 32)) return TC_ERR_ARG;
     const void* ptrs[] = {a->A, a->wstream, a->ln_g, a->ln_b, a->film, a->xres, a->xout, a->n2_g, a->n2_b, a->rope,
                           a->q_out, a->b1, a->b2, a->film3, a->n4_g, a->n4_b, a->b3, a->nn_g, a->nn_b, a->k_out,

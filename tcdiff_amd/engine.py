@@ -64,6 +64,8 @@ class DenoiserEngine:
         # the f32 parity mode keeps the reference's two GEMMs (and its summation order)
         self.fold_in = self.dt == L.DT_BF16 and os.environ.get("TCDIFF_FOLD_IN", "1") != "0"
         self.kin = K.round_up(self.dn * self.nf, 64)
+        # ... and final_layer folded into the last decoder layer's linear3 (the last chain launch writes the output)
+        self.fold_out = self.use_chain and os.environ.get("TCDIFF_FOLD_OUT", "1") != "0"
         self.reset_graphs()
 
     def reset_graphs(self):
@@ -128,7 +130,21 @@ class DenoiserEngine:
             parts = [self._stages_n512(w[p + "cfc.w"])]
             for c in range(4):
                 parts += [f1[c], f2[c]]
-            parts.append(self._stages_n512(w[p + "l3.w"]))
+            if l + 1 < self.NL or not self.fold_out:
+                parts.append(self._stages_n512(w[p + "l3.w"]))
+            else:
+                # the last layer's linear3 and final_layer are two linear maps with nothing in between
+                # (model/model.py:344,623): W_f (W_3 h + b_3) + b_f.  The chain's last GEMM takes W_f W_3 (151 of its 512
+                # output rows, the rest zero) and writes the network output itself; no separate final projection launch.
+                W3 = self.sd_f32(f"seqTransDecoder.stack.{l}.linear3.weight")
+                b3 = self.sd_f32(f"seqTransDecoder.stack.{l}.linear3.bias")
+                Wf, bf = self.sd_f32("final_layer.weight"), self.sd_f32("final_layer.bias")
+                Wo = torch.zeros(512, 512, device=self.dev, dtype=torch.float32)
+                Wo[:self.nf] = Wf @ W3
+                bo = torch.zeros(512, device=self.dev, dtype=torch.float32)
+                bo[:self.nf] = Wf @ b3 + bf
+                w[p + "l3out.b"] = bo.contiguous()
+                parts.append(self._stages_n512(Wo.to(self.T).contiguous()))
             if l + 1 < self.NL:
                 qkv = w[f"l{l + 1}.qkv.w"]
                 parts += [self._stages_n512(qkv[0:512]), self._stages_n512(qkv[512:1024]),
@@ -144,6 +160,7 @@ class DenoiserEngine:
         """Repack a reference-keyed state_dict (model/model.py:440-540 names) for the kernels."""
         w, f, p = {}, self._f32, self._pack
         g = lambda k: sd[k].detach()
+        self.sd_f32 = lambda k: sd[k].detach().to(self.dev, torch.float32)
         w["in.w"], w["in.b"] = p(g("input_projection.weight"), 192), f(g("input_projection.bias"))
         for i, j in ((0, "f1"), (2, "f2"), (4, "f3")):
             w[j + ".w"] = p(g(f"relative_projection_layer.{i}.weight"))
@@ -209,6 +226,7 @@ class DenoiserEngine:
         self.w = w
         if self.use_chain:
             self._build_chain_streams()
+        self.sd_f32 = None
         self.weights_version = version
         self.tables_key = None
         self.reset_graphs()
@@ -453,6 +471,8 @@ class DenoiserEngine:
             else:
                 K.gemm_rowln(dt, b["h"], w[p + "l3.w"], R, 512, bias=w[p + "l3.b"], Lseq=Lq,
                              flags=L.ROW_BIAS | L.ROW_STORE_H, hout=b["h"])
+        if self.fold_out:
+            return b["out"]      # written by the last chain launch (final_layer folded into its linear3)
         # final layer (model/model.py:623)
         K.gemm_tile(dt, b["h"], w["fin.w"], R, self.nf, 512, bias=w["fin.b"], mode=L.EPI_STORE_F32, out=b["out"], ldc=152)
         return b["out"]
@@ -474,10 +494,11 @@ class DenoiserEngine:
         last = l + 1 == NL
         nn = f"l{l + 1}.norm1." if not last else None
         tail = dict(b1=w[p + "ff1.b"], b2=w[p + "ff2.b"], film3=film0[:, (l * 3 + 2) * 1024:], n4_g=w[p + "norm4.g"],
-                    n4_b=w[p + "norm4.b"], n4_eps=1e-5, b3=w[p + "l3.b"],
+                    n4_b=w[p + "norm4.b"], n4_eps=1e-5, b3=w[p + "l3out.b"] if last and self.fold_out else w[p + "l3.b"],
                     nn_g=None if last else w[nn + "g"], nn_b=None if last else w[nn + "b"], nn_eps=1e-5,
                     q_out=None if last else b["Q"], k_out=None if last else b["K"], v_out=None if last else b["V"],
-                    h_out=b["h"] if last else None, scale_q=0.125, Lp=self.Lp, H=H)
+                    h_out=(b["out"] if self.fold_out else b["h"]) if last else None,
+                    out_ld=152 if last and self.fold_out else 0, scale_q=0.125, Lp=self.Lp, H=H)
         head = dict(a_mod=Rs if l == 0 else 0, ln_g=w[p + "sln.g"], ln_b=w[p + "sln.b"], ln_eps=1e-6,
                     film=film0[:, (l * 3 + 0) * 1024:], film_ld=fld, xres=b["xs"] if l == 0 else b["xa"],
                     xres_mod=Rs if l == 0 else 0, xres_rowmajor=l == 0, xout=b["xa"], n2_g=w[p + "norm2.g"],
