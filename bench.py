@@ -101,8 +101,8 @@ def family_flops_per_step(B, dn, S, NL=8, H=8, nf=151, ff=1024):
     tile = 2.0 * Rs * nf * 512 + 2.0 * B * S * 1024 * 512 * dn + 2.0 * B * S * 1024 * 1024   # input proj, f1, f2
     tile += 2.0 * 2 * B * 512 * (NL * 3 * 1024)               # FiLM stack
     tile += 2.0 * Rs * 1536 * 512                              # layer-0 QKV
-    tile += 2.0 * R * nf * 512                                 # final layer
-    att, chain = 0.0, 0.0
+    att, chain = 0.0, 2.0 * R * nf * 512                       # final layer: executed by the last chain launch (folded into
+                                                               # its linear3); input projection: by the first fusion GEMM
     for l in range(NL):
         nseq_sa = B if l == 0 else 2 * B
         att += 4.0 * nseq_sa * H * Lq * Lq * 64
