@@ -184,6 +184,12 @@ int tcdiff_adan_step(const tcdiff_adan_chunk* chunks, int n_chunks, const tcdiff
 #define TC_CHAIN_B_LAST 2
 #define TC_CHAIN_FULL 3
 #define TC_CHAIN_FULL_LAST 4
+#define TC_CHAIN_FRONT 5 /* last fusion linear of one dancer over a block of 64 FRAMES (A = bf16 [M frames][1024], weights
+                            rows [512 d, 512 d + 512) of relative_projection_layer.4, K = 1024: 64 stages) -> layer 0's
+                            residual input xout (token row = frame dn + d, column-blocked with M dn rows); then layer 0's
+                            norm1 (nn_g, nn_b) + rotary and w_qs / w_ks / w_vs (32 stages each) -> Q, K, V images.  M =
+                            frames, L = TOKENS per sequence, b3 = all 512 dn biases; wstream = [dn][8 waves][160 stages];
+                            grid = blocks x dn.  Replaces model/model.py:526-528,561 and layer 0's :326,374-383,78-80. */
 
 typedef struct {
     int mode, n_stages;
@@ -226,6 +232,7 @@ typedef struct {
      * wave instruction touches are then one contiguous kilobyte instead of 32 separate 32-byte pieces */
     int xres_rowmajor;     /* 1: xres is a plain row-major [*,512] matrix */
     int rope_rows;         /* rows of the column-blocked rotary table (>= L) */
+    int dn;                /* TC_CHAIN_FRONT: dancers */
     int out_ld;            /* *_LAST modes: 0 -> h_out = bf16 [M,512] rows of linear3; > 0 -> h_out = fp32 [M][out_ld], the
                               first out_ld columns of linear3 (the caller folded final_layer into its weights and bias:
                               model/model.py:344,623); out_ld % 4 == 0 */

@@ -16,7 +16,7 @@ ROW_BIAS, ROW_LN_POST, ROW_FILM, ROW_RES, ROW_STORE_X, ROW_NEXT_LN, ROW_STORE_H,
     1, 2, 4, 8, 16, 32, 64, 128
 SAMPLER_DDPM, SAMPLER_DDIM = 0, 1
 SAMPLER_ADVANCE = 0x100          # OR into the mode: sampler_update also advances counter[3] (step_prologue protocol)
-CHAIN_A, CHAIN_B, CHAIN_B_LAST, CHAIN_FULL, CHAIN_FULL_LAST = 0, 1, 2, 3, 4
+CHAIN_A, CHAIN_B, CHAIN_B_LAST, CHAIN_FULL, CHAIN_FULL_LAST, CHAIN_FRONT = 0, 1, 2, 3, 4, 5
 
 _vp, _i, _f, _l = C.c_void_p, C.c_int, C.c_float, C.c_long
 
@@ -42,7 +42,7 @@ class ChainArgs(C.Structure):
                 ("k_out", _vp), ("v_out", _vp), ("h_out", _vp), ("film_ld", _i), ("ln_eps", _f), ("n2_eps", _f),
                 ("n4_eps", _f), ("nn_eps", _f), ("scale_q", _f), ("lnb_g", _vp), ("lnb_b", _vp), ("filmb", _vp),
                 ("n3_g", _vp), ("n3_b", _vp), ("kf", _vp), ("vf", _vp), ("n_shared", _i), ("nkt", _i), ("Lk", _i),
-                ("xres_rowmajor", _i), ("rope_rows", _i), ("out_ld", _i)]
+                ("xres_rowmajor", _i), ("rope_rows", _i), ("dn", _i), ("out_ld", _i)]
 
 
 class StepPrologueArgs(C.Structure):

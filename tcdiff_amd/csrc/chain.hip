@@ -362,7 +362,8 @@ DEVINL void norm_to_lds(const f32x16_t (&acc)[2][2], const float (&nmr)[2], cons
 DEVINL char* stage_area(char* smem, int wave) { return smem + (wave < 7 ? wave * 4096 : CH_STG7); }
 template <bool SCALE>   // Q carries 1 / sqrt(d_k); K and V are stored as they are
 DEVINL void store_heads(const f32x16_t (&acc)[2][2], void* base, float scale, int L, int Lp, int H, int m0, int M,
-                        int wave, int lane, char* smem) {
+                        int wave, int lane, char* smem, int dn = 1, int dancer = 0) {
+    // rows are FRAMES m0 .. of dancer `dancer` (token = frame dn + dancer; dn = 1: rows are tokens); L tokens per sequence
 #ifdef CH_ABLATE_STORES   // timing experiment only: how much of the Q / K / V tail is the head-major scatter?
     if (M > 0) return;
 #endif
@@ -371,6 +372,7 @@ DEVINL void store_heads(const f32x16_t (&acc)[2][2], void* base, float scale, in
     const int r = lane & 31, h = lane >> 5;
     char* stg = stage_area(smem, wave);
     const int row0 = lane >> 3, ch = lane & 7;      // read side: row row0 + 8 k, 16-byte chunk ch
+    const int Lf = L / dn;                          // frames per sequence
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
@@ -389,11 +391,11 @@ DEVINL void store_heads(const f32x16_t (&acc)[2][2], void* base, float scale, in
             }
         // the LDS queue of a wave is in order: its reads below see its writes above
         int m = m0 + 32 * mi + row0;
-        const int seq = m / L;
-        int tok = m - seq * L;
-        // destination of (sequence, head = wave, token, chunk): +8 tokens = +1 KB; past the end of a sequence the next
-        // one starts (H * Lp - L) rows further
-        uint16_t* dst = reinterpret_cast<uint16_t*>(base) + (((long)seq * H + wave) * Lp + tok) * 64 + ch * 8;
+        const int seq = m / Lf;
+        int tokf = m - seq * Lf;
+        // destination of (sequence, head = wave, token, chunk): +8 frames = +8 dn tokens of 128 bytes; past the end of a
+        // sequence the next one starts (H * Lp - L) rows further
+        uint16_t* dst = reinterpret_cast<uint16_t*>(base) + (((long)seq * H + wave) * Lp + tokf * dn + dancer) * 64 + ch * 8;
         const long wrap = ((long)H * Lp - L) * 64;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -401,10 +403,10 @@ DEVINL void store_heads(const f32x16_t (&acc)[2][2], void* base, float scale, in
             const u32x4 v = *reinterpret_cast<const u32x4*>(stg + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
             if (m < M) *reinterpret_cast<u32x4*>(dst) = v;
             m += 8;
-            tok += 8;
-            dst += 8 * 64;
-            if (tok >= L) {
-                tok -= L;
+            tokf += 8;
+            dst += 8 * 64 * dn;
+            if (tokf >= Lf) {
+                tokf -= Lf;
                 dst += wrap;
             }
         }
@@ -549,14 +551,20 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     constexpr bool HAS_A = MODE == TC_CHAIN_A || MODE == TC_CHAIN_FULL || MODE == TC_CHAIN_FULL_LAST;   // fc + norm2 + w_qs
     constexpr bool FULL = MODE == TC_CHAIN_FULL || MODE == TC_CHAIN_FULL_LAST;                          // + cross-attention
     constexpr bool LAST = MODE == TC_CHAIN_B_LAST || MODE == TC_CHAIN_FULL_LAST;
+    // TC_CHAIN_FRONT: the last fusion linear of ONE dancer for a block of 64 FRAMES (A = 64 rows of 1024), which is layer
+    // 0's residual input, then layer 0's norm1 + rotary and Q / K / V -- the tail of chain B with a K = 1024 GEMM in
+    // front.  Frame F, dancer d <-> token row F dn + d (model/model.py:561; model/diffusion.py:640,651).
+    constexpr bool FRONT = MODE == TC_CHAIN_FRONT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int m0 = xcd_remap(blockIdx.x, gridDim.x) * 64;
+    const int dn = FRONT ? a.dn : 1;
+    const int dancer = FRONT ? (int)(blockIdx.x % (unsigned)dn) : 0;
+    const int m0 = FRONT ? (int)(blockIdx.x / (unsigned)dn) * 64 : xcd_remap(blockIdx.x, gridDim.x) * 64;
     CH_T(0);
     CH_TC(60);
-    const int M = a.M, L = a.L;
+    const int M = a.M, L = a.L;        // FRONT: M = frames, L = TOKENS per sequence
     char* abuf = smem + CH_ABUF;
     char* h1c = smem + CH_H1C;
     float* scr = reinterpret_cast<float*>(smem + CH_SCR);
@@ -603,19 +611,22 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
 
     // ---- the block's input rows (attention output) -> LDS, the first CH_D weight stages -> registers, constants -> LDS
 #pragma unroll
-    for (int kt = 0; kt < 8; ++kt)
-        stage_glds<64, 8>(abuf + kt * 8192, reinterpret_cast<const char*>(a.A) + kt * TC_ROWB, 1024, m0, M, a.a_mod, wave,
-                          lane);
+    for (int kt = 0; kt < (FRONT ? 16 : 8); ++kt)      // FRONT: 64 rows of 1024 = the activation block and its twin, contiguous
+        stage_glds<64, 8>(abuf + kt * 8192, reinterpret_cast<const char*>(a.A) + kt * TC_ROWB, FRONT ? 2048 : 1024, m0, M,
+                          a.a_mod, wave, lane);
     WStream ws;
     ws.rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(reinterpret_cast<const char*>(a.wstream)) + (long)wave * a.n_stages * CH_STAGE, 0,
+        const_cast<char*>(reinterpret_cast<const char*>(a.wstream)) + ((long)dancer * 8 + wave) * a.n_stages * CH_STAGE, 0,
         a.n_stages * CH_STAGE, 0x00020000);   // raw buffer (stride 0), bounds = the wave's stream, 32-bit data format
     ws.voff = (unsigned)lane * 16u;
     ws.pos = 0;
     ws.last = (unsigned)a.n_stages - 1;
 #pragma unroll
     for (int i = 0; i < CH_D; ++i) ws_load(ws, i, (unsigned)i);
-    {
+    if (FRONT) {
+        const float* const v[6] = {a.b3 + 512 * dancer, a.nn_g, a.nn_b, nullptr, nullptr, nullptr};
+        store_consts(fetch_consts(nullptr, v));
+    } else {
         const float* const v[6] = {a.ln_g, a.ln_b, a.n2_g, a.n2_b, nullptr, nullptr};
         store_consts(fetch_consts(a.film, v));
     }
@@ -634,8 +645,11 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     };
     float nmr[2], rstd[2];             // LayerNorm of the current rows: u = fma(v, rstd, nmr)
     RowPipe rp;                        // residual rows, later rotary rows, of this lane
-    const __amdgpu_buffer_rsrc_t xo = f32_buffer(a.xout, (long)M * 512);   // the residual stream out
-    int pos[2] = {mc[0] % L, mc[1] % L};
+    // token row of this lane's rows in the residual stream, and its position in its sequence
+    const int trow[2] = {mc[0] * dn + dancer, mc[1] * dn + dancer};
+    const long xrows = (long)M * dn;
+    const __amdgpu_buffer_rsrc_t xo = f32_buffer(a.xout, xrows * 512);     // the residual stream out
+    int pos[2] = {trow[0] % L, trow[1] % L};
     Consts nxt;
 
     // fc epilogue: LayerNorm(eps), FiLM, residual -> x in the accumulators and in xout (model/model.py:103-106,171-173,
@@ -719,6 +733,7 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
         CH_T(36);
         lds_barrier();
     }
+    if constexpr (!FRONT) {
     // ================= cross-attention block tail: fc + LayerNorm(1e-6) + FiLM + residual (model/model.py:334)
     clear();
     phase_n512<32>(acc, abuf, ws, lane);
@@ -817,10 +832,14 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     norm_to_lds<false>(acc, nmr, rstd, vecp(3), vecp(4), rp, abuf, wave, lane, nullptr);
     lds_barrier();
     store_consts(nxt);                 // b3, norm1': read after the barrier that follows linear3
-    // ================= x' = linear3(norm4(x)) + b3, no residual (model/model.py:344)
+    }   // !FRONT
+    // ================= x' = linear3(norm4(x)) + b3, no residual (model/model.py:344); FRONT: the last fusion linear of this
+    // block's dancer over K = 1024 (model/model.py:526-528), whose output is layer 0's residual input
     CH_T(24);
     clear();
-    if (LAST)
+    if (FRONT)
+        phase_n512<64>(acc, abuf, ws, lane);
+    else if (LAST)
         phase_n512<32, true>(acc, abuf, ws, lane);
     else
         phase_n512<32>(acc, abuf, ws, lane);
@@ -851,7 +870,7 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
                     pk.y = pack_bf2(o[2], o[3]);
                     *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.h_out) + (long)mc[mi] * 512 + n) = pk;
                 } else {
-                    cb_store(xo, M, wave, 4 * ni + gq, mc[mi], h, o);
+                    cb_store(xo, xrows, wave, 4 * ni + gq, trow[mi], h, o);
                 }
             }
             CH_FENCE();
@@ -868,16 +887,16 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     clear();
     phase_n512<32, false, CH_QKV_R>(acc, abuf, ws, lane);
     CH_T(29);
-    store_heads<true>(acc, a.q_out, a.scale_q, L, a.Lp, a.H, m0, M, wave, lane, smem);
+    store_heads<true>(acc, a.q_out, a.scale_q, L, a.Lp, a.H, m0, M, wave, lane, smem, dn, dancer);
     clear();
     phase_n512<32, false, CH_QKV_R>(acc, abuf, ws, lane);
     CH_T(30);
-    store_heads<false>(acc, a.k_out, 1.0f, L, a.Lp, a.H, m0, M, wave, lane, smem);
+    store_heads<false>(acc, a.k_out, 1.0f, L, a.Lp, a.H, m0, M, wave, lane, smem, dn, dancer);
     CH_T(31);
     clear();
     phase_n512<32, true, CH_QKV_R>(acc, smem + CH_ABUF2, ws, lane);
     CH_T(32);
-    store_heads<false>(acc, a.v_out, 1.0f, L, a.Lp, a.H, m0, M, wave, lane, smem);
+    store_heads<false>(acc, a.v_out, 1.0f, L, a.Lp, a.H, m0, M, wave, lane, smem, dn, dancer);
     CH_T(33);
     CH_TC(61);
 }
@@ -886,21 +905,30 @@ static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 
 extern "C" int tcdiff_chain(const tcdiff_chain_args* a, hipStream_t stream) {
     if (!a || a->M <= 0 || a->L <= 0 || !a->A || !a->wstream) return TC_ERR_ARG;
-    if (a->L < 64) return TC_ERR_UNSUPPORTED;   // a 64-row block must touch at most two sequences
+    const bool front = a->mode == TC_CHAIN_FRONT;
+    if (!front && a->L < 64) return TC_ERR_UNSUPPORTED;   // a 64-row block must touch at most two sequences
     const int want = a->mode == TC_CHAIN_A ? 64 : a->mode == TC_CHAIN_B ? 288 : a->mode == TC_CHAIN_B_LAST ? 192 :
-                     a->mode == TC_CHAIN_FULL ? 352 : a->mode == TC_CHAIN_FULL_LAST ? 256 : -1;
+                     a->mode == TC_CHAIN_FULL ? 352 : a->mode == TC_CHAIN_FULL_LAST ? 256 : front ? 160 : -1;
     if (want < 0 || a->n_stages != want) return TC_ERR_ARG;
-    if (!a->ln_g || !a->ln_b || !a->film || a->film_ld % 4 || !a->xres || !a->xout || !a->n2_g || !a->n2_b) return TC_ERR_ARG;
     if (a->out_ld < 0 || a->out_ld % 4 || a->out_ld > 512) return TC_ERR_ARG;
-    if ((long)(a->a_mod > 0 ? a->a_mod : a->M) * 1024 >= (1L << 32)) return TC_ERR_ARG;
     const void* ptrs[] = {a->A, a->wstream, a->ln_g, a->ln_b, a->film, a->xres, a->xout, a->n2_g, a->n2_b, a->rope,
                           a->q_out, a->b1, a->b2, a->film3, a->n4_g, a->n4_b, a->b3, a->nn_g, a->nn_b, a->k_out,
                           a->v_out, a->h_out, a->lnb_g, a->lnb_b, a->filmb, a->n3_g, a->n3_b, a->kf, a->vf};
     for (const void* p : ptrs)
         if (p && !al16(p)) return TC_ERR_ALIGN;
-    const bool has_a = a->mode == TC_CHAIN_A || a->mode >= TC_CHAIN_FULL;
-    const bool has_b = a->mode != TC_CHAIN_A;
-    const bool full = a->mode >= TC_CHAIN_FULL;
+    if (front) {
+        // A = bf16 [M frames][1024]; b3 = the 512 dn biases of the last fusion linear; xout = layer 0's residual input
+        if (a->dn <= 0 || a->L % a->dn || a->L / a->dn < 8 || !a->b3 || !a->nn_g || !a->nn_b || !a->rope || !a->xout ||
+            !a->q_out || !a->k_out || !a->v_out || a->H != 8 || a->Lp <= 0 || a->a_mod != 0)
+            return TC_ERR_ARG;
+        if ((long)a->M * 2048 >= (1L << 32)) return TC_ERR_ARG;
+    } else {
+        if (!a->ln_g || !a->ln_b || !a->film || a->film_ld % 4 || !a->xres || !a->xout || !a->n2_g || !a->n2_b) return TC_ERR_ARG;
+        if ((long)(a->a_mod > 0 ? a->a_mod : a->M) * 1024 >= (1L << 32)) return TC_ERR_ARG;
+    }
+    const bool has_a = a->mode == TC_CHAIN_A || a->mode == TC_CHAIN_FULL || a->mode == TC_CHAIN_FULL_LAST;
+    const bool has_b = a->mode != TC_CHAIN_A && !front;
+    const bool full = a->mode == TC_CHAIN_FULL || a->mode == TC_CHAIN_FULL_LAST;
     const bool last = a->mode == TC_CHAIN_B_LAST || a->mode == TC_CHAIN_FULL_LAST;
     if (has_a && (!a->rope || a->H != 8)) return TC_ERR_ARG;
     if (a->mode == TC_CHAIN_A && (!a->q_out || a->Lp <= 0)) return TC_ERR_ARG;
@@ -914,11 +942,12 @@ extern "C" int tcdiff_chain(const tcdiff_chain_args* a, hipStream_t stream) {
         return TC_ERR_ARG;
     static tc_dev_state dev_state;
     const int n_cu = tc_device_once(dev_state, [](int) {
-        const void* fns[5] = {reinterpret_cast<const void*>(chain_kernel<TC_CHAIN_A>),
+        const void* fns[6] = {reinterpret_cast<const void*>(chain_kernel<TC_CHAIN_A>),
                               reinterpret_cast<const void*>(chain_kernel<TC_CHAIN_B>),
                               reinterpret_cast<const void*>(chain_kernel<TC_CHAIN_B_LAST>),
                               reinterpret_cast<const void*>(chain_kernel<TC_CHAIN_FULL>),
-                              reinterpret_cast<const void*>(chain_kernel<TC_CHAIN_FULL_LAST>)};
+                              reinterpret_cast<const void*>(chain_kernel<TC_CHAIN_FULL_LAST>),
+                              reinterpret_cast<const void*>(chain_kernel<TC_CHAIN_FRONT>)};
         for (const void* f : fns) {
             hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, CH_SMEM);
             if (e != hipSuccess) return e;
@@ -926,8 +955,9 @@ extern "C" int tcdiff_chain(const tcdiff_chain_args* a, hipStream_t stream) {
         return hipSuccess;
     });
     if (n_cu < 0) return n_cu;
-    dim3 grid((a->M + 63) / 64);
+    dim3 grid(((a->M + 63) / 64) * (front ? a->dn : 1));
     switch (a->mode) {
+        case TC_CHAIN_FRONT: hipLaunchKernelGGL(chain_kernel<TC_CHAIN_FRONT>, grid, dim3(512), CH_SMEM, stream, *a); break;
         case TC_CHAIN_A: hipLaunchKernelGGL(chain_kernel<TC_CHAIN_A>, grid, dim3(512), CH_SMEM, stream, *a); break;
         case TC_CHAIN_B: hipLaunchKernelGGL(chain_kernel<TC_CHAIN_B>, grid, dim3(512), CH_SMEM, stream, *a); break;
         case TC_CHAIN_B_LAST: hipLaunchKernelGGL(chain_kernel<TC_CHAIN_B_LAST>, grid, dim3(512), CH_SMEM, stream, *a); break;

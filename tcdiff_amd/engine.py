@@ -66,6 +66,8 @@ class DenoiserEngine:
         self.kin = K.round_up(self.dn * self.nf, 64)
         # ... and final_layer folded into the last decoder layer's linear3 (the last chain launch writes the output)
         self.fold_out = self.use_chain and os.environ.get("TCDIFF_FOLD_OUT", "1") != "0"
+        # ... and the last fusion linear + layer 0's norm1 / rotary / Q, K, V as one chain launch per (frame block, dancer)
+        self.front = self.use_full and os.environ.get("TCDIFF_FRONT", "1") != "0" and self.S >= 8
         self.reset_graphs()
 
     def reset_graphs(self):
@@ -122,6 +124,13 @@ class DenoiserEngine:
 
     def _build_chain_streams(self):
         w = self.w
+        if self.front:
+            # TC_CHAIN_FRONT: per dancer, the 512 rows of the last fusion linear it owns (K = 1024: 64 stages), then layer
+            # 0's w_qs / w_ks / w_vs (32 stages each)
+            qkv = w["l0.qkv.w"]
+            tail = [self._stages_n512(qkv[0:512]), self._stages_n512(qkv[512:1024]), self._stages_n512(qkv[1024:1536])]
+            w["front"] = torch.stack([torch.cat([self._stages_n512(w["f3.w"][512 * d:512 * d + 512])] + tail, 1)
+                                      for d in range(self.dn)]).contiguous()          # [dn][8 waves][160][1024]
         for l in range(self.NL):
             p = f"l{l}."
             w[p + "chainA"] = torch.cat([self._stages_n512(w[p + "sfc.w"]), self._stages_n512(w[p + "cq.w"])],
@@ -423,10 +432,17 @@ class DenoiserEngine:
         K.gemm_tile(dt, b["f1"], w["f2.w"], B * S, 1024, 1024, bias=w["f2.b"], act=L.ACT_RELU, out=b["f2"], ldc=1024)
         # last fusion linear, one group per dancer in ONE launch: group d writes token rows m*dn + d (de-interleave:
         # frame row m, dancer d -> token m*dn + d); fused with layer-0 norm1 + rotary
-        K.gemm_rowln(dt, b["f2"], w["f3.w"], B * S, 1024, bias=w["f3.b"], xout=b["xs"], Lseq=Lq,
-                     flags=L.ROW_BIAS | L.ROW_STORE_X | L.ROW_NEXT_LN | L.ROW_STORE_H | L.ROW_STORE_ROT,
-                     nln_g=w["l0.norm1.g"], nln_b=w["l0.norm1.b"], nln_eps=1e-5, hout=b["h"], rout=b["rot"],
-                     rope=rope, out_mul=dn, out_add=0, groups=dn)
+        if self.front:
+            # ... as ONE chain launch per (64-frame block, dancer) that also runs layer 0's norm1, rotary and Q / K / V
+            # projections; b["xs"] (layer 0's residual input) is then column-blocked like the rest of the stream
+            K.chain(L.CHAIN_FRONT, 160, B * S, Lq, b["f2"], w["front"], b3=w["f3.b"], nn_g=w["l0.norm1.g"],
+                    nn_b=w["l0.norm1.b"], nn_eps=1e-5, rope=w["rope_cb"], xout=b["xs"], q_out=b["Q"], k_out=b["K"],
+                    v_out=b["V"], scale_q=0.125, Lp=self.Lp, H=H, dn=dn)
+        else:
+            K.gemm_rowln(dt, b["f2"], w["f3.w"], B * S, 1024, bias=w["f3.b"], xout=b["xs"], Lseq=Lq,
+                         flags=L.ROW_BIAS | L.ROW_STORE_X | L.ROW_NEXT_LN | L.ROW_STORE_H | L.ROW_STORE_ROT,
+                         nln_g=w["l0.norm1.g"], nln_b=w["l0.norm1.b"], nln_eps=1e-5, hout=b["h"], rout=b["rot"],
+                         rope=rope, out_mul=dn, out_add=0, groups=dn)
         Kc0 = b["Kc"][:, kv_slot0:]
         Vc0 = b["Vc"][:, kv_slot0:]
         for l in range(NL):
@@ -486,7 +502,7 @@ class DenoiserEngine:
         nseq = branches * B
         p = f"l{l}."
         rope = w["rope_cb"]
-        if l == 0:
+        if l == 0 and not self.front:
             K.gemm_tile(dt, b["rot"], w[p + "qkv.w"], Rs, 1536, 512, A2=b["h"], split_n=1024, mode=L.EPI_QKV_HEADS,
                         out=b["Q"], out_k=b["K"], out_v=b["V"], scale_q=0.125, Lseq=Lq, Lp=self.Lp, H=H, n_q=512,
                         n_k=512)
@@ -501,7 +517,7 @@ class DenoiserEngine:
                     out_ld=152 if last and self.fold_out else 0, scale_q=0.125, Lp=self.Lp, H=H)
         head = dict(a_mod=Rs if l == 0 else 0, ln_g=w[p + "sln.g"], ln_b=w[p + "sln.b"], ln_eps=1e-6,
                     film=film0[:, (l * 3 + 0) * 1024:], film_ld=fld, xres=b["xs"] if l == 0 else b["xa"],
-                    xres_mod=Rs if l == 0 else 0, xres_rowmajor=l == 0, xout=b["xa"], n2_g=w[p + "norm2.g"],
+                    xres_mod=Rs if l == 0 else 0, xres_rowmajor=l == 0 and not self.front, xout=b["xa"], n2_g=w[p + "norm2.g"],
                     n2_b=w[p + "norm2.b"], n2_eps=1e-5, rope=rope)     # b["xa"] is COLUMN-BLOCKED on this path
         if self.use_full:
             # self-attention tail, cross-attention (K / V from the fragment-ordered caches) and feed-forward in ONE launch

@@ -249,3 +249,49 @@ def test_fused_layer_chain_against_chain_a_attention_chain_b(last):
         print(f"fused layer chain ({'last' if last else 'mid'}): {nm} max/mean diff {d[0]:.2e}/{d[1]:.2e} (max |.| {float(a.float().abs().max()):.2f})")
         # the in-kernel softmax sums in another order and feeds O straight on: isolated bf16 flips, spread by the GEMMs
         assert d[0] < 1.5e-1 and d[1] < 4e-3
+
+
+def test_front_chain_against_rowln_plus_qkv_tile():
+    """TC_CHAIN_FRONT (last fusion linear of each dancer over 64-frame blocks + layer 0's norm1 / rotary / Q, K, V) against
+    the two launches it replaces, gemm_rowln with dancer groups and the QKV gemm_tile, on random data: 3 dancers, frames
+    per sequence not a multiple of anything (S = 70: blocks straddle sequences), a ragged last block."""
+    dt, bf = L.DT_BF16, torch.bfloat16
+    dn, S, nseq, H = 3, 70, 3, 8
+    Lq, Mf = dn * S, nseq * S                    # tokens per sequence, frames
+    Rs = Mf * dn
+    Lp = K.round_up(Lq, 128)
+    f2 = rnd(Mf, 1024, seed=101, scale=0.5).to(bf)
+    W3 = rnd(512 * dn, 1024, seed=102, scale=1024 ** -0.5).to(bf)
+    b3 = 0.1 * rnd(512 * dn, seed=103)
+    Wqkv = rnd(1536, 512, seed=104, scale=512 ** -0.5).to(bf)
+    g1, b1 = 1 + 0.1 * rnd(512, seed=105), 0.1 * rnd(512, seed=106)
+    rope = torch.empty(Lq, 512, device=DEV)
+    K.rope_table((1.0 / (10000 ** (torch.arange(0, 512, 2).float() / 512))).to(DEV), rope, Lq)
+    z = lambda *s_, dtype=bf: torch.zeros(*s_, device=DEV, dtype=dtype)
+    # ---- the two launches
+    xs1, h, rot = z(Rs, 512, dtype=torch.float32), z(Rs, 512), z(Rs, 512)
+    K.gemm_rowln(dt, f2, W3, Mf, 1024, bias=b3, xout=xs1, Lseq=Lq,
+                 flags=L.ROW_BIAS | L.ROW_STORE_X | L.ROW_NEXT_LN | L.ROW_STORE_H | L.ROW_STORE_ROT, nln_g=g1, nln_b=b1,
+                 nln_eps=1e-5, hout=h, rout=rot, rope=rope, out_mul=dn, out_add=0, groups=dn)
+    Q1, K1, V1 = z(nseq, H, Lp, 64), z(nseq, H, Lp, 64), z(nseq, H, Lp, 64)
+    K.gemm_tile(dt, rot, Wqkv, Rs, 1536, 512, A2=h, split_n=1024, mode=L.EPI_QKV_HEADS, out=Q1, out_k=K1, out_v=V1,
+                scale_q=0.125, Lseq=Lq, Lp=Lp, H=H, n_q=512, n_k=512)
+    # ---- one launch
+    E = DenoiserEngine
+    tail = [E._stages_n512(Wqkv[i * 512:(i + 1) * 512]) for i in range(3)]
+    ws = torch.stack([torch.cat([E._stages_n512(W3[512 * d:512 * d + 512])] + tail, 1) for d in range(dn)]).contiguous()
+    assert ws.shape == (dn, 8, 160, 1024)
+    xs2 = z(Rs, 512, dtype=torch.float32)
+    Q2, K2, V2 = z(nseq, H, Lp, 64), z(nseq, H, Lp, 64), z(nseq, H, Lp, 64)
+    K.chain(L.CHAIN_FRONT, 160, Mf, Lq, f2, ws, b3=b3, nn_g=g1, nn_b=b1, nn_eps=1e-5, rope=K.to_cb(rope), xout=xs2, q_out=Q2,
+            k_out=K2, v_out=V2, scale_q=0.125, Lp=Lp, H=H, dn=dn)
+    torch.cuda.synchronize()
+    md = lambda a_, b_: (float((a_.float() - b_.float()).abs().max()), float((a_.float() - b_.float()).abs().mean()))
+    dx = md(xs1, K.from_cb(xs2, Rs))
+    print(f"front chain: x max/mean diff {dx[0]:.2e}/{dx[1]:.2e} (|x| max {float(xs1.abs().max()):.2f})")
+    assert dx[0] < 1e-4                                          # fp32 accumulators of the same bf16 products
+    for nm, a_, b_ in (("Q", Q1, Q2), ("K", K1, K2), ("V", V1, V2)):
+        d = md(a_, b_)
+        print(f"front chain: {nm} image max/mean diff {d[0]:.2e}/{d[1]:.2e} (max |.| {float(a_.float().abs().max()):.2f})")
+        assert d[0] < 6e-2 and d[1] < 5e-4                          # isolated bf16 rounding flips
+        assert float(b_[:, :, Lq:].abs().max()) == 0.0              # padding rows untouched
