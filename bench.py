@@ -92,17 +92,18 @@ def family_flops_per_step(B, dn, S, NL=8, H=8, nf=151, ff=1024):
     """ALGORITHMIC FLOPs of one two-branch DDPM step of B clips, per kernel family (2 FLOP per MAC; the shapes are
     SURVEY.md 2.3 / Appendix B, layer-0 self-attention evaluated once for both branches as the engine does).
     `chain` = the row-block chain launches (csrc/chain.hip): every projection of a layer behind the self-attention
-    (fc, w_qs, cross-attention, fc, linear1/2/3, next w_qs/w_ks/w_vs); `attention` = self-attention;
-    `gemm_tile` / `gemm_rowln` = what is left outside the layers (input + fusion projection, FiLM stack, layer-0 QKV, final)."""
+    (fc, w_qs, cross-attention, fc, linear1/2/3, next w_qs/w_ks/w_vs), the final layer (folded into the last linear3) and
+    the front launch (last fusion linear + layer-0 QKV); `attention` = self-attention; `gemm_tile` = what is left outside
+    the layers (FiLM stack, input projection + fusion linears 1-2); `gemm_rowln` is not launched per step any more."""
     Lq = dn * S
     Rs, R = B * Lq, 2 * B * Lq
     M = S + 2
-    rowln = 2.0 * B * S * 1024 * 512 * dn                      # last fusion-projection linear
+    rowln = 0.0
     tile = 2.0 * Rs * nf * 512 + 2.0 * B * S * 1024 * 512 * dn + 2.0 * B * S * 1024 * 1024   # input proj, f1, f2
     tile += 2.0 * 2 * B * 512 * (NL * 3 * 1024)               # FiLM stack
-    tile += 2.0 * Rs * 1536 * 512                              # layer-0 QKV
     att, chain = 0.0, 2.0 * R * nf * 512                       # final layer: executed by the last chain launch (folded into
                                                                # its linear3); input projection: by the first fusion GEMM
+    chain += 2.0 * B * S * 1024 * 512 * dn + 2.0 * Rs * 1536 * 512   # front launch: last fusion linear + layer-0 QKV
     for l in range(NL):
         nseq_sa = B if l == 0 else 2 * B
         att += 4.0 * nseq_sa * H * Lq * Lq * 64
