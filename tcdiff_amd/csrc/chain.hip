@@ -265,6 +265,17 @@ DEVINL void row_stats(const f32x16_t (&acc)[2][2], float* scr, int wave, int lan
 }
 
 // constants of an epilogue come from LDS (staged by stage_consts): no long-latency loads, no long-lived registers
+// Byte offset of this lane's first column (64 wave + 4 h) in a 512-float LDS vector, as a value the compiler cannot take
+// apart: the per-iteration column offsets then fold into the ds_read immediates instead of being recomputed (under
+// register pressure hipcc rematerialised ~2 VALU adds per constant read: 90 per epilogue).
+DEVINL int col_base_bytes(int wave, int h) {
+    int v = (64 * wave + 4 * h) * 4;
+    asm volatile("" : "+v"(v));
+    return v;
+}
+DEVINL f32x4_t lds4b(const char* base, int byte_off) {
+    return *reinterpret_cast<const f32x4_t*>(base + byte_off);
+}
 DEVINL f32x4_t lds4(const char* base, int float_index) {
     return *reinterpret_cast<const f32x4_t*>(base + float_index * 4);
 }
@@ -322,11 +333,11 @@ DEVINL void norm_to_lds(const f32x16_t (&acc)[2][2], const float (&nmr)[2], cons
     lane = fresh_v(lane);
     wave = fresh_s(wave);
     const int r = lane & 31, h = lane >> 5;
+    const int cb0 = col_base_bytes(wave, h);
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
         const int ni = it >> 2, gq = it & 3;
-        const int n = 64 * wave + 32 * ni + 8 * gq + 4 * h;
-        const f32x4_t g4 = lds4(g, n), b4 = lds4(b, n);
+        const f32x4_t g4 = lds4b(g + cb0, 32 * it), b4 = lds4b(b + cb0, 32 * it);
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
             float u[4];
@@ -661,15 +672,18 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
         CH_T(stamp + 1);
         // fresh copies: the two inlined instances of this epilogue must not share (and keep alive) their addresses
         const int hh = fresh_v(h), wv = fresh_s(wave);
-        const int mcl[2] = {fresh_v(mc[0]), fresh_v(mc[1])}, sx[2] = {fresh_v(sidx[0]), fresh_v(sidx[1])};
+        const int mcl[2] = {fresh_v(mc[0]), fresh_v(mc[1])};
+        const int cb0 = col_base_bytes(wv, hh);
+        // FiLM rows of this lane's two rows: sequence 0 or 1 of the block (4 KB apart), as opaque byte offsets too
+        int fb[2] = {sidx[0] * 4096 + cb0, sidx[1] * 4096 + cb0};
+        asm volatile("" : "+v"(fb[0]), "+v"(fb[1]));
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int ni = it >> 2, gq = it & 3;
-            const int n = 64 * wv + 32 * ni + 8 * gq + 4 * hh;
-            const f32x4_t g4 = lds4(vecp(0), n), b4 = lds4(vecp(1), n);
+            const f32x4_t g4 = lds4b(vecp(0) + cb0, 32 * it), b4 = lds4b(vecp(1) + cb0, 32 * it);
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {
-                const f32x4_t sc = lds4(cfilm, sx[mi] * 1024 + n), sh = lds4(cfilm, sx[mi] * 1024 + 512 + n);
+                const f32x4_t sc = lds4b(cfilm + fb[mi], 32 * it), sh = lds4b(cfilm + fb[mi], 2048 + 32 * it);
                 const f32x4_t x4 = rp.q[it & 3][mi];
                 f32x4_t o;
 #pragma unroll
@@ -798,14 +812,16 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     }
     // linear2 bias, FiLM, residual (the x this lane stored above), norm4 -> LDS
     rp_start(rp, a.xout, mc, M, M, wave, h);
+    const int cb2 = col_base_bytes(fresh_s(wave), fresh_v(h));
+    int fb2[2] = {sidx[0] * 4096 + cb2, sidx[1] * 4096 + cb2};
+    asm volatile("" : "+v"(fb2[0]), "+v"(fb2[1]));
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
         const int ni = it >> 2, gq = it & 3;
-        const int n = 64 * wave + 32 * ni + 8 * gq + 4 * h;
-        const f32x4_t b4 = lds4(vecp(2), n);
+        const f32x4_t b4 = lds4b(vecp(2) + cb2, 32 * it);
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
-            const f32x4_t sc = lds4(cfilm, sidx[mi] * 1024 + n), sh = lds4(cfilm, sidx[mi] * 1024 + 512 + n);
+            const f32x4_t sc = lds4b(cfilm + fb2[mi], 32 * it), sh = lds4b(cfilm + fb2[mi], 2048 + 32 * it);
             const f32x4_t x4 = rp.q[it & 3][mi];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -845,12 +861,13 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
         phase_n512<32>(acc, abuf, ws, lane);
     CH_T(25);
     lds_barrier();
+    const int cb3 = col_base_bytes(fresh_s(wave), fresh_v(h));
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
             const int n = 64 * wave + 32 * ni + 8 * gq + 4 * h;
-            const f32x4_t b4 = lds4(vecp(0), n);
+            const f32x4_t b4 = lds4b(vecp(0) + cb3, 32 * (4 * ni + gq));
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {
                 f32x4_t o;
