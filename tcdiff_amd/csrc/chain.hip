@@ -52,6 +52,9 @@
 #ifndef CH_QKV_R
 #define CH_QKV_R CH_D        // ring depth of the Q / K / V GEMMs at the end of the launch
 #endif
+#ifndef CH_XP
+#define CH_XP 3              // K / V register sets of the pipelined in-kernel cross-attention for a 5-tile memory (0: never)
+#endif
 #define CH_STAGE 2048
 
 typedef const float* fptr;
@@ -546,6 +549,134 @@ DEVINL void cross_attention(const f32x16_t (&qacc)[2][2], const tcdiff_chain_arg
     }
 }
 
+// The same cross-attention with the K / V fragment loads of later tiles in flight while a tile is computed, for a memory of
+// exactly NKT tiles (the benchmark's 150 + 2 keys: NKT = 5).  The loop above exposes one L2 round trip per tile (a dependent
+// chain K -> S -> softmax -> P -> V of ~0.3 us of work per ~1 us of latency, 10 tiles per wave).  Here the (<= 2 NKT) tiles
+// of a row tile are straight-line code over NSET register sets (a rolled loop would carry them through phis, and a copy
+// of a set in flight is a vmcnt drain), addressed through a raw buffer (SGPR descriptor + SGPR tile offset).  The sets
+// need the weight ring's registers: the caller runs the GEMM in front without refilling the ring and re-primes it behind.
+template <int NKT, int NSET>
+DEVINL void cross_attention_p(const f32x16_t (&qacc)[2][2], const tcdiff_chain_args& a, int m0, char* abuf, int wave,
+                              int lane) {
+    static_assert(NSET == 2 || NSET == 3, "two or three K / V register sets");
+    lane = fresh_v(lane);
+    wave = fresh_s(wave);
+    const int r = lane & 31, h = lane >> 5;
+    const int M = a.M, L = a.L;
+    u32x4 qf[2][4];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int s16 = 0; s16 < 4; ++s16) {
+            const int ni = s16 >> 1, o8 = 8 * (s16 & 1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                qf[mi][s16][j] = pack_bf2(qacc[mi][ni][o8 + 2 * j] * a.scale_q, qacc[mi][ni][o8 + 2 * j + 1] * a.scale_q);
+        }
+    constexpr float LOG2E = 1.4426950408889634f;
+    const unsigned voff = (unsigned)lane * 16u;
+    const __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.kf), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.vf), 0, -1, 0x00020000);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        int ra = m0 + 32 * mi, rb = ra + 31;
+        ra = ra < M ? ra : M - 1;
+        rb = rb < M ? rb : M - 1;
+        const int sa = ra / L, sb = rb / L;                 // wave-uniform; sb - sa is 0 or 1
+        int mrow = m0 + 32 * mi + r;
+        mrow = mrow < M ? mrow : M - 1;
+        const int my_seq = mrow / L;
+        const int J = (sb - sa + 1) * NKT;                  // tiles of this row tile
+        auto fetch = [&](int j, u32x4 (&kc)[4], u32x4 (&vc)[4]) {   // tile j = (sequence sa + j / NKT, key tile j % NKT)
+            const int seq = sa + (j >= NKT ? 1 : 0), kt = j >= NKT ? j - NKT : j;
+            const int kv = seq < a.n_shared ? 0 : seq - a.n_shared + (a.n_shared > 0 ? 1 : 0);
+            const unsigned so = (unsigned)(((kv * a.H + wave) * NKT + kt) * 4096);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                kc[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(kr, voff + 1024u * i, so, 0));
+                vc[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(vr, voff + 1024u * i, so, 0));
+            }
+        };
+        f32x16_t o[2];
+        float m_run = -INFINITY, l_run = 0.0f;
+        auto tile = [&](int j, const u32x4 (&kc)[4], const u32x4 (&vc)[4]) {
+            const int kt = j >= NKT ? j - NKT : j;
+            if (kt == 0) {
+                zero(o[0]);
+                zero(o[1]);
+                m_run = -INFINITY;
+                l_run = 0.0f;
+            }
+            f32x16_t s;
+            zero(s);
+#pragma unroll
+            for (int s16 = 0; s16 < 4; ++s16) MmaBF16::mma(s, kc[s16], qf[mi][s16]);
+            if (kt * 32 + 32 > a.Lk) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q)
+                    if (kt * 32 + acc_row(q, h) >= a.Lk) s[q] = -INFINITY;
+            }
+            float mx = s[0];
+#pragma unroll
+            for (int q = 1; q < 16; ++q) mx = fmaxf(mx, s[q]);
+            mx = fmaxf(mx, other_half(mx)) * LOG2E;
+            const float m_new = fmaxf(m_run, mx);
+            f32x2_t rs2 = {0.0f, 0.0f};
+            const f32x2_t l2 = {LOG2E, LOG2E}, nm = {-m_new, -m_new};
+#pragma unroll
+            for (int q = 0; q < 16; q += 2) {
+                const f32x2_t x = __builtin_elementwise_fma(f32x2_t{s[q], s[q + 1]}, l2, nm);
+                const f32x2_t pp = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+                s[q] = pp[0];
+                s[q + 1] = pp[1];
+                rs2 += pp;
+            }
+            float rs = rs2[0] + rs2[1];
+            rs += other_half(rs);
+            if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                l_run *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) o[dt][q] *= alpha;
+                m_run = m_new;
+            }
+            l_run += rs;
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+                u32x4 pf;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) pf[jj] = pack_bf2(s[8 * sp + 2 * jj], s[8 * sp + 2 * jj + 1]);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) MmaBF16::mma(o[dt], vc[sp * 2 + dt], pf);
+            }
+            if (kt == NKT - 1 && my_seq == sa + (j >= NKT ? 1 : 0)) {   // this sequence is done: rows that belong to it
+                const float inv = 1.0f / l_run;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        uint2 pk;
+                        pk.x = pack_bf2(o[dt][4 * gq + 0] * inv, o[dt][4 * gq + 1] * inv);
+                        pk.y = pack_bf2(o[dt][4 * gq + 2] * inv, o[dt][4 * gq + 3] * inv);
+                        *reinterpret_cast<uint2*>(abuf + wave * 8192 + tile_off(32 * mi + r, 4 * dt + gq) + 8 * h) = pk;
+                    }
+            }
+        };
+        u32x4 kk[NSET][4], vv[NSET][4];
+#pragma unroll
+        for (int p = 0; p < NSET - 1; ++p) fetch(p, kk[p], vv[p]);     // NKT >= NSET - 1
+#pragma unroll
+        for (int j = 0; j < 2 * NKT; ++j) {                  // straight-line: tiles beyond J are skipped (wave-uniform)
+            if (j < J) {
+                if (j + NSET - 1 < J) fetch(j + NSET - 1, kk[(j + NSET - 1) % NSET], vv[(j + NSET - 1) % NSET]);
+                tile(j, kk[j % NSET], vv[j % NSET]);
+            }
+        }
+    }
+}
+
 #ifdef CH_STAMP   // diagnostic build: per-phase timestamps of block 0, every wave, into the (otherwise unused) h_out buffer
 #define CH_T(i) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (MODE == TC_CHAIN_B || MODE == TC_CHAIN_FULL)) \
         reinterpret_cast<unsigned long long*>(a.h_out)[(threadIdx.x >> 6) * 64 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -557,7 +688,8 @@ DEVINL void cross_attention(const f32x16_t (&qacc)[2][2], const tcdiff_chain_arg
 #define CH_T(i) do { } while (0)
 #endif
 
-template <int MODE>
+// XP > 0: the pipelined in-kernel cross-attention with XP register sets (memory of exactly 5 key tiles), see cross_attention_p
+template <int MODE, int XP = 0>
 __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     constexpr bool HAS_A = MODE == TC_CHAIN_A || MODE == TC_CHAIN_FULL || MODE == TC_CHAIN_FULL_LAST;   // fc + norm2 + w_qs
     constexpr bool FULL = MODE == TC_CHAIN_FULL || MODE == TC_CHAIN_FULL_LAST;                          // + cross-attention
@@ -739,11 +871,22 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
             store_heads<true>(acc, a.q_out, a.scale_q, L, a.Lp, a.H, m0, M, wave, lane, smem);
             return;
         }
-        phase_n512<32>(acc, abuf, ws, lane);
         // ================= cross-attention in place (the Q image never leaves the registers)
-        CH_T(35);
-        lds_barrier();                 // every wave is out of the w_qs GEMM: the activation block becomes O
-        cross_attention(acc, a, m0, abuf, wave, lane);
+        if constexpr (XP > 0) {
+            // pipelined form: the weight ring is left empty behind the w_qs GEMM (its registers hold K / V tiles in the
+            // cross-attention) and re-primed with the next GEMM's first stages afterwards
+            phase_n512<32, true>(acc, abuf, ws, lane);
+            CH_T(35);
+            lds_barrier();             // every wave is out of the w_qs GEMM: the activation block becomes O
+            cross_attention_p<5, XP>(acc, a, m0, abuf, wave, lane);
+#pragma unroll
+            for (int i = 0; i < CH_D; ++i) ws_load(ws, i, ws.pos + i);
+        } else {
+            phase_n512<32>(acc, abuf, ws, lane);
+            CH_T(35);
+            lds_barrier();             // every wave is out of the w_qs GEMM: the activation block becomes O
+            cross_attention(acc, a, m0, abuf, wave, lane);
+        }
         CH_T(36);
         lds_barrier();
     }
@@ -959,6 +1102,15 @@ extern "C" int tcdiff_chain(const tcdiff_chain_args* a, hipStream_t stream) {
         return TC_ERR_ARG;
     static tc_dev_state dev_state;
     const int n_cu = tc_device_once(dev_state, [](int) {
+#if CH_XP > 0
+        {
+            const void* xf[2] = {reinterpret_cast<const void*>(chain_kernel<TC_CHAIN_FULL, CH_XP>),
+                                 reinterpret_cast<const void*>(chain_kernel<TC_CHAIN_FULL_LAST, CH_XP>)};
+            for (const void* f : xf)
+                if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, CH_SMEM) != hipSuccess)
+                    return hipErrorInvalidValue;
+        }
+#endif
         const void* fns[6] = {reinterpret_cast<const void*>(chain_kernel<TC_CHAIN_A>),
                               reinterpret_cast<const void*>(chain_kernel<TC_CHAIN_B>),
                               reinterpret_cast<const void*>(chain_kernel<TC_CHAIN_B_LAST>),
@@ -978,8 +1130,19 @@ extern "C" int tcdiff_chain(const tcdiff_chain_args* a, hipStream_t stream) {
         case TC_CHAIN_A: hipLaunchKernelGGL(chain_kernel<TC_CHAIN_A>, grid, dim3(512), CH_SMEM, stream, *a); break;
         case TC_CHAIN_B: hipLaunchKernelGGL(chain_kernel<TC_CHAIN_B>, grid, dim3(512), CH_SMEM, stream, *a); break;
         case TC_CHAIN_B_LAST: hipLaunchKernelGGL(chain_kernel<TC_CHAIN_B_LAST>, grid, dim3(512), CH_SMEM, stream, *a); break;
+#if CH_XP > 0
+        case TC_CHAIN_FULL:
+            if (a->nkt == 5) hipLaunchKernelGGL((chain_kernel<TC_CHAIN_FULL, CH_XP>), grid, dim3(512), CH_SMEM, stream, *a);
+            else hipLaunchKernelGGL(chain_kernel<TC_CHAIN_FULL>, grid, dim3(512), CH_SMEM, stream, *a);
+            break;
+        default:
+            if (a->nkt == 5) hipLaunchKernelGGL((chain_kernel<TC_CHAIN_FULL_LAST, CH_XP>), grid, dim3(512), CH_SMEM, stream, *a);
+            else hipLaunchKernelGGL(chain_kernel<TC_CHAIN_FULL_LAST>, grid, dim3(512), CH_SMEM, stream, *a);
+            break;
+#else
         case TC_CHAIN_FULL: hipLaunchKernelGGL(chain_kernel<TC_CHAIN_FULL>, grid, dim3(512), CH_SMEM, stream, *a); break;
         default: hipLaunchKernelGGL(chain_kernel<TC_CHAIN_FULL_LAST>, grid, dim3(512), CH_SMEM, stream, *a); break;
+#endif
     }
     TC_CHECK_LAUNCH();
     return TC_OK;

@@ -179,13 +179,14 @@ def test_chain_b_kernel_against_op_by_op_sequence(last):
         assert dx[0] < 6e-2 and dx[1] < 2e-3
 
 
+@pytest.mark.parametrize("S", [60, 150])      # 62 keys: the rolled cross-attention loop; 152 keys = 5 tiles: the pipelined one
 @pytest.mark.parametrize("last", [False, True])
-def test_fused_layer_chain_against_chain_a_attention_chain_b(last):
+def test_fused_layer_chain_against_chain_a_attention_chain_b(last, S):
     """TC_CHAIN_FULL (cross-attention inside the launch, K / V from the fragment-ordered images) against the three
     launches it replaces on the same random data: blocks that straddle two sequences (L = 120: the second 32-row tile of
     block 1 crosses a sequence boundary), a shared null-conditioning slot for the first sequences, a ragged tail."""
     dt, bf = L.DT_BF16, torch.bfloat16
-    Lq, nseq, H, S = 120, 5, 8, 60
+    Lq, nseq, H = 120, 5, 8
     M = nseq * Lq - 9
     Lp, Lk = K.round_up(Lq, 128), S + 2
     Lpc, nkt = K.round_up(Lk, 128), (Lk + 31) // 32
