@@ -53,7 +53,10 @@
 #define CH_QKV_R CH_D        // ring depth of the Q / K / V GEMMs at the end of the launch
 #endif
 #ifndef CH_XP
-#define CH_XP 3              // K / V register sets of the pipelined in-kernel cross-attention for a 5-tile memory (0: never)
+#define CH_XP 0              // K / V register sets of the pipelined in-kernel cross-attention for a 5-tile memory (0: off).
+                             // Measured with 2 and 3 sets: the launch takes the same time (115.1 / 116.5 vs 115.7 / 114.3 us,
+                             // same box): the cross-attention streams 640 KB of K / V per block and is bound by that, like
+                             // the weight stream, not by the round trip per tile.  Kept as a build option (-DCH_XP=3).
 #endif
 #define CH_STAGE 2048
 
