@@ -681,10 +681,13 @@ DEVINL void cross_attention_p(const f32x16_t (&qacc)[2][2], const tcdiff_chain_a
 }
 
 #ifdef CH_STAMP   // diagnostic build: per-phase timestamps of block 0, every wave, into the (otherwise unused) h_out buffer
-#define CH_T(i) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (MODE == TC_CHAIN_B || MODE == TC_CHAIN_FULL)) \
+#ifndef CH_STAMP_BLOCK
+#define CH_STAMP_BLOCK 0      // the LOGICAL 64-row block that writes the stamps (7 = rows 448..511: straddles two 450-row sequences)
+#endif
+#define CH_T(i) do { if (m0 == 64 * CH_STAMP_BLOCK && (threadIdx.x & 63) == 0 && (MODE == TC_CHAIN_B || MODE == TC_CHAIN_FULL)) \
         reinterpret_cast<unsigned long long*>(a.h_out)[(threadIdx.x >> 6) * 64 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 // the shader-clock counter beside the 100 MHz one: slots 60 / 61 = s_memtime at the first / last stamp
-#define CH_TC(i) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (MODE == TC_CHAIN_B || MODE == TC_CHAIN_FULL)) \
+#define CH_TC(i) do { if (m0 == 64 * CH_STAMP_BLOCK && (threadIdx.x & 63) == 0 && (MODE == TC_CHAIN_B || MODE == TC_CHAIN_FULL)) \
         reinterpret_cast<unsigned long long*>(a.h_out)[(threadIdx.x >> 6) * 64 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define CH_TC(i) do { } while (0)
