@@ -8,8 +8,10 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-template <int BARRIER, int VALU>   // barrier between phases (0/1), VALU instructions per wave between phases (x64)
-__global__ __launch_bounds__(512) void probe(const u32x4* __restrict__ buf, int n_stages, float* out, unsigned long long* tm) {
+template <int BARRIER, int VALU, int STORES = 0>   // barrier between phases (0/1), VALU instructions per wave between phases
+                                               // (x64), 16-byte global stores per lane at the end of the gap
+__global__ __launch_bounds__(512) void probe(const u32x4* __restrict__ buf, int n_stages, float* out, unsigned long long* tm,
+                                            float* sink = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < 65536 / 4; i += 512) reinterpret_cast<float*>(smem)[i] = 1.0f;
@@ -58,6 +60,12 @@ __global__ __launch_bounds__(512) void probe(const u32x4* __restrict__ buf, int 
 #pragma unroll
             for (int k = 0; k < 64; ++k) junk = __builtin_fmaf(junk, 1.0001f, 0.5f);
         }
+        if (STORES) {   // an epilogue's row stores: 32 rows x 32 bytes per instruction, column-blocked like the kernel's
+            float* sp = sink + ((size_t)blockIdx.x * 8 + wave) * 16384 / 4 + (s0 & 1) * 0;
+#pragma unroll
+            for (int k = 0; k < STORES; ++k)
+                *reinterpret_cast<float4*>(sp + k * 256 + lane * 4) = make_float4(junk, junk, junk, junk);
+        }
         if (BARRIER && VALU) __syncthreads();
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
@@ -67,10 +75,12 @@ __global__ __launch_bounds__(512) void probe(const u32x4* __restrict__ buf, int 
     if (blockIdx.x == 0 && lane == 0) { tm[wave * 2] = t1 - t0; tm[wave * 2 + 1] = tg; }
 }
 
-template <int BARRIER, int VALU>
+template <int BARRIER, int VALU, int STORES = 0>
 void run(const u32x4* const* bufs, int nbuf, int n_stages, float* out, unsigned long long* tm, int nblk, const char* name) {
-    hipFuncSetAttribute((const void*)probe<BARRIER, VALU>, hipFuncAttributeMaxDynamicSharedMemorySize, 159744);
-    for (int i = 0; i < nbuf + 8; ++i) probe<BARRIER, VALU><<<nblk, 512, 159744>>>(bufs[i % nbuf], n_stages, out, tm);
+    static float* sink = nullptr;
+    if (!sink) hipMalloc(&sink, (size_t)256 * 8 * 16384);
+    hipFuncSetAttribute((const void*)probe<BARRIER, VALU, STORES>, hipFuncAttributeMaxDynamicSharedMemorySize, 159744);
+    for (int i = 0; i < nbuf + 8; ++i) probe<BARRIER, VALU, STORES><<<nblk, 512, 159744>>>(bufs[i % nbuf], n_stages, out, tm, sink);
     hipDeviceSynchronize();
     unsigned long long h[16];
     hipMemcpy(h, tm, sizeof(h), hipMemcpyDeviceToHost);
@@ -93,6 +103,7 @@ int main() {
         run<0, 20>(bufs, NB, n_stages, out, tm, nb, "1280 VALU between phases");
         run<1, 20>(bufs, NB, n_stages, out, tm, nb, "barrier + 1280 VALU + barrier");
         run<1, 40>(bufs, NB, n_stages, out, tm, nb, "barrier + 2560 VALU + barrier");
+        run<1, 20, 16>(bufs, NB, n_stages, out, tm, nb, "... 1280 VALU + 16 KB stores/wave");
     }
     return 0;
 }
