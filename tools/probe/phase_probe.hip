@@ -8,7 +8,8 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-template <int BARRIER, int VALU, int STORES = 0>   // barrier between phases (0/1), VALU instructions per wave between phases
+template <int BARRIER, int VALU, int STORES = 0, int COLD = 0>   // COLD: all phases as straight-line code (every instruction
+                                               // fetched once, like the kernel); barrier between phases (0/1), VALU instructions per wave between phases
                                                // (x64), 16-byte global stores per lane at the end of the gap
 __global__ __launch_bounds__(512) void probe(const u32x4* __restrict__ buf, int n_stages, float* out, unsigned long long* tm,
                                             float* sink = nullptr) {
@@ -34,7 +35,8 @@ __global__ __launch_bounds__(512) void probe(const u32x4* __restrict__ buf, int 
     };
     float junk = (float)lane;
     unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), tg = 0;
-    for (int s0 = 0; s0 + 32 <= n_stages; s0 += 32) {
+#pragma unroll (COLD ? 11 : 1)
+    for (int s0 = 0; s0 + 32 <= (COLD ? 352 : n_stages); s0 += 32) {
         const unsigned long long p0 = __builtin_amdgcn_s_memrealtime();
         u32x4 a0 = frag(0, r), a1 = frag(0, 32 + r);
 #pragma unroll
@@ -75,12 +77,12 @@ __global__ __launch_bounds__(512) void probe(const u32x4* __restrict__ buf, int 
     if (blockIdx.x == 0 && lane == 0) { tm[wave * 2] = t1 - t0; tm[wave * 2 + 1] = tg; }
 }
 
-template <int BARRIER, int VALU, int STORES = 0>
+template <int BARRIER, int VALU, int STORES = 0, int COLD = 0>
 void run(const u32x4* const* bufs, int nbuf, int n_stages, float* out, unsigned long long* tm, int nblk, const char* name) {
     static float* sink = nullptr;
     if (!sink) hipMalloc(&sink, (size_t)256 * 8 * 16384);
-    hipFuncSetAttribute((const void*)probe<BARRIER, VALU, STORES>, hipFuncAttributeMaxDynamicSharedMemorySize, 159744);
-    for (int i = 0; i < nbuf + 8; ++i) probe<BARRIER, VALU, STORES><<<nblk, 512, 159744>>>(bufs[i % nbuf], n_stages, out, tm, sink);
+    hipFuncSetAttribute((const void*)probe<BARRIER, VALU, STORES, COLD>, hipFuncAttributeMaxDynamicSharedMemorySize, 159744);
+    for (int i = 0; i < nbuf + 8; ++i) probe<BARRIER, VALU, STORES, COLD><<<nblk, 512, 159744>>>(bufs[i % nbuf], n_stages, out, tm, sink);
     hipDeviceSynchronize();
     unsigned long long h[16];
     hipMemcpy(h, tm, sizeof(h), hipMemcpyDeviceToHost);
@@ -104,6 +106,8 @@ int main() {
         run<1, 20>(bufs, NB, n_stages, out, tm, nb, "barrier + 1280 VALU + barrier");
         run<1, 40>(bufs, NB, n_stages, out, tm, nb, "barrier + 2560 VALU + barrier");
         run<1, 20, 16>(bufs, NB, n_stages, out, tm, nb, "... 1280 VALU + 16 KB stores/wave");
+        run<1, 20, 0, 1>(bufs, NB, n_stages, out, tm, nb, "barrier + 1280 VALU, straight-line");
+        run<0, 0, 0, 1>(bufs, NB, n_stages, out, tm, nb, "continuous, straight-line");
     }
     return 0;
 }
