@@ -48,6 +48,7 @@ typedef struct ihipStream_t* hipStream_t;
 #define TC_EPI_STORE_T 0   /* out[m][n] = T(act(acc + bias[n]))                                       */
 #define TC_EPI_STORE_F32 1 /* out[m][n] = act(acc + bias[n]) as fp32                                  */
 #define TC_EPI_QKV_HEADS 2 /* scatter to the head-major Q / K / V images read by tcdiff_attention     */
+#define TC_EPI_ATOMIC_F32 3 /* out[m][n] += acc (fp32 atomics; split-K): only through tcdiff_gemm_splitk */
 
 typedef struct {
     int mode;          /* TC_EPI_* */
@@ -62,6 +63,7 @@ typedef struct {
     int n_q, n_k;      /* QKV: columns [0,n_q) are Q, [n_q,n_q+n_k) are K, the rest V (multiples of 128) */
     int tok_off;       /* QKV: added to the token index  */
     int seq_off;       /* QKV: added to the sequence index */
+    int k_splits;      /* TC_EPI_ATOMIC_F32: workgroups per output tile (set by tcdiff_gemm_splitk; 0 elsewhere) */
 } tcdiff_tile_epi;
 
 /* C[M,N] = A[M,K] * W[N,K]^T with epilogue.  If A2 != NULL, output columns >= split_n (a multiple of 128)
@@ -372,6 +374,135 @@ typedef struct {
 } tcdiff_ema_chunk;
 int tcdiff_ema_update(const tcdiff_ema_chunk* chunks, int n_chunks, float beta, float one_minus_beta,
                       hipStream_t stream);
+
+/* =====================================================================================================================
+ * Training step: train-mode forward pieces and the backward pass (csrc/train_ops.hip, attention_train.hip, gemm.hip).
+ * The reference has no backward code: it is torch autograd over model/model.py + model/diffusion.py:636-741, driven by
+ * accelerator.backward(total_loss) at TCDiff.py:232.  tcdiff_amd/train_engine.py sequences these launchers as an
+ * explicit forward + reverse schedule behind ONE torch.autograd.Function.
+ *
+ * Gradient dtypes: the gradient of a T-typed activation is T; the gradient of the fp32 residual stream is fp32;
+ * parameter gradients are fp32 and ACCUMULATE (+=) into caller-zeroed buffers.
+ *
+ * Dropout (train mode; model/model.py:98,103,240,244-245,383,396,400-401 and nn.MultiheadAttention's weights) is a
+ * counter-based hash of (seed, site, flat element index) -- csrc/train_common.h -- regenerated by the backward kernels.
+ * `seed` is a DEVICE int[2] (NULL = {0,0}); drop_thr = floor(p * 2^32) (0 disables), drop_scale = 1 / (1 - p). */
+#define TC_SITE_ENC(i, k) (4 * (i) + (k))        /* encoder layer i: k = 0 attention weights, 1 dropout1, 2 inner, 3 dropout2 */
+#define TC_SITE_DEC(l, k) (16 + 8 * (l) + (k))   /* decoder layer l: k = 0 self weights, 1 self fc, 2 dropout1, 3 cross
+                                                    weights, 4 cross fc, 5 dropout2, 6 inner, 7 dropout3 */
+
+/* dst[r][c] = T(src[r][c]) (c < cols; zeros for cols <= c < cols_pad) and/or dstT[c][r] = T(src[r][c]) (r < rows; zeros
+ * for rows <= r < rows_pad), c < cols.  src is fp32 (src_f32 != 0) or T.  colsum (optional, fp32 [cols], caller-zeroed)
+ * += sum_r src[r][c]: the bias gradient of an nn.Linear while its dY is being repacked.  Produces the K-contiguous
+ * operands tcdiff_gemm_tile needs for dgrad (W^T) and wgrad (dY^T, X^T). */
+int tcdiff_cast_transpose(int dtype, int src_f32, const void* src, int rows, int cols, int ld_src, void* dst, int ld_dst,
+                          int cols_pad, void* dstT, int ld_dstT, int rows_pad, float* colsum, hipStream_t stream);
+
+/* Split-K GEMM with fp32 accumulation into `out`: out[m][n] += sum_k A[m][k] W[n][k] (atomic adds; `splits` workgroups
+ * share each 128x128 tile).  The weight gradient dW[N,K] += dY^T X of every nn.Linear, with M = out features, N = in
+ * features and the contraction over the token rows. */
+int tcdiff_gemm_splitk(int dtype, const void* A, const void* W, int M, int N, int K, int lda, int ldw, float* out,
+                       int ldc, int splits, hipStream_t stream);
+
+/* y = T(dropout(act(a)))  /  da = dy * mask / (1 - p) * act'(a).  a, da: fp32 (a_f32 != 0) or T [rows][ld_a]; y, dy:
+ * T [rows][ld_y]; columns >= cols of y / da are written as zeros up to the leading dimension.  Hash index = r * cols + c.
+ * Replaces the activations + nn.Dropout of model/model.py:244,400 (GELU), :490-494,522-528 (ReLU), :454-458,157 (Mish),
+ * :496-501 (SiLU) and their autograd. */
+int tcdiff_act_drop(int dtype, int a_f32, const void* a, int ld_a, void* y, int ld_y, int rows, int cols, int act,
+                    const int* seed, int site, uint32_t drop_thr, float drop_scale, hipStream_t stream);
+int tcdiff_act_drop_bwd(int dtype, int a_f32, const void* a, int ld_a, const void* dy, int ld_y, void* da, int rows,
+                        int cols, int act, const int* seed, int site, uint32_t drop_thr, float drop_scale,
+                        hipStream_t stream);
+
+/* The row-local glue between two GEMMs of a transformer block, forward and backward, one wave per 512-wide row:
+ *   u = dropout_pre(z + bias);  y = dropout_post(LayerNorm_post(u));  v = (scale + 1) y + shift;  xn = xres + v;
+ *   hn = LayerNorm_next(xn);  rot = rotary(hn, pos)                      (each stage optional: TC_ROWF_* flags)
+ * = model/model.py:103-106 (fc dropout + layer_norm), :327,334,339 (dropout1..3 + featurewise_affine + residual),
+ *   :326,332,338,344 (the next norm), :375,387-388 (rotary); encoder :220-221,240,245.
+ * Backward (tcdiff_row_bwd) recomputes the forward from (z, xres) and returns d_z (T), d_xres (fp32), per-sequence FiLM
+ * gradients (atomic += into d_film) and per-block partial sums of the LayerNorm / bias gradients in `partials`
+ * ([grid blocks][5][512] fp32: d_bias, d_ln_g, d_ln_b, d_nln_g, d_nln_b), folded by tcdiff_row_param_reduce. */
+#define TC_ROWF_BIAS 1
+#define TC_ROWF_DROP_PRE 2
+#define TC_ROWF_LN_POST 4
+#define TC_ROWF_DROP_POST 8
+#define TC_ROWF_FILM 16
+#define TC_ROWF_RES 32
+#define TC_ROWF_STORE_X 64
+#define TC_ROWF_NEXT_LN 128
+#define TC_ROWF_STORE_H 256    /* hout = T(hn), or T(xn) without NEXT_LN */
+#define TC_ROWF_STORE_ROT 512
+typedef struct {
+    int flags, M, L;           /* rows; rows per sequence (FiLM row = m / L); M % L == 0 */
+    const float* z;            /* fp32 [M][512] */
+    const float* bias;
+    const float* ln_g; const float* ln_b; float ln_eps;
+    const float* film; int film_ld;   /* film[seq * film_ld + c] scale, + 512 shift */
+    const float* xres;
+    float* xout;
+    const float* nln_g; const float* nln_b; float nln_eps;
+    void* hout; void* rout;
+    const float* rope; int pos_mod, pos_base;   /* rotary position = pos_base + m % pos_mod */
+    const int* seed; uint32_t drop_thr; float drop_scale; int site_pre, site_post;
+    /* backward only */
+    const float* d_xn;         /* fp32 [M][512] or NULL: gradient reaching xn through the residual path of the next block */
+    const void* d_h;           /* T [M][512] or NULL */
+    const void* d_rot;         /* T [M][512] or NULL */
+    void* d_z;                 /* T [M][512] */
+    float* d_xres;             /* fp32 [M][512] (TC_ROWF_RES) */
+    float* d_film; int dfilm_ld;
+    float* partials; int chunks;   /* grid = chunks x (M / L) blocks; partials [chunks * M / L][5][512] */
+    int dz_f32;                /* != 0: d_z is fp32 (its consumer is not a GEMM: pooled / memory rows of the conditioning path) */
+} tcdiff_row_args;
+int tcdiff_row_fwd(int dtype, const tcdiff_row_args* a, hipStream_t stream);
+int tcdiff_row_bwd(int dtype, const tcdiff_row_args* a, hipStream_t stream);
+/* dst[k][c] += sum_blocks partials[blk][k][c] for the non-NULL dst[k], k < 5 */
+int tcdiff_row_param_reduce(const float* partials, int n_blocks, float* d_bias, float* d_ln_g, float* d_ln_b,
+                            float* d_nln_g, float* d_nln_b, hipStream_t stream);
+
+/* Train-mode attention: as tcdiff_attention (one K/V per sequence), plus dropout on the softmax weights
+ * (model/model.py:98; nn.MultiheadAttention dropout) and lse[seq][H][Lp_q] = log2 sum_k 2^(s log2 e) for the backward. */
+int tcdiff_attention_train(int dtype, const void* Q, const void* K, const void* V, void* O, float* lse, int n_seq, int H,
+                           int Lq, int Lk, int Lp_q, int Lp_k, int ldo, const int* seed, int site, uint32_t drop_thr,
+                           float drop_scale, hipStream_t stream);
+/* Backward of the above (P is recomputed from Q, K and lse; the dropout bits are regenerated).  dO: head-major image
+ * T[n_seq][H][Lp_q][64] (zero pad rows); O: token-major T as written by the forward.  Outputs are token-major T:
+ *   dQ[(seq Lq + q) ld_dq + head 64 + d] (times scale_q: the gradient with respect to the UNSCALED projection),
+ *   dK[(seq Lk + k) ld_dkv + head 64 + d], dV likewise.   delta: fp32 workspace [n_seq][H][Lp_q].
+ * Two launches (query-major for dQ, key-major for dK / dV): no atomics, bitwise reproducible. */
+int tcdiff_attention_bwd(int dtype, const void* Q, const void* K, const void* V, const void* O, const void* dO,
+                         const float* lse, float* delta, void* dQ, int ld_dq, void* dK, void* dV, int ld_dkv, int n_seq,
+                         int H, int Lq, int Lk, int Lp_q, int Lp_k, int ldo, float scale_q, const int* seed, int site,
+                         uint32_t drop_thr, float drop_scale, hipStream_t stream);
+
+/* small fp32 helpers of the conditioning path and their adjoints */
+/* out[r][c] = a[r * ld_a + c] + b[r * ld_b + c], c < cols */
+int tcdiff_add_rows(const float* a, int ld_a, const float* b, int ld_b, float* out, int ld_out, int rows, int cols,
+                    hipStream_t stream);
+/* out[b] = keep[b] ? x[b] : nul (broadcast), rows of `n` floats  (torch.where(keep_mask, ., null_*), model/model.py:585-589,609-610) */
+int tcdiff_select_rows(const float* x, const float* nul, const unsigned char* keep, float* out, int B, long n,
+                       hipStream_t stream);
+/* dx[b] = keep[b] ? g[b] : 0 (dx may be NULL);  dnul += sum over not-kept b of g[b] (caller-zeroed, may be NULL) */
+int tcdiff_select_rows_bwd(const float* g, const unsigned char* keep, float* dx, float* dnul, int B, long n,
+                           hipStream_t stream);
+/* dx[b][s][c] = g_tok[b][s][c] (NULL = 0) + g_pool[b][c] / S: adjoint of {tokens used as they are, tokens.mean(-2)} */
+int tcdiff_pool_bwd(const float* g_tok, const float* g_pool, float* dx, int B, int S, int C, hipStream_t stream);
+
+/* out[k] = coef[k] * mean_b terms[b][k] for the four terms of tcdiff_loss_terms (coef = 0.636, 2.964, 0.646, 10.942),
+ * out[4] = their sum (model/diffusion.py:735-741). */
+int tcdiff_loss_total(const float* terms, int b, float* out, hipStream_t stream);
+
+/* d total / d model_out and d total / d joints_model of the four loss terms (model/diffusion.py:668-741) for
+ * total = 0.636 mean_b recon + 2.964 mean_b vel + 0.646 mean_b fk + 10.942 mean_b foot times `gscale` (the incoming
+ * gradient of the scalar).  d_out [b][S*dn][C] receives the reconstruction + velocity part (every element written);
+ * d_joints [b*S*dn][24][3] the FK + foot part (every element written). */
+int tcdiff_loss_terms_bwd(const float* model_out, const float* x_start, const float* joints_model,
+                          const float* joints_target, const float* p2_weight, const long* t, const float* gscale,
+                          float* d_out, float* d_joints, int b, int dn, int S, int C, int l1, hipStream_t stream);
+/* Reverse of tcdiff_ax_from_6v + tcdiff_smpl_fk for the model branch: d_joints -> += d_out[row][4..6] (root) and
+ * += d_out[row][7 + 6 j ..] (6-D rotations); motion rows [n][C]. */
+int tcdiff_fk_bwd(const float* motion, const float* d_joints, long n, int C, const int* parents, const float* offsets,
+                  float* d_out, hipStream_t stream);
 
 /* library identification */
 const char* tcdiff_version(void);

@@ -106,6 +106,51 @@ def mish(x: torch.Tensor) -> torch.Tensor:
     return x * torch.tanh(F.softplus(x))
 
 
+# ----------------------------------------------------------------------------------------------
+# train-mode dropout: the product's counter hash (tcdiff_amd/csrc/train_common.h), evaluated in numpy
+# ----------------------------------------------------------------------------------------------
+def _fmix32(h: np.ndarray) -> np.ndarray:
+    """MurmurHash3's 32-bit finaliser on uint32 arrays (wrap-around arithmetic through uint64)."""
+    h = h.astype(np.uint64)
+    h ^= h >> np.uint64(16)
+    h = (h * np.uint64(0x85EBCA6B)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(13)
+    h = (h * np.uint64(0xC2B2AE35)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(16)
+    return h
+
+
+def dropout_keep(seed, site: int, shape, p: float) -> torch.Tensor:
+    """keep mask (bool, `shape`) of dropout site `site`: element with C-order flat index x is kept iff
+    fmix32((x * 0x9E3779B1) ^ key) >= floor(p * 2^32), key = fmix32(seed0 ^ (0x9E3779B9 * (site + 1))) ^ seed1."""
+    n = int(np.prod(shape))
+    s0, s1 = np.uint64(seed[0] & 0xFFFFFFFF), np.uint64(seed[1] & 0xFFFFFFFF)
+    key = _fmix32(np.array([s0 ^ np.uint64((0x9E3779B9 * (site + 1)) & 0xFFFFFFFF)], dtype=np.uint64))[0] ^ s1
+    x = np.arange(n, dtype=np.uint64) & np.uint64(0xFFFFFFFF)
+    h = _fmix32(((x * np.uint64(0x9E3779B1)) & np.uint64(0xFFFFFFFF)) ^ key)
+    return torch.from_numpy((h >= np.uint64(int(p * 4294967296.0))).reshape(shape))
+
+
+class DropPlan:
+    """Train-mode dropout with the product's masks: plan(x, site) = x * keep / (1 - p)  (nn.Dropout, F.dropout).
+    Sites: encoder layer i -> 4 i + {0 attention weights, 1 dropout1, 2 feed-forward inner, 3 dropout2}; decoder layer l
+    -> 16 + 8 l + {0 self weights, 1 self fc out, 2 dropout1, 3 cross weights, 4 cross fc out, 5 dropout2, 6 inner,
+    7 dropout3}  (model/model.py:98,103,240,244-245,383,396,400-401)."""
+
+    def __init__(self, seed, p: float):
+        self.seed, self.p = (int(seed[0]), int(seed[1])), float(p)
+
+    def __call__(self, x: torch.Tensor, site: int) -> torch.Tensor:
+        if self.p <= 0.0:
+            return x
+        keep = dropout_keep(self.seed, site, tuple(x.shape), self.p)
+        return torch.where(keep, x * np.float32(1.0 / (1.0 - self.p)), torch.zeros_like(x))
+
+
+def _nodrop(x, site):
+    return x
+
+
 def layer_norm(x, sd: SD, prefix: str, eps: float) -> torch.Tensor:
     return F.layer_norm(x, (x.shape[-1],), sd[prefix + ".weight"], sd[prefix + ".bias"], eps)
 
@@ -119,17 +164,18 @@ def _heads(x: torch.Tensor, n_head: int) -> torch.Tensor:
     return x.view(b, n, n_head, -1).transpose(1, 2)  # (b,h,n,dk)
 
 
-def sbi_msa(q_in, k_in, v_in, sd: SD, prefix: str, n_head: int) -> torch.Tensor:
-    """SBI_MSA.forward with trj_dist=None, eval mode (model/model.py:71-107).
+def sbi_msa(q_in, k_in, v_in, sd: SD, prefix: str, n_head: int, drop=_nodrop, site0: int = 0) -> torch.Tensor:
+    """SBI_MSA.forward with trj_dist=None (model/model.py:71-107); drop: train-mode dropout on the softmax weights (site0)
+    and on the fc output (site0 + 1), :98,103.
 
     softmax((Q/8) K^T) V, bias-free projections, bias-free fc, LayerNorm(eps=1e-6).
     The ``indexed_matrix`` product (:82-83) does not reach the output and is omitted."""
     q = _heads(F.linear(q_in, sd[prefix + ".w_qs.weight"]), n_head)
     k = _heads(F.linear(k_in, sd[prefix + ".w_ks.weight"]), n_head)
     v = _heads(F.linear(v_in, sd[prefix + ".w_vs.weight"]), n_head)
-    att = torch.softmax(torch.matmul(q / (DK ** 0.5), k.transpose(2, 3)), dim=-1)
+    att = drop(torch.softmax(torch.matmul(q / (DK ** 0.5), k.transpose(2, 3)), dim=-1), site0)
     o = torch.matmul(att, v).transpose(1, 2).reshape(q_in.shape[0], q_in.shape[1], -1)
-    o = F.linear(o, sd[prefix + ".fc.weight"])
+    o = drop(F.linear(o, sd[prefix + ".fc.weight"]), site0 + 1)
     return layer_norm(o, sd, prefix + ".layer_norm", 1e-6)
 
 
@@ -149,7 +195,7 @@ def gelu(x):
     return F.gelu(x)  # exact erf form: TCDiff.py:85 passes F.gelu
 
 
-def encoder_layer(x, sd: SD, prefix: str, freqs, n_head: int) -> torch.Tensor:
+def encoder_layer(x, sd: SD, prefix: str, freqs, n_head: int, drop=_nodrop, site0: int = 0) -> torch.Tensor:
     """TransformerEncoderLayer, norm_first, eval (model/model.py:211-245).
 
     nn.MultiheadAttention with packed in_proj (+bias), q=k=rot(LN1 x), v=LN1 x, out_proj with bias."""
@@ -160,25 +206,26 @@ def encoder_layer(x, sd: SD, prefix: str, freqs, n_head: int) -> torch.Tensor:
     q = _heads(F.linear(qk, w[:d], b[:d]), n_head)
     k = _heads(F.linear(qk, w[d:2 * d], b[d:2 * d]), n_head)
     v = _heads(F.linear(h, w[2 * d:], b[2 * d:]), n_head)
-    att = torch.softmax(torch.matmul(q, k.transpose(2, 3)) / math.sqrt(d // n_head), dim=-1)
+    att = drop(torch.softmax(torch.matmul(q, k.transpose(2, 3)) / math.sqrt(d // n_head), dim=-1), site0)
     o = torch.matmul(att, v).transpose(1, 2).reshape(x.shape)
-    x = x + linear(o, sd, prefix + ".self_attn.out_proj")
+    x = x + drop(linear(o, sd, prefix + ".self_attn.out_proj"), site0 + 1)
     h = layer_norm(x, sd, prefix + ".norm2", 1e-5)
-    return x + linear(gelu(linear(h, sd, prefix + ".linear1")), sd, prefix + ".linear2")
+    return x + drop(linear(drop(gelu(linear(h, sd, prefix + ".linear1")), site0 + 2), sd, prefix + ".linear2"), site0 + 3)
 
 
-def decoder_layer(x, mem, t, sd: SD, prefix: str, freqs, n_head: int) -> torch.Tensor:
+def decoder_layer(x, mem, t, sd: SD, prefix: str, freqs, n_head: int, drop=_nodrop, site0: int = 0) -> torch.Tensor:
     """FiLMTransformerDecoderLayer.forward, norm_first, eval (model/model.py:323-344,371).
 
     The traj_Modulation result (:346-355) is discarded by ``return x`` (:371): not computed."""
     h = layer_norm(x, sd, prefix + ".norm1", 1e-5)
     qk = rotary(h, freqs)
-    x = x + affine(sbi_msa(qk, qk, h, sd, prefix + ".self_attn", n_head), film(t, sd, prefix + ".film1"))
+    a = drop(sbi_msa(qk, qk, h, sd, prefix + ".self_attn", n_head, drop, site0), site0 + 2)
+    x = x + affine(a, film(t, sd, prefix + ".film1"))
     h = layer_norm(x, sd, prefix + ".norm2", 1e-5)
-    c = sbi_msa(rotary(h, freqs), rotary(mem, freqs), mem, sd, prefix + ".multihead_attn", n_head)
-    x = x + affine(c, film(t, sd, prefix + ".film2"))
+    c = sbi_msa(rotary(h, freqs), rotary(mem, freqs), mem, sd, prefix + ".multihead_attn", n_head, drop, site0 + 3)
+    x = x + affine(drop(c, site0 + 5), film(t, sd, prefix + ".film2"))
     h = layer_norm(x, sd, prefix + ".norm3", 1e-5)
-    f = linear(gelu(linear(h, sd, prefix + ".linear1")), sd, prefix + ".linear2")
+    f = drop(linear(drop(gelu(linear(h, sd, prefix + ".linear1")), site0 + 6), sd, prefix + ".linear2"), site0 + 7)
     x = x + affine(f, film(t, sd, prefix + ".film3"))
     return linear(layer_norm(x, sd, prefix + ".norm4", 1e-5), sd, prefix + ".linear3")  # NO residual (:344)
 
@@ -196,7 +243,7 @@ def infer_config(sd: SD) -> dict:
     return dict(latent=latent, nfeats=nfeats, dn=dn, seq_len=seq_len, n_layers=n_layers, n_head=n_head)
 
 
-def music_branch(sd: SD, cond_embed: torch.Tensor, cfg: dict):
+def music_branch(sd: SD, cond_embed: torch.Tensor, cfg: dict, drop=_nodrop):
     """Step-invariant part of DanceDecoder.forward (model/model.py:572-583,593-597):
     returns (cond_tokens (B,S,D) before the keep-mask select, cond_hidden (B,D) for kept clips)."""
     b, clen, _ = cond_embed.shape
@@ -205,7 +252,7 @@ def music_branch(sd: SD, cond_embed: torch.Tensor, cfg: dict):
     c = cond_embed.reshape(b, clen // 2, -1).float()
     tok = linear(F.relu(linear(c, sd, "cond_projection.0")), sd, "cond_projection.2")
     for i in range(2):
-        tok = encoder_layer(tok, sd, f"cond_encoder.{i}", sd["rotary.freqs"], cfg["n_head"])
+        tok = encoder_layer(tok, sd, f"cond_encoder.{i}", sd["rotary.freqs"], cfg["n_head"], drop, 4 * i)
     return tok
 
 
@@ -217,8 +264,8 @@ def cond_hidden_of(sd: SD, tokens: torch.Tensor) -> torch.Tensor:
 
 
 def decoder_forward(sd: SD, x, cond_embed, times, cond_drop_prob: float = 0.0,
-                    keep_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """DanceDecoder.forward, eval, trj_dist=None (model/model.py:548-624).
+                    keep_mask: Optional[torch.Tensor] = None, drop=_nodrop) -> torch.Tensor:
+    """DanceDecoder.forward, trj_dist=None (model/model.py:548-624); eval mode, or train mode with `drop` a DropPlan.
 
     keep_mask: optional explicit bool (B,) (else prob_mask_like semantics, model/utils.py:52-58)."""
     cfg = infer_config(sd)
@@ -241,7 +288,7 @@ def decoder_forward(sd: SD, x, cond_embed, times, cond_drop_prob: float = 0.0,
         else:
             keep_mask = torch.zeros(B).float().uniform_(0, 1) < p
     # :572-589 music tokens, null select
-    tok = music_branch(sd, cond_embed, cfg)
+    tok = music_branch(sd, cond_embed, cfg, drop)
     tok = torch.where(keep_mask[:, None, None], tok, sd["null_cond_embed"].to(tok.dtype))
     # :593-610 pooled hidden, null select
     ch = cond_hidden_of(sd, tok)
@@ -254,7 +301,7 @@ def decoder_forward(sd: SD, x, cond_embed, times, cond_drop_prob: float = 0.0,
     mem = layer_norm(torch.cat((tok, ttok), dim=-2), sd, "norm_cond", 1e-5)
     # :621 decoder stack, :623 final layer
     for i in range(cfg["n_layers"]):
-        x = decoder_layer(x, mem, t, sd, f"seqTransDecoder.stack.{i}", sd["rotary.freqs"], cfg["n_head"])
+        x = decoder_layer(x, mem, t, sd, f"seqTransDecoder.stack.{i}", sd["rotary.freqs"], cfg["n_head"], drop, 16 + 8 * i)
     return linear(x, sd, "final_layer")
 
 
@@ -773,7 +820,8 @@ def smpl_fk(rotations: torch.Tensor, root_positions: torch.Tensor) -> torch.Tens
 
 
 def p_losses(sd: SD, tab, x_start: torch.Tensor, cond: torch.Tensor, t: torch.Tensor, noise: torch.Tensor,
-             keep_mask: torch.Tensor, loss_type: str = "l2", with_fk: bool = True, model_out: Optional[torch.Tensor] = None):
+             keep_mask: torch.Tensor, loss_type: str = "l2", with_fk: bool = True, model_out: Optional[torch.Tensor] = None,
+             drop=_nodrop):
     """model/diffusion.py:636-741 with the random draws injected: x_start (b, dn, S, C) dataset layout, noise in the
     PERMUTED layout (b, S, dn, C) as the reference draws it, keep_mask (b,) bool = prob_mask_like's result (eval mode:
     Dropout is the identity).  Returns (total, (recon, velocity, fk, foot)) with the reference's weights."""
@@ -783,7 +831,7 @@ def p_losses(sd: SD, tab, x_start: torch.Tensor, cond: torch.Tensor, t: torch.Te
     x_noisy = q_sample(tab, xs, t, noise).clone()
     x_noisy[:, :, :, [4, 5]] = xs[:, :, :, [4, 5]]
     x_noisy = x_noisy.reshape(bs, sq * dn, c)
-    out = decoder_forward(sd, x_noisy, cond, t, keep_mask=keep_mask) if model_out is None else model_out
+    out = decoder_forward(sd, x_noisy, cond, t, keep_mask=keep_mask, drop=drop) if model_out is None else model_out
     w = tab["p2_loss_weight"][t]
     mo, tg = out.reshape(bs, sq, dn, c), xs.reshape(bs, sq, dn, c)
     loss = lf(mo, tg).reshape(bs, -1).mean(1) * w

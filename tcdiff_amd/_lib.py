@@ -24,7 +24,7 @@ _vp, _i, _f, _l = C.c_void_p, C.c_int, C.c_float, C.c_long
 class TileEpi(C.Structure):
     _fields_ = [("mode", _i), ("act", _i), ("scale_q", _f), ("bias", _vp), ("out", _vp), ("out_k", _vp),
                 ("out_v", _vp), ("ldc", _i), ("L", _i), ("Lp", _i), ("H", _i), ("n_q", _i), ("n_k", _i),
-                ("tok_off", _i), ("seq_off", _i)]
+                ("tok_off", _i), ("seq_off", _i), ("k_splits", _i)]
 
 
 class RowEpi(C.Structure):
@@ -50,6 +50,20 @@ class StepPrologueArgs(C.Structure):
                 ("n_seq", _i), ("tab", _vp), ("n_t", _i), ("Kc", _vp), ("Vc", _vp), ("Kf", _vp), ("Vf", _vp),
                 ("NL", _i), ("n_kv", _i), ("H", _i), ("Lp", _i), ("nkt", _i), ("tok0", _i), ("x", _vp), ("xin", _vp),
                 ("rows", _i), ("nfeat", _i), ("ld_xin", _i)]
+
+
+class RowArgs(C.Structure):
+    """tcdiff_row_args (include/tcdiff_hip.h): the row-local block glue of the training step, forward and backward."""
+    _fields_ = [("flags", _i), ("M", _i), ("L", _i), ("z", _vp), ("bias", _vp), ("ln_g", _vp), ("ln_b", _vp),
+                ("ln_eps", _f), ("film", _vp), ("film_ld", _i), ("xres", _vp), ("xout", _vp), ("nln_g", _vp),
+                ("nln_b", _vp), ("nln_eps", _f), ("hout", _vp), ("rout", _vp), ("rope", _vp), ("pos_mod", _i),
+                ("pos_base", _i), ("seed", _vp), ("drop_thr", C.c_uint32), ("drop_scale", _f), ("site_pre", _i),
+                ("site_post", _i), ("d_xn", _vp), ("d_h", _vp), ("d_rot", _vp), ("d_z", _vp), ("d_xres", _vp),
+                ("d_film", _vp), ("dfilm_ld", _i), ("partials", _vp), ("chunks", _i), ("dz_f32", _i)]
+
+
+ROWF_BIAS, ROWF_DROP_PRE, ROWF_LN_POST, ROWF_DROP_POST, ROWF_FILM, ROWF_RES, ROWF_STORE_X, ROWF_NEXT_LN, ROWF_STORE_H, \
+    ROWF_STORE_ROT = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
 
 
 class AdanScalars(C.Structure):
@@ -84,6 +98,24 @@ _SIGS = {
     "tcdiff_sampler_constrain": [_i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, C.c_uint64, _i, _vp],
     "tcdiff_ema_update": [_vp, _i, _f, _f, _vp],
     "tcdiff_cfg_combine": [_vp, _vp, _i, _f, _vp, _i, _i, _vp],
+    # training step (csrc/train_ops.hip, attention_train.hip, gemm.hip)
+    "tcdiff_cast_transpose": [_i, _i, _vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp, _vp],
+    "tcdiff_gemm_splitk": [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp],
+    "tcdiff_act_drop": [_i, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, C.c_uint32, _f, _vp],
+    "tcdiff_act_drop_bwd": [_i, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i, C.c_uint32, _f, _vp],
+    "tcdiff_row_fwd": [_i, C.POINTER(RowArgs), _vp],
+    "tcdiff_row_bwd": [_i, C.POINTER(RowArgs), _vp],
+    "tcdiff_row_param_reduce": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "tcdiff_attention_train": [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, C.c_uint32, _f, _vp],
+    "tcdiff_attention_bwd": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i,
+                             _f, _vp, _i, C.c_uint32, _f, _vp],
+    "tcdiff_add_rows": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp],
+    "tcdiff_select_rows": [_vp, _vp, _vp, _vp, _i, _l, _vp],
+    "tcdiff_select_rows_bwd": [_vp, _vp, _vp, _vp, _i, _l, _vp],
+    "tcdiff_pool_bwd": [_vp, _vp, _vp, _i, _i, _i, _vp],
+    "tcdiff_loss_total": [_vp, _i, _vp, _vp],
+    "tcdiff_loss_terms_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "tcdiff_fk_bwd": [_vp, _vp, _l, _i, C.POINTER(_i), C.POINTER(_f), _vp, _vp],
 }
 
 EXPORTS = sorted(list(_SIGS) + ["tcdiff_version"])

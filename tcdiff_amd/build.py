@@ -8,8 +8,10 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SRC = [os.path.join(HERE, "csrc", f) for f in ("gemm.hip", "attention.hip", "ops.hip", "chain.hip", "train.hip")]
-HDR = [os.path.join(HERE, "csrc", "common.h"), os.path.join(ROOT, "include", "tcdiff_hip.h")]
+SRC = [os.path.join(HERE, "csrc", f) for f in ("gemm.hip", "attention.hip", "ops.hip", "chain.hip", "train.hip", "train_ops.hip",
+                                               "attention_train.hip")]
+HDR = [os.path.join(HERE, "csrc", h) for h in ("common.h", "attn_common.h", "train_common.h", "fk_math.h")] + \
+    [os.path.join(ROOT, "include", "tcdiff_hip.h")]
 LIB = os.path.join(HERE, "libtcdiff_gfx950.so")
 
 

@@ -72,7 +72,11 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(const char* __restrict__
     const int r = lane & 31, h = lane >> 5;
     // 1-D grid, XCD-remapped: an XCD owns a contiguous range of row panels with all their column tiles
     const int ntn = (N + 127) / 128;
-    const int tile_id = xcd_remap(blockIdx.x, gridDim.x);
+    // split-K (TC_EPI_ATOMIC_F32): `k_splits` workgroups share a tile, each with a contiguous range of k-tiles
+    const int nsplit = e.k_splits > 1 ? e.k_splits : 1;
+    const int ntiles = gridDim.x / nsplit;
+    const int split = blockIdx.x / ntiles;
+    const int tile_id = xcd_remap(blockIdx.x - split * ntiles, ntiles);
     const int m0 = (tile_id / ntn) * 128, n0 = (tile_id % ntn) * 128;
     const char* Ause = (A2 != nullptr && n0 >= split_n) ? A2 : A;
 
@@ -85,7 +89,9 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(const char* __restrict__
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.0f;
 
-    const int nk = K / P::KT;
+    const int nk_all = K / P::KT;
+    const int kt0 = (int)(((long)nk_all * split) / nsplit);
+    const int nk = (int)(((long)nk_all * (split + 1)) / nsplit) - kt0;      // >= 1: the launcher keeps splits <= k-tiles
     constexpr int STAGE = 2 * 128 * TC_ROWB;  // [A tile | W tile]
     constexpr int WOFF = 128 * TC_ROWB;
 
@@ -93,7 +99,7 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(const char* __restrict__
     // tile t of the k-loop -> slot t % NS; past the end the last tile is re-issued (never read), so that the number of
     // DMA instructions in flight behind a tile is the same in every trip: 8 per tile and wave
     auto issue = [&](int t) {
-        const int tt = t < nk ? t : nk - 1;
+        const int tt = kt0 + (t < nk ? t : nk - 1);
         char* dst = smem + (t % NS) * STAGE;
         stage_glds<128, 4>(dst, Ause + (long)tt * TC_ROWB, lda_b, m0, M, a_mod, wave, lane);
         stage_glds<128, 4>(dst + WOFF, W + (long)tt * TC_ROWB, ldw_b, n0, N, 0, wave, lane);
@@ -166,6 +172,41 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(const char* __restrict__
                             if (n + t < N) dst[t] = v[t];
                     }
                 }
+        }
+        return;
+    }
+
+    if (e.mode == TC_EPI_ATOMIC_F32) {
+        // out[m][n] += acc: the tile goes through LDS (two passes of 64 rows, fp32) so that every atomic wave-instruction
+        // covers 64 CONSECUTIVE floats of one output row -- 256 contiguous bytes, the shape the memory-side atomic units
+        // take at full rate (MI355X_MICROARCH.md, Global float atomics); a lane-per-row scatter of 16-byte pieces is ~17x slower.
+        constexpr int RSF = 128 * 4 + 16;
+        float* out = reinterpret_cast<float*>(e.out);
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            if (wm == pass) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int ml = i * 32 + r;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int nl = wn * 64 + j * 32 + 8 * g + 4 * h;
+                            const f32x4_t pk = {acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                            *reinterpret_cast<f32x4_t*>(smem + ml * RSF + nl * 4) = pk;
+                        }
+                }
+            }
+            __syncthreads();
+#pragma unroll 4
+            for (int c = tid; c < 64 * 128; c += 256) {
+                const int row = c >> 7, col = c & 127;
+                const int m = m0 + pass * 64 + row, n = n0 + col;
+                if (m < M && n < N)
+                    unsafeAtomicAdd(out + (long)m * e.ldc + n, *reinterpret_cast<const float*>(smem + row * RSF + col * 4));
+            }
+            if (pass == 0) __syncthreads();
         }
         return;
     }
@@ -461,9 +502,8 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(const char* __restrict_
 // =================================================================================================
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-extern "C" int tcdiff_gemm_tile(int dtype, const void* A, const void* A2, int split_n, const void* W, int M, int N,
-                                int K, int lda, int ldw, int a_mod, const tcdiff_tile_epi* epi,
-                                hipStream_t stream) {
+static int launch_tile(int dtype, const void* A, const void* A2, int split_n, const void* W, int M, int N, int K,
+                       int lda, int ldw, int a_mod, const tcdiff_tile_epi* epi, hipStream_t stream) {
     if (!A || !W || !epi || M <= 0 || N <= 0 || K <= 0) return TC_ERR_ARG;
     if (dtype != TC_DTYPE_BF16 && dtype != TC_DTYPE_F32) return TC_ERR_ARG;
     const int es = dtype == TC_DTYPE_BF16 ? 2 : 4;
@@ -487,8 +527,15 @@ extern "C" int tcdiff_gemm_tile(int dtype, const void* A, const void* A2, int sp
         if (!aligned16(epi->out)) return TC_ERR_ALIGN;
     }
     tcdiff_tile_epi e = *epi;
+    if (e.mode == TC_EPI_ATOMIC_F32) {
+        if (e.bias || e.act != TC_ACT_NONE || A2) return TC_ERR_ARG;
+        if (e.k_splits < 1) e.k_splits = 1;
+        if (e.k_splits > K / kt) e.k_splits = K / kt;
+    } else {
+        e.k_splits = 1;
+    }
     const int actk = e.act <= TC_ACT_GELU ? e.act : 3;   // 3 = runtime choice between the setup-only Mish / SiLU
-    dim3 grid(((N + 127) / 128) * ((M + 127) / 128));
+    dim3 grid(((N + 127) / 128) * ((M + 127) / 128) * e.k_splits);
     static tc_dev_state dev_state;
     const int n_cu = tc_device_once(dev_state, [](int) {
         hipError_t err = hipSuccess;
@@ -503,7 +550,7 @@ extern "C" int tcdiff_gemm_tile(int dtype, const void* A, const void* A2, int sp
     });
     if (n_cu < 0) return n_cu;
     // about one tile per CU and a k-loop long enough to matter: four stages, one workgroup per CU
-    const bool deep = (long)grid.x * 4 <= (long)n_cu * 5 && K / kt >= 3;
+    const bool deep = (long)grid.x * 4 <= (long)n_cu * 5 && K / kt / e.k_splits >= 3;
 #define TC_LAUNCH_TILE(POL, ACTK)                                                                                       \
     if (deep)                                                                                                           \
         hipLaunchKernelGGL((gemm_tile_kernel<POL, ACTK, 4>), grid, dim3(256), 4 * 2 * 128 * TC_ROWB, stream,            \
@@ -527,6 +574,25 @@ extern "C" int tcdiff_gemm_tile(int dtype, const void* A, const void* A2, int sp
     }
     TC_CHECK_LAUNCH();
     return TC_OK;
+}
+
+extern "C" int tcdiff_gemm_tile(int dtype, const void* A, const void* A2, int split_n, const void* W, int M, int N,
+                                int K, int lda, int ldw, int a_mod, const tcdiff_tile_epi* epi,
+                                hipStream_t stream) {
+    if (epi && epi->mode == TC_EPI_ATOMIC_F32) return TC_ERR_ARG;      // reached through tcdiff_gemm_splitk only
+    return launch_tile(dtype, A, A2, split_n, W, M, N, K, lda, ldw, a_mod, epi, stream);
+}
+
+// dW += dY^T X and friends: out[m][n] += sum_k A[m][k] W[n][k], `splits` workgroups per tile (include/tcdiff_hip.h)
+extern "C" int tcdiff_gemm_splitk(int dtype, const void* A, const void* W, int M, int N, int K, int lda, int ldw,
+                                  float* out, int ldc, int splits, hipStream_t stream) {
+    if (!out || ldc < N || splits < 1) return TC_ERR_ARG;
+    tcdiff_tile_epi e = {};
+    e.mode = TC_EPI_ATOMIC_F32;
+    e.out = out;
+    e.ldc = ldc;
+    e.k_splits = splits;
+    return launch_tile(dtype, A, nullptr, 0, W, M, N, K, lda, ldw, 0, &e, stream);
 }
 
 extern "C" int tcdiff_gemm_rowln(int dtype, const void* A, const void* W, int M, int K, int lda, int ldw, int a_mod,

@@ -10,6 +10,7 @@
 //   Adan.step                                  model/adan.py:33-123
 // The pytorch3d arithmetic is restated from its published definitions (oracle/tcdiff_oracle.py, "parity unpinned").
 #include "common.h"
+#include "fk_math.h"
 #include "tcdiff_hip.h"
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -46,65 +47,9 @@ extern "C" int tcdiff_q_sample_traj(const float* x_start, const float* noise, co
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// rotation conversions (real-first quaternions)
+// rotation conversions and the SMPL chain: the per-pose arithmetic is csrc/fk_math.h (shared with the backward kernels of
+// train_ops.hip and, compiled for the host, with tests/host/fk_host.cpp)
 // ---------------------------------------------------------------------------------------------------------------------
-struct Q4 { float w, x, y, z; };
-struct V3 { float x, y, z; };
-
-DEVINL V3 normalize3(V3 a) {       // F.normalize: v / max(|v|, 1e-12)
-    const float n = fmaxf(sqrtf(a.x * a.x + a.y * a.y + a.z * a.z), 1e-12f);
-    return V3{a.x / n, a.y / n, a.z / n};
-}
-DEVINL float sqrt_pos(float v) { return v > 0.0f ? sqrtf(v) : 0.0f; }
-
-// 6-D -> rotation matrix rows b1, b2, b3 (Gram-Schmidt) -> quaternion (candidate with the largest |component|)
-DEVINL Q4 quat_from_6d(const float* d6) {
-    const V3 a1{d6[0], d6[1], d6[2]}, a2{d6[3], d6[4], d6[5]};
-    const V3 b1 = normalize3(a1);
-    const float dt = b1.x * a2.x + b1.y * a2.y + b1.z * a2.z;
-    const V3 b2 = normalize3(V3{a2.x - dt * b1.x, a2.y - dt * b1.y, a2.z - dt * b1.z});
-    const V3 b3{b1.y * b2.z - b1.z * b2.y, b1.z * b2.x - b1.x * b2.z, b1.x * b2.y - b1.y * b2.x};
-    const float m00 = b1.x, m01 = b1.y, m02 = b1.z, m10 = b2.x, m11 = b2.y, m12 = b2.z, m20 = b3.x, m21 = b3.y, m22 = b3.z;
-    const float q0 = sqrt_pos(1.0f + m00 + m11 + m22), q1 = sqrt_pos(1.0f + m00 - m11 - m22);
-    const float q2 = sqrt_pos(1.0f - m00 + m11 - m22), q3 = sqrt_pos(1.0f - m00 - m11 + m22);
-    int best = 0;                   // argmax, first maximum wins (torch.argmax)
-    float bm = q0;
-    if (q1 > bm) { bm = q1; best = 1; }
-    if (q2 > bm) { bm = q2; best = 2; }
-    if (q3 > bm) { bm = q3; best = 3; }
-    const float den = 2.0f * fmaxf(bm, 0.1f);
-    Q4 r;
-    if (best == 0) r = Q4{q0 * q0, m21 - m12, m02 - m20, m10 - m01};
-    else if (best == 1) r = Q4{m21 - m12, q1 * q1, m10 + m01, m02 + m20};
-    else if (best == 2) r = Q4{m02 - m20, m10 + m01, q2 * q2, m12 + m21};
-    else r = Q4{m10 - m01, m20 + m02, m21 + m12, q3 * q3};
-    return Q4{r.w / den, r.x / den, r.y / den, r.z / den};
-}
-DEVINL V3 axis_angle_from_quat(Q4 q) {
-    const float nrm = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z);
-    const float half = atan2f(nrm, q.w), ang = 2.0f * half;
-    const float k = fabsf(ang) < 1e-6f ? 0.5f - (ang * ang) / 48.0f : sinf(half) / ang;
-    return V3{q.x / k, q.y / k, q.z / k};
-}
-DEVINL Q4 quat_from_axis_angle(V3 a) {
-    const float ang = sqrtf(a.x * a.x + a.y * a.y + a.z * a.z), half = ang * 0.5f;
-    const float k = fabsf(ang) < 1e-6f ? 0.5f - (ang * ang) / 48.0f : sinf(half) / ang;
-    return Q4{cosf(half), a.x * k, a.y * k, a.z * k};
-}
-DEVINL Q4 qmul_raw(Q4 a, Q4 b) {
-    return Q4{a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
-              a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x, a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
-}
-DEVINL Q4 qmul_std(Q4 a, Q4 b) {
-    Q4 r = qmul_raw(a, b);
-    if (r.w < 0.0f) r = Q4{-r.w, -r.x, -r.y, -r.z};
-    return r;
-}
-DEVINL V3 qapply(Q4 q, V3 p) {
-    const Q4 t = qmul_raw(qmul_raw(q, Q4{0.0f, p.x, p.y, p.z}), Q4{q.w, -q.x, -q.y, -q.z});
-    return V3{t.x, t.y, t.z};
-}
-
 // one thread per rotation: rotation j of row i is the 6 floats at in + i * row_stride + 6 j; out [n_rows * per_row][3]
 __global__ void ax_from_6v_kernel(const float* __restrict__ in, long n_rows, int per_row, long row_stride,
                                   float* __restrict__ out) {
@@ -128,38 +73,20 @@ extern "C" int tcdiff_ax_from_6v(const float* rot6d, long n_rows, int per_row, l
 
 // SMPL chain: one thread per pose.  parents / offsets are the SMPL constants of vis.py:48-101 (passed in so that a
 // caller-supplied skeleton works too); joints whose parents precede them (true for SMPL) only.
-#define TC_FK_J 24
-struct tcdiff_fk_skel { int parent[TC_FK_J]; int has_children[TC_FK_J]; float off[TC_FK_J][3]; };
-
-__global__ void smpl_fk_kernel(const float* __restrict__ aa, const float* __restrict__ root, long n, tcdiff_fk_skel sk,
+__global__ void smpl_fk_kernel(const float* __restrict__ aa, const float* __restrict__ root, long n, FkSkel sk,
                                float* __restrict__ joints) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Q4 rw[TC_FK_J];
-    V3 pw[TC_FK_J];
-    const float* a = aa + i * (TC_FK_J * 3);
+    float out[TC_FK_J * 3];
+    fk_forward(aa + i * (TC_FK_J * 3), root + i * 3, sk, out, nullptr);
 #pragma unroll
-    for (int j = 0; j < TC_FK_J; ++j) {
-        const Q4 q = quat_from_axis_angle(V3{a[3 * j], a[3 * j + 1], a[3 * j + 2]});
-        const int p = sk.parent[j];
-        if (p < 0) {
-            pw[j] = V3{root[i * 3], root[i * 3 + 1], root[i * 3 + 2]};
-            rw[j] = q;
-        } else {
-            const V3 o = qapply(rw[p], V3{sk.off[j][0], sk.off[j][1], sk.off[j][2]});
-            pw[j] = V3{o.x + pw[p].x, o.y + pw[p].y, o.z + pw[p].z};
-            rw[j] = sk.has_children[j] ? qmul_std(rw[p], q) : q;
-        }
-        joints[(i * TC_FK_J + j) * 3 + 0] = pw[j].x;
-        joints[(i * TC_FK_J + j) * 3 + 1] = pw[j].y;
-        joints[(i * TC_FK_J + j) * 3 + 2] = pw[j].z;
-    }
+    for (int q = 0; q < TC_FK_J * 3; ++q) joints[i * (TC_FK_J * 3) + q] = out[q];
 }
 
 extern "C" int tcdiff_smpl_fk(const float* axis_angle, const float* root, long n, const int* parents,
                               const float* offsets, float* joints, hipStream_t stream) {
     if (!axis_angle || !root || !parents || !offsets || !joints || n <= 0) return TC_ERR_ARG;
-    tcdiff_fk_skel sk;
+    FkSkel sk;
     for (int j = 0; j < TC_FK_J; ++j) sk.has_children[j] = 0;
     for (int j = 0; j < TC_FK_J; ++j) {
         sk.parent[j] = parents[j];

@@ -81,6 +81,49 @@ class EMA:
         return new if old is None else old * self.beta + (1 - self.beta) * new
 
 
+class _LossFn(torch.autograd.Function):
+    """total = 0.636 recon + 2.964 velocity + 0.646 fk + 10.942 foot (reference model/diffusion.py:668-741) of the denoiser
+    output, forward and backward in HIP kernels (csrc/train.hip, csrc/train_ops.hip): 6-D rotations -> axis-angle ->
+    SMPL chain -> the four per-clip means; the reverse pass differentiates the same chain by hand (csrc/fk_math.h)."""
+
+    @staticmethod
+    def forward(ctx, out, x_start, t, p2w, parents, offsets, l1):
+        dev = out.device
+        bs, dn, sq, c = x_start.shape
+        out = out.detach().float().contiguous()
+        n = bs * sq * dn
+        xs_rows = x_start.permute(0, 2, 1, 3).reshape(n, c).contiguous()      # target rows in token order (a copy)
+        joints = []
+        for rows in (out.reshape(n, c), xs_rows):
+            aa = torch.empty(n, 24, 3, device=dev)
+            K.ax_from_6v(rows[:, 7:], n, 24, c, aa)               # channels: 4 contact, 3 root, 24 x 6 rotations
+            jt = torch.empty(n, 24, 3, device=dev)
+            K.smpl_fk(aa, rows[:, 4:7].contiguous(), n, parents, offsets, jt)
+            joints.append(jt)
+        terms = torch.empty(bs, 4, device=dev)
+        K.loss_terms(out, x_start, joints[0], joints[1], p2w, t, terms, bs, dn, sq, c, l1=l1)
+        tot = torch.empty(5, device=dev)
+        K.loss_total(terms, bs, tot)
+        m = tot[:4].clone()
+        ctx.save_for_backward(out, x_start, t, p2w, joints[0], joints[1])
+        ctx.meta = (parents, offsets, l1)
+        ctx.mark_non_differentiable(m)
+        return tot[4].clone(), m
+
+    @staticmethod
+    def backward(ctx, g_total, _g_terms):
+        out, x_start, t, p2w, jm, jt = ctx.saved_tensors
+        parents, offsets, l1 = ctx.meta
+        bs, dn, sq, c = x_start.shape
+        n = bs * sq * dn
+        d_out = torch.empty_like(out)
+        d_j = torch.empty(n, 24, 3, device=out.device)
+        gs = g_total.detach().reshape(1).float().contiguous()
+        K.loss_terms_bwd(out, x_start, jm, jt, p2w, t, gs, d_out, d_j, bs, dn, sq, c, l1)
+        K.fk_bwd(out.reshape(n, c), d_j, n, c, parents, offsets, d_out.reshape(n, c))
+        return d_out, None, None, None, None, None, None
+
+
 FOOT_JOINTS = [1, 2, 3, 4, 5, 7, 8, 10, 11]  # lower-body joints of ddim_sample_Footwork (model/diffusion.py:307)
 
 
@@ -595,18 +638,27 @@ class GaussianDiffusion(nn.Module):
     def partial_denoise(self, x, cond, t):
         return self.p_sample_loop(x.shape, cond, noise=self.noise_to_t(x, t), start_point=t)
 
-    # ---- training loss, forward (reference model/diffusion.py:636-753) ---------------------------------------------------
-    @torch.no_grad()
+    # ---- training loss (reference model/diffusion.py:636-753) ---------------------------------------------------------------
+    def _skeleton(self, dev):
+        from .fk import SMPLSkeleton
+        smpl = self.smpl
+        if smpl is None or not hasattr(smpl, "_parents"):
+            smpl = self.__dict__.setdefault("_smpl_hip", SMPLSkeleton(dev))
+        return [int(p) for p in smpl._parents], smpl._offsets.detach().cpu().tolist()
+
     def p_losses(self, x_start, cond, t, trj_dist=None, *, noise=None, keep_mask=None):
-        """The four-term training loss (reference model/diffusion.py:636-741), FORWARD ONLY: q_sample with the
-        trajectory channels restored, one conditional evaluation of the denoiser (keep mask ~ 1 - cond_drop_prob), then
-        reconstruction, velocity, SMPL-FK and foot-skate terms -- each a HIP kernel (csrc/train.hip).  Returns
-        ``(total, (recon, velocity, fk, foot))`` like the reference.  No autograd graph is recorded: the backward pass
-        (and with it a full training step) is the next row of the scope table, so Dropout is the identity here
-        (the reference's eval-mode arithmetic).  Keyword-only extras inject the random draws (parity tests):
-        ``noise`` in the permuted (b, S, dn, C) layout the reference draws it in, ``keep_mask`` (b,) bool."""
+        """The four-term training loss (reference model/diffusion.py:636-741): q_sample with the trajectory channels
+        restored, one evaluation of the denoiser (keep mask ~ 1 - cond_drop_prob; dropout live in ``.train()`` mode), then
+        reconstruction, velocity, SMPL-FK and foot-skate terms -- every stage a HIP kernel.  Returns
+        ``(total, (recon, velocity, fk, foot))`` like the reference; with gradients enabled ``total`` carries an autograd
+        graph of two nodes (loss terms, denoiser) whose backward passes are HIP kernels too (csrc/train_ops.hip,
+        tcdiff_amd/train_engine.py), so ``TCDiff.train_loop`` (TCDiff.py:227-234) runs unchanged.
+        Keyword-only extras inject the random draws (parity tests): ``noise`` in the permuted (b, S, dn, C) layout the
+        reference draws it in, ``keep_mask`` (b,) bool; the dropout seed through ``self.model.train_seed``."""
         if trj_dist is not None:
             raise L.TcdiffError("trj_dist is not supported (never passed by the reference's callers, TCDiff.py:227-229)")
+        if self.predict_epsilon:
+            raise L.TcdiffError("p_losses implements predict_epsilon=False (TCDiff.py:96)")
         dev = self._device()
         if dev.type != "cuda":
             raise L.TcdiffError("p_losses runs on MI355X only (no CPU fallback)")
@@ -619,31 +671,11 @@ class GaussianDiffusion(nn.Module):
         x_noisy = torch.empty(bs, sq * dn, c, device=dev)
         K.q_sample_traj(x_start, noise, t, self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod, x_noisy, bs, dn,
                         sq, c)
-        out = self.model(x_noisy, cond, t, cond_drop_prob=self.cond_drop_prob, keep_mask=keep_mask).contiguous()
-        # FK of prediction and target: 6-D rotations are channels 7.. of the 151 (4 contact, 3 root, 24 x 6)
-        from .fk import SMPLSkeleton
-        smpl = self.smpl
-        if smpl is None or not hasattr(smpl, "_parents"):
-            smpl = self.__dict__.setdefault("_smpl_hip", SMPLSkeleton(dev))
-        parents = [int(p) for p in smpl._parents]
-        offsets = smpl._offsets.detach().cpu().tolist()
-        xs_rows = x_start.permute(0, 2, 1, 3).reshape(bs * sq * dn, c).contiguous()      # target rows, token order
-        joints = []
-        for rows in (out.reshape(bs * sq * dn, c), xs_rows):
-            n = rows.shape[0]
-            aa = torch.empty(n, 24, 3, device=dev)
-            if rows.stride(0) != c or rows.stride(1) != 1:
-                raise L.TcdiffError("internal: motion rows must be contiguous")
-            K.ax_from_6v(rows[:, 7:], n, 24, c, aa)
-            jt = torch.empty(n, 24, 3, device=dev)
-            K.smpl_fk(aa, rows[:, 4:7].contiguous(), n, parents, offsets, jt)
-            joints.append(jt)
-        terms = torch.empty(bs, 4, device=dev)
-        K.loss_terms(out, x_start, joints[0], joints[1], self.p2_loss_weight, t, terms, bs, dn, sq, c,
-                     l1=self.loss_type == "l1")
-        m = terms.mean(0)
-        losses = (0.636 * m[0], 2.964 * m[1], 0.646 * m[2], 10.942 * m[3])
-        return sum(losses), losses
+        out = self.model(x_noisy, cond, t, cond_drop_prob=self.cond_drop_prob, keep_mask=keep_mask)
+        parents, offsets = self._skeleton(dev)
+        total, terms = _LossFn.apply(out, x_start, t, self.p2_loss_weight, parents, offsets, self.loss_type == "l1")
+        m = terms
+        return total, (m[0], m[1], m[2], m[3])
 
     def loss(self, x, cond, t_override=None, trj_dist=None):
         batch_size = len(x)

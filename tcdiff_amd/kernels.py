@@ -224,3 +224,102 @@ def adan_chunk_table(params, grads, ms, vs, ns, pgs, device):
 
 def adan_step(table, scalars):
     L.check(L.load().tcdiff_adan_step(_p(table), table.shape[0], C.byref(scalars), stream()), "tcdiff_adan_step")
+
+
+# ---- training step: train-mode forward pieces and the backward pass ---------------------------------------------------
+def drop_params(p: float):
+    """(threshold, scale) of the counter-hash dropout (csrc/train_common.h): keep iff hash >= floor(p * 2^32)."""
+    if p <= 0.0:
+        return 0, 1.0
+    return int(p * 4294967296.0), 1.0 / (1.0 - p)
+
+
+def cast_transpose(dt, src, rows, cols, ld_src, *, dst=None, ld_dst=0, cols_pad=0, dstT=None, ld_dstT=0, rows_pad=0,
+                   colsum=None):
+    src_f32 = int(src.dtype == torch.float32)           # fp32 source (always, in the f32 mode) or a T-typed one
+    rc = L.load().tcdiff_cast_transpose(dt, src_f32, _p(src), rows, cols, ld_src, _p(dst), ld_dst, cols_pad, _p(dstT),
+                                        ld_dstT, rows_pad, _p(colsum), stream())
+    L.check(rc, "tcdiff_cast_transpose")
+
+
+def gemm_splitk(dt, A, W, M, N, K, lda, ldw, out, ldc, splits):
+    L.check(L.load().tcdiff_gemm_splitk(dt, _p(A), _p(W), M, N, K, lda, ldw, _p(out), ldc, splits, stream()),
+            "tcdiff_gemm_splitk")
+
+
+def act_drop(dt, a, ld_a, y, ld_y, rows, cols, act, seed=None, site=0, thr=0, scale=1.0):
+    a_f32 = int(a.dtype == torch.float32)
+    L.check(L.load().tcdiff_act_drop(dt, a_f32, _p(a), ld_a, _p(y), ld_y, rows, cols, act, _p(seed), site, thr, scale,
+                                     stream()), "tcdiff_act_drop")
+
+
+def act_drop_bwd(dt, a, ld_a, dy, ld_y, da, rows, cols, act, seed=None, site=0, thr=0, scale=1.0):
+    a_f32 = int(a.dtype == torch.float32)
+    L.check(L.load().tcdiff_act_drop_bwd(dt, a_f32, _p(a), ld_a, _p(dy), ld_y, _p(da), rows, cols, act, _p(seed), site,
+                                         thr, scale, stream()), "tcdiff_act_drop_bwd")
+
+
+def row_args(**kw) -> "L.RowArgs":
+    a = L.RowArgs()
+    for k, v in kw.items():
+        setattr(a, k, v.data_ptr() if isinstance(v, torch.Tensor) else v)
+    return a
+
+
+def row_fwd(dt, a):
+    L.check(L.load().tcdiff_row_fwd(dt, C.byref(a), stream()), "tcdiff_row_fwd")
+
+
+def row_bwd(dt, a):
+    L.check(L.load().tcdiff_row_bwd(dt, C.byref(a), stream()), "tcdiff_row_bwd")
+
+
+def row_param_reduce(partials, n_blocks, d_bias=None, d_ln_g=None, d_ln_b=None, d_nln_g=None, d_nln_b=None):
+    L.check(L.load().tcdiff_row_param_reduce(_p(partials), n_blocks, _p(d_bias), _p(d_ln_g), _p(d_ln_b), _p(d_nln_g),
+                                             _p(d_nln_b), stream()), "tcdiff_row_param_reduce")
+
+
+def attention_train(dt, Q, K, V, O, lse, n_seq, H, Lq, Lk, Lp_q, Lp_k, ldo, seed, site, thr, scale):
+    L.check(L.load().tcdiff_attention_train(dt, _p(Q), _p(K), _p(V), _p(O), _p(lse), n_seq, H, Lq, Lk, Lp_q, Lp_k, ldo,
+                                            _p(seed), site, thr, scale, stream()), "tcdiff_attention_train")
+
+
+def attention_bwd(dt, Q, K, V, O, dO, lse, delta, dQ, ld_dq, dK, dV, ld_dkv, n_seq, H, Lq, Lk, Lp_q, Lp_k, ldo, scale_q,
+                  seed, site, thr, scale):
+    L.check(L.load().tcdiff_attention_bwd(dt, _p(Q), _p(K), _p(V), _p(O), _p(dO), _p(lse), _p(delta), _p(dQ), ld_dq,
+                                          _p(dK), _p(dV), ld_dkv, n_seq, H, Lq, Lk, Lp_q, Lp_k, ldo, scale_q, _p(seed),
+                                          site, thr, scale, stream()), "tcdiff_attention_bwd")
+
+
+def add_rows(a, ld_a, b, ld_b, out, ld_out, rows, cols):
+    L.check(L.load().tcdiff_add_rows(_p(a), ld_a, _p(b), ld_b, _p(out), ld_out, rows, cols, stream()), "tcdiff_add_rows")
+
+
+def select_rows(x, nul, keep_u8, out, B, n):
+    L.check(L.load().tcdiff_select_rows(_p(x), _p(nul), _p(keep_u8), _p(out), B, n, stream()), "tcdiff_select_rows")
+
+
+def select_rows_bwd(g, keep_u8, dx, dnul, B, n):
+    L.check(L.load().tcdiff_select_rows_bwd(_p(g), _p(keep_u8), _p(dx), _p(dnul), B, n, stream()),
+            "tcdiff_select_rows_bwd")
+
+
+def pool_bwd(g_tok, g_pool, dx, B, S, Cn):
+    L.check(L.load().tcdiff_pool_bwd(_p(g_tok), _p(g_pool), _p(dx), B, S, Cn, stream()), "tcdiff_pool_bwd")
+
+
+def loss_total(terms, b, out):
+    L.check(L.load().tcdiff_loss_total(_p(terms), b, _p(out), stream()), "tcdiff_loss_total")
+
+
+def loss_terms_bwd(model_out, x_start, joints_model, joints_target, p2_weight, t, gscale, d_out, d_joints, b, dn, S, Cn,
+                   l1):
+    L.check(L.load().tcdiff_loss_terms_bwd(_p(model_out), _p(x_start), _p(joints_model), _p(joints_target), _p(p2_weight),
+                                           _p(t), _p(gscale), _p(d_out), _p(d_joints), b, dn, S, Cn, int(l1), stream()),
+            "tcdiff_loss_terms_bwd")
+
+
+def fk_bwd(motion, d_joints, n, Cn, parents, offsets, d_out):
+    par = (C.c_int * 24)(*[int(p) for p in parents])
+    off = (C.c_float * 72)(*[float(v) for row in offsets for v in row])
+    L.check(L.load().tcdiff_fk_bwd(_p(motion), _p(d_joints), n, Cn, par, off, _p(d_out), stream()), "tcdiff_fk_bwd")

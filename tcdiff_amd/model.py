@@ -131,6 +131,7 @@ class DanceDecoder(nn.Module):
         self.cond_feature_dim = cond_feature_dim
         self.ff_size, self.num_layers, self.num_heads = ff_size, num_layers, num_heads
         self.compute_dtype = compute_dtype
+        self.dropout_p = float(dropout)
         D = latent_dim
 
         self.rotary = RotaryEmbedding(dim=D)
@@ -160,6 +161,8 @@ class DanceDecoder(nn.Module):
         self.traj_embedding = nn.Sequential(nn.Linear(2, 64), nn.ReLU(), nn.Linear(64, D))
         self._engine: Optional[DenoiserEngine] = None
         self._engines = {}
+        self._train_engine = None
+        self.train_seed = None          # (int, int): inject the dropout seed of the next train-mode forward (parity tests)
 
     # ------------------------------------------------------------------------------------------
     # engine plumbing
@@ -196,6 +199,28 @@ class DanceDecoder(nn.Module):
         self.compute_dtype = compute_dtype
         self._engine = None
         self._engines = {}
+        self._train_engine = None
+
+    def train_engine(self):
+        """The (lazily built) training-step engine: operand packs, flat gradient buffer, forward / backward schedule."""
+        from .train_engine import TrainEngine
+        eng = self._train_engine
+        dev = next(self.parameters()).device
+        if eng is None or eng.dev != dev or eng.dt != K.dtype_id(self.compute_dtype):
+            eng = TrainEngine(self, self.compute_dtype)
+            self._train_engine = eng
+        return eng
+
+    def __deepcopy__(self, memo):
+        # GaussianDiffusion deep-copies the model into master_model (model/diffusion.py:101): engines hold device
+        # workspaces and a back-reference to the module -- the copy builds its own
+        import copy
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = None if k in ("_engine", "_train_engine") else ({} if k == "_engines" else copy.deepcopy(v, memo))
+        return new
 
     # ------------------------------------------------------------------------------------------
     # reference API
@@ -236,14 +261,35 @@ class DanceDecoder(nn.Module):
 
     def forward(self, x: Tensor, cond_embed: Tensor, times: Tensor, cond_drop_prob: float = 0.0, trj_dist=None, *,
                 keep_mask: Optional[Tensor] = None):
-        """One denoiser evaluation (model/model.py:548-624), inference only (no autograd graph is recorded).
+        """One denoiser evaluation (model/model.py:548-624).
 
+        With gradients enabled the call records ONE autograd node whose forward and backward are the explicit HIP
+        schedule of tcdiff_amd/train_engine.py: in ``.train()`` mode with the reference's dropout (probability
+        ``dropout`` of the constructor, counter-hash masks keyed by a seed drawn from torch's generator or injected through
+        ``self.train_seed``), in ``.eval()`` mode with dropout off.  Under ``torch.no_grad()`` it is the inference engine.
         ``trj_dist`` is accepted for signature parity; the reference never passes it (TCDiff.py:227-229)."""
         if trj_dist is not None:
             raise L.TcdiffError("trj_dist is not supported (never used by the reference's callers)")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
-            raise L.TcdiffError("the MI355X path is inference-only in this round: wrap the call in torch.no_grad() "
-                                "and .eval() (training step = SURVEY.md 8(f) 'next' row)")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            from .train_engine import denoiser_train
+            B = x.shape[0]
+            dev = next(self.parameters()).device
+            self.train_engine()          # raises off-GPU (no CPU fallback)
+            p_keep = 1 - cond_drop_prob
+            if keep_mask is not None:
+                keep = keep_mask.to(device=dev, dtype=torch.bool).reshape(B)
+            elif p_keep == 1:
+                keep = torch.ones(B, dtype=torch.bool, device=dev)
+            elif p_keep == 0:
+                keep = torch.zeros(B, dtype=torch.bool, device=dev)
+            else:
+                keep = torch.zeros(B, device=dev).float().uniform_(0, 1) < p_keep       # model/utils.py:52-58
+            seed = self.train_seed
+            if seed is None:
+                seed = tuple(int(v) for v in torch.randint(0, 2 ** 31 - 1, (2,)))
+            self.train_seed = None
+            return denoiser_train(self, x.reshape(B, -1, self.nfeats).to(dev), cond_embed, times, keep, seed,
+                                  self.dropout_p if self.training else 0.0)
         with torch.no_grad():
             B = x.shape[0]
             x = x.reshape(B, -1, self.nfeats).float().contiguous()

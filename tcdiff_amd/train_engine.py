@@ -1,0 +1,706 @@
+"""Training step of the TCDiff denoiser on MI355X: train-mode forward and the backward pass as an explicit schedule of
+HIP launches (libtcdiff_gfx950.so), behind ONE ``torch.autograd.Function``.
+
+The reference trains with torch autograd over ``DanceDecoder.forward`` (model/model.py:548-624, train mode: nn.Dropout at
+:98,103,240,244-245,383,396,400-401 and inside nn.MultiheadAttention) and ``accelerator.backward(total_loss)``
+(TCDiff.py:227-234).  Here ``DanceDecoder.forward`` with gradients enabled calls :func:`denoiser_train`, whose forward runs
+the kernels below and keeps the activations the reverse pass needs, and whose backward walks the same graph in reverse:
+
+  nn.Linear            forward  tcdiff_gemm_tile;  dgrad = tcdiff_gemm_tile against the transposed weight pack;
+                       wgrad = tcdiff_gemm_splitk over the token rows (dY^T and X^T repacked by tcdiff_cast_transpose,
+                       which also yields the bias gradient)
+  attention            tcdiff_attention_train / tcdiff_attention_bwd (weights recomputed, dropout bits regenerated)
+  everything between   tcdiff_row_fwd / tcdiff_row_bwd (bias, dropout, LayerNorms, FiLM, residual, rotary) and
+                       tcdiff_act_drop(_bwd); the conditioning path's selects / pool / adds have their own adjoints
+
+Gradients land in ONE flat fp32 buffer (fused linears contiguous) of which every parameter's ``.grad`` is a view: the
+data-parallel all-reduce (tcdiff_amd/dist.py) runs on slices of that buffer without a copy.  torch contributes device
+memory, the stream and the autograd hook -- no arithmetic.  There is no CPU path: off-GPU this module raises.
+
+One forward may be outstanding per model (the engine keeps its activations until the matching backward), which is what
+TCDiff.train_loop does (TCDiff.py:227-234).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+from . import kernels as K
+
+DEAD = ("traj_Modulation", "traj_embedding", "embeddings_table")      # parameters the forward never uses (model/model.py:346-355,371,557)
+_ALLOW_CPU = False          # tools/dryrun_train.py only: host-side dry run of the schedule against a stub library
+
+
+def _is_dead(name: str) -> bool:
+    return any(d in name for d in DEAD)
+
+
+class _Lin:
+    """One nn.Linear, or several stacked along the output dimension and evaluated as one GEMM."""
+
+    def __init__(self, eng: "TrainEngine", key: str, wnames: Sequence[str], bnames: Optional[Sequence[str]] = None,
+                 split: int = 0):
+        self.eng, self.key, self.wnames, self.bnames, self.split = eng, key, list(wnames), list(bnames or []), split
+        ps = [eng.params[n] for n in self.wnames]
+        self.K = ps[0].shape[1]
+        self.rows = [p.shape[0] for p in ps]
+        self.N = sum(self.rows)
+        self.Kp = K.round_up(self.K, eng.kt)
+        self.groups = [(0, split), (split, self.N)] if split else [(0, self.N)]
+        self.Wf = torch.zeros(self.N, self.Kp, device=eng.dev, dtype=eng.T)
+        self.WbT = [torch.zeros(self.K, K.round_up(hi - lo, eng.kt), device=eng.dev, dtype=eng.T) for lo, hi in self.groups]
+        self.bias = torch.zeros(self.N, device=eng.dev, dtype=torch.float32) if self.bnames else None
+
+    def pack(self):
+        """(Re)build the operand packs from the fp32 master parameters: W as [N, Kp] and, per operand group, W^T."""
+        eng, r0 = self.eng, 0
+        es = self.Wf.element_size()
+        for name, n in zip(self.wnames, self.rows):
+            w = eng.params[name].detach()
+            gi = 1 if (self.split and r0 >= self.split) else 0
+            lo = self.groups[gi][0]
+            wt = self.WbT[gi]
+            K.cast_transpose(eng.dt, w, n, self.K, self.K, dst=self.Wf[r0:], ld_dst=self.Kp, cols_pad=self.Kp,
+                             dstT=wt.view(-1)[r0 - lo:], ld_dstT=wt.shape[1], rows_pad=n)
+            r0 += n
+        if self.bias is not None:
+            o = 0
+            for name in self.bnames:
+                b = eng.params[name].detach()
+                self.bias[o:o + b.numel()].copy_(b)
+                o += b.numel()
+
+    # ---- forward ---------------------------------------------------------------------------------------------------
+    def fwd(self, A, M, *, A2=None, out=None, f32=False, ldc=None, heads=None, rows=None):
+        """out[M, N] = A W^T + b.  f32: fp32 output, else T.  heads = dict(out, out_k, out_v, scale_q, Lseq, Lp, n_q, n_k):
+        scatter to head-major images.  rows = (lo, hi): only that slice of the stacked outputs."""
+        eng = self.eng
+        lo, hi = rows if rows else (0, self.N)
+        W = self.Wf[lo:hi]
+        bias = self.bias[lo:hi] if self.bias is not None else None
+        if heads:
+            K.gemm_tile(eng.dt, A, W, M, hi - lo, self.Kp, A2=A2, split_n=self.split if A2 is not None else 0, bias=bias,
+                        mode=L.EPI_QKV_HEADS, H=eng.H, **heads)
+            return None
+        K.gemm_tile(eng.dt, A, W, M, hi - lo, self.Kp, A2=A2, split_n=self.split if A2 is not None else 0, bias=bias,
+                    mode=L.EPI_STORE_F32 if f32 else L.EPI_STORE_T, out=out, ldc=ldc if ldc else hi - lo)
+        return out
+
+    # ---- backward --------------------------------------------------------------------------------------------------
+    def bwd(self, dY, ld_dy, M, Xs, want):
+        """dY [M, N] (fp32 or T, leading dimension ld_dy).  Xs[g]: T operand [M, Kp] of group g.  want[g]: None, or
+        ("T" | "F32", out tensor, ldc) or ("HEADS", dict) -- where the input gradient of group g goes.
+        Weight gradients accumulate into the flat gradient buffer; the bias gradient is the column sum of dY."""
+        eng = self.eng
+        dt, kt = eng.dt, eng.kt
+        N, Mp = self.N, K.round_up(M, kt)
+        Np = K.round_up(N, kt)
+        gW = eng.gW[self.key]
+        gb = eng.gB.get(self.key)
+        dYt = torch.empty(N, Mp, device=eng.dev, dtype=eng.T)
+        direct = dY.dtype == eng.T and ld_dy == Np and N == Np     # dY itself is a valid K-contiguous operand
+        if direct:
+            dYT = dY
+            K.cast_transpose(dt, dY, M, N, ld_dy, dstT=dYt, ld_dstT=Mp, rows_pad=Mp, colsum=gb)
+        else:
+            dYT = torch.empty(M, Np, device=eng.dev, dtype=eng.T)
+            K.cast_transpose(dt, dY, M, N, ld_dy, dst=dYT, ld_dst=Np, cols_pad=Np, dstT=dYt, ld_dstT=Mp, rows_pad=Mp,
+                             colsum=gb)
+        outs = []
+        for gi, (lo, hi) in enumerate(self.groups):
+            ng = hi - lo
+            ngp = self.WbT[gi].shape[1]
+            w = want[gi]
+            if w is not None:                                   # dX_g = dY[:, lo:hi] W[lo:hi]
+                A = dYT.view(-1)[lo:]
+                if w[0] == "HEADS":
+                    K.gemm_tile(dt, A, self.WbT[gi], M, self.K, ngp, lda=Np, mode=L.EPI_QKV_HEADS, H=eng.H, **w[1])
+                else:
+                    K.gemm_tile(dt, A, self.WbT[gi], M, self.K, ngp, lda=Np,
+                                mode=L.EPI_STORE_F32 if w[0] == "F32" else L.EPI_STORE_T, out=w[1], ldc=w[2])
+            X = Xs[gi]
+            Xt = torch.empty(self.K, Mp, device=eng.dev, dtype=eng.T)
+            K.cast_transpose(dt, X, M, self.K, X.shape[1], dstT=Xt, ld_dstT=Mp, rows_pad=Mp)
+            tiles = ((ng + 127) // 128) * ((self.K + 127) // 128)
+            splits = max(1, min(512 // tiles, Mp // kt, 64))
+            K.gemm_splitk(dt, dYt[lo:], Xt, ng, self.K, Mp, Mp, Mp, gW[lo * self.K:], self.K, splits)
+        return outs
+
+
+class TrainEngine:
+    """Packed weights, flat gradient buffer and the forward / backward schedule of one DanceDecoder."""
+
+    def __init__(self, model, compute: str):
+        L.load()
+        self.model = model
+        self.params: Dict[str, torch.nn.Parameter] = dict(model.named_parameters())
+        p0 = next(iter(self.params.values()))
+        if p0.device.type != "cuda" and not _ALLOW_CPU:
+            raise L.TcdiffError("the training step runs on MI355X only (no CPU fallback; the CPU oracle is test-only)")
+        self.dev = p0.device
+        self.dt = K.dtype_id(compute)
+        self.T = K.TORCH_DT[self.dt]
+        self.kt = K.k_tile(self.dt)
+        c = model.engine_config()
+        if c["latent"] != 512 or c["n_head"] * 64 != 512:
+            raise L.TcdiffError("gfx950 kernels are built for latent_dim=512, 8 heads x 64 (TCDiff.py:76-87)")
+        self.H, self.NL, self.S, self.dn, self.nf, self.ff = c["n_head"], c["n_layers"], c["seq_len"], c["dn"], \
+            c["nfeats"], c["ff"]
+        self.Cd = c["cond_dim"]
+        self.Lq = self.S * self.dn
+        self.Lp = K.round_up(self.Lq, 128)
+        self.Lps = K.round_up(self.S, 128)
+        self.Lpc = K.round_up(self.S + 2, 128)
+        self.p_drop = float(getattr(model, "dropout_p", 0.1))
+        self.seed = torch.zeros(2, device=self.dev, dtype=torch.int32)
+        self.packed_version = None
+        self.sv = None
+        self._define()
+        half = 256
+        self.sin_freq = torch.exp(torch.arange(half) * -(math.log(10000) / (half - 1))).to(self.dev)   # model/utils.py:43-44
+        n_pos = max(self.Lq, self.S + 2)
+        self.rope = torch.empty(n_pos, 512, device=self.dev, dtype=torch.float32)
+        K.rope_table(model.rotary.freqs.detach().float().contiguous(), self.rope, n_pos)
+
+    # ------------------------------------------------------------------------------------------------------------------
+    # parameter groups and the flat gradient buffer
+    # ------------------------------------------------------------------------------------------------------------------
+    def _define(self):
+        lins: Dict[str, _Lin] = {}
+
+        def lin(key, w, b=None, split=0):
+            lins[key] = _Lin(self, key, w, b, split)
+
+        def wb(prefix):
+            return [prefix + ".weight"], [prefix + ".bias"]
+
+        lin("in", *wb("input_projection"))
+        for i, k in ((0, "f1"), (2, "f2"), (4, "f3")):
+            lin(k, *wb(f"relative_projection_layer.{i}"))
+        lin("t1", *wb("time_mlp.1"))
+        lin("tct", ["to_time_cond.0.weight", "to_time_tokens.0.weight"], ["to_time_cond.0.bias", "to_time_tokens.0.bias"])
+        lin("c0", *wb("cond_projection.0"))
+        lin("c2", *wb("cond_projection.2"))
+        for i in range(2):
+            q = f"cond_encoder.{i}."
+            lin(f"e{i}.qkv", [q + "self_attn.in_proj_weight"], [q + "self_attn.in_proj_bias"], split=1024)
+            lin(f"e{i}.o", *wb(q + "self_attn.out_proj"))
+            lin(f"e{i}.l1", *wb(q + "linear1"))
+            lin(f"e{i}.l2", *wb(q + "linear2"))
+        lin("na1", *wb("non_attn_cond_projection.1"))
+        lin("na3", *wb("non_attn_cond_projection.3"))
+        st = "seqTransDecoder.stack."
+        for l in range(self.NL):
+            q = f"{st}{l}."
+            lin(f"l{l}.qkv", [q + "self_attn.w_qs.weight", q + "self_attn.w_ks.weight", q + "self_attn.w_vs.weight"],
+                split=1024)
+            lin(f"l{l}.sfc", [q + "self_attn.fc.weight"])
+            lin(f"l{l}.cq", [q + "multihead_attn.w_qs.weight"])
+            lin(f"l{l}.cfc", [q + "multihead_attn.fc.weight"])
+            lin(f"l{l}.ff1", *wb(q + "linear1"))
+            lin(f"l{l}.ff2", *wb(q + "linear2"))
+            lin(f"l{l}.l3", *wb(q + "linear3"))
+        nk = 512 * self.NL
+        lin("ckv", [f"{st}{l}.multihead_attn.w_ks.weight" for l in range(self.NL)] +
+            [f"{st}{l}.multihead_attn.w_vs.weight" for l in range(self.NL)], split=nk)
+        film = [f"{st}{l}.film{i}.block.1" for l in range(self.NL) for i in (1, 2, 3)]
+        lin("film", [f + ".weight" for f in film], [f + ".bias" for f in film])
+        lin("fin", *wb("final_layer"))
+        self.lins = lins
+        # flat gradient buffer: [stacked weights | stacked biases] of every fused linear, then the remaining live parameters
+        used, off, self.slot = set(), 0, {}
+        for lk in lins.values():
+            for names in (lk.wnames, lk.bnames):                 # stacked parts are contiguous; every stack starts 16-byte aligned
+                off = K.round_up(off, 4)
+                for n in names:
+                    self.slot[n] = (off, self.params[n].numel())
+                    off += self.params[n].numel()
+                    used.add(n)
+        for n, p in self.params.items():
+            if n not in used and not _is_dead(n):
+                off = K.round_up(off, 4)                         # 16-byte aligned rows for the row kernels
+                self.slot[n] = (off, p.numel())
+                off += p.numel()
+        self.n_grad = off
+        self.order = list(self.params.keys())
+        self._new_flat()
+
+    def _new_flat(self):
+        self.flat = torch.zeros(self.n_grad, device=self.dev, dtype=torch.float32)
+        self.gW, self.gB = {}, {}
+        for key, lk in self.lins.items():
+            o0 = self.slot[lk.wnames[0]][0]
+            self.gW[key] = self.flat[o0:o0 + lk.N * lk.K]
+            if lk.bnames:
+                b0 = self.slot[lk.bnames[0]][0]
+                self.gB[key] = self.flat[b0:b0 + lk.N]
+
+    def g(self, name: str) -> torch.Tensor:
+        o, n = self.slot[name]
+        return self.flat[o:o + n]
+
+    def grad_views(self) -> List[Optional[torch.Tensor]]:
+        out = []
+        for n in self.order:
+            if n in self.slot:
+                o, cnt = self.slot[n]
+                out.append(self.flat[o:o + cnt].view(self.params[n].shape))
+            else:
+                out.append(None)
+        return out
+
+    def repack(self):
+        ver = tuple(p._version for p in self.params.values())
+        if ver != self.packed_version:
+            for lk in self.lins.values():
+                lk.pack()
+            self.packed_version = ver
+
+    def P(self, name):           # fp32 master parameter (LayerNorm weights, null embeddings)
+        return self.params[name].detach()
+
+    # ------------------------------------------------------------------------------------------------------------------
+    # small launch helpers
+    # ------------------------------------------------------------------------------------------------------------------
+    def z(self, *shape, dtype=None):
+        return torch.zeros(*shape, device=self.dev, dtype=self.T if dtype is None else dtype)
+
+    def e(self, *shape, dtype=None):
+        return torch.empty(*shape, device=self.dev, dtype=self.T if dtype is None else dtype)
+
+    def _row(self, **kw):
+        a = K.row_args(seed=self.seed, drop_thr=self.thr, drop_scale=self.dscale, **kw)
+        return a
+
+    def row_fwd(self, **kw):
+        K.row_fwd(self.dt, self._row(**kw))
+
+    def row_bwd(self, *, M, L_, ln=None, nln=None, **kw):
+        """runs tcdiff_row_bwd + the reduction of its LayerNorm partials into the flat gradient buffer.
+        ln / nln: parameter-name prefixes of the post / next LayerNorm (their gradients)."""
+        chunks = max(1, min(8, L_ // 16))
+        nblk = chunks * (M // L_)
+        part = self.e(nblk, 5, 512, dtype=torch.float32)
+        K.row_bwd(self.dt, self._row(M=M, L=L_, partials=part, chunks=chunks, **kw))
+        if ln or nln:
+            K.row_param_reduce(part, nblk, None, self.g(ln + ".weight") if ln else None, self.g(ln + ".bias") if ln else None,
+                               self.g(nln + ".weight") if nln else None, self.g(nln + ".bias") if nln else None)
+
+    def act_fwd(self, a, rows, cols, act, site=None):
+        y = self.e(rows, a.shape[1])
+        thr, sc = (self.thr, self.dscale) if site is not None else (0, 1.0)
+        K.act_drop(self.dt, a, a.shape[1], y, y.shape[1], rows, cols, act, self.seed, site or 0, thr, sc)
+        return y
+
+    def act_bwd(self, a, dy, rows, cols, act, site=None):
+        da = self.e(rows, a.shape[1], dtype=a.dtype)
+        thr, sc = (self.thr, self.dscale) if site is not None else (0, 1.0)
+        K.act_drop_bwd(self.dt, a, a.shape[1], dy, dy.shape[1], da, rows, cols, act, self.seed, site or 0, thr, sc)
+        return da
+
+    # ------------------------------------------------------------------------------------------------------------------
+    # forward
+    # ------------------------------------------------------------------------------------------------------------------
+    def forward(self, x, cond, times, keep, seed: Tuple[int, int], p_drop: float):
+        """x (B, Lq, nf) fp32, cond (B, 2S(+1), Cd), times (B,) long, keep (B,) bool -> out (B, Lq, nf) fp32.
+        model/model.py:548-624 with train-mode dropout (probability p_drop; 0 = the eval-mode arithmetic)."""
+        if self.sv is not None and self.sv.get("pending"):
+            pass        # a forward without its backward (e.g. a validation pass with gradients enabled): simply overwritten
+        dt, lins = self.dt, self.lins
+        B = x.shape[0]
+        S, dn, Lq, nf, H, NL, Cd = self.S, self.dn, self.Lq, self.nf, self.H, self.NL, self.Cd
+        M, Ms, Mc = B * Lq, B * S, B * (S + 2)
+        self.thr, self.dscale = K.drop_params(p_drop)
+        self.seed.copy_(torch.tensor([seed[0] & 0x7FFFFFFF, seed[1] & 0x7FFFFFFF], dtype=torch.int32))
+        self.repack()
+        sv = dict(B=B, pending=True)
+        P, e, z = self.P, self.e, self.z
+        f32 = torch.float32
+        x = x.reshape(M, nf).float().contiguous()
+        cond = cond.to(self.dev).float().contiguous()
+        clen = cond.shape[1]
+        if clen // 2 != S:
+            raise L.TcdiffError(f"cond length {clen} does not pair into seq_len={S} tokens (model/model.py:572-589)")
+        keep_u8 = keep.to(device=self.dev, dtype=torch.uint8).contiguous()
+        sv["keep"] = keep_u8
+
+        # ---- music branch: cond_projection, two encoder layers (model/model.py:572-583,211-245) -------------------------
+        kc0 = lins["c0"].Kp
+        cin = z(Ms, kc0)
+        K.convert_pad(dt, cond, cin, Ms, 2 * Cd, kc0, rows_per_batch=S, batch_stride=clen * Cd, row_stride=2 * Cd)
+        kc1 = lins["c2"].Kp
+        c0a = z(Ms, kc1)
+        lins["c0"].fwd(cin, Ms, out=c0a, ldc=kc1)
+        c1 = self.act_fwd(c0a, Ms, Cd, L.ACT_RELU)
+        tok = e(Ms, 512, dtype=f32)
+        lins["c2"].fwd(c1, Ms, out=tok, f32=True)
+        sv.update(cin=cin, c0a=c0a, c1=c1, tok0=tok)
+        mh, mrot = e(Ms, 512), e(Ms, 512)
+        self.row_fwd(flags=L.ROWF_NEXT_LN | L.ROWF_STORE_H | L.ROWF_STORE_ROT, M=Ms, L=S, z=tok,
+                     nln_g=P("cond_encoder.0.norm1.weight"), nln_b=P("cond_encoder.0.norm1.bias"), nln_eps=1e-5, hout=mh,
+                     rout=mrot, rope=self.rope, pos_mod=S)
+        enc = []
+        for i in range(2):
+            q = f"cond_encoder.{i}."
+            s = dict(x_in=tok, h=mh, rot=mrot)
+            Qi, Ki, Vi = z(B, H, self.Lps, 64), z(B, H, self.Lps, 64), z(B, H, self.Lps, 64)
+            lins[f"e{i}.qkv"].fwd(mrot, Ms, A2=mh, heads=dict(out=Qi, out_k=Ki, out_v=Vi, scale_q=0.125, Lseq=S,
+                                                               Lp=self.Lps, n_q=512, n_k=512))
+            O, lse = e(Ms, 512), z(B, H, self.Lps, dtype=f32)
+            K.attention_train(dt, Qi, Ki, Vi, O, lse, B, H, S, S, self.Lps, self.Lps, 512, self.seed, 4 * i + 0, self.thr,
+                              self.dscale)
+            zo = e(Ms, 512, dtype=f32)
+            lins[f"e{i}.o"].fwd(O, Ms, out=zo, f32=True)
+            x2, h2 = e(Ms, 512, dtype=f32), e(Ms, 512)
+            self.row_fwd(flags=L.ROWF_DROP_PRE | L.ROWF_RES | L.ROWF_STORE_X | L.ROWF_NEXT_LN | L.ROWF_STORE_H, M=Ms, L=S,
+                         z=zo, xres=tok, xout=x2, nln_g=P(q + "norm2.weight"), nln_b=P(q + "norm2.bias"), nln_eps=1e-5,
+                         hout=h2, site_pre=4 * i + 1)
+            a = e(Ms, 1024)
+            lins[f"e{i}.l1"].fwd(h2, Ms, out=a)
+            f = self.act_fwd(a, Ms, 1024, L.ACT_GELU, site=4 * i + 2)
+            zf = e(Ms, 512, dtype=f32)
+            lins[f"e{i}.l2"].fwd(f, Ms, out=zf, f32=True)
+            x3 = e(Ms, 512, dtype=f32)
+            fl = L.ROWF_DROP_PRE | L.ROWF_RES | L.ROWF_STORE_X
+            if i == 0:
+                mh, mrot = e(Ms, 512), e(Ms, 512)
+                self.row_fwd(flags=fl | L.ROWF_NEXT_LN | L.ROWF_STORE_H | L.ROWF_STORE_ROT, M=Ms, L=S, z=zf, xres=x2,
+                             xout=x3, nln_g=P("cond_encoder.1.norm1.weight"), nln_b=P("cond_encoder.1.norm1.bias"),
+                             nln_eps=1e-5, hout=mh, rout=mrot, rope=self.rope, pos_mod=S, site_pre=4 * i + 3)
+            else:
+                self.row_fwd(flags=fl, M=Ms, L=S, z=zf, xres=x2, xout=x3, site_pre=4 * i + 3)
+            s.update(Q=Qi, K=Ki, V=Vi, O=O, lse=lse, zo=zo, x2=x2, h2=h2, a=a, f=f, zf=zf)
+            enc.append(s)
+            tok = x3
+        sv["enc"] = enc
+        # ---- null-conditioning select, pooled hidden (model/model.py:585-597,609-610) -----------------------------------
+        sel_tok = e(B, S * 512, dtype=f32)
+        K.select_rows(tok, P("null_cond_embed").reshape(-1), keep_u8, sel_tok, B, S * 512)
+        pooled = e(B, 512, dtype=f32)
+        K.mean_pool(sel_tok, pooled, B, S, 512)
+        ph = e(B, 512)
+        self.row_fwd(flags=L.ROWF_NEXT_LN | L.ROWF_STORE_H, M=B, L=1, z=pooled, nln_g=P("non_attn_cond_projection.0.weight"),
+                     nln_b=P("non_attn_cond_projection.0.bias"), nln_eps=1e-5, hout=ph)
+        pa = e(B, 512)
+        lins["na1"].fwd(ph, B, out=pa)
+        pb = self.act_fwd(pa, B, 512, L.ACT_SILU)
+        hid = e(B, 512, dtype=f32)
+        lins["na3"].fwd(pb, B, out=hid, f32=True)
+        sel_hid = e(B, 512, dtype=f32)
+        K.select_rows(hid, P("null_cond_hidden").reshape(-1), keep_u8, sel_hid, B, 512)
+        sv.update(pooled=pooled, ph=ph, pa=pa, pb=pb)
+        # ---- time path (model/model.py:601-612) and the FiLM generators (:154-168) ----------------------------------------
+        emb = e(B, 512)
+        K.sinusoidal(dt, times.to(device=self.dev, dtype=torch.int32).contiguous(), B, self.sin_freq, emb)
+        ta = e(B, 2048)
+        lins["t1"].fwd(emb, B, out=ta)
+        th = self.act_fwd(ta, B, 2048, L.ACT_MISH)
+        tcat = e(B, 1536, dtype=f32)                      # [to_time_cond | to_time_tokens]
+        lins["tct"].fwd(th, B, out=tcat, f32=True)
+        pre = e(B, 512, dtype=f32)
+        K.add_rows(tcat, 1536, sel_hid, 512, pre, 512, B, 512)            # t += cond_hidden (:612)
+        fin = self.act_fwd(pre, B, 512, L.ACT_MISH)
+        nfilm = NL * 3 * 1024
+        film = e(B, nfilm, dtype=f32)
+        lins["film"].fwd(fin, B, out=film, f32=True)
+        sv.update(emb=emb, ta=ta, th=th, pre=pre, fin=fin, film=film)
+        # ---- memory = norm_cond(cat(tokens, time tokens)) and every layer's cross-attention K / V (:615-616,386-396) --------
+        memin = torch.cat([sel_tok.view(B, S, 512), tcat[:, 512:].reshape(B, 2, 512)], 1).contiguous()   # copies only
+        mem_h, mem_rot = e(Mc, 512), e(Mc, 512)
+        self.row_fwd(flags=L.ROWF_NEXT_LN | L.ROWF_STORE_H | L.ROWF_STORE_ROT, M=Mc, L=S + 2, z=memin.view(Mc, 512),
+                     nln_g=P("norm_cond.weight"), nln_b=P("norm_cond.bias"), nln_eps=1e-5, hout=mem_h, rout=mem_rot,
+                     rope=self.rope, pos_mod=S + 2)
+        Kc, Vc = z(NL, B, H, self.Lpc, 64), z(NL, B, H, self.Lpc, 64)
+        nk = 512 * NL
+        for l in range(NL):
+            hd = dict(out=None, scale_q=1.0, Lseq=S + 2, Lp=self.Lpc, n_q=0)
+            lins["ckv"].fwd(mem_rot, Mc, heads=dict(out_k=Kc[l], out_v=None, n_k=512, **hd), rows=(512 * l, 512 * l + 512))
+            lins["ckv"].fwd(mem_h, Mc, heads=dict(out_k=None, out_v=Vc[l], n_k=0, **hd), rows=(nk + 512 * l, nk + 512 * l + 512))
+        sv.update(memin=memin, mem_h=mem_h, mem_rot=mem_rot, Kc=Kc, Vc=Vc)
+        # ---- motion: input projection + fusion projection (model/model.py:560-561) --------------------------------------------
+        xin = z(M, lins["in"].Kp)
+        K.convert_pad(dt, x, xin, M, nf, lins["in"].Kp)
+        xp = e(M, 512)
+        lins["in"].fwd(xin, M, out=xp)
+        xpf = xp.view(Ms, 512 * dn)
+        f1a = e(Ms, 1024)
+        lins["f1"].fwd(xpf, Ms, out=f1a)
+        f1 = self.act_fwd(f1a, Ms, 1024, L.ACT_RELU)
+        f2a = e(Ms, 1024)
+        lins["f2"].fwd(f1, Ms, out=f2a)
+        f2 = self.act_fwd(f2a, Ms, 1024, L.ACT_RELU)
+        xs = e(Ms, 512 * dn, dtype=f32)
+        lins["f3"].fwd(f2, Ms, out=xs, f32=True)
+        xs = xs.view(M, 512)
+        st = "seqTransDecoder.stack."
+        h1, r1 = e(M, 512), e(M, 512)
+        self.row_fwd(flags=L.ROWF_NEXT_LN | L.ROWF_STORE_H | L.ROWF_STORE_ROT, M=M, L=Lq, z=xs, nln_g=P(st + "0.norm1.weight"),
+                     nln_b=P(st + "0.norm1.bias"), nln_eps=1e-5, hout=h1, rout=r1, rope=self.rope, pos_mod=Lq)
+        sv.update(xin=xin, xpf=xpf, f1a=f1a, f1=f1, f2a=f2a, f2=f2, xs=xs)
+        # ---- decoder layers (model/model.py:308-344) ---------------------------------------------------------------------------
+        layers = []
+        xcur = xs
+        Lp, Lpc = self.Lp, self.Lpc
+        for l in range(NL):
+            q = f"{st}{l}."
+            s = dict(x=xcur, h1=h1, r1=r1)
+            sd = 16 + 8 * l
+            Q, Kk, V = z(B, H, Lp, 64), z(B, H, Lp, 64), z(B, H, Lp, 64)
+            lins[f"l{l}.qkv"].fwd(r1, M, A2=h1, heads=dict(out=Q, out_k=Kk, out_v=V, scale_q=0.125, Lseq=Lq, Lp=Lp, n_q=512,
+                                                            n_k=512))
+            O, lse = e(M, 512), z(B, H, Lp, dtype=f32)
+            K.attention_train(dt, Q, Kk, V, O, lse, B, H, Lq, Lq, Lp, Lp, 512, self.seed, sd + 0, self.thr, self.dscale)
+            z1 = e(M, 512, dtype=f32)
+            lins[f"l{l}.sfc"].fwd(O, M, out=z1, f32=True)
+            x2, r2 = e(M, 512, dtype=f32), e(M, 512)
+            blk = L.ROWF_DROP_PRE | L.ROWF_LN_POST | L.ROWF_DROP_POST | L.ROWF_FILM | L.ROWF_RES | L.ROWF_STORE_X | L.ROWF_NEXT_LN
+            self.row_fwd(flags=blk | L.ROWF_STORE_ROT, M=M, L=Lq, z=z1, ln_g=P(q + "self_attn.layer_norm.weight"),
+                         ln_b=P(q + "self_attn.layer_norm.bias"), ln_eps=1e-6, film=film[:, (3 * l) * 1024:], film_ld=nfilm,
+                         xres=xcur, xout=x2, nln_g=P(q + "norm2.weight"), nln_b=P(q + "norm2.bias"), nln_eps=1e-5, rout=r2,
+                         rope=self.rope, pos_mod=Lq, site_pre=sd + 1, site_post=sd + 2)
+            Qc = z(B, H, Lp, 64)
+            lins[f"l{l}.cq"].fwd(r2, M, heads=dict(out=Qc, out_k=None, out_v=None, scale_q=0.125, Lseq=Lq, Lp=Lp, n_q=512, n_k=0))
+            Oc, lsec = e(M, 512), z(B, H, Lp, dtype=f32)
+            K.attention_train(dt, Qc, Kc[l], Vc[l], Oc, lsec, B, H, Lq, S + 2, Lp, Lpc, 512, self.seed, sd + 3, self.thr,
+                              self.dscale)
+            z2 = e(M, 512, dtype=f32)
+            lins[f"l{l}.cfc"].fwd(Oc, M, out=z2, f32=True)
+            x3, h3 = e(M, 512, dtype=f32), e(M, 512)
+            self.row_fwd(flags=blk | L.ROWF_STORE_H, M=M, L=Lq, z=z2, ln_g=P(q + "multihead_attn.layer_norm.weight"),
+                         ln_b=P(q + "multihead_attn.layer_norm.bias"), ln_eps=1e-6, film=film[:, (3 * l + 1) * 1024:],
+                         film_ld=nfilm, xres=x2, xout=x3, nln_g=P(q + "norm3.weight"), nln_b=P(q + "norm3.bias"), nln_eps=1e-5,
+                         hout=h3, site_pre=sd + 4, site_post=sd + 5)
+            a = e(M, 1024)
+            lins[f"l{l}.ff1"].fwd(h3, M, out=a)
+            f = self.act_fwd(a, M, 1024, L.ACT_GELU, site=sd + 6)
+            z3 = e(M, 512, dtype=f32)
+            lins[f"l{l}.ff2"].fwd(f, M, out=z3, f32=True)
+            h4 = e(M, 512)
+            # x4 itself is not kept: the layer output linear3(norm4(x4)) has no residual (model/model.py:344)
+            self.row_fwd(flags=L.ROWF_DROP_PRE | L.ROWF_FILM | L.ROWF_RES | L.ROWF_NEXT_LN | L.ROWF_STORE_H, M=M, L=Lq, z=z3,
+                         film=film[:, (3 * l + 2) * 1024:], film_ld=nfilm, xres=x3, nln_g=P(q + "norm4.weight"),
+                         nln_b=P(q + "norm4.bias"), nln_eps=1e-5, hout=h4, site_pre=sd + 7)
+            z4 = e(M, 512, dtype=f32)
+            lins[f"l{l}.l3"].fwd(h4, M, out=z4, f32=True)
+            s.update(Q=Q, K=Kk, V=V, O=O, lse=lse, z1=z1, x2=x2, r2=r2, Qc=Qc, Oc=Oc, lsec=lsec, z2=z2, x3=x3, h3=h3, a=a, f=f,
+                     z3=z3, h4=h4, z4=z4)
+            layers.append(s)
+            if l + 1 < NL:
+                h1, r1 = e(M, 512), e(M, 512)
+                self.row_fwd(flags=L.ROWF_NEXT_LN | L.ROWF_STORE_H | L.ROWF_STORE_ROT, M=M, L=Lq, z=z4,
+                             nln_g=P(f"{st}{l + 1}.norm1.weight"), nln_b=P(f"{st}{l + 1}.norm1.bias"), nln_eps=1e-5, hout=h1,
+                             rout=r1, rope=self.rope, pos_mod=Lq)
+                xcur = z4
+        sv["layers"] = layers
+        hT = e(M, 512)
+        K.cast_transpose(dt, z4, M, 512, 512, dst=hT, ld_dst=512, cols_pad=512)
+        out = e(M, nf, dtype=f32)
+        lins["fin"].fwd(hT, M, out=out, f32=True, ldc=nf)
+        sv["hT"] = hT
+        self.sv = sv
+        return out.view(B, Lq, nf)
+
+    # ------------------------------------------------------------------------------------------------------------------
+    # backward
+    # ------------------------------------------------------------------------------------------------------------------
+    def backward(self, d_out: torch.Tensor) -> List[Optional[torch.Tensor]]:
+        sv = self.sv
+        if sv is None or not sv.get("pending"):
+            raise L.TcdiffError("backward without a matching train-mode forward (one forward may be outstanding per model)")
+        sv["pending"] = False
+        dt, lins = self.dt, self.lins
+        B = sv["B"]
+        S, dn, Lq, nf, H, NL = self.S, self.dn, self.Lq, self.nf, self.H, self.NL
+        M, Ms, Mc = B * Lq, B * S, B * (S + 2)
+        Lp, Lpc, Lps = self.Lp, self.Lpc, self.Lps
+        e, z, P = self.e, self.z, self.P
+        f32 = torch.float32
+        st = "seqTransDecoder.stack."
+        # a parameter's .grad may still alias the previous step's flat buffer (the caller accumulates across calls
+        # instead of zero_grad): never overwrite gradients somebody still holds
+        p_first = self.params[next(iter(self.slot))]
+        if p_first.grad is not None and p_first.grad.untyped_storage().data_ptr() == self.flat.untyped_storage().data_ptr():
+            self._new_flat()
+        else:
+            self.flat.zero_()
+        d_out = d_out.reshape(M, nf).float().contiguous()
+        nfilm = NL * 3 * 1024
+        dfilm = z(B, nfilm, dtype=f32)
+        nk = 512 * NL
+        dKV = e(Mc, 2 * nk)                              # [dK of layer 0..NL-1 | dV of layer 0..NL-1], token-major
+
+        # ---- final layer --------------------------------------------------------------------------------------------------
+        dhT = e(M, 512)
+        lins["fin"].bwd(d_out, nf, M, [sv["hT"]], [("T", dhT, 512)])
+        g_x, g_h, g_r = None, None, None                  # gradients reaching the NEXT layer's inputs (x fp32, h1 / r1 T)
+        dz4 = dhT
+        for l in reversed(range(NL)):
+            s = sv["layers"][l]
+            q = f"{st}{l}."
+            sd = 16 + 8 * l
+            if l + 1 < NL:                                # x' = linear3(.) feeds the next layer: residual + norm1 + rotary
+                dz4 = e(M, 512)
+                self.row_bwd(M=M, L_=Lq, nln=f"{st}{l + 1}.norm1", flags=L.ROWF_NEXT_LN | L.ROWF_STORE_H | L.ROWF_STORE_ROT,
+                             z=s["z4"], nln_g=P(f"{st}{l + 1}.norm1.weight"), nln_b=P(f"{st}{l + 1}.norm1.bias"), nln_eps=1e-5,
+                             rope=self.rope, pos_mod=Lq, d_xn=g_x, d_h=g_h, d_rot=g_r, d_z=dz4)
+            dh4 = e(M, 512)
+            lins[f"l{l}.l3"].bwd(dz4, 512, M, [s["h4"]], [("T", dh4, 512)])
+            # feed-forward block
+            dz3, gx3 = e(M, 512), e(M, 512, dtype=f32)
+            self.row_bwd(M=M, L_=Lq, nln=q + "norm4", flags=L.ROWF_DROP_PRE | L.ROWF_FILM | L.ROWF_RES | L.ROWF_NEXT_LN | L.ROWF_STORE_H,
+                         z=s["z3"], film=sv["film"][:, (3 * l + 2) * 1024:], film_ld=nfilm, xres=s["x3"],
+                         nln_g=P(q + "norm4.weight"), nln_b=P(q + "norm4.bias"), nln_eps=1e-5, site_pre=sd + 7, d_h=dh4, d_z=dz3,
+                         d_xres=gx3, d_film=dfilm[:, (3 * l + 2) * 1024:], dfilm_ld=nfilm)
+            df = e(M, 1024)
+            lins[f"l{l}.ff2"].bwd(dz3, 512, M, [s["f"]], [("T", df, 1024)])
+            da = self.act_bwd(s["a"], df, M, 1024, L.ACT_GELU, site=sd + 6)
+            dh3 = e(M, 512)
+            lins[f"l{l}.ff1"].bwd(da, 1024, M, [s["h3"]], [("T", dh3, 512)])
+            # cross-attention block
+            blk = L.ROWF_DROP_PRE | L.ROWF_LN_POST | L.ROWF_DROP_POST | L.ROWF_FILM | L.ROWF_RES | L.ROWF_NEXT_LN
+            dz2, gx2 = e(M, 512), e(M, 512, dtype=f32)
+            self.row_bwd(M=M, L_=Lq, ln=q + "multihead_attn.layer_norm", nln=q + "norm3", flags=blk | L.ROWF_STORE_H, z=s["z2"],
+                         ln_g=P(q + "multihead_attn.layer_norm.weight"), ln_b=P(q + "multihead_attn.layer_norm.bias"),
+                         ln_eps=1e-6, film=sv["film"][:, (3 * l + 1) * 1024:], film_ld=nfilm, xres=s["x2"],
+                         nln_g=P(q + "norm3.weight"), nln_b=P(q + "norm3.bias"), nln_eps=1e-5, site_pre=sd + 4, site_post=sd + 5,
+                         d_xn=gx3, d_h=dh3, d_z=dz2, d_xres=gx2, d_film=dfilm[:, (3 * l + 1) * 1024:], dfilm_ld=nfilm)
+            dOc = z(B, H, Lp, 64)
+            lins[f"l{l}.cfc"].bwd(dz2, 512, M, [s["Oc"]], [("HEADS", dict(out=dOc, out_k=None, out_v=None, scale_q=1.0, Lseq=Lq,
+                                                                             Lp=Lp, n_q=512, n_k=0))])
+            dQc, delta = e(M, 512), z(B, H, Lp, dtype=f32)
+            K.attention_bwd(dt, s["Qc"], sv["Kc"][l], sv["Vc"][l], s["Oc"], dOc, s["lsec"], delta, dQc, 512,
+                            dKV.view(-1)[512 * l:], dKV.view(-1)[nk + 512 * l:], 2 * nk, B, H, Lq, S + 2, Lp, Lpc, 512, 0.125,
+                            self.seed, sd + 3, self.thr, self.dscale)
+            dr2 = e(M, 512)
+            lins[f"l{l}.cq"].bwd(dQc, 512, M, [s["r2"]], [("T", dr2, 512)])
+            # self-attention block
+            dz1, gx1 = e(M, 512), e(M, 512, dtype=f32)
+            self.row_bwd(M=M, L_=Lq, ln=q + "self_attn.layer_norm", nln=q + "norm2", flags=blk | L.ROWF_STORE_ROT, z=s["z1"],
+                         ln_g=P(q + "self_attn.layer_norm.weight"), ln_b=P(q + "self_attn.layer_norm.bias"), ln_eps=1e-6,
+                         film=sv["film"][:, (3 * l) * 1024:], film_ld=nfilm, xres=s["x"], nln_g=P(q + "norm2.weight"),
+                         nln_b=P(q + "norm2.bias"), nln_eps=1e-5, rope=self.rope, pos_mod=Lq, site_pre=sd + 1, site_post=sd + 2,
+                         d_xn=gx2, d_rot=dr2, d_z=dz1, d_xres=gx1, d_film=dfilm[:, (3 * l) * 1024:], dfilm_ld=nfilm)
+            dO = z(B, H, Lp, 64)
+            lins[f"l{l}.sfc"].bwd(dz1, 512, M, [s["O"]], [("HEADS", dict(out=dO, out_k=None, out_v=None, scale_q=1.0, Lseq=Lq,
+                                                                           Lp=Lp, n_q=512, n_k=0))])
+            dQKV, delta = e(M, 1536), z(B, H, Lp, dtype=f32)
+            K.attention_bwd(dt, s["Q"], s["K"], s["V"], s["O"], dO, s["lse"], delta, dQKV, 1536, dQKV.view(-1)[512:],
+                            dQKV.view(-1)[1024:], 1536, B, H, Lq, Lq, Lp, Lp, 512, 0.125, self.seed, sd + 0, self.thr,
+                            self.dscale)
+            g_r, g_h = e(M, 512), e(M, 512)
+            lins[f"l{l}.qkv"].bwd(dQKV, 1536, M, [s["r1"], s["h1"]], [("T", g_r, 512), ("T", g_h, 512)])
+            g_x = gx1
+        # ---- front: layer 0's norm1 / rotary on the fusion projection's output, then the fusion MLP -----------------------------
+        dxs = e(M, 512)
+        self.row_bwd(M=M, L_=Lq, nln=st + "0.norm1", flags=L.ROWF_NEXT_LN | L.ROWF_STORE_H | L.ROWF_STORE_ROT, z=sv["xs"],
+                     nln_g=P(st + "0.norm1.weight"), nln_b=P(st + "0.norm1.bias"), nln_eps=1e-5, rope=self.rope, pos_mod=Lq,
+                     d_xn=g_x, d_h=g_h, d_rot=g_r, d_z=dxs)
+        df2 = e(Ms, 1024)
+        lins["f3"].bwd(dxs.view(Ms, 512 * dn), 512 * dn, Ms, [sv["f2"]], [("T", df2, 1024)])
+        df2a = self.act_bwd(sv["f2a"], df2, Ms, 1024, L.ACT_RELU)
+        df1 = e(Ms, 1024)
+        lins["f2"].bwd(df2a, 1024, Ms, [sv["f1"]], [("T", df1, 1024)])
+        df1a = self.act_bwd(sv["f1a"], df1, Ms, 1024, L.ACT_RELU)
+        dxp = e(Ms, 512 * dn)
+        lins["f1"].bwd(df1a, 1024, Ms, [sv["xpf"]], [("T", dxp, 512 * dn)])
+        lins["in"].bwd(dxp.view(M, 512), 512, M, [sv["xin"]], [None])
+        # ---- cross-attention K / V of all layers -> memory rows ---------------------------------------------------------------------
+        d_mrot, d_mh = e(Mc, 512), e(Mc, 512)
+        lins["ckv"].bwd(dKV, 2 * nk, Mc, [sv["mem_rot"], sv["mem_h"]], [("T", d_mrot, 512), ("T", d_mh, 512)])
+        d_memin = e(Mc, 512, dtype=f32)
+        self.row_bwd(M=Mc, L_=S + 2, nln="norm_cond", flags=L.ROWF_NEXT_LN | L.ROWF_STORE_H | L.ROWF_STORE_ROT,
+                     z=sv["memin"].view(Mc, 512), nln_g=P("norm_cond.weight"), nln_b=P("norm_cond.bias"), nln_eps=1e-5,
+                     rope=self.rope, pos_mod=S + 2, d_h=d_mh, d_rot=d_mrot, d_z=d_memin, dz_f32=1)
+        d_memin = d_memin.view(B, S + 2, 512)
+        g_tok_mem = d_memin[:, :S].contiguous()            # copies only
+        # ---- FiLM generators and the time path ------------------------------------------------------------------------------------------
+        dfin = e(B, 512)
+        lins["film"].bwd(dfilm, nfilm, B, [sv["fin"]], [("T", dfin, 512)])
+        d_pre = self.act_bwd(sv["pre"], dfin, B, 512, L.ACT_MISH)          # fp32: = d t_base = d cond_hidden
+        d_tcat = e(B, 1536, dtype=f32)
+        d_tcat[:, :512].copy_(d_pre)
+        d_tcat[:, 512:].copy_(d_memin[:, S:].reshape(B, 1024))
+        dth = e(B, 2048)
+        lins["tct"].bwd(d_tcat, 1536, B, [sv["th"]], [("T", dth, 2048)])
+        dta = self.act_bwd(sv["ta"], dth, B, 2048, L.ACT_MISH)
+        lins["t1"].bwd(dta, 2048, B, [sv["emb"]], [None])
+        # ---- pooled hidden, null-conditioning selects ---------------------------------------------------------------------------------------
+        d_hid = e(B, 512, dtype=f32)
+        K.select_rows_bwd(d_pre, sv["keep"], d_hid, self.g("null_cond_hidden"), B, 512)
+        dpb = e(B, 512)
+        lins["na3"].bwd(d_hid, 512, B, [sv["pb"]], [("T", dpb, 512)])
+        dpa = self.act_bwd(sv["pa"], dpb, B, 512, L.ACT_SILU)
+        dph = e(B, 512)
+        lins["na1"].bwd(dpa, 512, B, [sv["ph"]], [("T", dph, 512)])
+        d_pool = e(B, 512, dtype=f32)
+        self.row_bwd(M=B, L_=1, nln="non_attn_cond_projection.0", flags=L.ROWF_NEXT_LN | L.ROWF_STORE_H, z=sv["pooled"],
+                     nln_g=P("non_attn_cond_projection.0.weight"), nln_b=P("non_attn_cond_projection.0.bias"), nln_eps=1e-5,
+                     d_h=dph, d_z=d_pool, dz_f32=1)
+        d_sel = e(B, S * 512, dtype=f32)
+        K.pool_bwd(g_tok_mem, d_pool, d_sel, B, S, 512)
+        g_tok = e(Ms, 512, dtype=f32)
+        K.select_rows_bwd(d_sel, sv["keep"], g_tok, self.g("null_cond_embed"), B, S * 512)
+        # ---- music encoder layers -------------------------------------------------------------------------------------------------------------
+        g_h, g_r = None, None
+        for i in reversed(range(2)):
+            s = sv["enc"][i]
+            q = f"cond_encoder.{i}."
+            dzf, gx2 = e(Ms, 512), e(Ms, 512, dtype=f32)
+            fl = L.ROWF_DROP_PRE | L.ROWF_RES
+            if i == 0:
+                self.row_bwd(M=Ms, L_=S, nln="cond_encoder.1.norm1", flags=fl | L.ROWF_NEXT_LN | L.ROWF_STORE_H | L.ROWF_STORE_ROT,
+                             z=s["zf"], xres=s["x2"], nln_g=P("cond_encoder.1.norm1.weight"), nln_b=P("cond_encoder.1.norm1.bias"),
+                             nln_eps=1e-5, rope=self.rope, pos_mod=S, site_pre=4 * i + 3, d_xn=g_tok, d_h=g_h, d_rot=g_r, d_z=dzf,
+                             d_xres=gx2)
+            else:
+                self.row_bwd(M=Ms, L_=S, flags=fl, z=s["zf"], xres=s["x2"], site_pre=4 * i + 3, d_xn=g_tok, d_z=dzf, d_xres=gx2)
+            df = e(Ms, 1024)
+            lins[f"e{i}.l2"].bwd(dzf, 512, Ms, [s["f"]], [("T", df, 1024)])
+            da = self.act_bwd(s["a"], df, Ms, 1024, L.ACT_GELU, site=4 * i + 2)
+            dh2 = e(Ms, 512)
+            lins[f"e{i}.l1"].bwd(da, 1024, Ms, [s["h2"]], [("T", dh2, 512)])
+            dzo, gx1 = e(Ms, 512), e(Ms, 512, dtype=f32)
+            self.row_bwd(M=Ms, L_=S, nln=q + "norm2", flags=fl | L.ROWF_NEXT_LN | L.ROWF_STORE_H, z=s["zo"], xres=s["x_in"],
+                         nln_g=P(q + "norm2.weight"), nln_b=P(q + "norm2.bias"), nln_eps=1e-5, site_pre=4 * i + 1, d_xn=gx2,
+                         d_h=dh2, d_z=dzo, d_xres=gx1)
+            dO = z(B, H, Lps, 64)
+            lins[f"e{i}.o"].bwd(dzo, 512, Ms, [s["O"]], [("HEADS", dict(out=dO, out_k=None, out_v=None, scale_q=1.0, Lseq=S,
+                                                                        Lp=Lps, n_q=512, n_k=0))])
+            dQKV, delta = e(Ms, 1536), z(B, H, Lps, dtype=f32)
+            K.attention_bwd(dt, s["Q"], s["K"], s["V"], s["O"], dO, s["lse"], delta, dQKV, 1536, dQKV.view(-1)[512:],
+                            dQKV.view(-1)[1024:], 1536, B, H, S, S, Lps, Lps, 512, 0.125, self.seed, 4 * i + 0, self.thr,
+                            self.dscale)
+            g_r, g_h = e(Ms, 512), e(Ms, 512)
+            lins[f"e{i}.qkv"].bwd(dQKV, 1536, Ms, [s["rot"], s["h"]], [("T", g_r, 512), ("T", g_h, 512)])
+            g_tok = gx1
+        dtok0 = e(Ms, 512)
+        self.row_bwd(M=Ms, L_=S, nln="cond_encoder.0.norm1", flags=L.ROWF_NEXT_LN | L.ROWF_STORE_H | L.ROWF_STORE_ROT, z=sv["tok0"],
+                     nln_g=P("cond_encoder.0.norm1.weight"), nln_b=P("cond_encoder.0.norm1.bias"), nln_eps=1e-5, rope=self.rope,
+                     pos_mod=S, d_xn=g_tok, d_h=g_h, d_rot=g_r, d_z=dtok0)
+        dc1 = z(Ms, sv["c1"].shape[1])
+        lins["c2"].bwd(dtok0, 512, Ms, [sv["c1"]], [("T", dc1, dc1.shape[1])])
+        dc0a = self.act_bwd(sv["c0a"], dc1, Ms, self.Cd, L.ACT_RELU)
+        lins["c0"].bwd(dc0a, dc0a.shape[1], Ms, [sv["cin"]], [None])
+        self.sv = None
+        return self.grad_views()
+
+
+class _DenoiserTrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, eng: TrainEngine, x, cond, times, keep, seed, p_drop, *params):
+        ctx.eng = eng
+        return eng.forward(x, cond, times, keep, seed, p_drop)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        grads = ctx.eng.backward(d_out)
+        return (None,) * 7 + tuple(grads)
+
+
+def denoiser_train(model, x, cond, times, keep, seed: Tuple[int, int], p_drop: float) -> torch.Tensor:
+    """DanceDecoder.forward with an autograd graph (train-mode dropout of probability p_drop, 0 = eval arithmetic)."""
+    eng = model.train_engine()
+    return _DenoiserTrainFn.apply(eng, x, cond, times, keep, seed, p_drop, *[eng.params[n] for n in eng.order])

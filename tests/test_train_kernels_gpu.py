@@ -1,0 +1,288 @@
+"""Kernel-level checks of the training-step launchers (through the C ABI) against plain torch evaluations of the same
+operator and torch autograd of it: operand repacking, split-K weight gradients, activation + dropout, the row-local block
+glue (forward and reverse), train-mode attention (forward and reverse) and the loss terms' reverse pass.  Dropout masks
+come from the oracle's numpy evaluation of the product's counter hash, so a mismatch in the hash shows up here first."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import tcdiff_oracle as O  # noqa: E402  (checker only)
+from tcdiff_amd import _lib as L  # noqa: E402
+from tcdiff_amd import kernels as K  # noqa: E402
+
+DEV = "cuda"
+SEED = (1234, 5678)
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def seed_dev():
+    return torch.tensor(SEED, dtype=torch.int32, device=DEV)
+
+
+def mode(compute):
+    dt = K.dtype_id(compute)
+    return dt, K.TORCH_DT[dt], (2e-6 if compute == "f32" else 1.5e-2)
+
+
+@pytest.mark.parametrize("compute", ["f32", "bf16"])
+@pytest.mark.parametrize("src_f32", [True, False])
+def test_cast_transpose_pads_and_column_sums(compute, src_f32):
+    dt, T, _ = mode(compute)
+    rows, cols, ld = 150, 151, 152
+    g = torch.Generator().manual_seed(1)
+    src = torch.randn(rows, ld, generator=g)
+    srcd = src.to(DEV) if src_f32 else src.to(DEV, T)
+    ref = srcd.float().cpu()[:, :cols]
+    cp, rp = 192, 192
+    dst = torch.full((rows, cp), 7.0, device=DEV, dtype=T)
+    dstT = torch.full((cols, rp), 7.0, device=DEV, dtype=T)
+    cs = torch.zeros(cols, device=DEV)
+    K.cast_transpose(dt, srcd, rows, cols, ld, dst=dst, ld_dst=cp, cols_pad=cp, dstT=dstT, ld_dstT=rp, rows_pad=rp, colsum=cs)
+    want = ref.to(T).float()
+    assert torch.equal(dst.float().cpu()[:, :cols], want) and float(dst.float()[:, cols:].abs().max()) == 0.0
+    assert torch.equal(dstT.float().cpu()[:, :rows], want.t()) and float(dstT.float()[:, rows:].abs().max()) == 0.0
+    assert rel(cs, ref.sum(0)) < 1e-6
+
+
+@pytest.mark.parametrize("compute", ["f32", "bf16"])
+def test_gemm_splitk_accumulates_the_weight_gradient(compute):
+    dt, T, tol = mode(compute)
+    kt = K.k_tile(dt)
+    n_out, n_in, rows = 200, 151, 1000                       # dW[n_out, n_in] += dY^T X over `rows` token rows
+    rp = K.round_up(rows, kt)
+    g = torch.Generator().manual_seed(2)
+    dYt = torch.zeros(n_out, rp, dtype=T)
+    Xt = torch.zeros(n_in, rp, dtype=T)
+    dYt[:, :rows] = torch.randn(n_out, rows, generator=g).to(T)
+    Xt[:, :rows] = torch.randn(n_in, rows, generator=g).to(T)
+    init = torch.randn(n_out, n_in, generator=g)
+    out = init.clone().to(DEV)
+    for splits in (1, 5):
+        out.copy_(init)
+        K.gemm_splitk(dt, dYt.to(DEV), Xt.to(DEV), n_out, n_in, rp, rp, rp, out, n_in, splits)
+        want = init.double() + dYt.double() @ Xt.double().t()
+        assert rel(out, want) < (1e-6 if compute == "f32" else 1e-5), splits
+
+
+@pytest.mark.parametrize("compute", ["f32", "bf16"])
+@pytest.mark.parametrize("act", [L.ACT_RELU, L.ACT_GELU, L.ACT_MISH, L.ACT_SILU])
+def test_act_drop_forward_and_backward(compute, act):
+    dt, T, tol = mode(compute)
+    rows, cols, ld = 37, 438, 448
+    g = torch.Generator().manual_seed(3)
+    a = (torch.randn(rows, ld, generator=g) * 2).to(T)
+    dy = torch.randn(rows, ld, generator=g).to(T)
+    thr, sc = K.drop_params(0.1)
+    site = 22
+    y = torch.full((rows, ld), 3.0, device=DEV, dtype=T)
+    K.act_drop(dt, a.to(DEV), ld, y, ld, rows, cols, act, seed_dev(), site, thr, sc)
+    keep = O.dropout_keep(SEED, site, (rows, cols), 0.1)
+    fn = {L.ACT_RELU: F.relu, L.ACT_GELU: F.gelu, L.ACT_MISH: F.mish, L.ACT_SILU: F.silu}[act]
+    ar = a[:, :cols].double().requires_grad_(True)
+    yr = fn(ar) * keep / 0.9
+    yr.backward(dy[:, :cols].double())
+    assert rel(y[:, :cols], yr.detach()) < max(tol, 1e-6) and float(y[:, cols:].float().abs().max()) == 0.0
+    # the same zero pattern: the hash is the oracle's
+    assert torch.equal((y[:, :cols].float().cpu() != 0) | (yr.detach() == 0), torch.ones(rows, cols, dtype=torch.bool))
+    da = torch.full((rows, ld), 3.0, device=DEV, dtype=T)
+    K.act_drop_bwd(dt, a.to(DEV), ld, dy.to(DEV), ld, da, rows, cols, act, seed_dev(), site, thr, sc)
+    assert rel(da[:, :cols], ar.grad) < max(tol, 1e-6) and float(da[:, cols:].float().abs().max()) == 0.0
+
+
+def _rope(n_pos):
+    freqs = (1.0 / (10000 ** (torch.arange(0, 512, 2).float() / 512))).to(DEV)
+    rope = torch.empty(n_pos, 512, device=DEV)
+    K.rope_table(freqs, rope, n_pos)
+    return rope
+
+
+def _rot_ref(u, cs):
+    up, cp = u.reshape(*u.shape[:-1], 256, 2), cs.reshape(*cs.shape[:-1], 256, 2)
+    c, s = cp[..., 0], cp[..., 1]
+    return torch.stack((up[..., 0] * c - up[..., 1] * s, up[..., 1] * c + up[..., 0] * s), -1).reshape(u.shape)
+
+
+ROW_CASES = {
+    "decoder self/cross block + rotary": L.ROWF_DROP_PRE | L.ROWF_LN_POST | L.ROWF_DROP_POST | L.ROWF_FILM | L.ROWF_RES | L.ROWF_STORE_X | L.ROWF_NEXT_LN | L.ROWF_STORE_H | L.ROWF_STORE_ROT,
+    "decoder feed-forward block": L.ROWF_DROP_PRE | L.ROWF_FILM | L.ROWF_RES | L.ROWF_STORE_X | L.ROWF_NEXT_LN | L.ROWF_STORE_H,
+    "norm + rotary only": L.ROWF_NEXT_LN | L.ROWF_STORE_H | L.ROWF_STORE_ROT,
+    "encoder residual + dropout": L.ROWF_BIAS | L.ROWF_DROP_PRE | L.ROWF_RES | L.ROWF_STORE_X,
+}
+
+
+@pytest.mark.parametrize("compute", ["f32", "bf16"])
+@pytest.mark.parametrize("case", list(ROW_CASES))
+def test_row_block_forward_and_backward_vs_torch_autograd(compute, case):
+    dt, T, tol = mode(compute)
+    f = ROW_CASES[case]
+    nseq, Ls = 3, 50
+    M = nseq * Ls
+    g = torch.Generator().manual_seed(4)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    z, xres, bias = rn(M, 512), rn(M, 512), rn(512) * 0.3
+    lg, lb, ng, nb = 1 + 0.1 * rn(512), 0.1 * rn(512), 1 + 0.1 * rn(512), 0.1 * rn(512)
+    film = 0.3 * rn(nseq, 2048)                                      # block at column 1024 of a wider FiLM row
+    rope = _rope(64)
+    d_xn, d_h, d_r = rn(M, 512), rn(M, 512).to(T), rn(M, 512).to(T)
+    thr, sc = K.drop_params(0.1)
+    sp, sq = 17, 18
+    dev = lambda t: t.to(DEV).contiguous()
+    zd, xd = dev(z), dev(xres)
+    xout, hout, rout = (torch.zeros(M, 512, device=DEV), torch.zeros(M, 512, device=DEV, dtype=T),
+                        torch.zeros(M, 512, device=DEV, dtype=T))
+    common = dict(flags=f, M=M, L=Ls, z=zd, bias=dev(bias), ln_g=dev(lg), ln_b=dev(lb), ln_eps=1e-6, film=dev(film)[:, 1024:],
+                  film_ld=2048, xres=xd, nln_g=dev(ng), nln_b=dev(nb), nln_eps=1e-5, rope=rope, pos_mod=Ls, pos_base=3,
+                  seed=seed_dev(), drop_thr=thr, drop_scale=sc, site_pre=sp, site_post=sq)
+    keepers = dict(common)           # keep the device tensors alive
+    K.row_fwd(dt, K.row_args(xout=xout, hout=hout, rout=rout, **common))
+    # ---- torch reference (float64, autograd) ---------------------------------------------------------------------------
+    D = torch.float64
+    zr, xr, br = z.to(D).requires_grad_(True), xres.to(D).requires_grad_(True), bias.to(D).requires_grad_(True)
+    lgr, lbr, ngr, nbr = (t.to(D).requires_grad_(True) for t in (lg, lb, ng, nb))
+    fr = film.to(D).requires_grad_(True)
+    v = zr
+    if f & L.ROWF_BIAS:
+        v = v + br
+    if f & L.ROWF_DROP_PRE:
+        v = v * O.dropout_keep(SEED, sp, (M, 512), 0.1) / 0.9
+    if f & L.ROWF_LN_POST:
+        v = F.layer_norm(v, (512,), lgr, lbr, 1e-6)
+    if f & L.ROWF_DROP_POST:
+        v = v * O.dropout_keep(SEED, sq, (M, 512), 0.1) / 0.9
+    if f & L.ROWF_FILM:
+        sc_, sh_ = fr[:, 1024:1536], fr[:, 1536:2048]
+        v = ((sc_ + 1)[:, None, :] * v.view(nseq, Ls, 512) + sh_[:, None, :]).reshape(M, 512)
+    if f & L.ROWF_RES:
+        v = xr + v
+    xn = v
+    u = F.layer_norm(xn, (512,), ngr, nbr, 1e-5) if f & L.ROWF_NEXT_LN else xn
+    pos = 3 + torch.arange(M) % Ls
+    rot = _rot_ref(u, rope.cpu().to(D)[pos])
+    loss = (xn * d_xn.to(D)).sum()
+    if f & L.ROWF_STORE_H:
+        loss = loss + (u * d_h.to(D)).sum()
+    if f & L.ROWF_STORE_ROT:
+        loss = loss + (rot * d_r.to(D)).sum()
+    loss.backward()
+    if f & L.ROWF_STORE_X:
+        assert rel(xout, xn.detach()) < 2e-6
+    if f & L.ROWF_STORE_H:
+        assert rel(hout, u.detach()) < max(tol / 3, 2e-6)
+    if f & L.ROWF_STORE_ROT:
+        assert rel(rout, rot.detach()) < max(tol / 3, 2e-6)
+    # ---- backward -----------------------------------------------------------------------------------------------------------
+    chunks = 3
+    part = torch.zeros(chunks * nseq, 5, 512, device=DEV)
+    d_z = torch.zeros(M, 512, device=DEV, dtype=T)
+    d_xres = torch.zeros(M, 512, device=DEV)
+    d_film = torch.zeros(nseq, 2048, device=DEV)
+    K.row_bwd(dt, K.row_args(d_xn=dev(d_xn), d_h=dev(d_h) if f & L.ROWF_STORE_H else None,
+                             d_rot=dev(d_r) if f & L.ROWF_STORE_ROT else None, d_z=d_z, d_xres=d_xres,
+                             d_film=d_film[:, 1024:], dfilm_ld=2048, partials=part, chunks=chunks, **common))
+    gb, glg, glb, gng, gnb = (torch.zeros(512, device=DEV) for _ in range(5))
+    K.row_param_reduce(part, chunks * nseq, gb, glg, glb, gng, gnb)
+    gtol = max(tol, 5e-6)
+    assert rel(d_z, zr.grad) < gtol
+    if f & L.ROWF_RES:
+        assert rel(d_xres, xr.grad) < 5e-6
+    if f & L.ROWF_BIAS:
+        assert rel(gb, br.grad) < 1e-5
+    if f & L.ROWF_LN_POST:
+        assert rel(glg, lgr.grad) < 1e-5 and rel(glb, lbr.grad) < 1e-5
+    if f & L.ROWF_NEXT_LN:
+        assert rel(gng, ngr.grad) < 1e-5 and rel(gnb, nbr.grad) < 1e-5
+    if f & L.ROWF_FILM:
+        assert rel(d_film[:, 1024:], fr.grad[:, 1024:]) < 1e-5 and float(d_film[:, :1024].abs().max()) == 0.0
+    assert keepers is not None
+
+
+def _images(x, Lp, T):
+    """[n, H, L, 64] -> zero-padded head-major image [n, H, Lp, 64] of dtype T"""
+    n, H, Lx, _ = x.shape
+    img = torch.zeros(n, H, Lp, 64, dtype=T)
+    img[:, :, :Lx] = x.to(T)
+    return img.to(DEV)
+
+
+@pytest.mark.parametrize("compute", ["f32", "bf16"])
+@pytest.mark.parametrize("Lq,Lk,p", [(120, 120, 0.1), (120, 62, 0.1), (450, 152, 0.0), (70, 130, 0.1)])
+def test_attention_train_forward_and_backward_vs_torch_autograd(compute, Lq, Lk, p):
+    dt, T, tol = mode(compute)
+    n, H = 2, 8
+    Lpq, Lpk = K.round_up(Lq, 128), K.round_up(Lk, 128)
+    g = torch.Generator().manual_seed(5)
+    q, k, v = (torch.randn(n, H, Lx, 64, generator=g) for Lx in (Lq, Lk, Lk))
+    do = torch.randn(n, H, Lq, 64, generator=g)
+    site = 16 + 8 * 3
+    thr, sc = K.drop_params(p)
+    Qi, Ki, Vi, dOi = _images(q * 0.125, Lpq, T), _images(k, Lpk, T), _images(v, Lpk, T), _images(do, Lpq, T)
+    O_ = torch.zeros(n * Lq, 512, device=DEV, dtype=T)
+    lse = torch.zeros(n, H, Lpq, device=DEV)
+    K.attention_train(dt, Qi, Ki, Vi, O_, lse, n, H, Lq, Lk, Lpq, Lpk, 512, seed_dev(), site, thr, sc)
+    D = torch.float64
+    qr = (Qi.cpu()[:, :, :Lq].to(D) * 8).requires_grad_(True)       # the UNSCALED projection output
+    kr, vr = Ki.cpu()[:, :, :Lk].to(D).requires_grad_(True), Vi.cpu()[:, :, :Lk].to(D).requires_grad_(True)
+    att = torch.softmax((qr * 0.125) @ kr.transpose(2, 3), -1)
+    lse_ref = torch.logsumexp((qr * 0.125) @ kr.transpose(2, 3), -1) / math.log(2.0)
+    if p > 0:
+        att = att * O.dropout_keep(SEED, site, (n, H, Lq, Lk), p) / (1 - p)
+    o = att @ vr
+    o.backward(dOi.cpu()[:, :, :Lq].to(D))
+    o_tok = o.detach().transpose(1, 2).reshape(n * Lq, 512)
+    assert rel(O_, o_tok) < max(tol, 3e-6), rel(O_, o_tok)
+    assert float((lse.cpu()[:, :, :Lq] - lse_ref.detach()).abs().max()) < (1e-4 if compute == "f32" else 5e-2)
+    delta = torch.zeros(n, H, Lpq, device=DEV)
+    dQ = torch.zeros(n * Lq, 1536, device=DEV, dtype=T)
+    dKV = torch.zeros(n * Lk, 1024, device=DEV, dtype=T)
+    K.attention_bwd(dt, Qi, Ki, Vi, O_, dOi, lse, delta, dQ, 1536, dKV, dKV.view(-1)[512:], 1024, n, H, Lq, Lk, Lpq, Lpk, 512,
+                    0.125, seed_dev(), site, thr, sc)
+    tok = lambda t, Lx: t.transpose(1, 2).reshape(n * Lx, 512)
+    gtol = max(tol * 1.5, 1e-5)
+    assert rel(dQ[:, :512], tok(qr.grad, Lq)) < gtol, rel(dQ[:, :512], tok(qr.grad, Lq))
+    assert rel(dKV[:, :512], tok(kr.grad, Lk)) < gtol, rel(dKV[:, :512], tok(kr.grad, Lk))
+    assert rel(dKV[:, 512:], tok(vr.grad, Lk)) < gtol, rel(dKV[:, 512:], tok(vr.grad, Lk))
+    assert float(dQ[:, 512:].float().abs().max()) == 0.0          # nothing written outside the addressed columns
+    # bitwise reproducible: no atomics in the attention backward
+    dQ2, dKV2 = torch.zeros_like(dQ), torch.zeros_like(dKV)
+    K.attention_bwd(dt, Qi, Ki, Vi, O_, dOi, lse, delta, dQ2, 1536, dKV2, dKV2.view(-1)[512:], 1024, n, H, Lq, Lk, Lpq, Lpk,
+                    512, 0.125, seed_dev(), site, thr, sc)
+    assert torch.equal(dQ, dQ2) and torch.equal(dKV, dKV2)
+
+
+@pytest.mark.parametrize("loss_type", ["l2", "l1"])
+def test_loss_function_backward_vs_oracle_autograd(loss_type):
+    """total(model_out) of model/diffusion.py:668-741, d total / d model_out, with contacts above 0.95 so that the
+    foot-skate term and its gradient are live (random-weight outputs never reach it)."""
+    from tcdiff_amd.diffusion import _LossFn
+    from tcdiff_amd.fk import SMPL_OFFSETS, SMPL_PARENTS
+    b, dn, S, C, T = 3, 2, 12, 151, 100
+    g = torch.Generator().manual_seed(6)
+    x_start = torch.randn(b, dn, S, C, generator=g) * 0.5
+    out = (x_start.permute(0, 2, 1, 3).reshape(b, S * dn, C) + 0.3 * torch.randn(b, S * dn, C, generator=g)).contiguous()
+    out[:, :, :4] = torch.rand(b, S * dn, 4, generator=g) * 1.2                 # some contacts > 0.95
+    t = torch.tensor([5, 50, 99])
+    tab = O.make_tables(T)
+    od = out.to(DEV).requires_grad_(True)
+    total, terms = _LossFn.apply(od, x_start.to(DEV), t.to(DEV), tab["p2_loss_weight"].to(DEV), SMPL_PARENTS, SMPL_OFFSETS,
+                                 loss_type == "l1")
+    (total * 1.7).backward()
+    orf = out.clone().requires_grad_(True)
+    # oracle p_losses with the model output injected (no denoiser evaluation)
+    o_total, o_losses = O.p_losses({}, tab, x_start, None, t, torch.zeros(b, S, dn, C), None, loss_type=loss_type, model_out=orf)
+    (o_total * 1.7).backward()
+    got = [float(v) for v in terms]
+    want = [float(v) for v in o_losses]
+    assert want[3] > 0, "the foot-skate term must be live in this test"
+    for a_, w_ in zip(got, want):
+        assert abs(a_ - w_) < 2e-5 * max(abs(w_), 1e-3), (got, want)
+    assert abs(float(total) - float(o_total)) < 2e-5 * abs(float(o_total))
+    assert rel(od.grad, orf.grad) < 2e-5, rel(od.grad, orf.grad)
