@@ -735,7 +735,12 @@ def rotation_6d_to_matrix(d6: torch.Tensor) -> torch.Tensor:
 
 
 def _sqrt_positive_part(x: torch.Tensor) -> torch.Tensor:
-    return torch.where(x > 0, torch.sqrt(torch.clamp(x, min=0)), torch.zeros_like(x))
+    """pytorch3d 0.7.1: sqrt by masked assignment -- zero where x <= 0 and, unlike a torch.where over sqrt(clamp(x)),
+    a clean ZERO subgradient there (where's unselected sqrt branch would contribute 0 * inf = NaN to autograd)."""
+    ret = torch.zeros_like(x)
+    m = x > 0
+    ret[m] = torch.sqrt(x[m])
+    return ret
 
 
 def matrix_to_quaternion(matrix: torch.Tensor) -> torch.Tensor:

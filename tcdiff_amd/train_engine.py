@@ -57,15 +57,17 @@ class _Lin:
     def pack(self):
         """(Re)build the operand packs from the fp32 master parameters: W as [N, Kp] and, per operand group, W^T."""
         eng, r0 = self.eng, 0
-        es = self.Wf.element_size()
-        for name, n in zip(self.wnames, self.rows):
+        for name, rows in zip(self.wnames, self.rows):
             w = eng.params[name].detach()
-            gi = 1 if (self.split and r0 >= self.split) else 0
-            lo = self.groups[gi][0]
-            wt = self.WbT[gi]
-            K.cast_transpose(eng.dt, w, n, self.K, self.K, dst=self.Wf[r0:], ld_dst=self.Kp, cols_pad=self.Kp,
-                             dstT=wt.view(-1)[r0 - lo:], ld_dstT=wt.shape[1], rows_pad=n)
-            r0 += n
+            # a parameter that spans the operand split (nn.MultiheadAttention's packed in_proj_weight) is packed in two pieces
+            cuts = [0, self.split - r0, rows] if (self.split and r0 < self.split < r0 + rows) else [0, rows]
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                gi = 1 if (self.split and r0 + a >= self.split) else 0
+                lo = self.groups[gi][0]
+                wt = self.WbT[gi]
+                K.cast_transpose(eng.dt, w[a:b], b - a, self.K, self.K, dst=self.Wf[r0 + a:], ld_dst=self.Kp, cols_pad=self.Kp,
+                                 dstT=wt.view(-1)[r0 + a - lo:], ld_dstT=wt.shape[1], rows_pad=b - a)
+            r0 += rows
         if self.bias is not None:
             o = 0
             for name in self.bnames:
@@ -100,13 +102,13 @@ class _Lin:
         Np = K.round_up(N, kt)
         gW = eng.gW[self.key]
         gb = eng.gB.get(self.key)
-        dYt = torch.empty(N, Mp, device=eng.dev, dtype=eng.T)
+        dYt = eng.e(N, Mp)
         direct = dY.dtype == eng.T and ld_dy == Np and N == Np     # dY itself is a valid K-contiguous operand
         if direct:
             dYT = dY
             K.cast_transpose(dt, dY, M, N, ld_dy, dstT=dYt, ld_dstT=Mp, rows_pad=Mp, colsum=gb)
         else:
-            dYT = torch.empty(M, Np, device=eng.dev, dtype=eng.T)
+            dYT = eng.e(M, Np)
             K.cast_transpose(dt, dY, M, N, ld_dy, dst=dYT, ld_dst=Np, cols_pad=Np, dstT=dYt, ld_dstT=Mp, rows_pad=Mp,
                              colsum=gb)
         outs = []
@@ -122,7 +124,7 @@ class _Lin:
                     K.gemm_tile(dt, A, self.WbT[gi], M, self.K, ngp, lda=Np,
                                 mode=L.EPI_STORE_F32 if w[0] == "F32" else L.EPI_STORE_T, out=w[1], ldc=w[2])
             X = Xs[gi]
-            Xt = torch.empty(self.K, Mp, device=eng.dev, dtype=eng.T)
+            Xt = eng.e(self.K, Mp)
             K.cast_transpose(dt, X, M, self.K, X.shape[1], dstT=Xt, ld_dstT=Mp, rows_pad=Mp)
             tiles = ((ng + 127) // 128) * ((self.K + 127) // 128)
             splits = max(1, min(512 // tiles, Mp // kt, 64))
@@ -268,7 +270,11 @@ class TrainEngine:
     def z(self, *shape, dtype=None):
         return torch.zeros(*shape, device=self.dev, dtype=self.T if dtype is None else dtype)
 
+    poison = False      # tests: fill every "empty" workspace with NaN, so that a kernel reading what nothing wrote shows up
+
     def e(self, *shape, dtype=None):
+        if self.poison:
+            return torch.full(shape, float("nan"), device=self.dev, dtype=self.T if dtype is None else dtype)
         return torch.empty(*shape, device=self.dev, dtype=self.T if dtype is None else dtype)
 
     def _row(self, **kw):

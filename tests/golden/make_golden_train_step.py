@@ -161,6 +161,7 @@ def main():
             out[f"s{k}_g:{n}"] = sample(g)
             out[f"s{k}_gn:{n}"] = np.float32(g.norm().item())
             og = sd_now[n].grad
+            assert bool(torch.isfinite(g).all()) and bool(torch.isfinite(og).all()), n
             rel = float((og - g).norm() / (g.norm() + 1e-30))
             worst = max(worst, rel)
         dead = [n for n, p in named.items() if p.grad is None]
