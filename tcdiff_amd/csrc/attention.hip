@@ -261,7 +261,7 @@ __global__ __launch_bounds__(512) void attention_res_kernel(const char* __restri
     if (c0 > 0) __syncthreads();           // every wave is done with the previous chunk
     for (int blk = wave; blk < nt * 8; blk += 8) {      // blk = 8 consecutive keys of the chunk
         const int row = blk * 8 + (lane >> 3);
-        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        const int chunk = (lane & 7) ^ tile_swz(row);
         typedef __attribute__((address_space(3))) void lds_void_t;
         typedef const __attribute__((address_space(1))) void gbl_void_t;
         __builtin_amdgcn_global_load_lds((gbl_void_t*)(Kg + (long)(c0 + row) * 128 + chunk * 16), (lds_void_t*)(Ks + blk * 1024), 16, 0, 0);
@@ -359,6 +359,9 @@ __global__ __launch_bounds__(512) void attention_res_kernel(const char* __restri
                     }
                 }
         };
+        // (Measured and dropped, round 3: the same tile as a software pipeline over the wave's two row groups -- S(g1) under
+        // the exp stream of g0, PV(g0) under the exp stream of g1, placed with sched_group_barrier; the ISA interleaves as
+        // asked, 246 VGPRs, no scratch -- 29.5 us per launch against 28.4: the SIMD's second wave already fills those gaps.)
         const int nfull = (Lk - c0 - 64 * (nt - 1)) <= 32 ? nt - 1 : nt;     // tiles that use both 32-key halves
 #pragma unroll 1
         for (int b = 0; b < nfull; ++b) tile(std::integral_constant<int, 2>{}, b);

@@ -82,7 +82,17 @@ DEVINL int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; 
 // group touches the 8 slot values {c^0..c^7} once per row parity = 16 distinct 16-B slots: conflict-free
 // (MI355X_MICROARCH.md LDS table; the plain (r & 7) form is 2-way).  ds_write_b128 serves 8 contiguous
 // lanes = one row's 8 chunks: conflict-free for any per-row permutation.
-DEVINL int tile_off(int row, int chunk) { return row * TC_ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
+// Which bijection of (row >> 1) & 7 is used matters for the TRANSPOSED reads (ds_read_b64_tr_b16 of a V^T / K^T / Q^T
+// fragment, attn_common.h v_frag): a 32-lane group of those touches 4 CONSECUTIVE rows x 64 contiguous bytes, and rows q
+// and q + 2 (same 128-byte half of the bank row) must land in different 64-byte quarters -- with the plain value they
+// differ in chunk bit 0 only and collide 2-way (round 2: SQ_LDS_BANK_CONFLICT = 34 % of the LDS-active cycles of
+// attention_res, i.e. every transposed read took two passes).  Bit-reversing the three bits moves row bit 1 to chunk bit 2:
+// the four rows then cover all 64 banks once.
+DEVINL int tile_swz(int row) {
+    const int x = row >> 1;
+    return ((x & 1) << 2) | (x & 2) | ((x >> 2) & 1);
+}
+DEVINL int tile_off(int row, int chunk) { return row * TC_ROWB + ((chunk ^ tile_swz(row)) << 4); }
 
 // ---- activations ---------------------------------------------------------------------------------
 // GELU keeps the reference's exact-erf definition (F.gelu default, TCDiff.py:85) with erf by Abramowitz-Stegun 7.1.28,
@@ -236,7 +246,7 @@ DEVINL void stage_glds(char* lds_tile, const char* src, long ld_bytes, int row0,
     for (int i = 0; i < PER; ++i) {
         const int blk = wave * PER + i;           // 1-KiB block = 8 tile rows
         const int row = blk * 8 + (lane >> 3);
-        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        const int chunk = (lane & 7) ^ tile_swz(row);
         int gr = row0 + row;
         gr = gr < row_limit ? gr : row_limit - 1;
         if (row_mod > 0) gr = gr % row_mod;

@@ -138,3 +138,47 @@ class GradientAllReducer:
             for p, v in zip(ps, views):
                 p.grad.copy_(v).div_(world)
         return len(work)
+
+
+class FlatGradientAllReducer:
+    """Gradient averaging of the HIP training step (tcdiff_amd/train_engine.py) across the ranks of the default process
+    group: the reference's intent of `accelerate launch` + DDP (TCDiff.py:51-52,108-111,232).
+
+    The training engine writes every parameter gradient into ONE flat fp32 buffer, laid out so that a decoder layer's
+    linears are contiguous; `ready(flat, lo, hi)` is called by the backward pass as soon as such a range is complete
+    (layer 7 first) and launches its all-reduce asynchronously -- on RCCL's own stream, behind an event of the compute
+    stream -- so the collective of layer l runs under the backward kernels of layers l-1 .. 0.  No copies into buckets: the
+    collective reads and writes the gradient memory itself.  xGMI is point-to-point (7 links x ~153 GB/s per GPU), a ring
+    all-reduce is bound by one link whatever the message size, so ranges are sent whole (13.6 MB per decoder layer; the
+    tail of ~100 MB in `bucket_bytes` pieces) rather than in NVSwitch-style 25 MB buckets.
+    `finish()` makes the compute stream wait for all of them; with RCCL the averaging is the collective's own
+    ReduceOp.AVG, with gloo (CPU tests) the sum is scaled afterwards."""
+
+    def __init__(self, bucket_bytes: int = 64 << 20):
+        self.bucket = max(1, bucket_bytes // 4)
+        self.work = []
+        self.launched = 0
+
+    @staticmethod
+    def active() -> bool:
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+    def ready(self, flat: torch.Tensor, lo: int, hi: int):
+        if not self.active() or hi <= lo:
+            return
+        avg = dist.get_backend() == "nccl"
+        for a in range(lo, hi, self.bucket):
+            piece = flat[a:min(hi, a + self.bucket)]
+            w = dist.all_reduce(piece, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, async_op=True)
+            self.work.append((w, None if avg else piece))
+            self.launched += 1
+
+    def finish(self) -> int:
+        world = dist.get_world_size() if self.active() else 1
+        n = len(self.work)
+        for w, piece in self.work:
+            w.wait()
+            if piece is not None:
+                piece.div_(world)           # gloo has no ReduceOp.AVG (test backend; RCCL averages in the collective)
+        self.work = []
+        return n

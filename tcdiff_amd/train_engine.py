@@ -228,6 +228,15 @@ class TrainEngine:
                 off += p.numel()
         self.n_grad = off
         self.order = list(self.params.keys())
+        # flat range of every decoder layer's linears (contiguous by construction): all-reduced as soon as the layer's
+        # backward has run, under the backward of the layers before it (tcdiff_amd/dist.py FlatGradientAllReducer)
+        self.layer_range = []
+        for l in range(self.NL):
+            first, last = lins[f"l{l}.qkv"], lins[f"l{l}.l3"]
+            lo = self.slot[first.wnames[0]][0]
+            o, n = self.slot[(last.bnames or last.wnames)[-1]]
+            self.layer_range.append((lo, o + n))
+        self.grad_sync = None         # None: average over the default process group when one with > 1 rank exists; False: never
         self._new_flat()
 
     def _new_flat(self):
@@ -532,6 +541,11 @@ class TrainEngine:
             self._new_flat()
         else:
             self.flat.zero_()
+        sync = None
+        if self.grad_sync is not False:
+            from .dist import FlatGradientAllReducer
+            if FlatGradientAllReducer.active():
+                sync = self.grad_sync = self.grad_sync or FlatGradientAllReducer()
         d_out = d_out.reshape(M, nf).float().contiguous()
         nfilm = NL * 3 * 1024
         dfilm = z(B, nfilm, dtype=f32)
@@ -599,6 +613,8 @@ class TrainEngine:
             g_r, g_h = e(M, 512), e(M, 512)
             lins[f"l{l}.qkv"].bwd(dQKV, 1536, M, [s["r1"], s["h1"]], [("T", g_r, 512), ("T", g_h, 512)])
             g_x = gx1
+            if sync is not None:                          # this layer's linears are complete: average them across the ranks now
+                sync.ready(self.flat, *self.layer_range[l])
         # ---- front: layer 0's norm1 / rotary on the fusion projection's output, then the fusion MLP -----------------------------
         dxs = e(M, 512)
         self.row_bwd(M=M, L_=Lq, nln=st + "0.norm1", flags=L.ROWF_NEXT_LN | L.ROWF_STORE_H | L.ROWF_STORE_ROT, z=sv["xs"],
@@ -691,6 +707,10 @@ class TrainEngine:
         dc0a = self.act_bwd(sv["c0a"], dc1, Ms, self.Cd, L.ACT_RELU)
         lins["c0"].bwd(dc0a, dc0a.shape[1], Ms, [sv["cin"]], [None])
         self.sv = None
+        if sync is not None:                              # everything outside the decoder layers, then wait for all of it
+            sync.ready(self.flat, 0, self.layer_range[0][0])
+            sync.ready(self.flat, self.layer_range[-1][1], self.n_grad)
+            sync.finish()
         return self.grad_views()
 
 

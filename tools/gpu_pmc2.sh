@@ -3,7 +3,7 @@
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rocprofv3 --list-avail 2>/dev/null | grep -oE "\b(SQ|TCP|TA|TCC|GRBM)_[A-Z0-9_]+" | sort -u > gpurun_out/counters_avail.txt; wc -l gpurun_out/counters_avail.txt
-ARGS="bench.py --steps 1 --warmup 1 --ddpm-steps 20 --no-cpu-baseline --no-kernel-profile --no-parity-mode"
+ARGS="bench.py --steps 1 --warmup 1 --ddpm-steps 20 --no-cpu-baseline --no-kernel-profile --no-parity-mode --no-train-step"
 i=0
 : > gpurun_out/pmc2_summary.txt
 for set in $SETS; do
