@@ -68,7 +68,7 @@ def _load_launch():
     return mod
 
 
-def launch_ranks(argv, world, timeout=None):
+def launch_ranks(argv, world, timeout=3600.0):
     """Start `world` ranks of this script; relay rank 0's last JSON line.  Returns the exit code."""
     rc, out0, errs = _load_launch().spawn_ranks([os.path.abspath(__file__), *argv], world, timeout=timeout)
     line = None

@@ -5,10 +5,10 @@ Same constructor, ``param_groups`` / ``state`` layout (``step``, ``prev_grad``, 
 ``optimizer_state_dict`` checkpoints interchange, TCDiff.py:271) and update rule -- including the first-step quirk: while
 ``step == 0`` the moments stay zero, so the first call only applies the weight decay (adan.py:71,96-107).
 
-For fp32 CUDA parameters the whole parameter list is updated by ONE launch of ``tcdiff_adan_step`` (the reference issues
-~15 elementwise kernels per tensor, 435 tensors), with the reference's rounding points (fused multiply-adds where torch's
-``add_(alpha=)`` / ``addcmul_`` fuse, IEEE sqrt / reciprocal / division).  Other parameters (CPU tensors, a
-``restart_cond``) take the reference's tensor arithmetic.
+The whole parameter list is updated by ONE launch of ``tcdiff_adan_step`` (the reference issues ~15 elementwise kernels per
+tensor, 435 tensors), with the reference's rounding points (fused multiply-adds where torch's ``add_(alpha=)`` /
+``addcmul_`` fuse, IEEE sqrt / reciprocal / division).  Like every other entry of this package it has no CPU fallback:
+parameters that are not contiguous fp32 CUDA tensors, or a ``restart_cond`` (never passed by the reference), raise.
 """
 from __future__ import annotations
 
@@ -74,30 +74,7 @@ class Adan(Optimizer):
                 for s in states:
                     s["step"] = step
                 continue
-            for p, state in zip(ps, states):         # the reference's arithmetic (model/adan.py:61-121)
-                data, grad = p.data, p.grad.data
-                assert not grad.is_sparse
-                step, m, v, n, prev_grad = state["step"], state["m"], state["v"], state["n"], state["prev_grad"]
-                if step > 0:
-                    m.mul_(1 - beta1).add_(grad, alpha=beta1)
-                    grad_diff = grad - prev_grad
-                    v.mul_(1 - beta2).add_(grad_diff, alpha=beta2)
-                    next_n = (grad + (1 - beta2) * grad_diff) ** 2
-                    n.mul_(1 - beta3).add_(next_n, alpha=beta3)
-                step += 1
-                correct_m, correct_v, correct_n = map(lambda b: 1 / (1 - (1 - b) ** step), (beta1, beta2, beta3))
-
-                def grad_step_(data, m, v, n):
-                    weighted_step_size = lr / (n * correct_n).sqrt().add_(eps)
-                    denom = 1 + weight_decay * lr
-                    data.addcmul_(weighted_step_size, (m * correct_m + (1 - beta2) * v * correct_v), value=-1.0).div_(denom)
-
-                grad_step_(data, m, v, n)
-                if exists(restart_cond) and restart_cond(state):
-                    m.data.copy_(grad)
-                    v.zero_()
-                    n.data.copy_(grad ** 2)
-                    grad_step_(data, m, v, n)
-                prev_grad.copy_(grad)
-                state["step"] = step
+            raise L.TcdiffError(
+                "Adan.step runs as one fused HIP launch over contiguous fp32 CUDA parameters with equal step counts and no "
+                "restart_cond (the configuration of TCDiff.py:110); there is no CPU / per-tensor fallback")
         return loss

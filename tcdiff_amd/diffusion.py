@@ -52,7 +52,7 @@ class EMA:
 
     On the GPU the whole parameter list is updated by ONE launch of tcdiff_ema_update (the reference issues three
     elementwise kernels per tensor, 435 tensors); the rounding is the reference's (`old * beta + (1 - beta) * new`,
-    products rounded separately).  Parameters that are not fp32 CUDA tensors take the reference's tensor arithmetic."""
+    products rounded separately).  No CPU fallback: parameters that are not contiguous fp32 CUDA tensors raise."""
 
     def __init__(self, beta):
         self.beta = beta
@@ -69,9 +69,8 @@ class EMA:
                                             cur_p[0].device) if fused else None
             self._table_key = key
         if self._table is None:
-            for c, m in zip(cur_p, ma_p):
-                m.data = self.update_average(m.data, c.data)
-            return
+            raise L.TcdiffError("EMA.update_model_average runs as one fused HIP launch over contiguous fp32 CUDA parameters "
+                                "(no CPU fallback): move both models to the GPU")
         K.ema_update(self._table, self.beta)
         # the kernel wrote through raw pointers: bump ._version so DanceDecoder._weights_version sees new weights
         # (packed bf16 copies, conditioning caches and captured graphs are keyed by it)

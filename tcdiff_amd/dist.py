@@ -68,17 +68,35 @@ def barrier():
         dist.barrier()
 
 
-def long_ddim_sample_sharded(diff, n_windows: int, Lq: int, nfeat: int, cond_local: torch.Tensor, x0_local, **kw):
+def long_ddim_sample_sharded(diff, n_windows: int, Lq: int, nfeat: int, cond_local: torch.Tensor, x0_local, *, seed: int,
+                             init_noise: torch.Tensor | None = None, **kw):
     """`GaussianDiffusion.long_ddim_sample` over the windows of one song sharded in contiguous blocks: the coupling
     inside a rank is part of the captured step, the one boundary per rank pair crosses RCCL point-to-point after every
-    step (tcdiff_amd/stitch.py halo_exchange), and the result is all-gathered.  Noise is keyed by the GLOBAL window
-    index, so the windows equal the single-GPU ones (reference model/diffusion.py:446-515 has no multi-GPU path)."""
+    step (tcdiff_amd/stitch.py halo_exchange), and the result is all-gathered (reference model/diffusion.py:446-515 has
+    no multi-GPU path).
+
+    Every random draw is a function of the GLOBAL window index, never of a rank's own generator: `seed` (required, the
+    same on every rank) keys the per-step Philox noise by (seed, global window, step, element), and the initial x_T of ALL
+    n_windows windows comes from one generator seeded with it (or from `init_noise` (n_windows, Lq, nfeat), identical on
+    every rank), of which a rank takes its slice -- so the result equals the single-process one for any world size.  Ranks
+    beyond the number of windows would own nothing and break the halo chain: n_windows >= world is required."""
     from .stitch import halo_exchange
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
+    if n_windows < world:
+        raise ValueError(f"long_ddim_sample_sharded: {n_windows} windows cannot be sharded over {world} ranks "
+                         "(every rank must own at least one window)")
+    if seed is None:
+        raise ValueError("long_ddim_sample_sharded needs an explicit seed, identical on every rank")
     lo, hi = shard_range(n_windows, rank, world)
+    if init_noise is None:
+        g = torch.Generator().manual_seed(int(seed))
+        init_noise = torch.randn(n_windows, Lq, nfeat, generator=g)
+    elif tuple(init_noise.shape) != (n_windows, Lq, nfeat):
+        raise ValueError("init_noise must hold x_T of ALL windows: (n_windows, Lq, nfeat)")
     row = (Lq // diff.seq_len) * nfeat
-    out = diff.long_ddim_sample((hi - lo, Lq, nfeat), cond_local, x0_local, clip_offset=lo,
+    out = diff.long_ddim_sample((hi - lo, Lq, nfeat), cond_local, x0_local, clip_offset=lo, seed=int(seed),
+                                init_noise=init_noise[lo:hi],
                                 halo_exchange=(lambda xv: halo_exchange(xv, diff.seq_len, row)) if world > 1 else None,
                                 **kw)
     return gather_samples(out, n_windows)

@@ -11,87 +11,107 @@ from typing import Dict, Optional
 import torch
 
 
-def _handle_zeros_in_scale(scale, copy=True, constant_mask=None):
-    if constant_mask is None:
-        constant_mask = scale < 10 * torch.finfo(scale.dtype).eps
-    if copy:
-        scale = scale.clone()
-    scale[constant_mask] = 1.0
-    return scale
-
-
 class MinMaxScaler:
-    """dataset/scaler.py:20-83 (attribute names kept: pickled reference scalers load into this class)."""
+    """Column-wise affine map onto ``feature_range`` fitted from the column minima and maxima -- the arithmetic of the
+    reference's dataset/scaler.py:20-83 (`x * scale_ + min_`, inverse `(x - min_) / scale_`, both IN PLACE), with its
+    attribute names, because reference checkpoints pickle instances of it (TCDiff.py:270) and they load into this class."""
 
     def __init__(self, feature_range=(0, 1), *, copy=True, clip=False):
-        self.feature_range = feature_range
-        self.copy = copy
-        self.clip = clip
+        self.feature_range, self.copy, self.clip = feature_range, copy, clip
 
     def fit(self, X):
-        feature_range = self.feature_range
-        if feature_range[0] >= feature_range[1]:
-            raise ValueError("Minimum of desired feature range must be smaller than maximum. Got %s." % str(feature_range))
-        data_min = torch.min(X, axis=0)[0]
-        data_max = torch.max(X, axis=0)[0]
-        self.n_samples_seen_ = X.shape[0]
-        data_range = data_max - data_min
-        self.scale_ = (feature_range[1] - feature_range[0]) / _handle_zeros_in_scale(data_range, copy=True)
-        self.min_ = feature_range[0] - data_min * self.scale_
-        self.data_min_, self.data_max_, self.data_range_ = data_min, data_max, data_range
+        lo, hi = self.feature_range
+        if not lo < hi:
+            raise ValueError(f"feature_range must be increasing, got {self.feature_range}")
+        cmin, cmax = X.amin(dim=0), X.amax(dim=0)
+        span = cmax - cmin
+        # a (near-)constant column gets a unit divisor instead of a division by ~0
+        divisor = torch.where(span < 10 * torch.finfo(span.dtype).eps, torch.ones_like(span), span)
+        self.scale_ = (hi - lo) / divisor
+        self.min_ = lo - cmin * self.scale_
+        self.data_min_, self.data_max_, self.data_range_, self.n_samples_seen_ = cmin, cmax, span, X.shape[0]
         return self
 
-    def transform(self, X):          # in place, like the reference
-        X *= self.scale_.to(X.device)
-        X += self.min_.to(X.device)
-        if self.clip:
-            torch.clip(X, self.feature_range[0], self.feature_range[1], out=X)
-        return X
+    def transform(self, X):
+        X.mul_(self.scale_.to(X.device)).add_(self.min_.to(X.device))
+        return X.clamp_(*self.feature_range) if self.clip else X
 
-    def inverse_transform(self, X):  # in place; a narrower X uses the LAST columns of the fitted ones (scaler.py:79-82)
-        X -= self.min_[-X.shape[1]:].to(X.device)
-        X /= self.scale_[-X.shape[1]:].to(X.device)
-        return X
+    def inverse_transform(self, X):
+        # a narrower X is taken to be the LAST columns of the fitted ones (the 147-wide motion without contacts)
+        n = X.shape[1]
+        return X.sub_(self.min_[-n:].to(X.device)).div_(self.scale_[-n:].to(X.device))
 
 
 class Normalizer:
-    """dataset/preprocess.py:28-43."""
+    """[-1, 1] min-max normaliser over the last axis (reference dataset/preprocess.py:28-43); `.scaler` as pickled there."""
 
     def __init__(self, data):
-        flat = data.reshape(-1, data.shape[-1])
-        self.scaler = MinMaxScaler((-1, 1), clip=True)
-        self.scaler.fit(flat)
+        self.scaler = MinMaxScaler((-1, 1), clip=True).fit(data.reshape(-1, data.shape[-1]))
 
     def normalize(self, x):
-        batch, seq, ch = x.shape
-        x = x.reshape(-1, ch)
-        return self.scaler.transform(x).reshape((batch, seq, ch))
+        return self.scaler.transform(x.reshape(-1, x.shape[-1])).reshape(x.shape)
 
     def unnormalize(self, x):
-        batch, seq, ch = x.shape
-        x = x.reshape(-1, ch)
-        x = torch.clip(x, -1, 1)  # clip to force compatibility
-        return self.scaler.inverse_transform(x).reshape((batch, seq, ch))
+        # values are forced into the fitted range first; the clamp makes the copy the inverse map then overwrites
+        return self.scaler.inverse_transform(x.reshape(-1, x.shape[-1]).clamp(-1, 1)).reshape(x.shape)
 
 
 # ---- checkpoints -------------------------------------------------------------------------------------------------------
+_REF_NAMES = {("dataset.preprocess", "Normalizer"): Normalizer, ("dataset.scaler", "MinMaxScaler"): MinMaxScaler}
+_SAFE_BUILTINS = {"set", "frozenset", "list", "dict", "tuple", "int", "float", "bool", "complex", "str", "bytes", "slice",
+                  "range", "bytearray", "getattr"}
+
+
 class _RefUnpickler(pickle.Unpickler):
     """Reference checkpoints pickle `dataset.preprocess.Normalizer` / `dataset.scaler.MinMaxScaler` instances
-    (TCDiff.py:270): map them to the classes above so a checkpoint loads without the reference on the path."""
-    _MAP = {("dataset.preprocess", "Normalizer"): Normalizer, ("dataset.scaler", "MinMaxScaler"): MinMaxScaler}
+    (TCDiff.py:270): they are mapped to the classes above, so a checkpoint loads without the reference on the path.
+    Everything else is held to an allow-list (torch's own rebuild helpers, collections, numpy array reconstruction, a few
+    builtins): a checkpoint is data, and an arbitrary global in it is refused rather than imported."""
 
     def find_class(self, module, name):
-        if (module, name) in self._MAP:
-            return self._MAP[(module, name)]
+        if (module, name) in _REF_NAMES:
+            return _REF_NAMES[(module, name)]
+        ok = (module == "torch" or module.startswith("torch.") or module == "collections"
+              or module in ("numpy", "numpy.core.multiarray", "numpy._core.multiarray", "numpy.core.numeric", "numpy._core.numeric")
+              or (module == "builtins" and name in _SAFE_BUILTINS)
+              or (module == "tcdiff_amd.io" and name in ("Normalizer", "MinMaxScaler")))
+        if not ok:
+            raise pickle.UnpicklingError(f"checkpoint refers to {module}.{name}, which is not on the allow-list")
         return super().find_class(module, name)
+
+
+class _RefPickler(pickle._Pickler):
+    """Writes the two classes above under the REFERENCE's module paths, so that a checkpoint saved here is loaded by the
+    reference's plain `torch.load` (TCDiff.py:70-74) exactly like one of its own."""
+    _OUT = {cls: mod_name for mod_name, cls in _REF_NAMES.items()}
+
+    def save_global(self, obj, name=None):
+        if obj in self._OUT:
+            module, qual = self._OUT[obj]
+            self.write(pickle.GLOBAL + f"{module}\n{qual}\n".encode("ascii"))
+            self.memoize(obj)
+            return
+        super().save_global(obj, name)
+
+    dispatch = dict(pickle._Pickler.dispatch)
+    dispatch[type] = save_global
 
 
 class _RefPickle:
     __name__ = "tcdiff_amd.io._RefPickle"
-    Unpickler = _RefUnpickler
+    Unpickler, Pickler = _RefUnpickler, _RefPickler
     load = staticmethod(lambda f, **kw: _RefUnpickler(f, **kw).load())
     loads = staticmethod(lambda b, **kw: _RefUnpickler(io.BytesIO(b), **kw).load())
-    dump, dumps, Pickler = pickle.dump, pickle.dumps, pickle.Pickler
+
+    @staticmethod
+    def dump(obj, f, protocol=None, **kw):
+        _RefPickler(f, protocol).dump(obj)
+
+    @staticmethod
+    def dumps(obj, protocol=None, **kw):
+        buf = io.BytesIO()
+        _RefPickler(buf, protocol).dump(obj)
+        return buf.getvalue()
 
 
 def wrap(x: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
@@ -103,9 +123,10 @@ def maybe_wrap(x, num):
 
 
 def save_checkpoint(path: str, diffusion, model, optim, normalizer) -> None:
-    """The four-key dictionary of TCDiff.py:266-273."""
+    """The four-key dictionary of TCDiff.py:266-273; the normalizer is written under the reference's class paths, so the
+    file is loadable by the reference as well as by `load_checkpoint`."""
     torch.save({"ema_state_dict": diffusion.master_model.state_dict(), "model_state_dict": model.state_dict(),
-                "optimizer_state_dict": optim.state_dict(), "normalizer": normalizer}, path)
+                "optimizer_state_dict": optim.state_dict(), "normalizer": normalizer}, path, pickle_module=_RefPickle)
 
 
 def load_checkpoint(path: str, model: Optional[torch.nn.Module] = None, EMA: bool = True, map_location="cpu"):

@@ -35,31 +35,48 @@ def rank_env(rank: int, world: int, port: int, base: Optional[Dict[str, str]] = 
 def spawn_ranks(argv: Sequence[str], world: int, *, python: str = sys.executable, timeout: Optional[float] = None,
                 extra_env: Optional[Dict[str, str]] = None) -> Tuple[int, str, List[str]]:
     """Run `python argv...` as `world` ranks.  Returns (exit_code, rank-0 stdout, per-rank stderr tails).
-    exit_code is 0 only if every rank exited 0."""
+    exit_code is 0 only if every rank exited 0.
+
+    Every rank writes to its own temporary files (a pipe that nobody drains blocks the writer after ~64 KB -- RCCL debug
+    logs, build output -- and with it the collective every other rank is waiting in), all ranks are polled together, and
+    as soon as one exits non-zero (or the deadline passes) the others are killed by PID instead of being left to wait for
+    a peer that will never arrive."""
+    import tempfile
     if world < 1:
         raise ValueError("world must be >= 1")
     port = free_port()
-    procs = []
+    procs, files = [], []
     for r in range(world):
         env = rank_env(r, world, port)
         if extra_env:
             env.update(extra_env)
-        procs.append(subprocess.Popen([python, *argv], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                                      text=True))
+        fo, fe = tempfile.TemporaryFile("w+"), tempfile.TemporaryFile("w+")
+        files.append((fo, fe))
+        procs.append(subprocess.Popen([python, *argv], env=env, stdout=fo, stderr=fe, text=True))
     deadline = None if timeout is None else time.time() + timeout
-    outs: List[Tuple[str, str]] = [("", "")] * world
     rc = 0
-    for r, p in enumerate(procs):
-        try:
-            left = None if deadline is None else max(1.0, deadline - time.time())
-            o, e = p.communicate(timeout=left)
-        except subprocess.TimeoutExpired:
-            for q in procs:            # exact PIDs we started, nothing pattern-based
-                if q.poll() is None:
-                    q.kill()
-            o, e = p.communicate()
-            rc = rc or 124
-        outs[r] = (o, e)
-        if p.returncode != 0:
-            rc = rc or (p.returncode if p.returncode is not None else 1)
+    while True:
+        codes = [p.poll() for p in procs]
+        failed = [c for c in codes if c not in (None, 0)]
+        if failed:
+            rc = failed[0]
+            break
+        if all(c == 0 for c in codes):
+            break
+        if deadline is not None and time.time() > deadline:
+            rc = 124
+            break
+        time.sleep(0.05)
+    for p in procs:                        # exact PIDs we started, nothing pattern-based
+        if p.poll() is None:
+            p.kill()
+    for p in procs:
+        p.wait()
+    outs = []
+    for fo, fe in files:
+        fo.seek(0)
+        fe.seek(0)
+        outs.append((fo.read(), fe.read()))
+        fo.close()
+        fe.close()
     return rc, outs[0][0], [e[-2000:] for _, e in outs]

@@ -23,6 +23,8 @@ def halo_exchange(x: torch.Tensor, seq_len: int, row_elems: int) -> None:
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return
     rank, world = dist.get_rank(), dist.get_world_size()
+    if x.shape[0] == 0:
+        raise ValueError("halo_exchange: a rank without windows breaks the neighbour chain (shard n_windows >= world)")
     half = seq_len // 2
     xv = x.view(x.shape[0], seq_len, row_elems)
     ops, recv = [], None

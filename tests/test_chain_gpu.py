@@ -296,3 +296,94 @@ def test_front_chain_against_rowln_plus_qkv_tile():
         print(f"front chain: {nm} image max/mean diff {d[0]:.2e}/{d[1]:.2e} (max |.| {float(a_.float().abs().max()):.2f})")
         assert d[0] < 6e-2 and d[1] < 5e-4                          # isolated bf16 rounding flips
         assert float(b_[:, :, Lq:].abs().max()) == 0.0              # padding rows untouched
+
+
+def test_fused_layer_chain_against_a_torch_evaluation_of_the_layer_tail():
+    """ONE TC_CHAIN_FULL launch against a plain torch (float64) evaluation of model/model.py:103-106,327,331-344 and the next
+    layer's :326,374-383 on the same bf16 operands -- not against another kernel of this library.  The reference rounds to
+    bf16 exactly where the kernel hands an activation to an MFMA (GEMM / attention operands), nowhere else."""
+    bf, D = torch.bfloat16, torch.float64
+    Lq, nseq, H, S = 120, 5, 8, 60
+    M = nseq * Lq - 9
+    Lp, Lk = K.round_up(Lq, 128), S + 2
+    Lpc, nkt = K.round_up(Lk, 128), (Lk + 31) // 32
+    n_shared, n_kv = 2, nseq - 2 + 1
+    Oa = rnd(M, 512, seed=151, scale=0.5).to(bf)
+    W = {n: rnd(*s, seed=160 + i, scale=s[1] ** -0.5).to(bf) for i, (n, s) in enumerate(
+        [("sfc", (512, 512)), ("cq", (512, 512)), ("cfc", (512, 512)), ("ff1", (1024, 512)), ("ff2", (512, 1024)),
+         ("l3", (512, 512)), ("qkv", (1536, 512))])}
+    vec = lambda seed, base=0.0, amp=0.1: base + amp * rnd(512, seed=seed)
+    gs = [vec(170 + i, 1 if i % 2 == 0 else 0) for i in range(12)]
+    bias1, bias2, bias3 = 0.05 * rnd(1024, seed=190), vec(191), vec(192)
+    film = 0.3 * rnd(nseq, 6144, seed=193)
+    xres = rnd(M, 512, seed=194)
+    rope_rm = torch.empty(Lq, 512, device=DEV)
+    K.rope_table((1.0 / (10000 ** (torch.arange(0, 512, 2).float() / 512))).to(DEV), rope_rm, Lq)
+    Kc = torch.zeros(n_kv, H, Lpc, 64, device=DEV, dtype=bf)
+    Vc = torch.zeros_like(Kc)
+    Kc[:, :, :Lk] = rnd(n_kv, H, Lk, 64, seed=195).to(bf)
+    Vc[:, :, :Lk] = rnd(n_kv, H, Lk, 64, seed=196).to(bf)
+    z = lambda *s, dtype=bf: torch.zeros(*s, device=DEV, dtype=dtype)
+    E = DenoiserEngine
+    f1, f2 = E._stages_ff1(W["ff1"]), E._stages_ff2(W["ff2"])
+    parts = [E._stages_n512(W["sfc"]), E._stages_n512(W["cq"]), E._stages_n512(W["cfc"])]
+    for c in range(4):
+        parts += [f1[c], f2[c]]
+    parts.append(E._stages_n512(W["l3"]))
+    parts += [E._stages_n512(W["qkv"][i * 512:(i + 1) * 512]) for i in range(3)]
+    wsF = torch.cat(parts, 1).contiguous()
+    Kf, Vf = z(n_kv, H, nkt * 2048), z(n_kv, H, nkt * 2048)
+    K.pack_kv_frags(Kc, Vc, Kf, Vf, n_kv, H, Lpc, nkt, 0, Lk)
+    x2 = K.to_cb(xres)
+    Q2, K2, V2 = z(nseq, H, Lp, 64), z(nseq, H, Lp, 64), z(nseq, H, Lp, 64)
+    K.chain(L.CHAIN_FULL, wsF.shape[1], M, Lq, Oa, wsF, ln_g=gs[0], ln_b=gs[1], ln_eps=1e-6, film=film, film_ld=6144, xres=x2,
+            xout=x2, n2_g=gs[2], n2_b=gs[3], rope=K.to_cb(rope_rm), lnb_g=gs[4], lnb_b=gs[5], filmb=film[:, 2048:], n3_g=gs[10],
+            n3_b=gs[11], kf=Kf, vf=Vf, n_shared=n_shared, nkt=nkt, Lk=Lk, q_out=Q2, k_out=K2, v_out=V2, b1=bias1, b2=bias2,
+            film3=film[:, 4096:], n4_g=gs[6], n4_b=gs[7], b3=bias3, nn_g=gs[8], nn_b=gs[9], scale_q=0.125, Lp=Lp, H=H)
+    torch.cuda.synchronize()
+    # ---- torch, float64, on the CPU ---------------------------------------------------------------------------------------
+    c = lambda t: t.detach().cpu().to(D)
+    rb = lambda t: t.to(bf).to(D)                        # the kernel's bf16 hand-offs
+    ln = lambda v, g, b, eps: F.layer_norm(v, (512,), c(g), c(b), eps)
+    seq = torch.arange(M) // Lq
+    pos = torch.arange(M) % Lq
+    cs = c(rope_rm)[pos].reshape(M, 256, 2)
+
+    def rot(u):
+        up = u.reshape(M, 256, 2)
+        return torch.stack((up[..., 0] * cs[..., 0] - up[..., 1] * cs[..., 1], up[..., 1] * cs[..., 0] + up[..., 0] * cs[..., 1]), -1).reshape(M, 512)
+
+    def aff(y, blk):
+        fm = c(film)[seq]
+        return (fm[:, 2048 * blk:2048 * blk + 512] + 1) * y + fm[:, 2048 * blk + 512:2048 * blk + 1024]
+    Wd = {k: c(v) for k, v in W.items()}
+    x = c(xres) + aff(ln(c(Oa) @ Wd["sfc"].t(), gs[0], gs[1], 1e-6), 0)
+    r2 = rb(rot(ln(x, gs[2], gs[3], 1e-5)))
+    q = rb((r2 @ Wd["cq"].t()) * 0.125).reshape(M, H, 64)
+    kv = torch.where(seq < n_shared, torch.zeros_like(seq), seq - n_shared + 1)
+    Kd, Vd = c(Kc)[:, :, :Lk], c(Vc)[:, :, :Lk]
+    sc = torch.einsum("mhd,mhkd->mhk", q, Kd[kv])
+    pu = torch.exp(sc - sc.amax(-1, keepdim=True))       # the kernel's P is the UNNORMALISED exp (a bf16 MFMA operand);
+    oc = rb((torch.einsum("mhk,mhkd->mhd", rb(pu), Vd[kv]) / pu.sum(-1, keepdim=True)).reshape(M, 512))   # 1 / l comes last
+    x = x + aff(ln(oc @ Wd["cfc"].t(), gs[4], gs[5], 1e-6), 1)
+    h3 = rb(ln(x, gs[10], gs[11], 1e-5))
+    a1 = rb(F.gelu(h3 @ Wd["ff1"].t() + c(bias1)))
+    x = x + aff(a1 @ Wd["ff2"].t() + c(bias2), 2)
+    h4 = rb(ln(x, gs[6], gs[7], 1e-5))
+    xn = h4 @ Wd["l3"].t() + c(bias3)
+    hn = ln(xn, gs[8], gs[9], 1e-5)
+    rn, hb = rb(rot(hn)), rb(hn)
+    Qr, Kr, Vr = (rn @ Wd["qkv"][:512].t()) * 0.125, rn @ Wd["qkv"][512:1024].t(), hb @ Wd["qkv"][1024:].t()
+    got_x = K.from_cb(x2, M).cpu().to(D)
+    dx = (got_x - xn).abs()
+    print(f"fused layer chain vs torch float64: x' max-abs {float(dx.max()):.2e}, mean-abs {float(dx.mean()):.2e} (|x'| max {float(xn.abs().max()):.2f})")
+    # what is left: bf16 hand-offs that land on the other side of a rounding boundary (one ulp = 2^-8 relative; the online
+    # softmax rounds P against a running maximum, torch against the final one), each spread over a row by the next GEMM
+    assert float(dx.max()) < 3e-2 and float(dx.mean()) < 4e-3
+    for nm, img, ref in (("Q", Q2, Qr), ("K", K2, Kr), ("V", V2, Vr)):
+        g = img.cpu().to(D)
+        tok = torch.stack([g[s_, :, :min(Lq, M - s_ * Lq)].transpose(0, 1).reshape(-1, 512) for s_ in range(nseq)]).reshape(-1, 512) \
+            if M == nseq * Lq else torch.cat([g[s_, :, :min(Lq, M - s_ * Lq)].transpose(0, 1).reshape(-1, 512) for s_ in range(nseq)])
+        d = (tok - ref).abs()
+        print(f"   {nm} image max-abs {float(d.max()):.2e}, mean-abs {float(d.mean()):.2e} (max |.| {float(ref.abs().max()):.2f})")
+        assert float(d.max()) < 8e-2 and float(d.mean()) < 4e-3

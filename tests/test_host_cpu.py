@@ -112,13 +112,18 @@ def test_product_code_never_imports_the_oracle():
             assert "import oracle" not in src and "from oracle" not in src, fn
 
 
-def test_ema_cpu_path_is_the_reference_formula():
-    """EMA over CPU parameters uses the reference's tensor arithmetic (model/diffusion.py:61-76)."""
+def test_adan_and_ema_have_no_cpu_fallback():
+    """Off-GPU the fused optimizer / EMA raise like every other entry of the package (no second arithmetic path)."""
+    import pytest
     import torch
+    from tcdiff_amd import Adan
+    from tcdiff_amd._lib import TcdiffError
     from tcdiff_amd.diffusion import EMA
     a, b = torch.nn.Linear(7, 5), torch.nn.Linear(7, 5)
-    want = [pa.data * 0.9999 + (1 - 0.9999) * pb.data for pa, pb in zip(a.parameters(), b.parameters())]
-    EMA(0.9999).update_model_average(a, b)
-    for pa, w in zip(a.parameters(), want):
-        assert torch.equal(pa.data, w)
-
+    with pytest.raises(TcdiffError):
+        EMA(0.9999).update_model_average(a, b)
+    for p in a.parameters():
+        p.grad = torch.ones_like(p)
+    with pytest.raises(TcdiffError):
+        Adan(a.parameters(), lr=1e-3).step()
+    assert EMA(0.9).update_average(torch.tensor(2.0), torch.tensor(4.0)) == 2.0 * 0.9 + (1 - 0.9) * 4.0   # the formula itself

@@ -46,9 +46,28 @@ def test_checkpoint_round_trip_and_x0(tmp_path):
                       cond_feature_dim=438, activation=F.gelu, required_dancer_num=2)
     ck = IO.load_checkpoint(p, m2, EMA=False)
     assert all(torch.equal(a, b) for a, b in zip(model.state_dict().values(), m2.state_dict().values()))
+    assert isinstance(ck["normalizer"], IO.Normalizer) and torch.equal(ck["normalizer"].scaler.scale_, norm.scaler.scale_)
+    # the file names the REFERENCE's classes, so the reference's plain torch.load reads it like one of its own
+    import zipfile
+    raw = zipfile.ZipFile(p).read([n for n in zipfile.ZipFile(p).namelist() if n.endswith("data.pkl")][0])
+    assert b"dataset.preprocess\nNormalizer" in raw and b"dataset.scaler\nMinMaxScaler" in raw and b"tcdiff_amd" not in raw
     assert IO.maybe_wrap({"a": 1}, 2) == {"module.a": 1} and IO.maybe_wrap({"a": 1}, 1) == {"a": 1}
     x = torch.randn(2, 3, 150, 151)
     x0 = IO.x0_from_motion(x)
     assert x0.shape == (2, 450, 3) and float(x0[..., 2].abs().max()) == 0
     assert torch.equal(x0.reshape(2, 150, 3, 3)[:, :, 1, :2], x[:, 1, :, 4:6])
     assert torch.equal(IO.x0_from_trajectory(x[..., 4:6]), x0)
+
+
+def test_checkpoint_loader_refuses_globals_outside_the_allow_list(tmp_path):
+    import pickle
+    import pytest
+
+    class Evil:
+        def __reduce__(self):
+            import os
+            return (os.system, ("true",))
+    p = str(tmp_path / "evil.pt")
+    torch.save({"normalizer": Evil()}, p)
+    with pytest.raises(pickle.UnpicklingError):
+        IO.load_checkpoint(p)

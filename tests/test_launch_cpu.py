@@ -62,3 +62,38 @@ def test_single_rank_default_is_not_a_launcher():
     assert p.returncode == 0, p.stderr
     res = json.loads(p.stdout.strip().splitlines()[-1])
     assert res["n_gpus"] == 1 and res["ranks_seen"] == 1 and res["clip_ranges"] == [[0, 16]]
+
+
+def test_eight_rank_launch_as_the_driver_runs_it(capfd):
+    """world 8 (the SCALE run's size): 8 processes here need ~8 x 0.6 GB of torch import, fine for this container"""
+    bench = _bench()
+    rc = bench.launch_ranks(["--gpus", "8", "--stub", "--batch", "16"], 8, timeout=600)
+    out = capfd.readouterr().out
+    assert rc == 0
+    res = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
+    assert res["n_gpus"] == 8 and res["ranks_seen"] == 8
+    assert res["clip_ranges"] == [[16 * r, 16 * r + 16] for r in range(8)]
+    assert abs(res["max_time"] - 0.008) < 1e-9
+
+
+def test_a_chatty_or_dead_peer_cannot_hang_the_launch():
+    """ranks used to be drained one at a time through pipes.  Rank 1 writes 1 MB to stderr (a pipe holds ~64 KB)
+    while rank 0 waits for it; then a peer that dies must take the survivors down instead of leaving them waiting."""
+    sys.path.insert(0, ROOT)
+    from tcdiff_amd import launch
+    import time
+    chatty = ("import os,sys,time\n"
+              "r=os.environ['RANK']\n"
+              "p='/tmp/tcdiff_launch_test_'+os.environ['MASTER_PORT']\n"
+              "if r=='1':\n"
+              "    sys.stderr.write('x'*(1<<20)); sys.stderr.flush(); open(p,'w').write('done')\n"
+              "else:\n"
+              "    t=time.time()\n"
+              "    while not os.path.exists(p) and time.time()-t<60: time.sleep(0.05)\n"
+              "    sys.stdout.write('ok' if os.path.exists(p) else 'stuck')\n")
+    rc, out0, errs = launch.spawn_ranks(["-c", chatty], 2, timeout=120)
+    assert rc == 0 and out0 == "ok" and len(errs[1]) == 2000
+    dead = "import os,sys,time\nif os.environ['RANK']=='1': sys.exit(5)\ntime.sleep(600)\n"
+    t0 = time.time()
+    rc, _, _ = launch.spawn_ranks(["-c", dead], 2, timeout=300)
+    assert rc == 5 and time.time() - t0 < 30

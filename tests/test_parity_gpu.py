@@ -258,7 +258,7 @@ def test_dead_parameters_do_not_change_the_output(c1):
 
 def test_bf16_mode_against_oracle():
     """throughput mode (bf16 MFMA operands, fp32 accumulate / residual / softmax / LayerNorm): deviation from the
-    fp32 oracle is bounded by bf16 operand rounding; stated bound 5e-2 max-abs on |x| <= 1 outputs after 20 steps."""
+    fp32 oracle is bounded by bf16 operand rounding; stated bound 2.5e-2 max-abs on |x| <= 1 outputs after 20 steps (observed ~1e-2)."""
     sd, model, diff = build(2, 60, 100, compute="bf16")
     cond = torch.stack([O.synth_cond(0, 60)])
     xT = torch.stack([O.synth_xT(0, 120)])
@@ -271,7 +271,7 @@ def test_bf16_mode_against_oracle():
     got = diff.p_sample_loop((1, 120, 151), cond, noise=xT, start_point=20, step_noise=dev_noise([0], 120))
     e2 = maxabs(got, want)
     print(f"bf16 mode vs fp32 oracle: one guided evaluation {e1:.2e}, 20 DDPM steps {e2:.2e}")
-    assert e1 < 5e-2 and e2 < 5e-2
+    assert e1 < 2.5e-2 and e2 < 2.5e-2
 
 
 def test_product_path_fails_loudly_off_gpu():
@@ -310,7 +310,7 @@ def test_c4_long_sequence_forward_and_steps_vs_oracle():
     assert e < 5e-4
 
 
-@pytest.mark.parametrize("compute,bound", [("f32", 5e-4), ("bf16", 5e-2)])
+@pytest.mark.parametrize("compute,bound", [("f32", 5e-4), ("bf16", 2.5e-2)])
 def test_c4_vs_reference_golden(golden_dir, compute, bound):
     """BASELINE config 4 against the REAL reference (tests/golden/make_golden_c4.py): a guided evaluation at t = 500 and
     the first two DDPM steps, 5 dancers x 300 frames."""
@@ -341,14 +341,14 @@ def test_c4_bf16_runs_and_is_close():
     got = model.guided_forward(xT.to(DEV), cond.to(DEV), tt.to(DEV), 2)
     e = maxabs(got[:1], want)
     print(f"C4 bf16 guided forward vs fp32 oracle: {e:.2e}")
-    assert e < 5e-2 and bool(torch.isfinite(got).all())
+    assert e < 2.5e-2 and bool(torch.isfinite(got).all())
 
 
 # ------------------------------------------------------------------------------------------------------------------
 # parity AT the benchmarked configuration (BASELINE config 2: 3 x 150, B = 16, bf16)
 # ------------------------------------------------------------------------------------------------------------------
-BF16_EVAL_BOUND = 5e-2      # one guided evaluation, |x| <= O(1) outputs: bf16 operand rounding through 8 layers
-BF16_STEPS_BOUND = 5e-2     # sampler state after a few steps / a full DDIM run
+BF16_EVAL_BOUND = 2.5e-2      # one guided evaluation, |x| <= O(1) outputs: bf16 operand rounding through 8 layers
+BF16_STEPS_BOUND = 2.5e-2    # sampler state after a few steps / a full DDIM run
 
 
 @pytest.fixture(scope="module")
@@ -494,7 +494,7 @@ def test_weights_written_by_fused_ema_and_adan_are_seen_by_the_next_forward():
     assert maxabs(ma(x, cond, t), y_cur) > 1e-4
 
 
-@pytest.mark.parametrize("compute,bound", [("f32", 1e-3), ("bf16", 5e-2)])
+@pytest.mark.parametrize("compute,bound", [("f32", 1e-3), ("bf16", 1.5e-2)])
 def test_c2_full_1000_step_loop_vs_reference_golden(golden_dir, compute, bound):
     """The north-star claim at the benchmark's own length: one clip of 3 dancers x 150 frames through ALL 1000 DDPM steps
     of the REAL reference's p_sample_loop with injected noise (tests/golden/make_golden_c2_full.py), here as clip 0 of a
