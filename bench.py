@@ -198,8 +198,20 @@ def kernel_roofline(times, n_steps, B_launch, streams, dn, S, dtype):
                 algorithmic_gflop_per_ddpm_step=round(flops[dom] / 1e9, 2),
                 hbm=dict(algorithmic_gbps=d["algo_gbps"], peak=PEAK_HBM_GBPS, frac=d["hbm_frac"],
                          algorithmic_mb_per_ddpm_step=round(nbytes[dom] / 1e6, 1)))
+    if dom == "chain":
+        # What actually bounds this launch (profiles/r03_chain_block_scaling.txt): every row block pulls the
+        # layer's weights out of its XCD's L2 (a CU cannot hold more than ~64 of the 14 400 rows), and the launch takes
+        # (blocks per XCD x bytes per block) / the rate an L2 delivers them at.  Reported beside the MFMA figure.
+        n_blk = (2 * B * dn * S + 63) // 64
+        per_step = (7 * 5.5 + 4.0) * 1024 * 1024 * n_blk + 160 * 2048 * 8 * ((B * S + 63) // 64) * dn
+        roof["l2_weight_stream"] = dict(
+            bytes_per_ddpm_step=int(per_step), achieved_gbps=round(per_step / (d["device_ms_per_ddpm_step"] * 1e-3) / 1e9, 1),
+            channel_peak_gbps=17200.0, measured_saturation_gbps=11600.0,
+            frac_of_measured_saturation=round(per_step / (d["device_ms_per_ddpm_step"] * 1e-3) / 1e9 / 11600.0, 3),
+            note="L2 -> CU weight bytes of the chain launches (row blocks x stream bytes) / their device time; channel peak = 8 XCDs x "
+                 "16 channels x 64 B x 2.1 GHz; saturation = what the same launch reaches at 32 blocks per XCD (chain_bench)")
     # HBM-side bytes from the committed rocprofv3 PMC passes of this command (never measured by this run: labelled)
-    for pm_name in ("r02_pmc.json", "r01_pmc.json"):
+    for pm_name in ("r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", pm_name)))
             roof["traffic"] = pm[dom]["bytes_per_launch"]

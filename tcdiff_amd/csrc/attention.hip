@@ -363,6 +363,8 @@ __global__ __launch_bounds__(512) void attention_res_kernel(const char* __restri
         // the exp stream of g0, PV(g0) under the exp stream of g1, placed with sched_group_barrier; the ISA interleaves as
         // asked, 246 VGPRs, no scratch -- 29.5 us per launch against 28.4: the SIMD's second wave already fills those gaps.)
         const int nfull = (Lk - c0 - 64 * (nt - 1)) <= 32 ? nt - 1 : nt;     // tiles that use both 32-key halves
+        // (Also measured and dropped: delaying waves 4-7 by ~half a tile (s_sleep 10 / 19 / 28) so that the SIMD's two waves are
+        // in different phases -- MI355X_MICROARCH.md, two waves per SIMD, item 9: within the +-1 % noise of the same box.)
 #pragma unroll 1
         for (int b = 0; b < nfull; ++b) tile(std::integral_constant<int, 2>{}, b);
         if (nfull < nt) tile(std::integral_constant<int, 1>{}, nt - 1);

@@ -713,12 +713,6 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     const int m0 = FRONT ? (int)(blockIdx.x / (unsigned)dn) * 64 : xcd_remap(blockIdx.x, gridDim.x) * 64;
     CH_T(0);
     CH_TC(60);
-#ifdef CH_STAGGER
-    // experiment: every second workgroup of an XCD starts CH_STAGGER x ~3.9 us late, so that the two halves of the chip are
-    // in their weight-streaming phases (which saturate the XCD's L2) at different times
-    if ((blockIdx.x >> 3) & 1)
-        for (int i = 0; i < CH_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-#endif
     const int M = a.M, L = a.L;        // FRONT: M = frames, L = TOKENS per sequence
     char* abuf = smem + CH_ABUF;
     char* h1c = smem + CH_H1C;

@@ -80,6 +80,25 @@ class EMA:
         return new if old is None else old * self.beta + (1 - self.beta) * new
 
 
+_SLEEP_CAL = {}
+
+
+def _sleep_cycles_per_us(device) -> float:
+    """torch.cuda._sleep counts cycles of a device timer; calibrated once per device against HIP events instead of assuming a
+    clock (the skew of the optional two-stream sampler used to hard-code 2 100 cycles per microsecond)."""
+    key = torch.device(device).index
+    if key not in _SLEEP_CAL:
+        with torch.cuda.device(device):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda._sleep(100_000)
+            s.record()
+            torch.cuda._sleep(4_000_000)
+            e.record()
+            e.synchronize()
+            _SLEEP_CAL[key] = 4_000_000 / max(s.elapsed_time(e) * 1e3, 1.0)
+    return _SLEEP_CAL[key]
+
+
 class _LossFn(torch.autograd.Function):
     """total = 0.636 recon + 2.964 velocity + 0.646 fk + 10.942 foot (reference model/diffusion.py:668-741) of the denoiser
     output, forward and backward in HIP kernels (csrc/train.hip, csrc/train_ops.hip): 6-D rotations -> axis-angle ->
@@ -336,7 +355,7 @@ class GaussianDiffusion(nn.Module):
                         for k, sk in enumerate(sides):
                             sk.wait_stream(main)
                             with torch.cuda.stream(sk):
-                                torch.cuda._sleep(int(self.dual_skew_us * (k + 1) * 2100))
+                                torch.cuda._sleep(int(self.dual_skew_us * (k + 1) * _sleep_cycles_per_us(main.device)))
                         side_started = True
                     graphs[gkey][0].replay()
                     for k, sk in enumerate(sides):
@@ -348,6 +367,10 @@ class GaussianDiffusion(nn.Module):
             else:                               # second visit: capture the step once, replay from now on
                 for k in [k for k in graphs if isinstance(k, tuple) and len(k) == 12 and k[8] == id(self.model) and k[7] != gens]:
                     del graphs[k]               # graphs of engines whose buffers have moved
+                live = [k for k in graphs if isinstance(k, tuple) and len(k) == 12]
+                for k in live[:max(0, len(live) - 15)]:
+                    del graphs[k]               # a bounded cache: at most 16 captured step graphs (oldest first) ...
+                    graphs.pop(("warm", k), None)   # ... and their warm-up marks
                 if not skewed:
                     graph = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(graph):

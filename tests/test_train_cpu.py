@@ -120,3 +120,69 @@ def test_p_losses_fk_and_foot_terms_are_finite_and_consistent():
                                    torch.tensor([True, True]))
     assert all(bool(torch.isfinite(l)) for l in losses) and abs(float(total) - sum(float(l) for l in losses)) < 1e-6
     assert float(losses[2]) > 0
+
+
+# ---- hand-written reverse mode of the FK / 6-D conversion (csrc/fk_math.h), compiled for the HOST -----------------------
+def _fk_host(tmp_path):
+    import ctypes as C
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = str(tmp_path / "fk_host.so")
+    subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-I" + os.path.join(root, "tcdiff_amd", "csrc"), "-o", so,
+                           os.path.join(root, "tests", "host", "fk_host.cpp")])
+    return C.CDLL(so)
+
+
+def test_fk_math_reverse_mode_on_the_host(tmp_path):
+    """The SAME source the HIP kernels compile (tcdiff_amd/csrc/fk_math.h) built with g++: forward values and the
+    hand-derived adjoints of ax_from_6v and of the SMPL chain against torch autograd through the oracle's restatement."""
+    import ctypes as C
+    lib = _fk_host(tmp_path)
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    g = torch.Generator().manual_seed(0)
+    n = 3000
+    d6 = torch.randn(n, 6, generator=g)
+    cot = torch.randn(n, 3, generator=g)
+    d6r = d6.clone().requires_grad_(True)
+    aa = O.ax_from_6v(d6r)
+    (aa * cot).sum().backward()
+    out, g6 = np.zeros((n, 3), np.float32), np.zeros((n, 6), np.float32)
+    d6n, cn = d6.numpy().copy(), cot.numpy().copy()
+    lib.host_ax_from_6v(fp(d6n), C.c_long(n), fp(out))
+    lib.host_ax_from_6v_bwd(fp(d6n), fp(cn), C.c_long(n), fp(g6))
+    assert np.abs(out - aa.detach().numpy()).max() < 1e-5
+    ref = d6r.grad.numpy()
+    assert np.isfinite(ref).all() and np.isfinite(g6).all()
+    assert np.linalg.norm(g6 - ref) / np.linalg.norm(ref) < 1e-5
+    N = 400
+    rot, root, gj = torch.randn(1, N, 24, 3, generator=g) * 0.8, torch.randn(1, N, 3, generator=g), torch.randn(1, N, 24, 3, generator=g)
+    rr, tr = rot.clone().requires_grad_(True), root.clone().requires_grad_(True)
+    j = O.smpl_fk(rr, tr)
+    (j * gj).sum().backward()
+    par = (C.c_int * 24)(*O.SMPL_PARENTS)
+    off = np.array(O.SMPL_OFFSETS, np.float32)
+    jo, gaa, gr = np.zeros((N, 24, 3), np.float32), np.zeros((N, 24, 3), np.float32), np.zeros((N, 3), np.float32)
+    an, rn, gn = rot[0].numpy().copy(), root[0].numpy().copy(), gj[0].numpy().copy()
+    lib.host_fk(fp(an), fp(rn), C.c_long(N), par, fp(off), fp(jo))
+    lib.host_fk_bwd(fp(an), fp(gn), C.c_long(N), par, fp(off), fp(gaa), fp(gr))
+    assert np.abs(jo - j[0].detach().numpy()).max() < 5e-6
+    assert np.abs(gaa - rr.grad[0].numpy()).max() < 2e-5 * float(rr.grad.abs().max())
+    assert np.abs(gr - tr.grad[0].numpy()).max() < 1e-5
+
+
+def test_dropout_hash_of_the_oracle_is_a_fair_independent_mask():
+    """oracle.dropout_keep == tcdiff_amd/csrc/train_common.h (held equal on the GPU by tests/test_train_kernels_gpu.py):
+    keep probability 1 - p, sites and seeds give unrelated masks, the mask is a pure function of its arguments."""
+    a = O.dropout_keep((1234, 5678), 17, (64, 512), 0.1)
+    b = O.dropout_keep((1234, 5678), 18, (64, 512), 0.1)
+    c = O.dropout_keep((1235, 5678), 17, (64, 512), 0.1)
+    assert abs(float(a.float().mean()) - 0.9) < 0.01 and abs(float(b.float().mean()) - 0.9) < 0.01
+    for other in (b, c):
+        agree = float((a == other).float().mean())
+        assert abs(agree - (0.81 + 0.01)) < 0.01           # independent masks agree with probability 0.9^2 + 0.1^2
+    assert torch.equal(a, O.dropout_keep((1234, 5678), 17, (64, 512), 0.1))
+    assert bool(O.dropout_keep((1, 2), 3, (10,), 0.0).all())
+    # train-mode oracle: the plan scales kept values by 1 / (1 - p)
+    x = torch.ones(64, 512)
+    y = O.DropPlan((1234, 5678), 0.1)(x, 17)
+    assert torch.equal(y != 0, a) and abs(float(y.max()) - 1 / 0.9) < 1e-6

@@ -1,20 +1,33 @@
 #!/bin/bash
-# round-2 measurement pass: full GPU suite, default bench, rocprofv3 kernel stats (200 steps), FETCH/WRITE PMC passes (30 steps)
+# round-3 measurement pass (one box visit): full GPU suite, parity log at the benchmarked config, default bench, rocprofv3 kernel
+# stats (200 steps), FETCH/WRITE PMC passes (30 steps), SQ counters (20 steps), chain block-count scaling, training-step bench
+R=r03
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-python -m pytest tests -q -x -m gpu 2>&1 | tail -4
-python -m pytest tests/test_parity_gpu.py -m gpu -s -q -k "c2 or bf16 or drift" > gpurun_out/r02_parity_at_benchmarked_config.log 2>&1; tail -3 gpurun_out/r02_parity_at_benchmarked_config.log
-python bench.py 2>gpurun_out/bench_default_err.log > gpurun_out/bench_default.json; tail -c 3000 gpurun_out/bench_default.json
+python -m pytest tests -q -m gpu 2>&1 | tail -3
+python -m pytest tests/test_parity_gpu.py -m gpu -s -q -k "c2 or bf16 or drift" > gpurun_out/${R}_parity_at_benchmarked_config.log 2>&1; tail -2 gpurun_out/${R}_parity_at_benchmarked_config.log
+python -m pytest tests/test_train_step_gpu.py -m gpu -s -q 2>&1 | grep -E "^\[f32\]|^\[bf16\]|passed|failed" > gpurun_out/${R}_train_step_parity.log; tail -3 gpurun_out/${R}_train_step_parity.log
+python bench.py 2>gpurun_out/bench_default_err.log > gpurun_out/${R}_bench_full_1000steps.json; tail -c 2500 gpurun_out/${R}_bench_full_1000steps.json
+python tools/chain_bench.py 2>/dev/null | grep "chain B" > gpurun_out/${R}_chain_block_scaling.txt; cat gpurun_out/${R}_chain_block_scaling.txt
+for b in 4 32; do python tools/train_bench.py --batch $b --iters 8 --kernels 2>/dev/null | tail -1; done > gpurun_out/${R}_train_step.jsonl; cut -c1-400 gpurun_out/${R}_train_step.jsonl
+ARGS="bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-profile --no-parity-mode --no-train-step"
 rm -rf gpurun_out/prof_trace
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_trace -- python3 bench.py --steps 1 --warmup 1 --ddpm-steps 200 --no-cpu-baseline --no-kernel-profile --no-parity-mode > gpurun_out/prof_trace.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_trace -- python3 $ARGS --ddpm-steps 200 > gpurun_out/prof_trace.log 2>&1
 echo "trace rc=$?"
-f=$(find gpurun_out/prof_trace -name "*kernel_stats.csv" | head -1); cp "$f" gpurun_out/r02_kernel_stats.csv; head -24 "$f" | cut -c1-160
-find gpurun_out/prof_trace -name "*kernel_trace.csv" -delete
+f=$(find gpurun_out/prof_trace -name "*kernel_stats.csv" | head -1); cp "$f" gpurun_out/${R}_kernel_stats_bench_200steps.csv; head -16 "$f" | cut -c1-160
+rm -rf gpurun_out/prof_trace
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/prof_$c
-  timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/prof_$c -- python3 bench.py --steps 1 --warmup 1 --ddpm-steps 30 --no-cpu-baseline --no-kernel-profile --no-parity-mode > gpurun_out/prof_$c.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/prof_$c -- python3 $ARGS --ddpm-steps 30 > gpurun_out/prof_$c.log 2>&1
   echo "$c rc=$?"
-  python3 tools/pmc_summary.py gpurun_out/prof_$c > gpurun_out/r02_pmc_${c}_30steps.txt
+  python3 tools/pmc_summary.py gpurun_out/prof_$c > gpurun_out/${R}_pmc_${c}_30steps.txt
   rm -rf gpurun_out/prof_$c
 done
-python3 tools/make_pmc_json.py gpurun_out/r02_pmc_FETCH_SIZE_30steps.txt gpurun_out/r02_pmc_WRITE_SIZE_30steps.txt gpurun_out/r02_pmc.json 0
+python3 tools/make_pmc_json.py gpurun_out/${R}_pmc_FETCH_SIZE_30steps.txt gpurun_out/${R}_pmc_WRITE_SIZE_30steps.txt gpurun_out/${R}_pmc.json 0
+SETS="SQ_LDS_BANK_CONFLICT,SQ_LDS_IDX_ACTIVE,SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES,SQ_INSTS_VALU,SQ_INSTS_MFMA,SQ_BUSY_CYCLES" bash tools/gpu_pmc2.sh > /dev/null 2>&1
+cp gpurun_out/pmc2_summary.txt gpurun_out/${R}_pmc_SQ_counters_20steps.txt; head -8 gpurun_out/${R}_pmc_SQ_counters_20steps.txt | cut -c1-250
+# the training step under rocprofv3 (kernel stats of 6 steps at batch 32)
+rm -rf gpurun_out/prof_train
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_train -- python3 tools/train_bench.py --batch 32 --iters 4 > gpurun_out/prof_train.log 2>&1
+f=$(find gpurun_out/prof_train -name "*kernel_stats.csv" | head -1); cp "$f" gpurun_out/${R}_kernel_stats_train_step_b32.csv; head -12 "$f" | cut -c1-160
+rm -rf gpurun_out/prof_train
