@@ -306,7 +306,8 @@ int tcdiff_step_end(int* counter, hipStream_t stream);
  * loop variable).  counter is int[4] = {current step, seed0, seed1, next step}; the launch reads counter[3] and writes
  * counter[0] = that step; tcdiff_sampler_update(mode | TC_SAMPLER_ADVANCE) later writes counter[3] = counter[0] + 1,
  * so that no tcdiff_step_end launch is needed.
- * Kc/Vc (row-major caches) or Kf/Vf (fragment images, bf16 only) may be NULL, not both; x may be NULL (no copy). */
+ * Kc/Vc (row-major caches) or Kf/Vf (fragment images, bf16 only) may be NULL, not both; x may be NULL (no copy); with
+ * film_tab the FiLM generator input (film_in) is not produced -- the step needs no FiLM GEMM. */
 typedef struct tcdiff_step_prologue_args {
     int* counter;
     const int* tseq;
@@ -322,6 +323,13 @@ typedef struct tcdiff_step_prologue_args {
     const float* x;       /* [rows][nfeat] fp32 x_t or NULL */
     void* xin;            /* [rows][ld_xin] model dtype, zero padded */
     int rows, nfeat, ld_xin;
+    /* FiLM rows from a per-job table instead of a per-step GEMM (NULL: off).  film_tab[n_t][film_rows][nfilm] fp32 holds
+     * Linear(Mish(t_base[t] + hidden_j)) of all 24 DenseFiLM blocks (model/model.py:154-168,612) for every timestep row t and
+     * every distinct conditioning row j (0 = the null conditioning shared by the unconditional branch, 1 + i = clip i);
+     * film_out[seq] <- film_tab[t][seq < n_unc ? 0 : seq - n_unc + 1] for seq < n_seq. */
+    const float* film_tab;
+    float* film_out;
+    int film_rows, nfilm, n_unc;
 } tcdiff_step_prologue_args;
 int tcdiff_step_prologue(int dtype, const tcdiff_step_prologue_args* a, hipStream_t stream);
 

@@ -49,7 +49,8 @@ class StepPrologueArgs(C.Structure):
     _fields_ = [("counter", _vp), ("tseq", _vp), ("tidx", _vp), ("t_base", _vp), ("hidden", _vp), ("film_in", _vp),
                 ("n_seq", _i), ("tab", _vp), ("n_t", _i), ("Kc", _vp), ("Vc", _vp), ("Kf", _vp), ("Vf", _vp),
                 ("NL", _i), ("n_kv", _i), ("H", _i), ("Lp", _i), ("nkt", _i), ("tok0", _i), ("x", _vp), ("xin", _vp),
-                ("rows", _i), ("nfeat", _i), ("ld_xin", _i)]
+                ("rows", _i), ("nfeat", _i), ("ld_xin", _i), ("film_tab", _vp), ("film_out", _vp), ("film_rows", _i),
+                ("nfilm", _i), ("n_unc", _i)]
 
 
 class RowArgs(C.Structure):

@@ -296,12 +296,20 @@ __global__ __launch_bounds__(256) void step_prologue_kernel(tcdiff_step_prologue
     const long n_film = (long)a.n_seq * 512;
     const long n_kv = (long)a.NL * a.n_kv * 2 * 1024;
     const long n_x = a.x ? (long)a.rows * a.ld_xin : 0;
-    const long total = n_film + n_kv + n_x;
+    const long q_tab = a.film_tab ? (long)a.n_seq * (a.nfilm / 4) : 0;       // float4 pieces of the gathered FiLM rows
+    const long total = n_film + n_kv + n_x + q_tab;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        if (i < n_film) {
+        if (i >= n_film + n_kv + n_x) {
+            const long k = i - (n_film + n_kv + n_x);
+            const int q4 = a.nfilm / 4;
+            const int seq = (int)(k / q4), c4 = (int)(k % q4);
+            const int j = seq < a.n_unc ? 0 : seq - a.n_unc + 1;
+            reinterpret_cast<f32x4_t*>(a.film_out)[(long)seq * q4 + c4] =
+                reinterpret_cast<const f32x4_t*>(a.film_tab)[((long)t * a.film_rows + j) * q4 + c4];
+        } else if (i < n_film) {
             const int c = (int)(i & 511);
             if (c == 0) a.tidx[i >> 9] = t;
-            ((E*)a.film_in)[i] = P::from_f32(mish_f(a.t_base[(long)t * 512 + c] + a.hidden[i]));
+            if (!a.film_tab) ((E*)a.film_in)[i] = P::from_f32(mish_f(a.t_base[(long)t * 512 + c] + a.hidden[i]));
         } else if (i < n_film + n_kv) {
             const long k = i - n_film;
             const int c = (int)(k & 1023), rr = (int)((k >> 10) & 1);
@@ -338,7 +346,12 @@ extern "C" int tcdiff_step_prologue(int dtype, const tcdiff_step_prologue_args* 
         (a->x && (!a->xin || a->rows <= 0 || a->ld_xin < a->nfeat)))
         return TC_ERR_ARG;
     if (a->Kf && dtype != TC_DTYPE_BF16) return TC_ERR_ARG;
-    const long total = (long)a->n_seq * 512 + (long)a->NL * a->n_kv * 2048 + (a->x ? (long)a->rows * a->ld_xin : 0);
+    if (a->film_tab && (!a->film_out || a->film_rows <= 0 || a->nfilm <= 0 || a->nfilm % 4 || a->n_unc < 0 ||
+                        a->n_seq - a->n_unc + 1 > a->film_rows ||
+                        ((reinterpret_cast<uintptr_t>(a->film_tab) | reinterpret_cast<uintptr_t>(a->film_out)) & 15)))
+        return TC_ERR_ARG;
+    const long total = (long)a->n_seq * 512 + (long)a->NL * a->n_kv * 2048 + (a->x ? (long)a->rows * a->ld_xin : 0) +
+                       (a->film_tab ? (long)a->n_seq * (a->nfilm / 4) : 0);
     const unsigned grid = (unsigned)std::min<long>((total + 255) / 256, 2048);
     if (dtype == TC_DTYPE_BF16)
         hipLaunchKernelGGL(step_prologue_kernel<MmaBF16>, dim3(grid), dim3(256), 0, stream, *a);

@@ -222,6 +222,14 @@ class GaussianDiffusion(nn.Module):
             eng.build_time_tables(torch.tensor(uniq, dtype=torch.int32, device=dev))
             eng.tables_key = key
             eng.reset_graphs()
+        # the FiLM rows of every (timestep, conditioning row) of this job as one GEMM; graphs hold the table's address
+        old = eng.film_tab.data_ptr() if eng.film_tab is not None else None
+        if os.environ.get("TCDIFF_FILM_TABLE", "1") != "0" and len(uniq) > 2:
+            tab = eng.build_film_table(B)
+        else:
+            eng.film_tab = tab = None
+        if (tab.data_ptr() if tab is not None else None) != old:
+            eng.reset_graphs()
         row_of = {t: i for i, t in enumerate(uniq)}
         return eng, [row_of[int(t)] for t in tseq]
 

@@ -53,6 +53,7 @@ class DenoiserEngine:
         self.weights_version = None
         self.plan_B = 0
         self.tables_key = None
+        self.film_tab = None
         self._sampler_state = None
         # row-block chain kernels (csrc/chain.hip): bf16 only; the f32 parity mode keeps the op-by-op kernels
         self.use_chain = self.dt == L.DT_BF16 and os.environ.get("TCDIFF_CHAIN", "1") != "0" and self.ff == 1024 \
@@ -362,6 +363,7 @@ class DenoiserEngine:
         for l in range(self.NL):
             K.gemm_tile(dt, th_r, w[f"l{l}.ckv.w"], 2 * n, 1024, 512, A2=th_h, split_n=512, out=tab[l], ldc=1024)
         self.t_base, self.kv_tab, self.n_t = t_base, tab, n
+        self.film_tab = None        # belongs to the previous tables
         self.tables_key = None      # callers that cache tables set the key after this returns
         self.reset_graphs()         # the tables moved: captured graphs point at the old ones
         return t_base, tab
@@ -384,6 +386,32 @@ class DenoiserEngine:
         K.gemm_tile(dt, b["film_in"], w["film.w"], n_rows_seq, nfilm, 512, bias=w["film.b"], mode=L.EPI_STORE_F32,
                     out=b["film"], ldc=nfilm)
 
+    def build_film_table(self, B: int, max_bytes: int = 8 << 30):
+        """FiLM (scale | shift) rows of all 24 DenseFiLM blocks for EVERY timestep row of the current time tables and every
+        distinct conditioning row of the job -- row 0: the null conditioning (all unconditional rows share it), row 1 + i:
+        clip i -- as ONE GEMM per job, [n_t (B + 1), 512] x [24 576, 512]^T (model/model.py:154-168,612).  The sampler's step
+        prologue then gathers 2B rows per step instead of a per-step GEMM that re-reads the 25 MB of FiLM weights for 32
+        rows.  b['hidden_all'][:B] must hold the null hidden row, [B:2B] the clips' (as _prepare leaves them).  1.67 GB at
+        T = 1000, B = 16; beyond `max_bytes` the table is not built and the per-step GEMM stays."""
+        nfilm = self.NL * NL_FILM * 1024
+        n_t, rows = self.n_t, B + 1
+        if n_t * rows * nfilm * 4 > max_bytes:
+            self.film_tab = None
+            return None
+        dev, b, w = self.dev, self.b, self.w
+        hid = torch.cat([b["hidden_all"][:1], b["hidden_all"][B:2 * B]], 0)                 # [B + 1, 512]: copies only
+        hb = hid.repeat(n_t, 1).contiguous()                                               # row (t, j) -> hidden j
+        ia = torch.arange(n_t, device=dev, dtype=torch.int32).repeat_interleave(rows).contiguous()
+        fin = torch.empty(n_t * rows, 512, device=dev, dtype=self.T)
+        K.add_act(self.dt, self.t_base, ia, hb, n_t * rows, L.ACT_MISH, out=fin)
+        tab = getattr(self, "_film_tab_buf", None)        # one buffer per shape, refilled per job: captured graphs keep its address
+        if tab is None or tab.shape != (n_t, rows, nfilm):
+            tab = self._film_tab_buf = torch.empty(n_t, rows, nfilm, device=dev, dtype=torch.float32)
+        K.gemm_tile(self.dt, fin, w["film.w"], n_t * rows, nfilm, 512, bias=w["film.b"], mode=L.EPI_STORE_F32, out=tab,
+                    ldc=nfilm)
+        self.film_tab = tab
+        return tab
+
     def _xin_shape(self, token_rows: int):
         """(rows, columns, padded pitch) of the model-dtype copy of x_t: one row per token, or -- with the input
         projection folded into the first fusion linear -- one row per frame (dn tokens, contiguous in x)"""
@@ -397,13 +425,19 @@ class DenoiserEngine:
         per_step_conditioning + network's convert_pad + step_end."""
         dt, w, b = self.dt, self.w, self.b
         full = self.use_full
+        nfilm = self.NL * NL_FILM * 1024
+        tab = getattr(self, "film_tab", None)
+        if tab is not None and tab.shape[1] * 2 - 2 != n_rows_seq:
+            tab = None                                # a table of another batch plan: fall back to the per-step GEMM
+        extra = {} if tab is None else dict(film_tab=tab, film_out=b["film"], film_rows=tab.shape[1], nfilm=nfilm,
+                                            n_unc=n_rows_seq // 2)
         K.step_prologue(dt, st["counter"], st["rows"], b["tidx"], self.t_base, b["hidden_all"], b["film_in"],
                         n_rows_seq, self.kv_tab, self.n_t, None if full else b["Kc"], None if full else b["Vc"],
                         b["Kf"] if full else None, b["Vf"] if full else None, self.NL, b["Kc"].shape[1], self.H,
-                        self.Lpc, self.nkt if full else 0, self.S, x, b["xin"], *self._xin_shape(rows))
-        nfilm = self.NL * NL_FILM * 1024
-        K.gemm_tile(dt, b["film_in"], w["film.w"], n_rows_seq, nfilm, 512, bias=w["film.b"], mode=L.EPI_STORE_F32,
-                    out=b["film"], ldc=nfilm)
+                        self.Lpc, self.nkt if full else 0, self.S, x, b["xin"], *self._xin_shape(rows), **extra)
+        if tab is None:
+            K.gemm_tile(dt, b["film_in"], w["film.w"], n_rows_seq, nfilm, 512, bias=w["film.b"], mode=L.EPI_STORE_F32,
+                        out=b["film"], ldc=nfilm)
 
     def network(self, x: torch.Tensor, B: int, branches: int, kv_slot0: int, n_shared: int, film_row0: int,
                 x_ready: bool = False):

@@ -52,7 +52,8 @@ class _Lin:
         self.groups = [(0, split), (split, self.N)] if split else [(0, self.N)]
         self.Wf = torch.zeros(self.N, self.Kp, device=eng.dev, dtype=eng.T)
         self.WbT = [torch.zeros(self.K, K.round_up(hi - lo, eng.kt), device=eng.dev, dtype=eng.T) for lo, hi in self.groups]
-        self.bias = torch.zeros(self.N, device=eng.dev, dtype=torch.float32) if self.bnames else None
+        # stacked biases need one contiguous copy; a lone bias is the parameter itself
+        self.bias = torch.zeros(self.N, device=eng.dev, dtype=torch.float32) if len(self.bnames) > 1 else None
 
     def pack(self):
         """(Re)build the operand packs from the fp32 master parameters: W as [N, Kp] and, per operand group, W^T."""
@@ -68,12 +69,14 @@ class _Lin:
                 K.cast_transpose(eng.dt, w[a:b], b - a, self.K, self.K, dst=self.Wf[r0 + a:], ld_dst=self.Kp, cols_pad=self.Kp,
                                  dstT=wt.view(-1)[r0 + a - lo:], ld_dstT=wt.shape[1], rows_pad=b - a)
             r0 += rows
-        if self.bias is not None:
+        if len(self.bnames) > 1:
             o = 0
             for name in self.bnames:
                 b = eng.params[name].detach()
                 self.bias[o:o + b.numel()].copy_(b)
                 o += b.numel()
+        elif self.bnames:
+            self.bias = eng.params[self.bnames[0]].detach()
 
     # ---- forward ---------------------------------------------------------------------------------------------------
     def fwd(self, A, M, *, A2=None, out=None, f32=False, ldc=None, heads=None, rows=None):
@@ -127,7 +130,8 @@ class _Lin:
             Xt = eng.e(self.K, Mp)
             K.cast_transpose(dt, X, M, self.K, X.shape[1], dstT=Xt, ld_dstT=Mp, rows_pad=Mp)
             tiles = ((ng + 127) // 128) * ((self.K + 127) // 128)
-            splits = max(1, min(512 // tiles, Mp // kt, 64))
+            # one workgroup per CU: measured (tools/gemm_shapes.py, 14 400 rows) 512x512: 16 splits 29 us, 32 splits 40 us, 1: 149 us
+            splits = max(1, min(256 // tiles, Mp // kt, 64))
             K.gemm_splitk(dt, dYt[lo:], Xt, ng, self.K, Mp, Mp, Mp, gW[lo * self.K:], self.K, splits)
         return outs
 
@@ -160,6 +164,7 @@ class TrainEngine:
         self.seed = torch.zeros(2, device=self.dev, dtype=torch.int32)
         self.packed_version = None
         self.sv = None
+        self._pz = {}
         self._define()
         half = 256
         self.sin_freq = torch.exp(torch.arange(half) * -(math.log(10000) / (half - 1))).to(self.dev)   # model/utils.py:43-44
@@ -281,6 +286,18 @@ class TrainEngine:
 
     poison = False      # tests: fill every "empty" workspace with NaN, so that a kernel reading what nothing wrote shows up
 
+    def pz(self, key, *shape, dtype=None):
+        """Persistent zero-initialised buffer (head-major images, lse / delta rows): kernels only ever write the valid rows, so
+        the zero padding written once stays valid and nothing is re-filled per step (345 fill launches, ~1 ms, at batch 32).
+        One buffer per (key, shape): what the backward still needs (Q, K, V, lse of every layer) has its own key."""
+        dtype = self.T if dtype is None else dtype
+        k = (key, tuple(shape), dtype)
+        t = self._pz.get(k)
+        if t is None:
+            t = torch.zeros(*shape, device=self.dev, dtype=dtype)
+            self._pz[k] = t
+        return t
+
     def e(self, *shape, dtype=None):
         if self.poison:
             return torch.full(shape, float("nan"), device=self.dev, dtype=self.T if dtype is None else dtype)
@@ -344,10 +361,10 @@ class TrainEngine:
 
         # ---- music branch: cond_projection, two encoder layers (model/model.py:572-583,211-245) -------------------------
         kc0 = lins["c0"].Kp
-        cin = z(Ms, kc0)
+        cin = self.pz("cin", Ms, kc0)
         K.convert_pad(dt, cond, cin, Ms, 2 * Cd, kc0, rows_per_batch=S, batch_stride=clen * Cd, row_stride=2 * Cd)
         kc1 = lins["c2"].Kp
-        c0a = z(Ms, kc1)
+        c0a = self.pz("c0a", Ms, kc1)
         lins["c0"].fwd(cin, Ms, out=c0a, ldc=kc1)
         c1 = self.act_fwd(c0a, Ms, Cd, L.ACT_RELU)
         tok = e(Ms, 512, dtype=f32)
@@ -361,10 +378,10 @@ class TrainEngine:
         for i in range(2):
             q = f"cond_encoder.{i}."
             s = dict(x_in=tok, h=mh, rot=mrot)
-            Qi, Ki, Vi = z(B, H, self.Lps, 64), z(B, H, self.Lps, 64), z(B, H, self.Lps, 64)
+            Qi, Ki, Vi = (self.pz(f"e{i}.{n}", B, H, self.Lps, 64) for n in "QKV")
             lins[f"e{i}.qkv"].fwd(mrot, Ms, A2=mh, heads=dict(out=Qi, out_k=Ki, out_v=Vi, scale_q=0.125, Lseq=S,
                                                                Lp=self.Lps, n_q=512, n_k=512))
-            O, lse = e(Ms, 512), z(B, H, self.Lps, dtype=f32)
+            O, lse = e(Ms, 512), self.pz(f"e{i}.lse", B, H, self.Lps, dtype=f32)
             K.attention_train(dt, Qi, Ki, Vi, O, lse, B, H, S, S, self.Lps, self.Lps, 512, self.seed, 4 * i + 0, self.thr,
                               self.dscale)
             zo = e(Ms, 512, dtype=f32)
@@ -428,7 +445,7 @@ class TrainEngine:
         self.row_fwd(flags=L.ROWF_NEXT_LN | L.ROWF_STORE_H | L.ROWF_STORE_ROT, M=Mc, L=S + 2, z=memin.view(Mc, 512),
                      nln_g=P("norm_cond.weight"), nln_b=P("norm_cond.bias"), nln_eps=1e-5, hout=mem_h, rout=mem_rot,
                      rope=self.rope, pos_mod=S + 2)
-        Kc, Vc = z(NL, B, H, self.Lpc, 64), z(NL, B, H, self.Lpc, 64)
+        Kc, Vc = self.pz("Kc", NL, B, H, self.Lpc, 64), self.pz("Vc", NL, B, H, self.Lpc, 64)
         nk = 512 * NL
         for l in range(NL):
             hd = dict(out=None, scale_q=1.0, Lseq=S + 2, Lp=self.Lpc, n_q=0)
@@ -436,7 +453,7 @@ class TrainEngine:
             lins["ckv"].fwd(mem_h, Mc, heads=dict(out_k=None, out_v=Vc[l], n_k=0, **hd), rows=(nk + 512 * l, nk + 512 * l + 512))
         sv.update(memin=memin, mem_h=mem_h, mem_rot=mem_rot, Kc=Kc, Vc=Vc)
         # ---- motion: input projection + fusion projection (model/model.py:560-561) --------------------------------------------
-        xin = z(M, lins["in"].Kp)
+        xin = self.pz("xin", M, lins["in"].Kp)
         K.convert_pad(dt, x, xin, M, nf, lins["in"].Kp)
         xp = e(M, 512)
         lins["in"].fwd(xin, M, out=xp)
@@ -463,10 +480,10 @@ class TrainEngine:
             q = f"{st}{l}."
             s = dict(x=xcur, h1=h1, r1=r1)
             sd = 16 + 8 * l
-            Q, Kk, V = z(B, H, Lp, 64), z(B, H, Lp, 64), z(B, H, Lp, 64)
+            Q, Kk, V = (self.pz(f"l{l}.{n}", B, H, Lp, 64) for n in "QKV")
             lins[f"l{l}.qkv"].fwd(r1, M, A2=h1, heads=dict(out=Q, out_k=Kk, out_v=V, scale_q=0.125, Lseq=Lq, Lp=Lp, n_q=512,
                                                             n_k=512))
-            O, lse = e(M, 512), z(B, H, Lp, dtype=f32)
+            O, lse = e(M, 512), self.pz(f"l{l}.lse", B, H, Lp, dtype=f32)
             K.attention_train(dt, Q, Kk, V, O, lse, B, H, Lq, Lq, Lp, Lp, 512, self.seed, sd + 0, self.thr, self.dscale)
             z1 = e(M, 512, dtype=f32)
             lins[f"l{l}.sfc"].fwd(O, M, out=z1, f32=True)
@@ -476,9 +493,9 @@ class TrainEngine:
                          ln_b=P(q + "self_attn.layer_norm.bias"), ln_eps=1e-6, film=film[:, (3 * l) * 1024:], film_ld=nfilm,
                          xres=xcur, xout=x2, nln_g=P(q + "norm2.weight"), nln_b=P(q + "norm2.bias"), nln_eps=1e-5, rout=r2,
                          rope=self.rope, pos_mod=Lq, site_pre=sd + 1, site_post=sd + 2)
-            Qc = z(B, H, Lp, 64)
+            Qc = self.pz(f"l{l}.Qc", B, H, Lp, 64)
             lins[f"l{l}.cq"].fwd(r2, M, heads=dict(out=Qc, out_k=None, out_v=None, scale_q=0.125, Lseq=Lq, Lp=Lp, n_q=512, n_k=0))
-            Oc, lsec = e(M, 512), z(B, H, Lp, dtype=f32)
+            Oc, lsec = e(M, 512), self.pz(f"l{l}.lsec", B, H, Lp, dtype=f32)
             K.attention_train(dt, Qc, Kc[l], Vc[l], Oc, lsec, B, H, Lq, S + 2, Lp, Lpc, 512, self.seed, sd + 3, self.thr,
                               self.dscale)
             z2 = e(M, 512, dtype=f32)
@@ -587,10 +604,10 @@ class TrainEngine:
                          ln_eps=1e-6, film=sv["film"][:, (3 * l + 1) * 1024:], film_ld=nfilm, xres=s["x2"],
                          nln_g=P(q + "norm3.weight"), nln_b=P(q + "norm3.bias"), nln_eps=1e-5, site_pre=sd + 4, site_post=sd + 5,
                          d_xn=gx3, d_h=dh3, d_z=dz2, d_xres=gx2, d_film=dfilm[:, (3 * l + 1) * 1024:], dfilm_ld=nfilm)
-            dOc = z(B, H, Lp, 64)
+            dOc = self.pz("dO", B, H, Lp, 64)
             lins[f"l{l}.cfc"].bwd(dz2, 512, M, [s["Oc"]], [("HEADS", dict(out=dOc, out_k=None, out_v=None, scale_q=1.0, Lseq=Lq,
                                                                              Lp=Lp, n_q=512, n_k=0))])
-            dQc, delta = e(M, 512), z(B, H, Lp, dtype=f32)
+            dQc, delta = e(M, 512), self.pz("delta", B, H, Lp, dtype=f32)
             K.attention_bwd(dt, s["Qc"], sv["Kc"][l], sv["Vc"][l], s["Oc"], dOc, s["lsec"], delta, dQc, 512,
                             dKV.view(-1)[512 * l:], dKV.view(-1)[nk + 512 * l:], 2 * nk, B, H, Lq, S + 2, Lp, Lpc, 512, 0.125,
                             self.seed, sd + 3, self.thr, self.dscale)
@@ -603,10 +620,10 @@ class TrainEngine:
                          film=sv["film"][:, (3 * l) * 1024:], film_ld=nfilm, xres=s["x"], nln_g=P(q + "norm2.weight"),
                          nln_b=P(q + "norm2.bias"), nln_eps=1e-5, rope=self.rope, pos_mod=Lq, site_pre=sd + 1, site_post=sd + 2,
                          d_xn=gx2, d_rot=dr2, d_z=dz1, d_xres=gx1, d_film=dfilm[:, (3 * l) * 1024:], dfilm_ld=nfilm)
-            dO = z(B, H, Lp, 64)
+            dO = self.pz("dO", B, H, Lp, 64)
             lins[f"l{l}.sfc"].bwd(dz1, 512, M, [s["O"]], [("HEADS", dict(out=dO, out_k=None, out_v=None, scale_q=1.0, Lseq=Lq,
                                                                            Lp=Lp, n_q=512, n_k=0))])
-            dQKV, delta = e(M, 1536), z(B, H, Lp, dtype=f32)
+            dQKV, delta = e(M, 1536), self.pz("delta", B, H, Lp, dtype=f32)
             K.attention_bwd(dt, s["Q"], s["K"], s["V"], s["O"], dO, s["lse"], delta, dQKV, 1536, dQKV.view(-1)[512:],
                             dQKV.view(-1)[1024:], 1536, B, H, Lq, Lq, Lp, Lp, 512, 0.125, self.seed, sd + 0, self.thr,
                             self.dscale)
@@ -688,10 +705,10 @@ class TrainEngine:
             self.row_bwd(M=Ms, L_=S, nln=q + "norm2", flags=fl | L.ROWF_NEXT_LN | L.ROWF_STORE_H, z=s["zo"], xres=s["x_in"],
                          nln_g=P(q + "norm2.weight"), nln_b=P(q + "norm2.bias"), nln_eps=1e-5, site_pre=4 * i + 1, d_xn=gx2,
                          d_h=dh2, d_z=dzo, d_xres=gx1)
-            dO = z(B, H, Lps, 64)
+            dO = self.pz("dOe", B, H, Lps, 64)
             lins[f"e{i}.o"].bwd(dzo, 512, Ms, [s["O"]], [("HEADS", dict(out=dO, out_k=None, out_v=None, scale_q=1.0, Lseq=S,
                                                                         Lp=Lps, n_q=512, n_k=0))])
-            dQKV, delta = e(Ms, 1536), z(B, H, Lps, dtype=f32)
+            dQKV, delta = e(Ms, 1536), self.pz("deltae", B, H, Lps, dtype=f32)
             K.attention_bwd(dt, s["Q"], s["K"], s["V"], s["O"], dO, s["lse"], delta, dQKV, 1536, dQKV.view(-1)[512:],
                             dQKV.view(-1)[1024:], 1536, B, H, S, S, Lps, Lps, 512, 0.125, self.seed, 4 * i + 0, self.thr,
                             self.dscale)
@@ -702,7 +719,7 @@ class TrainEngine:
         self.row_bwd(M=Ms, L_=S, nln="cond_encoder.0.norm1", flags=L.ROWF_NEXT_LN | L.ROWF_STORE_H | L.ROWF_STORE_ROT, z=sv["tok0"],
                      nln_g=P("cond_encoder.0.norm1.weight"), nln_b=P("cond_encoder.0.norm1.bias"), nln_eps=1e-5, rope=self.rope,
                      pos_mod=S, d_xn=g_tok, d_h=g_h, d_rot=g_r, d_z=dtok0)
-        dc1 = z(Ms, sv["c1"].shape[1])
+        dc1 = self.pz("dc1", Ms, sv["c1"].shape[1])
         lins["c2"].bwd(dtok0, 512, Ms, [sv["c1"]], [("T", dc1, dc1.shape[1])])
         dc0a = self.act_bwd(sv["c0a"], dc1, Ms, self.Cd, L.ACT_RELU)
         lins["c0"].bwd(dc0a, dc0a.shape[1], Ms, [sv["cin"]], [None])
