@@ -267,6 +267,11 @@ __global__ __launch_bounds__(512) void attention_res_kernel(const char* __restri
         __builtin_amdgcn_global_load_lds((gbl_void_t*)(Kg + (long)(c0 + row) * 128 + chunk * 16), (lds_void_t*)(Ks + blk * 1024), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((gbl_void_t*)(Vg + (long)(c0 + row) * 128 + chunk * 16), (lds_void_t*)(Vs + blk * 1024), 16, 0, 0);
     }
+    // (Tried and dropped: replacing this full drain by counted waits, `s_waitcnt vmcnt(2 (nt - 1 - b))` + barrier in front of
+    // tile b, so that tile 0 starts one tile's worth of DMA after the launch.  The backend's wait-count pass treats an LDS-DMA
+    // in flight as aliasing EVERY later ds_read and puts its own `s_waitcnt vmcnt(0)` in front of the first K fragment read
+    // of each tile -- visible in the ISA -- so the drain happens anyway, one tile later.  Avoiding it needs every LDS read of
+    // the tile in inline asm with hand-counted lgkmcnt; not worth it for ~4 us of a 28-us launch.)
     sync_dma();
 
     if (act0) {
