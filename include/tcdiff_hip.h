@@ -406,11 +406,33 @@ int tcdiff_ema_update(const tcdiff_ema_chunk* chunks, int n_chunks, float beta, 
 int tcdiff_cast_transpose(int dtype, int src_f32, const void* src, int rows, int cols, int ld_src, void* dst, int ld_dst,
                           int cols_pad, void* dstT, int ld_dstT, int rows_pad, float* colsum, hipStream_t stream);
 
+/* The same for a table of fp32 matrices in ONE launch -- the operand packs (W as T [N, Kp] and W^T as T [K, Np]) of every
+ * nn.Linear, rebuilt from the fp32 master parameters after each optimizer step (the reference's autocast does the
+ * equivalent cast per use: accelerate mixed_precision, TCDiff.py:96-104).  `descs_dev` is a DEVICE array; fill each entry's
+ * src .. rows_pad, call tcdiff_ct_desc_init (host) for tiles_x / vec and the tile count, and set tile0 to the running sum
+ * of the counts; n_tiles = the total. */
+typedef struct tcdiff_ct_desc {
+    const void* src;                  /* fp32 [rows][ld_src] */
+    void* dst;                        /* T [rows][ld_dst], columns cols .. cols_pad zero-filled; or NULL */
+    void* dstT;                       /* T [cols][ld_dstT], columns rows .. rows_pad zero-filled; or NULL */
+    int rows, cols, ld_src, ld_dst, cols_pad, ld_dstT, rows_pad;
+    int tile0, tiles_x, vec;          /* tile0: caller; tiles_x, vec: tcdiff_ct_desc_init */
+} tcdiff_ct_desc;
+int tcdiff_ct_desc_init(int dtype, tcdiff_ct_desc* d);
+int tcdiff_cast_transpose_multi(int dtype, const tcdiff_ct_desc* descs_dev, int n_desc, int n_tiles, hipStream_t stream);
+
 /* Split-K GEMM with fp32 accumulation into `out`: out[m][n] += sum_k A[m][k] W[n][k] (atomic adds; `splits` workgroups
  * share each 128x128 tile).  The weight gradient dW[N,K] += dY^T X of every nn.Linear, with M = out features, N = in
  * features and the contraction over the token rows. */
 int tcdiff_gemm_splitk(int dtype, const void* A, const void* W, int M, int N, int K, int lda, int ldw, float* out,
                        int ldc, int splits, hipStream_t stream);
+
+/* The weight gradient without transposed copies: out[m][n] += sum_k A[k][m] B[k][n], A = dY [tokens][lda], B = X
+ * [tokens][ldb] as the forward left them (token-major).  M, N multiples of 128, K (tokens) a multiple of the k-tile (64
+ * bf16 / 32 f32), else TC_ERR_UNSUPPORTED and the caller goes through tcdiff_cast_transpose + tcdiff_gemm_splitk.
+ * Autograd of nn.Linear's weight in the reference (torch addmm backward; model/model.py:78-80,103,399-401). */
+int tcdiff_gemm_tn(int dtype, const void* A, const void* B, int M, int N, int K, int lda, int ldb, float* out, int ldc,
+                   int splits, hipStream_t stream);
 
 /* y = T(dropout(act(a)))  /  da = dy * mask / (1 - p) * act'(a).  a, da: fp32 (a_f32 != 0) or T [rows][ld_a]; y, dy:
  * T [rows][ld_y]; columns >= cols of y / da are written as zeros up to the leading dimension.  Hash index = r * cols + c.

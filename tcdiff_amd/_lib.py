@@ -63,6 +63,12 @@ class RowArgs(C.Structure):
                 ("d_film", _vp), ("dfilm_ld", _i), ("partials", _vp), ("chunks", _i), ("dz_f32", _i)]
 
 
+class CtDesc(C.Structure):
+    """tcdiff_ct_desc (include/tcdiff_hip.h): one matrix of tcdiff_cast_transpose_multi's table."""
+    _fields_ = [("src", _vp), ("dst", _vp), ("dstT", _vp), ("rows", _i), ("cols", _i), ("ld_src", _i), ("ld_dst", _i),
+                ("cols_pad", _i), ("ld_dstT", _i), ("rows_pad", _i), ("tile0", _i), ("tiles_x", _i), ("vec", _i)]
+
+
 ROWF_BIAS, ROWF_DROP_PRE, ROWF_LN_POST, ROWF_DROP_POST, ROWF_FILM, ROWF_RES, ROWF_STORE_X, ROWF_NEXT_LN, ROWF_STORE_H, \
     ROWF_STORE_ROT = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
 
@@ -102,6 +108,9 @@ _SIGS = {
     # training step (csrc/train_ops.hip, attention_train.hip, gemm.hip)
     "tcdiff_cast_transpose": [_i, _i, _vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp, _vp],
     "tcdiff_gemm_splitk": [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp],
+    "tcdiff_gemm_tn": [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp],
+    "tcdiff_ct_desc_init": [_i, C.POINTER(CtDesc)],
+    "tcdiff_cast_transpose_multi": [_i, _vp, _i, _i, _vp],
     "tcdiff_act_drop": [_i, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, C.c_uint32, _f, _vp],
     "tcdiff_act_drop_bwd": [_i, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i, C.c_uint32, _f, _vp],
     "tcdiff_row_fwd": [_i, C.POINTER(RowArgs), _vp],

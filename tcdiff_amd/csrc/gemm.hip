@@ -34,7 +34,7 @@
 //   rows), so each lane ends up holding 4 CONSECUTIVE output columns of one output row per register quad;
 //   gemm_rowln dumps its fp32 64x512 tile to LDS and finishes LayerNorm/FiLM/residual/rotary in a row-wise pass
 //   (one wave per row, 16-byte loads/stores, wave-wide shuffle reductions) exactly like ops.hip::ln_rot.
-#include "common.h"
+#include "attn_common.h"      // v_frag: transposed MFMA fragments of a staged [k][64 columns] tile (the TN form)
 #include "tcdiff_hip.h"
 
 #ifdef TC_STAMP
@@ -59,7 +59,11 @@ extern "C" int tcdiff_debug_stamp_buffer(void* p) {
 // outside the decoder layers (FiLM stack, input / fusion / final projection: 152-228 tiles, K up to 1536).  With two
 // stages every k-tile waits out what is left of a ~1.2 us DMA round trip after 0.25 us of MFMA work (25 us for K =
 // 1536); with four the DMA of tile kt + 3 is issued while tile kt is computed.
-template <class P, int ACT, int NS>
+// TN = true: out[m][n] = sum_k A[k][m] W[k][n] -- BOTH operands row-major over the contraction index (the weight gradient
+// dW = dY^T X straight from the token-major dY and X: no transposed copies).  A k-tile is staged as [KT rows of k][128
+// columns] in 128-byte column blocks (the layout of attention's V tile), and every fragment is the transposed read of
+// attn_common.h::v_frag (ds_read_b64_tr_b16 for bf16).  Requires M, N multiples of 128 and K a multiple of the k-tile.
+template <class P, int ACT, int NS, bool TN = false>
 __global__ __launch_bounds__(256) void gemm_tile_kernel(const char* __restrict__ A, const char* __restrict__ A2,
                                                         int split_n, const char* __restrict__ W, int M, int N,
                                                         int K, long lda_b, long ldw_b, int a_mod, tcdiff_tile_epi e) {
@@ -101,8 +105,19 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(const char* __restrict__
     auto issue = [&](int t) {
         const int tt = kt0 + (t < nk ? t : nk - 1);
         char* dst = smem + (t % NS) * STAGE;
-        stage_glds<128, 4>(dst, Ause + (long)tt * TC_ROWB, lda_b, m0, M, a_mod, wave, lane);
-        stage_glds<128, 4>(dst + WOFF, W + (long)tt * TC_ROWB, ldw_b, n0, N, 0, wave, lane);
+        if constexpr (TN) {
+            // column block u (128 bytes of m / n) of the k-tile's KT rows -> LDS [u][KT][128 B]; 2 (bf16) or 4 (f32) per operand
+#pragma unroll
+            for (int u = 0; u < ES; ++u) {
+                stage_glds<P::KT, 4>(dst + u * (P::KT * TC_ROWB), Ause + (long)m0 * ES + u * TC_ROWB, lda_b, tt * P::KT, K, 0,
+                                     wave, lane);
+                stage_glds<P::KT, 4>(dst + WOFF + u * (P::KT * TC_ROWB), W + (long)n0 * ES + u * TC_ROWB, ldw_b, tt * P::KT, K,
+                                     0, wave, lane);
+            }
+        } else {
+            stage_glds<128, 4>(dst, Ause + (long)tt * TC_ROWB, lda_b, m0, M, a_mod, wave, lane);
+            stage_glds<128, 4>(dst + WOFF, W + (long)tt * TC_ROWB, ldw_b, n0, N, 0, wave, lane);
+        }
     };
 #pragma unroll
     for (int t = 0; t < NS - 1; ++t) issue(t);
@@ -118,8 +133,26 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(const char* __restrict__
         __syncthreads();
         issue(kt + NS - 1);
         const int cur = kt % NS;
-        const char* ta = smem + cur * STAGE + (wm * 64) * TC_ROWB;
+        const char* ta = smem + cur * STAGE + (wm * 64) * TC_ROWB;       // TN: the 8-KB [KT][64 columns] tile of this wave's m range
         const char* tw = smem + cur * STAGE + WOFF + (wn * 64) * TC_ROWB;
+        if constexpr (TN) {
+            typedef AttnCfg<P> C;
+#pragma unroll
+            for (int k32 = 0; k32 < C::NKT; ++k32)
+#pragma unroll
+                for (int st = 0; st < C::PV_STEPS; ++st) {
+                    u32x4 fa[2], fw[2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) fa[i] = v_frag<P>(ta, i, k32, st, lane);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) fw[j] = v_frag<P>(tw, j, k32, st, lane);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) P::mma(acc[i][j], fw[j], fa[i]);
+                }
+            continue;
+        }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             u32x4 fa[2], fw[2];
@@ -593,6 +626,45 @@ extern "C" int tcdiff_gemm_splitk(int dtype, const void* A, const void* W, int M
     e.ldc = ldc;
     e.k_splits = splits;
     return launch_tile(dtype, A, nullptr, 0, W, M, N, K, lda, ldw, 0, &e, stream);
+}
+
+// out[m][n] += sum_k A[k][m] B[k][n]: the same accumulation with both operands row-major over k (include/tcdiff_hip.h)
+extern "C" int tcdiff_gemm_tn(int dtype, const void* A, const void* B, int M, int N, int K, int lda, int ldb, float* out,
+                              int ldc, int splits, hipStream_t stream) {
+    if (!A || !B || !out || M <= 0 || N <= 0 || K <= 0 || ldc < N || splits < 1 || lda < M || ldb < N) return TC_ERR_ARG;
+    if (dtype != TC_DTYPE_BF16 && dtype != TC_DTYPE_F32) return TC_ERR_ARG;
+    const int es = dtype == TC_DTYPE_BF16 ? 2 : 4;
+    const int kt = dtype == TC_DTYPE_BF16 ? 64 : 32;
+    if (M % 128 || N % 128 || K % kt) return TC_ERR_UNSUPPORTED;       // no column clamp, no k tail: the caller repacks instead
+    if (!aligned16(A) || !aligned16(B) || !aligned16(out) || ((long)lda * es) % 16 || ((long)ldb * es) % 16) return TC_ERR_ALIGN;
+    if ((long)K * lda * es >= (1L << 32) || (long)K * ldb * es >= (1L << 32)) return TC_ERR_ARG;   // 32-bit staging offsets
+    tcdiff_tile_epi e = {};
+    e.mode = TC_EPI_ATOMIC_F32;
+    e.out = out;
+    e.ldc = ldc;
+    e.k_splits = splits < K / kt ? splits : K / kt;
+    static tc_dev_state dev_state;
+    const int n_cu = tc_device_once(dev_state, [](int) {
+        hipError_t a = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tile_kernel<MmaBF16, 0, 4, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 128 * TC_ROWB);
+        hipError_t b = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tile_kernel<MmaF32, 0, 4, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 128 * TC_ROWB);
+        return a != hipSuccess ? a : b;
+    });
+    if (n_cu < 0) return n_cu;
+    dim3 grid((N / 128) * (M / 128) * e.k_splits);
+    const bool deep = (long)grid.x * 4 <= (long)n_cu * 5 && K / kt / e.k_splits >= 3;
+#define TC_LAUNCH_TN(POL, NSV)                                                                                         \
+    hipLaunchKernelGGL((gemm_tile_kernel<POL, 0, NSV, true>), grid, dim3(256), NSV * 2 * 128 * TC_ROWB, stream,          \
+                       (const char*)A, (const char*)nullptr, 0, (const char*)B, M, N, K, (long)lda * es, (long)ldb * es, 0, e)
+    if (dtype == TC_DTYPE_BF16) {
+        if (deep) TC_LAUNCH_TN(MmaBF16, 4); else TC_LAUNCH_TN(MmaBF16, 2);
+    } else {
+        if (deep) TC_LAUNCH_TN(MmaF32, 4); else TC_LAUNCH_TN(MmaF32, 2);
+    }
+#undef TC_LAUNCH_TN
+    TC_CHECK_LAUNCH();
+    return TC_OK;
 }
 
 extern "C" int tcdiff_gemm_rowln(int dtype, const void* A, const void* W, int M, int K, int lda, int ldw, int a_mod,

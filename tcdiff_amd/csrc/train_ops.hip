@@ -45,14 +45,12 @@ DEVINL void load4(const S* p, float (&v)[4]) {      // 4 consecutive source elem
 }
 
 template <class P, class S>
-__global__ __launch_bounds__(256) void cast_transpose_kernel(const S* __restrict__ src, int rows, int cols, int ld_src,
-                                                             typename P::elem_t* __restrict__ dst, int ld_dst, int cols_pad,
-                                                             typename P::elem_t* __restrict__ dstT, int ld_dstT,
-                                                             int rows_pad, float* __restrict__ colsum, int vec_src,
-                                                             int vec_dst, int vec_dstT) {
-    __shared__ float tile[64][65];
+DEVINL void cast_transpose_tile(float (&tile)[64][65], int bx, int by, const S* __restrict__ src, int rows, int cols, int ld_src,
+                                typename P::elem_t* __restrict__ dst, int ld_dst, int cols_pad,
+                                typename P::elem_t* __restrict__ dstT, int ld_dstT, int rows_pad, float* __restrict__ colsum,
+                                int vec_src, int vec_dst, int vec_dstT) {
     const int tid = threadIdx.x;
-    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int r0 = by * 64, c0 = bx * 64;
     const int lr = tid >> 4, lc = (tid & 15) * 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -99,6 +97,37 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const S* __restrict
     }
 }
 
+template <class P, class S>
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const S* __restrict__ src, int rows, int cols, int ld_src,
+                                                             typename P::elem_t* __restrict__ dst, int ld_dst, int cols_pad,
+                                                             typename P::elem_t* __restrict__ dstT, int ld_dstT,
+                                                             int rows_pad, float* __restrict__ colsum, int vec_src,
+                                                             int vec_dst, int vec_dstT) {
+    __shared__ float tile[64][65];
+    cast_transpose_tile<P, S>(tile, blockIdx.x, blockIdx.y, src, rows, cols, ld_src, dst, ld_dst, cols_pad, dstT, ld_dstT,
+                              rows_pad, colsum, vec_src, vec_dst, vec_dstT);
+}
+
+// The same over a TABLE of matrices in one launch (the weight packs of every nn.Linear after an optimizer step: ~125
+// matrices, most of them 512 x 512 -- as separate launches 0.7 ms of 5-us kernels): block -> descriptor by bisection over
+// the descriptors' first-tile indices (wave-uniform), then the tile of that matrix.
+template <class P>
+__global__ __launch_bounds__(256) void cast_transpose_multi_kernel(const tcdiff_ct_desc* __restrict__ descs, int n_desc) {
+    __shared__ float tile[64][65];
+    int lo = 0, hi = n_desc - 1;
+    const int b = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].tile0 <= b) lo = mid; else hi = mid - 1;
+    }
+    const tcdiff_ct_desc d = descs[lo];
+    const int t = b - d.tile0;
+    cast_transpose_tile<P, float>(tile, t % d.tiles_x, t / d.tiles_x, reinterpret_cast<const float*>(d.src), d.rows, d.cols,
+                                  d.ld_src, reinterpret_cast<typename P::elem_t*>(d.dst), d.ld_dst, d.cols_pad,
+                                  reinterpret_cast<typename P::elem_t*>(d.dstT), d.ld_dstT, d.rows_pad, nullptr, d.vec & 1,
+                                  (d.vec >> 1) & 1, (d.vec >> 2) & 1);
+}
+
 static bool al(const void* p, int a) { return (reinterpret_cast<uintptr_t>(p) & (uintptr_t)(a - 1)) == 0; }
 
 extern "C" int tcdiff_cast_transpose(int dtype, int src_f32, const void* src, int rows, int cols, int ld_src, void* dst,
@@ -124,6 +153,34 @@ extern "C" int tcdiff_cast_transpose(int dtype, int src_f32, const void* src, in
 #undef TC_CT
     TC_CHECK_LAUNCH();
     return TC_OK;
+}
+
+extern "C" int tcdiff_cast_transpose_multi(int dtype, const tcdiff_ct_desc* descs_dev, int n_desc, int n_tiles,
+                                           hipStream_t stream) {
+    if (!descs_dev || n_desc <= 0 || n_tiles <= 0) return TC_ERR_ARG;
+    if (dtype == TC_DTYPE_BF16)
+        hipLaunchKernelGGL(cast_transpose_multi_kernel<MmaBF16>, dim3(n_tiles), dim3(256), 0, stream, descs_dev, n_desc);
+    else if (dtype == TC_DTYPE_F32)
+        hipLaunchKernelGGL(cast_transpose_multi_kernel<MmaF32>, dim3(n_tiles), dim3(256), 0, stream, descs_dev, n_desc);
+    else return TC_ERR_ARG;
+    TC_CHECK_LAUNCH();
+    return TC_OK;
+}
+
+// fills the host-side fields a descriptor derives from the others (tiles_x, n_tiles -> return value, vec); tile0 is the
+// caller's running sum.  Returns the number of 64 x 64 tiles of this matrix, or a negative error code.
+extern "C" int tcdiff_ct_desc_init(int dtype, tcdiff_ct_desc* d) {
+    if (!d || !d->src || d->rows <= 0 || d->cols <= 0 || d->ld_src < d->cols || (!d->dst && !d->dstT)) return TC_ERR_ARG;
+    if (dtype != TC_DTYPE_BF16 && dtype != TC_DTYPE_F32) return TC_ERR_ARG;
+    if (d->dst && (d->cols_pad < d->cols || d->ld_dst < d->cols_pad)) return TC_ERR_ARG;
+    if (d->dstT && (d->rows_pad < d->rows || d->ld_dstT < d->rows_pad)) return TC_ERR_ARG;
+    const int es = dtype == TC_DTYPE_BF16 ? 2 : 4;
+    const int span_c = d->dst ? d->cols_pad : d->cols, span_r = d->dstT ? d->rows_pad : d->rows;
+    d->tiles_x = (span_c + 63) / 64;
+    const int vs = al(d->src, 16) && d->ld_src % 4 == 0, vd = d->dst && al(d->dst, 4 * es) && d->ld_dst % 4 == 0;
+    const int vt = d->dstT && al(d->dstT, 4 * es) && d->ld_dstT % 4 == 0;
+    d->vec = vs | (vd << 1) | (vt << 2);
+    return d->tiles_x * ((span_r + 63) / 64);
 }
 
 // =====================================================================================================================
@@ -356,10 +413,14 @@ __global__ __launch_bounds__(256) void row_fwd_kernel(tcdiff_row_args a) {
     }
 }
 
-// grid = (chunks, M / L): a block works inside ONE sequence, so its FiLM gradient goes to one row of d_film
+// grid = (chunks, M / L): a block works inside ONE sequence, so its FiLM gradient goes to one row of d_film.  Eight waves
+// per block and up to 16 blocks per sequence: a wave walks its rows serially (each row is a chain of loads and two wave
+// reductions), so the launch needs waves, not work per wave -- with 4 waves x 8 blocks per sequence (one wave per SIMD at
+// 32 sequences) it ran at a quarter of the HBM rate.
+constexpr int ROWB_WAVES = 8;
 template <class P>
-__global__ __launch_bounds__(256) void row_bwd_kernel(tcdiff_row_args a) {
-    __shared__ float red[4][5][512];
+__global__ __launch_bounds__(64 * ROWB_WAVES) void row_bwd_kernel(tcdiff_row_args a) {
+    __shared__ float red[ROWB_WAVES / 2][7][512];       // 56 KB: the upper four waves deposit, the lower four add theirs
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c0 = 4 * lane, c1 = 256 + 4 * lane, f = a.flags;
     const int seq = blockIdx.y;
@@ -380,7 +441,7 @@ __global__ __launch_bounds__(256) void row_bwd_kernel(tcdiff_row_args a) {
         fs.a += 1.0f;
         fs.b += 1.0f;
     }
-    for (int m = lo + wave; m < hi; m += 4) {
+    for (int m = lo + wave; m < hi; m += ROWB_WAVES) {
         const RowFwd o = row_forward(a, m, c0, c1, dpre, dpost);
         // ---- gradient reaching xn -----------------------------------------------------------------------------------
         Row8 gh = zero;                                    // d / d hn (the next LayerNorm's output, or xn itself without it)
@@ -437,30 +498,43 @@ __global__ __launch_bounds__(256) void row_bwd_kernel(tcdiff_row_args a) {
             else st_row_T<P>(a.d_z, m, c0, c1, gu);
         }
     }
-    // ---- FiLM gradients of this sequence: a few adders per address -----------------------------------------------------
-    if ((f & TC_ROWF_FILM) && a.d_film) {
-        float* dp = a.d_film + (long)seq * a.dfilm_ld;
+    // ---- block sums through LDS: [bias, ln_g, ln_b, nln_g, nln_b] -> one partial row per block (folded by row_param_reduce);
+    // [FiLM scale, FiLM shift] -> atomics on this sequence's d_film row, issued as consecutive floats per wave instruction
+    // (256-byte segments, the full-rate shape; a lane-strided scatter per wave was 8 M slow atomics per launch)
+    const bool film = (f & TC_ROWF_FILM) && a.d_film;
+    if (!a.partials && !film) return;
+    const Row8* accs[7] = {&acc_bias, &acc_g, &acc_b, &acc_g2, &acc_b2, &acc_s, &acc_sh};
+    constexpr int HW = ROWB_WAVES / 2;
+    if (wave >= HW) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            unsafeAtomicAdd(dp + c0 + t, acc_s.a[t]);
-            unsafeAtomicAdd(dp + c1 + t, acc_s.b[t]);
-            unsafeAtomicAdd(dp + 512 + c0 + t, acc_sh.a[t]);
-            unsafeAtomicAdd(dp + 512 + c1 + t, acc_sh.b[t]);
+        for (int k = 0; k < 7; ++k) {
+            *reinterpret_cast<f32x4_t*>(&red[wave - HW][k][c0]) = accs[k]->a;
+            *reinterpret_cast<f32x4_t*>(&red[wave - HW][k][c1]) = accs[k]->b;
         }
     }
-    // ---- parameter gradients: sum the four waves, one partial row per block (folded by row_param_reduce) ---------------
-    if (!a.partials) return;
-    const Row8* accs[5] = {&acc_bias, &acc_g, &acc_b, &acc_g2, &acc_b2};
+    __syncthreads();
+    if (wave < HW) {
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        *reinterpret_cast<f32x4_t*>(&red[wave][k][c0]) = accs[k]->a;
-        *reinterpret_cast<f32x4_t*>(&red[wave][k][c1]) = accs[k]->b;
+        for (int k = 0; k < 7; ++k) {
+            *reinterpret_cast<f32x4_t*>(&red[wave][k][c0]) += accs[k]->a;
+            *reinterpret_cast<f32x4_t*>(&red[wave][k][c1]) += accs[k]->b;
+        }
     }
     __syncthreads();
-    float* out = a.partials + ((long)blockIdx.y * gridDim.x + blockIdx.x) * (5 * 512);
     const float* rf = &red[0][0][0];
-    for (int i = threadIdx.x; i < 5 * 512; i += 256)
-        out[i] = (rf[i] + rf[5 * 512 + i]) + (rf[2 * 5 * 512 + i] + rf[3 * 5 * 512 + i]);
+    constexpr int WS = 7 * 512;
+    if (a.partials) {
+        float* out = a.partials + ((long)blockIdx.y * gridDim.x + blockIdx.x) * (5 * 512);
+        for (int i = threadIdx.x; i < 5 * 512; i += 64 * ROWB_WAVES)
+            out[i] = (rf[i] + rf[WS + i]) + (rf[2 * WS + i] + rf[3 * WS + i]);
+    }
+    if (film) {
+        float* dp = a.d_film + (long)seq * a.dfilm_ld;
+        for (int i = threadIdx.x; i < 2 * 512; i += 64 * ROWB_WAVES) {
+            const int j = 5 * 512 + i;
+            unsafeAtomicAdd(dp + i, (rf[j] + rf[WS + j]) + (rf[2 * WS + j] + rf[3 * WS + j]));
+        }
+    }
 }
 
 static int check_row_args(const tcdiff_row_args* a, bool bwd) {
@@ -505,8 +579,8 @@ extern "C" int tcdiff_row_bwd(int dtype, const tcdiff_row_args* a, hipStream_t s
     const int rc = check_row_args(a, true);
     if (rc != TC_OK) return rc;
     dim3 grid(a->chunks, a->M / a->L);
-    if (dtype == TC_DTYPE_BF16) hipLaunchKernelGGL(row_bwd_kernel<MmaBF16>, grid, dim3(256), 0, stream, *a);
-    else hipLaunchKernelGGL(row_bwd_kernel<MmaF32>, grid, dim3(256), 0, stream, *a);
+    if (dtype == TC_DTYPE_BF16) hipLaunchKernelGGL(row_bwd_kernel<MmaBF16>, grid, dim3(64 * ROWB_WAVES), 0, stream, *a);
+    else hipLaunchKernelGGL(row_bwd_kernel<MmaF32>, grid, dim3(64 * ROWB_WAVES), 0, stream, *a);
     TC_CHECK_LAUNCH();
     return TC_OK;
 }

@@ -248,6 +248,43 @@ def gemm_splitk(dt, A, W, M, N, K, lda, ldw, out, ldc, splits):
             "tcdiff_gemm_splitk")
 
 
+def gemm_tn_ok(dt, M, N, K) -> bool:
+    """shapes tcdiff_gemm_tn takes (everything else is repacked by cast_transpose and goes through gemm_splitk)"""
+    return M % 128 == 0 and N % 128 == 0 and K % k_tile(dt) == 0
+
+
+def gemm_tn(dt, A, B, M, N, K, lda, ldb, out, ldc, splits):
+    """out[m][n] += sum_k A[k][m] B[k][n] (both operands row-major over the contraction index)."""
+    L.check(L.load().tcdiff_gemm_tn(dt, _p(A), _p(B), M, N, K, lda, ldb, _p(out), ldc, splits, stream()), "tcdiff_gemm_tn")
+
+
+def ct_table(dt, entries, device):
+    """Device table for cast_transpose_multi.  entries: dicts with src (fp32 tensor view), rows, cols, ld_src and dst /
+    ld_dst / cols_pad and / or dstT / ld_dstT / rows_pad.  Returns (table tensor, n_desc, n_tiles); the table holds raw
+    pointers, so the caller keeps the tensors alive and rebuilds it when one of them is reallocated."""
+    lib = L.load()
+    n, tile0 = len(entries), 0
+    arr = (L.CtDesc * n)()
+    for d, e in zip(arr, entries):
+        if e["src"].dtype != torch.float32:
+            raise L.TcdiffError("cast_transpose_multi takes fp32 sources")
+        d.src, d.dst, d.dstT = _p(e["src"]), _p(e.get("dst")), _p(e.get("dstT"))
+        d.rows, d.cols, d.ld_src = e["rows"], e["cols"], e["ld_src"]
+        d.ld_dst, d.cols_pad, d.ld_dstT, d.rows_pad = e.get("ld_dst", 0), e.get("cols_pad", 0), e.get("ld_dstT", 0), \
+            e.get("rows_pad", 0)
+        d.tile0 = tile0
+        cnt = lib.tcdiff_ct_desc_init(dt, C.byref(d))
+        L.check(min(cnt, 0), "tcdiff_ct_desc_init")
+        tile0 += cnt
+    raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone()
+    return raw.to(device), n, tile0
+
+
+def cast_transpose_multi(dt, table):
+    tab, n, tiles = table
+    L.check(L.load().tcdiff_cast_transpose_multi(dt, _p(tab), n, tiles, stream()), "tcdiff_cast_transpose_multi")
+
+
 def act_drop(dt, a, ld_a, y, ld_y, rows, cols, act, seed=None, site=0, thr=0, scale=1.0):
     a_f32 = int(a.dtype == torch.float32)
     L.check(L.load().tcdiff_act_drop(dt, a_f32, _p(a), ld_a, _p(y), ld_y, rows, cols, act, _p(seed), site, thr, scale,

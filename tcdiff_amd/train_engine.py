@@ -55,9 +55,10 @@ class _Lin:
         # stacked biases need one contiguous copy; a lone bias is the parameter itself
         self.bias = torch.zeros(self.N, device=eng.dev, dtype=torch.float32) if len(self.bnames) > 1 else None
 
-    def pack(self):
-        """(Re)build the operand packs from the fp32 master parameters: W as [N, Kp] and, per operand group, W^T."""
-        eng, r0 = self.eng, 0
+    def pack_entries(self):
+        """Descriptors of tcdiff_cast_transpose_multi that (re)build this linear's operand packs from the fp32 master
+        parameters: W as [N, Kp] and, per operand group, W^T."""
+        eng, r0, out = self.eng, 0, []
         for name, rows in zip(self.wnames, self.rows):
             w = eng.params[name].detach()
             # a parameter that spans the operand split (nn.MultiheadAttention's packed in_proj_weight) is packed in two pieces
@@ -66,15 +67,15 @@ class _Lin:
                 gi = 1 if (self.split and r0 + a >= self.split) else 0
                 lo = self.groups[gi][0]
                 wt = self.WbT[gi]
-                K.cast_transpose(eng.dt, w[a:b], b - a, self.K, self.K, dst=self.Wf[r0 + a:], ld_dst=self.Kp, cols_pad=self.Kp,
-                                 dstT=wt.view(-1)[r0 + a - lo:], ld_dstT=wt.shape[1], rows_pad=b - a)
+                out.append(dict(src=w[a:b], rows=b - a, cols=self.K, ld_src=self.K, dst=self.Wf[r0 + a:], ld_dst=self.Kp,
+                                cols_pad=self.Kp, dstT=wt.view(-1)[r0 + a - lo:], ld_dstT=wt.shape[1], rows_pad=b - a))
             r0 += rows
+        return out
+
+    def pack_bias(self):
+        eng = self.eng
         if len(self.bnames) > 1:
-            o = 0
-            for name in self.bnames:
-                b = eng.params[name].detach()
-                self.bias[o:o + b.numel()].copy_(b)
-                o += b.numel()
+            torch.cat([eng.params[n].detach().reshape(-1) for n in self.bnames], out=self.bias)
         elif self.bnames:
             self.bias = eng.params[self.bnames[0]].detach()
 
@@ -105,13 +106,21 @@ class _Lin:
         Np = K.round_up(N, kt)
         gW = eng.gW[self.key]
         gb = eng.gB.get(self.key)
-        dYt = eng.e(N, Mp)
         direct = dY.dtype == eng.T and ld_dy == Np and N == Np     # dY itself is a valid K-contiguous operand
-        if direct:
+        # weight gradient straight from the token-major dY and X (tcdiff_gemm_tn) where the shapes allow; otherwise dY^T / X^T
+        # are repacked by cast_transpose for tcdiff_gemm_splitk
+        tn = direct and M == Mp and all(K.gemm_tn_ok(dt, hi - lo, self.K, M) and Xs[gi].dtype == eng.T
+                                        for gi, (lo, hi) in enumerate(self.groups))
+        dYt = None
+        if tn:
             dYT = dY
+            if gb is not None:
+                K.cast_transpose(dt, dY, M, N, ld_dy, colsum=gb)
+        elif direct:
+            dYT, dYt = dY, eng.e(N, Mp)
             K.cast_transpose(dt, dY, M, N, ld_dy, dstT=dYt, ld_dstT=Mp, rows_pad=Mp, colsum=gb)
         else:
-            dYT = eng.e(M, Np)
+            dYT, dYt = eng.e(M, Np), eng.e(N, Mp)
             K.cast_transpose(dt, dY, M, N, ld_dy, dst=dYT, ld_dst=Np, cols_pad=Np, dstT=dYt, ld_dstT=Mp, rows_pad=Mp,
                              colsum=gb)
         outs = []
@@ -127,11 +136,14 @@ class _Lin:
                     K.gemm_tile(dt, A, self.WbT[gi], M, self.K, ngp, lda=Np,
                                 mode=L.EPI_STORE_F32 if w[0] == "F32" else L.EPI_STORE_T, out=w[1], ldc=w[2])
             X = Xs[gi]
-            Xt = eng.e(self.K, Mp)
-            K.cast_transpose(dt, X, M, self.K, X.shape[1], dstT=Xt, ld_dstT=Mp, rows_pad=Mp)
             tiles = ((ng + 127) // 128) * ((self.K + 127) // 128)
             # one workgroup per CU: measured (tools/gemm_shapes.py, 14 400 rows) 512x512: 16 splits 29 us, 32 splits 40 us, 1: 149 us
             splits = max(1, min(256 // tiles, Mp // kt, 64))
+            if tn:
+                K.gemm_tn(dt, dY.view(-1)[lo:], X, ng, self.K, M, ld_dy, X.shape[1], gW[lo * self.K:], self.K, splits)
+                continue
+            Xt = eng.e(self.K, Mp)
+            K.cast_transpose(dt, X, M, self.K, X.shape[1], dstT=Xt, ld_dstT=Mp, rows_pad=Mp)
             K.gemm_splitk(dt, dYt[lo:], Xt, ng, self.K, Mp, Mp, Mp, gW[lo * self.K:], self.K, splits)
         return outs
 
@@ -163,6 +175,7 @@ class TrainEngine:
         self.p_drop = float(getattr(model, "dropout_p", 0.1))
         self.seed = torch.zeros(2, device=self.dev, dtype=torch.int32)
         self.packed_version = None
+        self._ct = self._ct_ptrs = self._ct_keep = None
         self.sv = None
         self._pz = {}
         self._define()
@@ -269,11 +282,19 @@ class TrainEngine:
         return out
 
     def repack(self):
+        """W / W^T operand packs of every linear from the fp32 masters, when a parameter changed (once per optimizer step):
+        ONE tcdiff_cast_transpose_multi launch over a device table of all ~125 matrices (as separate launches 0.7 ms)."""
         ver = tuple(p._version for p in self.params.values())
-        if ver != self.packed_version:
-            for lk in self.lins.values():
-                lk.pack()
-            self.packed_version = ver
+        if ver == self.packed_version:
+            return
+        ptrs = tuple(p.data_ptr() for p in self.params.values())
+        if self._ct is None or self._ct_ptrs != ptrs:              # parameters (re)allocated: the table holds raw pointers
+            ents = [d for lk in self.lins.values() for d in lk.pack_entries()]
+            self._ct, self._ct_ptrs, self._ct_keep = K.ct_table(self.dt, ents, self.dev), ptrs, ents
+        K.cast_transpose_multi(self.dt, self._ct)
+        for lk in self.lins.values():
+            lk.pack_bias()
+        self.packed_version = ver
 
     def P(self, name):           # fp32 master parameter (LayerNorm weights, null embeddings)
         return self.params[name].detach()
@@ -313,7 +334,7 @@ class TrainEngine:
     def row_bwd(self, *, M, L_, ln=None, nln=None, **kw):
         """runs tcdiff_row_bwd + the reduction of its LayerNorm partials into the flat gradient buffer.
         ln / nln: parameter-name prefixes of the post / next LayerNorm (their gradients)."""
-        chunks = max(1, min(8, L_ // 16))
+        chunks = max(1, min(16, L_ // 16))      # blocks per sequence (8 waves each): >= 4 waves per SIMD at 32 x 450 rows
         nblk = chunks * (M // L_)
         part = self.e(nblk, 5, 512, dtype=torch.float32)
         K.row_bwd(self.dt, self._row(M=M, L=L_, partials=part, chunks=chunks, **kw))

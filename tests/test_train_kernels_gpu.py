@@ -74,6 +74,51 @@ def test_gemm_splitk_accumulates_the_weight_gradient(compute):
 
 
 @pytest.mark.parametrize("compute", ["f32", "bf16"])
+def test_gemm_tn_weight_gradient_from_token_major_operands(compute):
+    """dW[n_out, n_in] += dY^T X with dY and X as the forward left them (token-major, leading dimensions wider than the
+    slices used: the fused Q|K|V gradient is read in place)."""
+    dt, T, tol = mode(compute)
+    n_out, n_in, rows, ld_dy, ldx = 256, 384, 1344, 640, 512          # 1344 = 21 k-tiles of 64 (42 of 32)
+    g = torch.Generator().manual_seed(12)
+    dY = torch.randn(rows, ld_dy, generator=g).to(T)
+    X = torch.randn(rows, ldx, generator=g).to(T)
+    init = torch.randn(n_out, n_in, generator=g)
+    c0 = 128                                                          # the slice dY[:, 128:384]
+    want = init.double() + dY[:, c0:c0 + n_out].double().t() @ X[:, :n_in].double()
+    out = init.clone().to(DEV)
+    for splits in (1, 2, 7, 64):
+        out.copy_(init)
+        K.gemm_tn(dt, dY.to(DEV).view(-1)[c0:], X.to(DEV), n_out, n_in, rows, ld_dy, ldx, out, n_in, splits)
+        assert rel(out, want) < (1e-6 if compute == "f32" else 1e-5), splits
+    assert K.gemm_tn_ok(dt, n_out, n_in, rows) and not K.gemm_tn_ok(dt, 200, n_in, rows) and not K.gemm_tn_ok(dt, n_out, n_in, 1000)
+    with pytest.raises(L.TcdiffError):                                 # unsupported shapes are refused, not rounded
+        K.gemm_tn(dt, dY.to(DEV), X.to(DEV), 200, n_in, rows, ld_dy, ldx, out, n_in, 1)
+
+
+@pytest.mark.parametrize("compute", ["f32", "bf16"])
+def test_cast_transpose_multi_equals_the_single_launches(compute):
+    dt, T, tol = mode(compute)
+    g = torch.Generator().manual_seed(13)
+    shapes = [(512, 512), (200, 151), (64, 1024), (1, 70), (1536, 512)]
+    srcs = [torch.randn(r, c, generator=g).to(DEV) for r, c in shapes]
+    kt = K.k_tile(dt)
+    ents, singles = [], []
+    for w, (r, c) in zip(srcs, shapes):
+        cp, rp = K.round_up(c, kt), K.round_up(r, kt)
+        d1, t1 = torch.full((r, cp), 7.0, device=DEV, dtype=T), torch.full((c, rp), 7.0, device=DEV, dtype=T)
+        d2, t2 = torch.full((r, cp), 9.0, device=DEV, dtype=T), torch.full((c, rp), 9.0, device=DEV, dtype=T)
+        ents.append(dict(src=w, rows=r, cols=c, ld_src=c, dst=d1, ld_dst=cp, cols_pad=cp, dstT=t1, ld_dstT=rp, rows_pad=rp))
+        K.cast_transpose(dt, w, r, c, c, dst=d2, ld_dst=cp, cols_pad=cp, dstT=t2, ld_dstT=rp, rows_pad=rp)
+        singles.append((d1, t1, d2, t2))
+    tab = K.ct_table(dt, ents, DEV)
+    K.cast_transpose_multi(dt, tab)
+    for (d1, t1, d2, t2), w, (r, c) in zip(singles, srcs, shapes):
+        assert torch.equal(d1, d2) and torch.equal(t1, t2)
+        assert torch.equal(d1[:, :c].float(), w.to(T).float()) and torch.equal(t1[:, :r].float(), w.t().to(T).float())
+        assert float(d1[:, c:].abs().max() if d1.shape[1] > c else 0) == 0.0
+
+
+@pytest.mark.parametrize("compute", ["f32", "bf16"])
 @pytest.mark.parametrize("act", [L.ACT_RELU, L.ACT_GELU, L.ACT_MISH, L.ACT_SILU])
 def test_act_drop_forward_and_backward(compute, act):
     dt, T, tol = mode(compute)
