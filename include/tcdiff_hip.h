@@ -450,8 +450,9 @@ int tcdiff_act_drop_bwd(int dtype, int a_f32, const void* a, int ld_a, const voi
  * = model/model.py:103-106 (fc dropout + layer_norm), :327,334,339 (dropout1..3 + featurewise_affine + residual),
  *   :326,332,338,344 (the next norm), :375,387-388 (rotary); encoder :220-221,240,245.
  * Backward (tcdiff_row_bwd) recomputes the forward from (z, xres) and returns d_z (T), d_xres (fp32), per-sequence FiLM
- * gradients (atomic += into d_film) and per-block partial sums of the LayerNorm / bias gradients in `partials`
- * ([grid blocks][5][512] fp32: d_bias, d_ln_g, d_ln_b, d_nln_g, d_nln_b), folded by tcdiff_row_param_reduce. */
+ * gradients (atomic += into d_film) and the LayerNorm / bias gradients -- either per-block partial sums in `partials`
+ * ([grid blocks][5][512] fp32: d_bias, d_ln_g, d_ln_b, d_nln_g, d_nln_b), folded by tcdiff_row_param_reduce in a fixed
+ * order, or atomic += into g_bias .. g_nln_b. */
 #define TC_ROWF_BIAS 1
 #define TC_ROWF_DROP_PRE 2
 #define TC_ROWF_LN_POST 4
@@ -483,6 +484,10 @@ typedef struct {
     float* d_film; int dfilm_ld;
     float* partials; int chunks;   /* grid = chunks x (M / L) blocks; partials [chunks * M / L][5][512] */
     int dz_f32;                /* != 0: d_z is fp32 (its consumer is not a GEMM: pooled / memory rows of the conditioning path) */
+    /* or, instead of `partials` + tcdiff_row_param_reduce: each block adds its sums straight into the gradients (fp32
+     * [512] each, NULL = skip; 512 consecutive atomics per block and vector).  g_bias = column sums of d_z: the bias
+     * gradient of the nn.Linear that produced z. */
+    float* g_bias; float* g_ln_g; float* g_ln_b; float* g_nln_g; float* g_nln_b;
 } tcdiff_row_args;
 int tcdiff_row_fwd(int dtype, const tcdiff_row_args* a, hipStream_t stream);
 int tcdiff_row_bwd(int dtype, const tcdiff_row_args* a, hipStream_t stream);

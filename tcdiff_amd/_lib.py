@@ -60,7 +60,8 @@ class RowArgs(C.Structure):
                 ("nln_b", _vp), ("nln_eps", _f), ("hout", _vp), ("rout", _vp), ("rope", _vp), ("pos_mod", _i),
                 ("pos_base", _i), ("seed", _vp), ("drop_thr", C.c_uint32), ("drop_scale", _f), ("site_pre", _i),
                 ("site_post", _i), ("d_xn", _vp), ("d_h", _vp), ("d_rot", _vp), ("d_z", _vp), ("d_xres", _vp),
-                ("d_film", _vp), ("dfilm_ld", _i), ("partials", _vp), ("chunks", _i), ("dz_f32", _i)]
+                ("d_film", _vp), ("dfilm_ld", _i), ("partials", _vp), ("chunks", _i), ("dz_f32", _i),
+                ("g_bias", _vp), ("g_ln_g", _vp), ("g_ln_b", _vp), ("g_nln_g", _vp), ("g_nln_b", _vp)]
 
 
 class CtDesc(C.Structure):

@@ -20,9 +20,12 @@
 //       fragments read transposed from the staged tiles.
 // S and dP are evaluated in both (7 MFMA products instead of 5) in exchange for no atomics: every output element is
 // written once, by one wave, in a fixed summation order -- bitwise reproducible gradients.
-#include "attn_common.h"
-#include "train_common.h"
+#include "attn_res.h"        // attention_res_kernel<NG, TRAIN>: the K/V-resident forward
 #include "tcdiff_hip.h"
+
+#ifndef TC_DKV_NG
+#define TC_DKV_NG 1      // 32-key groups per wave of the resident dK / dV kernel (2 would need ~280 VGPRs: spills)
+#endif
 
 // the B operand of the second product from an accumulator tile: k-step `st` of a 32-row tile (see attention.hip)
 template <class P>
@@ -432,6 +435,281 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const char* __restric
 }
 
 // =====================================================================================================================
+// backward, operand-resident variants (bf16, L <= 512): the structure of attn_res.h.  The streaming kernels above pay one
+// barrier and one global -> register -> LDS hop per 64-row tile with 32 rows of independent work per wave (latency-bound:
+// ~10 % of the MFMA rate at 450 x 450); here the two streamed operands of a (sequence, head) are loaded ONCE by LDS-DMA
+// (2 x <= 64 KB), a wave owns NG groups of 32 rows that share every fragment read, and the loop has no barrier.
+//   dq:  K, V resident; a wave owns 32 NG queries (Q', dO fragments, lse, delta in registers)
+//   dkv: Q', dO resident (+ lse, delta rows); a wave owns 32 NG keys (K, V fragments in registers)
+// =====================================================================================================================
+DEVINL void res_stage_images(char* A_s, char* B_s, const char* Ag, const char* Bg, int nt, int wave, int lane) {
+    for (int blk = wave; blk < nt * 8; blk += 8) {      // blk = 8 consecutive rows
+        const int row = blk * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ tile_swz(row);
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(Ag + (long)row * 128 + chunk * 16), (lds_void_t*)(A_s + blk * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(Bg + (long)row * 128 + chunk * 16), (lds_void_t*)(B_s + blk * 1024), 16, 0, 0);
+    }
+}
+
+// 32 output rows x 64 features of one group through 4 KB of wave-private LDS -> 16-byte pieces of full 128-byte rows
+// (attn_res.h's output path): acc[dt] holds features dt*32 + 8 g + 4 h + {0..3} of row r
+DEVINL void res_store_rows(char* stg, const f32x16_t (&acc)[2], float scale, uint16_t* dst, long row0_elem, int ld, int rows_ok,
+                           int lane) {
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            uint2 pk;
+            pk.x = pack_bf2(acc[dt][4 * q4 + 0] * scale, acc[dt][4 * q4 + 1] * scale);
+            pk.y = pack_bf2(acc[dt][4 * q4 + 2] * scale, acc[dt][4 * q4 + 3] * scale);
+            *reinterpret_cast<uint2*>(stg + r * 128 + (((4 * dt + q4) ^ ((r >> 1) & 7)) << 4) + 8 * h) = pk;
+        }
+    const int srow0 = lane >> 3, sch = lane & 7;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int row = srow0 + 8 * k;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(stg + row * 128 + ((sch ^ ((row >> 1) & 7)) << 4));
+        if (row < rows_ok) *reinterpret_cast<u32x4*>(dst + row0_elem + (long)row * ld + sch * 8) = v;
+    }
+}
+
+template <int NG>
+__global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(const char* __restrict__ Q, const char* __restrict__ K,
+                                                              const char* __restrict__ V, const char* __restrict__ dO,
+                                                              const float* __restrict__ lse, const float* __restrict__ delta,
+                                                              uint16_t* __restrict__ dQ, int ld_dq, int H, int Lq, int Lk,
+                                                              int Lp_q, int Lp_k, float scale_q, const int* __restrict__ seed,
+                                                              int site, uint32_t thr, float dscale) {
+    typedef MmaBF16 P;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int nqb = (Lq + 256 * NG - 1) / (256 * NG);
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int qb = wg % nqb, head = (wg / nqb) % H, seq = wg / (nqb * H);
+    const int bh = seq * H + head;
+    const int nt = (Lk + 63) / 64;                       // <= 8 (the launcher checks Lk <= 512)
+    char* Ks = smem;
+    char* Vs = smem + nt * 8192;
+    res_stage_images(Ks, Vs, K + (long)bh * Lp_k * 128, V + (long)bh * Lp_k * 128, nt, wave, lane);
+    const int qbase = qb * 256 * NG + wave * 32 * NG;
+    u32x4 qf[NG][4], df[NG][4];
+    float my_lse[NG], my_delta[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int qg = qbase + g * 32 + r;
+        const int qrow = qg < Lp_q ? qg : Lp_q - 1;
+        const char* Qg = Q + ((long)bh * Lp_q + qrow) * 128;
+        const char* Dg = dO + ((long)bh * Lp_q + qrow) * 128;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            qf[g][ks] = *reinterpret_cast<const u32x4*>(Qg + (2 * ks + h) * 16);
+            df[g][ks] = *reinterpret_cast<const u32x4*>(Dg + (2 * ks + h) * 16);
+        }
+        my_lse[g] = qg < Lq ? lse[(long)bh * Lp_q + qg] : 0.0f;
+        my_delta[g] = qg < Lq ? delta[(long)bh * Lp_q + qg] : 0.0f;
+    }
+    const DropCtx dc = drop_ctx(seed, site, thr, dscale);
+    f32x16_t dq[NG][2];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) dq[g][dt][q] = 0.0f;
+    sync_dma();
+    const int ngrp = qbase >= Lq ? 0 : (NG > 1 && qbase + 32 < Lq ? NG : 1);      // wave-uniform: active row groups
+    if (ngrp > 0) {
+        constexpr float LOG2E = 1.4426950408889634f;
+        const int nkt = (Lk + 31) / 32;
+#pragma unroll 1
+        for (int kt = 0; kt < nkt; ++kt) {
+            const char* kt_base = Ks + (kt >> 1) * 8192;
+            const char* vt_base = Vs + (kt >> 1) * 8192;
+            const int k32 = kt & 1, kv0 = kt * 32;
+            f32x16_t s[NG], dp[NG];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const u32x4 kf = *reinterpret_cast<const u32x4*>(kt_base + tile_off(k32 * 32 + r, 2 * ks + h));
+                const u32x4 vf = *reinterpret_cast<const u32x4*>(vt_base + tile_off(k32 * 32 + r, 2 * ks + h));
+                if (ks == 0) {
+                    const f32x16_t z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) { s[g] = z; dp[g] = z; }
+                }
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    P::mma(s[g], kf, qf[g][ks]);         // S^T   = K Q'^T
+                    P::mma(dp[g], vf, df[g][ks]);        // dPd^T = V dO^T
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const uint32_t xrow = ((uint32_t)bh * (uint32_t)Lq + (uint32_t)(qbase + g * 32 + r)) * (uint32_t)Lk;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int key = kv0 + acc_row(q, h);
+                    const float p = key < Lk ? __builtin_amdgcn_exp2f(fmaf(s[g][q], LOG2E, -my_lse[g])) : 0.0f;
+                    float gd = dp[g][q];
+                    if (thr) gd = drop_apply(dc, xrow + (uint32_t)key, gd);
+                    s[g][q] = p * (gd - my_delta[g]);    // dS^T
+                }
+            }
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                u32x4 pf[NG];
+#pragma unroll
+                for (int g = 0; g < NG; ++g) pf[g] = pack_frag<P>(s[g], st);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const u32x4 ktf = v_frag<P>(kt_base, dt, k32, st, lane);
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) P::mma(dq[g][dt], ktf, pf[g]);      // dQ'^T += K^T dS^T
+                }
+            }
+        }
+    }
+    char* stg = smem + 2 * nt * 8192 + wave * 4096;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        if (g >= ngrp) continue;
+        const int q0 = qbase + g * 32;
+        res_store_rows(stg, dq[g], scale_q, dQ, ((long)seq * Lq + q0) * ld_dq + head * 64, ld_dq, Lq - q0, lane);
+    }
+}
+
+template <int NG>
+__global__ __launch_bounds__(512) void attn_bwd_dkv_res_kernel(const char* __restrict__ Q, const char* __restrict__ K,
+                                                               const char* __restrict__ V, const char* __restrict__ dO,
+                                                               const float* __restrict__ lse, const float* __restrict__ delta,
+                                                               uint16_t* __restrict__ dK, uint16_t* __restrict__ dV, int ld_dkv,
+                                                               int H, int Lq, int Lk, int Lp_q, int Lp_k,
+                                                               const int* __restrict__ seed, int site, uint32_t thr,
+                                                               float dscale) {
+    typedef MmaBF16 P;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int nkb = (Lk + 256 * NG - 1) / (256 * NG);
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int kb = wg % nkb, head = (wg / nkb) % H, seq = wg / (nkb * H);
+    const int bh = seq * H + head;
+    const int nt = (Lq + 63) / 64;                       // query tiles, <= 8
+    char* Qs = smem;
+    char* Ds = smem + nt * 8192;
+    float* lse_s = reinterpret_cast<float*>(smem + 2 * nt * 8192);      // [nt * 64] each: lse, then delta
+    float* del_s = lse_s + nt * 64;
+    res_stage_images(Qs, Ds, Q + (long)bh * Lp_q * 128, dO + (long)bh * Lp_q * 128, nt, wave, lane);
+    for (int i = tid; i < nt * 64; i += 512) {
+        const bool ok = i < Lq;                          // rows beyond Lq: p is forced to 0 below, any finite value does
+        lse_s[i] = ok ? lse[(long)bh * Lp_q + i] : 0.0f;
+        del_s[i] = ok ? delta[(long)bh * Lp_q + i] : 0.0f;
+    }
+    const int kbase = kb * 256 * NG + wave * 32 * NG;
+    u32x4 kf[NG][4], vf[NG][4];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int key = kbase + g * 32 + r;
+        const int krow = key < Lp_k ? key : Lp_k - 1;
+        const char* Kg = K + ((long)bh * Lp_k + krow) * 128;
+        const char* Vg = V + ((long)bh * Lp_k + krow) * 128;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            kf[g][ks] = *reinterpret_cast<const u32x4*>(Kg + (2 * ks + h) * 16);
+            vf[g][ks] = *reinterpret_cast<const u32x4*>(Vg + (2 * ks + h) * 16);
+        }
+    }
+    const DropCtx dc = drop_ctx(seed, site, thr, dscale);
+    f32x16_t dk[NG][2], dv[NG][2];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { dk[g][dt][q] = 0.0f; dv[g][dt][q] = 0.0f; }
+    sync_dma();
+    const int ngrp = kbase >= Lk ? 0 : (NG > 1 && kbase + 32 < Lk ? NG : 1);
+    if (ngrp > 0) {
+        constexpr float LOG2E = 1.4426950408889634f;
+        const int nqt = (Lq + 31) / 32;
+#pragma unroll 1
+        for (int qt = 0; qt < nqt; ++qt) {
+            const char* qt_base = Qs + (qt >> 1) * 8192;
+            const char* dt_base = Ds + (qt >> 1) * 8192;
+            const int q32 = qt & 1, q0 = qt * 32;
+            f32x16_t s[NG], dp[NG];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const u32x4 qfr = *reinterpret_cast<const u32x4*>(qt_base + tile_off(q32 * 32 + r, 2 * ks + h));
+                const u32x4 dfr = *reinterpret_cast<const u32x4*>(dt_base + tile_off(q32 * 32 + r, 2 * ks + h));
+                if (ks == 0) {
+                    const f32x16_t z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) { s[g] = z; dp[g] = z; }
+                }
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    P::mma(s[g], qfr, kf[g][ks]);        // S   = Q' K^T  (query in registers, key on the lane)
+                    P::mma(dp[g], dfr, vf[g][ks]);       // dPd = dO V^T
+                }
+            }
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int qi0 = q0 + 8 * g4 + 4 * h;     // registers 4 g4 .. 4 g4 + 3 are consecutive queries
+                const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(lse_s + qi0);
+                const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(del_s + qi0);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const int key = kbase + g * 32 + r;
+                    const bool key_ok = key < Lk;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int q = 4 * g4 + t, qi = qi0 + t;
+                        const bool ok = key_ok && qi < Lq;
+                        const float p = ok ? __builtin_amdgcn_exp2f(fmaf(s[g][q], LOG2E, -l4[t])) : 0.0f;
+                        const bool keep = thr ? drop_keep(dc, ((uint32_t)bh * (uint32_t)Lq + (uint32_t)qi) * (uint32_t)Lk + (uint32_t)key) : true;
+                        const float pd = keep ? p * dscale : 0.0f;
+                        const float gd = keep ? dp[g][q] * dscale : 0.0f;
+                        s[g][q] = pd;                                    // Pd
+                        dp[g][q] = ok ? p * (gd - d4[t]) : 0.0f;         // dS
+                    }
+                }
+            }
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                u32x4 pf[NG], sf[NG];
+#pragma unroll
+                for (int g = 0; g < NG; ++g) { pf[g] = pack_frag<P>(s[g], st); sf[g] = pack_frag<P>(dp[g], st); }
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const u32x4 dOt = v_frag<P>(dt_base, dt, q32, st, lane);
+                    const u32x4 Qt = v_frag<P>(qt_base, dt, q32, st, lane);
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        P::mma(dv[g][dt], dOt, pf[g]);   // dV^T += dO^T Pd
+                        P::mma(dk[g][dt], Qt, sf[g]);    // dK^T += Q'^T dS
+                    }
+                }
+            }
+        }
+    }
+    // the output staging areas take the place of the Q' image: every wave must be out of the loop first
+    __syncthreads();
+    char* stg = smem + wave * 4096;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        if (g >= ngrp) continue;
+        const int k0 = kbase + g * 32;
+        const long off = ((long)seq * Lk + k0) * ld_dkv + head * 64;
+        res_store_rows(stg, dk[g], 1.0f, dK, off, ld_dkv, Lk - k0, lane);
+        res_store_rows(stg, dv[g], 1.0f, dV, off, ld_dkv, Lk - k0, lane);
+    }
+}
+
+// =====================================================================================================================
 // C ABI
 // =====================================================================================================================
 static bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -443,6 +721,31 @@ extern "C" int tcdiff_attention_train(int dtype, const void* Q, const void* K, c
     if (dtype != TC_DTYPE_BF16 && dtype != TC_DTYPE_F32) return TC_ERR_ARG;
     if (Lp_q % 128 != 0 || Lp_k % 64 != 0 || Lp_q < Lq || Lp_k < Lk || ldo < H * 64 || ldo % 4 != 0) return TC_ERR_ARG;
     if (!a16(Q) || !a16(K) || !a16(V) || !a16(O)) return TC_ERR_ALIGN;
+    if (dtype == TC_DTYPE_BF16 && Lp_q >= 512 && ldo % 8 == 0) {
+        // the K/V-resident kernel of the sampler (attn_res.h) with dropout and lse: 450 x 450 at 32 sequences 61 -> 3x us
+        const int ntm = (Lk + 63) / 64 < ATT_RES_MAXT ? (Lk + 63) / 64 : ATT_RES_MAXT;
+        const int smem_bytes = 2 * ntm * 8192 + 8 * 4096;
+        static tc_dev_state dev_state;
+        const int n_cu = tc_device_once(dev_state, [](int) {
+            hipError_t a = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_res_kernel<1, true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_RES_MAXT * 8192 + 8 * 4096);
+            hipError_t b = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_res_kernel<2, true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_RES_MAXT * 8192 + 8 * 4096);
+            return a != hipSuccess ? a : b;
+        });
+        if (n_cu < 0) return n_cu;
+        const int ng = ((Lq + 255) / 256) * H * n_seq <= n_cu ? 1 : 2;
+        const int nqb = (Lq + 256 * ng - 1) / (256 * ng);
+        const AttnTrainArgs ta = {lse, seed, site, drop_thr, drop_scale};
+        if (ng == 1)
+            hipLaunchKernelGGL((attention_res_kernel<1, true>), dim3(nqb * H * n_seq), dim3(512), smem_bytes, stream,
+                               (const char*)Q, (const char*)K, (const char*)V, (char*)O, H, Lq, Lk, Lp_q, Lp_k, ldo, 0, ta);
+        else
+            hipLaunchKernelGGL((attention_res_kernel<2, true>), dim3(nqb * H * n_seq), dim3(512), smem_bytes, stream,
+                               (const char*)Q, (const char*)K, (const char*)V, (char*)O, H, Lq, Lk, Lp_q, Lp_k, ldo, 0, ta);
+        TC_CHECK_LAUNCH();
+        return TC_OK;
+    }
     dim3 grid((Lp_q / 128) * H * n_seq);
     if (dtype == TC_DTYPE_BF16)
         hipLaunchKernelGGL(attention_train_kernel<MmaBF16>, grid, dim3(256), 0, stream, (const char*)Q, (const char*)K,
@@ -483,7 +786,33 @@ extern "C" int tcdiff_attention_bwd(int dtype, const void* Q, const void* K, con
         return TC_ERR_ARG;
     if (!a16(Q) || !a16(K) || !a16(V) || !a16(dO) || !a16(dQ) || !a16(dK) || !a16(dV) || !a16(lse) || !a16(delta))
         return TC_ERR_ALIGN;
-    if (dtype == TC_DTYPE_BF16)
+    if (dtype == TC_DTYPE_BF16 && Lq >= 256 && Lq <= 512 && Lk <= 512 && ld_dq % 8 == 0 && ld_dkv % 8 == 0) {
+        // operand-resident kernels (the training shapes: 450 x 450 self-attention, 450 x 152 cross-attention)
+        constexpr int DQ_NG = 2, DKV_NG = TC_DKV_NG;
+        const int ntk = (Lk + 63) / 64, ntq = (Lq + 63) / 64;
+        const int smem_dq = 2 * ntk * 8192 + 8 * 4096;
+        const int dkv_need = 2 * ntq * 8192 + 2 * ntq * 64 * 4;
+        const int smem_dkv = dkv_need > 8 * 4096 ? dkv_need : 8 * 4096;
+        static tc_dev_state dev_state;
+        const int n_cu = tc_device_once(dev_state, [](int) {
+            hipError_t a = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_res_kernel<DQ_NG>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 8192 + 8 * 4096);
+            hipError_t b = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_res_kernel<DKV_NG>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 8192 + 2 * 8 * 64 * 4);
+            return a != hipSuccess ? a : b;
+        });
+        if (n_cu < 0) return n_cu;
+        const long nd = (long)n_seq * H * Lq;
+        hipLaunchKernelGGL(attn_delta_kernel<MmaBF16>, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, stream,
+                           (const uint16_t*)dO, (const uint16_t*)O, delta, n_seq * H, H, Lq, Lp_q, ldo);
+        const int nqb = (Lq + 256 * DQ_NG - 1) / (256 * DQ_NG), nkb = (Lk + 256 * DKV_NG - 1) / (256 * DKV_NG);
+        hipLaunchKernelGGL(attn_bwd_dq_res_kernel<DQ_NG>, dim3(nqb * H * n_seq), dim3(512), smem_dq, stream, (const char*)Q,
+                           (const char*)K, (const char*)V, (const char*)dO, lse, delta, (uint16_t*)dQ, ld_dq, H, Lq, Lk, Lp_q,
+                           Lp_k, scale_q, seed, site, drop_thr, drop_scale);
+        hipLaunchKernelGGL(attn_bwd_dkv_res_kernel<DKV_NG>, dim3(nkb * H * n_seq), dim3(512), smem_dkv, stream, (const char*)Q,
+                           (const char*)K, (const char*)V, (const char*)dO, lse, delta, (uint16_t*)dK, (uint16_t*)dV, ld_dkv, H,
+                           Lq, Lk, Lp_q, Lp_k, seed, site, drop_thr, drop_scale);
+    } else if (dtype == TC_DTYPE_BF16)
         launch_attn_bwd<MmaBF16>(Q, K, V, O, dO, lse, delta, dQ, ld_dq, dK, dV, ld_dkv, n_seq, H, Lq, Lk, Lp_q, Lp_k, ldo,
                                  scale_q, seed, site, drop_thr, drop_scale, stream);
     else

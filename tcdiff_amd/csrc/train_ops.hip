@@ -189,7 +189,8 @@ extern "C" int tcdiff_ct_desc_init(int dtype, tcdiff_ct_desc* d) {
 template <class P, class S, bool BWD>
 __global__ __launch_bounds__(256) void act_drop_kernel(const S* __restrict__ a, int ld_a, const typename P::elem_t* __restrict__ dy,
                                                        void* __restrict__ out, int ld_o, int rows, int cols, int act,
-                                                       const int* __restrict__ seed, int site, uint32_t thr, float dscale) {
+                                                       const int* __restrict__ seed, int site, uint32_t thr, float dscale,
+                                                       int vec) {
     // forward: out = y (T, [rows][ld_o]);  backward: out = da (S, [rows][ld_a]), dy T [rows][ld_o]
     typedef typename P::elem_t T;
     const int ld_w = BWD ? ld_a : ld_o;                  // leading dimension of the tensor being written
@@ -199,31 +200,58 @@ __global__ __launch_bounds__(256) void act_drop_kernel(const S* __restrict__ a, 
     const int row = (int)(i / quads), c4 = (int)(i % quads) * 4;
     const DropCtx dc = drop_ctx(seed, site, thr, dscale);
     float v[4];
+    // whole quads inside the valid columns move as ONE access per tensor (the launcher checks alignment: `vec`); the
+    // element-wise path is for ragged widths (438-wide music features) -- as scalar 2-byte accesses this kernel ran at a
+    // third of the HBM rate
+    const bool full = vec && c4 + 3 < cols;
+    float xa[4] = {0.f, 0.f, 0.f, 0.f}, ga[4] = {0.f, 0.f, 0.f, 0.f};
+    if (full) {
+        load4<S>(a + (long)row * ld_a + c4, xa);
+        if (BWD) load4<T>(dy + (long)row * ld_o + c4, ga);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (c4 + j < cols) {
+                xa[j] = ld_elem<S>(a + (long)row * ld_a + c4 + j);
+                if (BWD) ga[j] = P::to_f32(dy[(long)row * ld_o + c4 + j]);
+            }
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int c = c4 + j;
         float r = 0.0f;
         if (c < cols) {
-            const float x = ld_elem<S>(a + (long)row * ld_a + c);
             const bool keep = thr ? drop_keep(dc, (uint32_t)row * (uint32_t)cols + (uint32_t)c) : true;
-            if (!BWD) r = keep ? apply_act(x, act) * dscale : 0.0f;
-            else r = keep ? P::to_f32(dy[(long)row * ld_o + c]) * dscale * act_grad(x, act) : 0.0f;
+            if (!BWD) r = keep ? apply_act(xa[j], act) * dscale : 0.0f;
+            else r = keep ? ga[j] * dscale * act_grad(xa[j], act) : 0.0f;
         }
         v[j] = r;
     }
     if (BWD) {
         S* op = reinterpret_cast<S*>(out) + (long)row * ld_a + c4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (c4 + j < ld_a) {
-                if (sizeof(S) == 4) reinterpret_cast<float*>(op)[j] = v[j];
-                else reinterpret_cast<uint16_t*>(op)[j] = f2bf(v[j]);
+        if (vec && c4 + 3 < ld_a) {
+            if (sizeof(S) == 4) *reinterpret_cast<f32x4_t*>(op) = f32x4_t{v[0], v[1], v[2], v[3]};
+            else {
+                uint2 pk;
+                pk.x = pack_bf2(v[0], v[1]);
+                pk.y = pack_bf2(v[2], v[3]);
+                *reinterpret_cast<uint2*>(op) = pk;
             }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (c4 + j < ld_a) {
+                    if (sizeof(S) == 4) reinterpret_cast<float*>(op)[j] = v[j];
+                    else reinterpret_cast<uint16_t*>(op)[j] = f2bf(v[j]);
+                }
+        }
     } else {
         T* op = reinterpret_cast<T*>(out) + (long)row * ld_o + c4;
+        if (vec && c4 + 3 < ld_o) store4_T<P>(op, v);
+        else
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (c4 + j < ld_o) op[j] = P::from_f32(v[j]);
+            for (int j = 0; j < 4; ++j)
+                if (c4 + j < ld_o) op[j] = P::from_f32(v[j]);
     }
 }
 
@@ -235,10 +263,11 @@ static int launch_act_drop(int dtype, int a_f32, const void* a, int ld_a, const 
     if (act < TC_ACT_NONE || act > TC_ACT_SILU) return TC_ERR_ARG;
     if (!thr) dscale = 1.0f;
     const long n = (long)rows * (((BWD ? ld_a : ld_o) + 3) / 4);
+    const int vec = al(a, 16) && al(out, 16) && (!dy || al(dy, 16)) && ld_a % 4 == 0 && ld_o % 4 == 0;
     dim3 grid((unsigned)((n + 255) / 256));
 #define TC_AD(POL, ST)                                                                                                   \
     hipLaunchKernelGGL((act_drop_kernel<POL, ST, BWD>), grid, dim3(256), 0, stream, (const ST*)a, ld_a,                     \
-                       (const POL::elem_t*)dy, out, ld_o, rows, cols, act, seed, site, thr, dscale)
+                       (const POL::elem_t*)dy, out, ld_o, rows, cols, act, seed, site, thr, dscale, vec)
     if (dtype == TC_DTYPE_BF16) {
         if (a_f32) TC_AD(MmaBF16, float); else TC_AD(MmaBF16, uint16_t);
     } else {
@@ -502,7 +531,7 @@ __global__ __launch_bounds__(64 * ROWB_WAVES) void row_bwd_kernel(tcdiff_row_arg
     // [FiLM scale, FiLM shift] -> atomics on this sequence's d_film row, issued as consecutive floats per wave instruction
     // (256-byte segments, the full-rate shape; a lane-strided scatter per wave was 8 M slow atomics per launch)
     const bool film = (f & TC_ROWF_FILM) && a.d_film;
-    if (!a.partials && !film) return;
+    if (!a.partials && !film && !a.g_bias && !a.g_ln_g && !a.g_ln_b && !a.g_nln_g && !a.g_nln_b) return;
     const Row8* accs[7] = {&acc_bias, &acc_g, &acc_b, &acc_g2, &acc_b2, &acc_s, &acc_sh};
     constexpr int HW = ROWB_WAVES / 2;
     if (wave >= HW) {
@@ -527,6 +556,13 @@ __global__ __launch_bounds__(64 * ROWB_WAVES) void row_bwd_kernel(tcdiff_row_arg
         float* out = a.partials + ((long)blockIdx.y * gridDim.x + blockIdx.x) * (5 * 512);
         for (int i = threadIdx.x; i < 5 * 512; i += 64 * ROWB_WAVES)
             out[i] = (rf[i] + rf[WS + i]) + (rf[2 * WS + i] + rf[3 * WS + i]);
+    }
+    float* const gdst[5] = {a.g_bias, a.g_ln_g, a.g_ln_b, a.g_nln_g, a.g_nln_b};
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        if (!gdst[k]) continue;                           // block-uniform
+        const int i = threadIdx.x, j = k * 512 + i;       // 512 threads = the 512 columns
+        unsafeAtomicAdd(gdst[k] + i, (rf[j] + rf[WS + j]) + (rf[2 * WS + j] + rf[3 * WS + j]));
     }
     if (film) {
         float* dp = a.d_film + (long)seq * a.dfilm_ld;
@@ -557,7 +593,8 @@ static int check_row_args(const tcdiff_row_args* a, bool bwd) {
         if ((f & TC_ROWF_FILM) && a->d_film && a->dfilm_ld % 4) return TC_ERR_ARG;
     }
     const void* ptrs[] = {a->z, a->bias, a->ln_g, a->ln_b, a->film, a->xres, a->xout, a->nln_g, a->nln_b, a->hout, a->rout,
-                          a->rope, a->d_xn, a->d_h, a->d_rot, a->d_z, a->d_xres, a->partials};
+                          a->rope, a->d_xn, a->d_h, a->d_rot, a->d_z, a->d_xres, a->partials, a->g_bias, a->g_ln_g, a->g_ln_b,
+                          a->g_nln_g, a->g_nln_b};
     for (const void* p : ptrs)
         if (p && !al(p, 16)) return TC_ERR_ALIGN;
     return TC_OK;

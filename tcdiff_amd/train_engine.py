@@ -96,7 +96,7 @@ class _Lin:
         return out
 
     # ---- backward --------------------------------------------------------------------------------------------------
-    def bwd(self, dY, ld_dy, M, Xs, want):
+    def bwd(self, dY, ld_dy, M, Xs, want, bias_done=False):
         """dY [M, N] (fp32 or T, leading dimension ld_dy).  Xs[g]: T operand [M, Kp] of group g.  want[g]: None, or
         ("T" | "F32", out tensor, ldc) or ("HEADS", dict) -- where the input gradient of group g goes.
         Weight gradients accumulate into the flat gradient buffer; the bias gradient is the column sum of dY."""
@@ -105,7 +105,7 @@ class _Lin:
         N, Mp = self.N, K.round_up(M, kt)
         Np = K.round_up(N, kt)
         gW = eng.gW[self.key]
-        gb = eng.gB.get(self.key)
+        gb = None if bias_done else eng.gB.get(self.key)      # bias_done: the producer of dY summed its columns already
         direct = dY.dtype == eng.T and ld_dy == Np and N == Np     # dY itself is a valid K-contiguous operand
         # weight gradient straight from the token-major dY and X (tcdiff_gemm_tn) where the shapes allow; otherwise dY^T / X^T
         # are repacked by cast_transpose for tcdiff_gemm_splitk
@@ -331,16 +331,19 @@ class TrainEngine:
     def row_fwd(self, **kw):
         K.row_fwd(self.dt, self._row(**kw))
 
-    def row_bwd(self, *, M, L_, ln=None, nln=None, **kw):
-        """runs tcdiff_row_bwd + the reduction of its LayerNorm partials into the flat gradient buffer.
-        ln / nln: parameter-name prefixes of the post / next LayerNorm (their gradients)."""
+    def row_bwd(self, *, M, L_, ln=None, nln=None, lin=None, **kw):
+        """tcdiff_row_bwd with its parameter gradients added straight into the flat gradient buffer.
+        ln / nln: parameter-name prefixes of the post / next LayerNorm; lin: key of the nn.Linear that produced z, whose bias
+        gradient is the column sum of d_z (then that linear's bwd is called with bias_done=True)."""
         chunks = max(1, min(16, L_ // 16))      # blocks per sequence (8 waves each): >= 4 waves per SIMD at 32 x 450 rows
-        nblk = chunks * (M // L_)
-        part = self.e(nblk, 5, 512, dtype=torch.float32)
-        K.row_bwd(self.dt, self._row(M=M, L=L_, partials=part, chunks=chunks, **kw))
-        if ln or nln:
-            K.row_param_reduce(part, nblk, None, self.g(ln + ".weight") if ln else None, self.g(ln + ".bias") if ln else None,
-                               self.g(nln + ".weight") if nln else None, self.g(nln + ".bias") if nln else None)
+        g = {}
+        if ln:
+            g.update(g_ln_g=self.g(ln + ".weight"), g_ln_b=self.g(ln + ".bias"))
+        if nln:
+            g.update(g_nln_g=self.g(nln + ".weight"), g_nln_b=self.g(nln + ".bias"))
+        if lin:
+            g.update(g_bias=self.gB[lin])
+        K.row_bwd(self.dt, self._row(M=M, L=L_, chunks=chunks, **g, **kw))
 
     def act_fwd(self, a, rows, cols, act, site=None):
         y = self.e(rows, a.shape[1])
@@ -601,19 +604,21 @@ class TrainEngine:
             sd = 16 + 8 * l
             if l + 1 < NL:                                # x' = linear3(.) feeds the next layer: residual + norm1 + rotary
                 dz4 = e(M, 512)
-                self.row_bwd(M=M, L_=Lq, nln=f"{st}{l + 1}.norm1", flags=L.ROWF_NEXT_LN | L.ROWF_STORE_H | L.ROWF_STORE_ROT,
+                self.row_bwd(M=M, L_=Lq, nln=f"{st}{l + 1}.norm1", lin=f"l{l}.l3",
+                             flags=L.ROWF_NEXT_LN | L.ROWF_STORE_H | L.ROWF_STORE_ROT,
                              z=s["z4"], nln_g=P(f"{st}{l + 1}.norm1.weight"), nln_b=P(f"{st}{l + 1}.norm1.bias"), nln_eps=1e-5,
                              rope=self.rope, pos_mod=Lq, d_xn=g_x, d_h=g_h, d_rot=g_r, d_z=dz4)
             dh4 = e(M, 512)
-            lins[f"l{l}.l3"].bwd(dz4, 512, M, [s["h4"]], [("T", dh4, 512)])
+            lins[f"l{l}.l3"].bwd(dz4, 512, M, [s["h4"]], [("T", dh4, 512)], bias_done=l + 1 < NL)
             # feed-forward block
             dz3, gx3 = e(M, 512), e(M, 512, dtype=f32)
-            self.row_bwd(M=M, L_=Lq, nln=q + "norm4", flags=L.ROWF_DROP_PRE | L.ROWF_FILM | L.ROWF_RES | L.ROWF_NEXT_LN | L.ROWF_STORE_H,
+            self.row_bwd(M=M, L_=Lq, nln=q + "norm4", lin=f"l{l}.ff2",
+                         flags=L.ROWF_DROP_PRE | L.ROWF_FILM | L.ROWF_RES | L.ROWF_NEXT_LN | L.ROWF_STORE_H,
                          z=s["z3"], film=sv["film"][:, (3 * l + 2) * 1024:], film_ld=nfilm, xres=s["x3"],
                          nln_g=P(q + "norm4.weight"), nln_b=P(q + "norm4.bias"), nln_eps=1e-5, site_pre=sd + 7, d_h=dh4, d_z=dz3,
                          d_xres=gx3, d_film=dfilm[:, (3 * l + 2) * 1024:], dfilm_ld=nfilm)
             df = e(M, 1024)
-            lins[f"l{l}.ff2"].bwd(dz3, 512, M, [s["f"]], [("T", df, 1024)])
+            lins[f"l{l}.ff2"].bwd(dz3, 512, M, [s["f"]], [("T", df, 1024)], bias_done=True)
             da = self.act_bwd(s["a"], df, M, 1024, L.ACT_GELU, site=sd + 6)
             dh3 = e(M, 512)
             lins[f"l{l}.ff1"].bwd(da, 1024, M, [s["h3"]], [("T", dh3, 512)])
@@ -711,24 +716,27 @@ class TrainEngine:
             dzf, gx2 = e(Ms, 512), e(Ms, 512, dtype=f32)
             fl = L.ROWF_DROP_PRE | L.ROWF_RES
             if i == 0:
-                self.row_bwd(M=Ms, L_=S, nln="cond_encoder.1.norm1", flags=fl | L.ROWF_NEXT_LN | L.ROWF_STORE_H | L.ROWF_STORE_ROT,
+                self.row_bwd(M=Ms, L_=S, nln="cond_encoder.1.norm1", lin=f"e{i}.l2",
+                             flags=fl | L.ROWF_NEXT_LN | L.ROWF_STORE_H | L.ROWF_STORE_ROT,
                              z=s["zf"], xres=s["x2"], nln_g=P("cond_encoder.1.norm1.weight"), nln_b=P("cond_encoder.1.norm1.bias"),
                              nln_eps=1e-5, rope=self.rope, pos_mod=S, site_pre=4 * i + 3, d_xn=g_tok, d_h=g_h, d_rot=g_r, d_z=dzf,
                              d_xres=gx2)
             else:
-                self.row_bwd(M=Ms, L_=S, flags=fl, z=s["zf"], xres=s["x2"], site_pre=4 * i + 3, d_xn=g_tok, d_z=dzf, d_xres=gx2)
+                self.row_bwd(M=Ms, L_=S, lin=f"e{i}.l2", flags=fl, z=s["zf"], xres=s["x2"], site_pre=4 * i + 3, d_xn=g_tok,
+                             d_z=dzf, d_xres=gx2)
             df = e(Ms, 1024)
-            lins[f"e{i}.l2"].bwd(dzf, 512, Ms, [s["f"]], [("T", df, 1024)])
+            lins[f"e{i}.l2"].bwd(dzf, 512, Ms, [s["f"]], [("T", df, 1024)], bias_done=True)
             da = self.act_bwd(s["a"], df, Ms, 1024, L.ACT_GELU, site=4 * i + 2)
             dh2 = e(Ms, 512)
             lins[f"e{i}.l1"].bwd(da, 1024, Ms, [s["h2"]], [("T", dh2, 512)])
             dzo, gx1 = e(Ms, 512), e(Ms, 512, dtype=f32)
-            self.row_bwd(M=Ms, L_=S, nln=q + "norm2", flags=fl | L.ROWF_NEXT_LN | L.ROWF_STORE_H, z=s["zo"], xres=s["x_in"],
+            self.row_bwd(M=Ms, L_=S, nln=q + "norm2", lin=f"e{i}.o", flags=fl | L.ROWF_NEXT_LN | L.ROWF_STORE_H, z=s["zo"],
+                         xres=s["x_in"],
                          nln_g=P(q + "norm2.weight"), nln_b=P(q + "norm2.bias"), nln_eps=1e-5, site_pre=4 * i + 1, d_xn=gx2,
                          d_h=dh2, d_z=dzo, d_xres=gx1)
             dO = self.pz("dOe", B, H, Lps, 64)
             lins[f"e{i}.o"].bwd(dzo, 512, Ms, [s["O"]], [("HEADS", dict(out=dO, out_k=None, out_v=None, scale_q=1.0, Lseq=S,
-                                                                        Lp=Lps, n_q=512, n_k=0))])
+                                                                        Lp=Lps, n_q=512, n_k=0))], bias_done=True)
             dQKV, delta = e(Ms, 1536), self.pz("deltae", B, H, Lps, dtype=f32)
             K.attention_bwd(dt, s["Q"], s["K"], s["V"], s["O"], dO, s["lse"], delta, dQKV, 1536, dQKV.view(-1)[512:],
                             dQKV.view(-1)[1024:], 1536, B, H, S, S, Lps, Lps, 512, 0.125, self.seed, 4 * i + 0, self.thr,
@@ -737,11 +745,12 @@ class TrainEngine:
             lins[f"e{i}.qkv"].bwd(dQKV, 1536, Ms, [s["rot"], s["h"]], [("T", g_r, 512), ("T", g_h, 512)])
             g_tok = gx1
         dtok0 = e(Ms, 512)
-        self.row_bwd(M=Ms, L_=S, nln="cond_encoder.0.norm1", flags=L.ROWF_NEXT_LN | L.ROWF_STORE_H | L.ROWF_STORE_ROT, z=sv["tok0"],
+        self.row_bwd(M=Ms, L_=S, nln="cond_encoder.0.norm1", lin="c2", flags=L.ROWF_NEXT_LN | L.ROWF_STORE_H | L.ROWF_STORE_ROT,
+                     z=sv["tok0"],
                      nln_g=P("cond_encoder.0.norm1.weight"), nln_b=P("cond_encoder.0.norm1.bias"), nln_eps=1e-5, rope=self.rope,
                      pos_mod=S, d_xn=g_tok, d_h=g_h, d_rot=g_r, d_z=dtok0)
         dc1 = self.pz("dc1", Ms, sv["c1"].shape[1])
-        lins["c2"].bwd(dtok0, 512, Ms, [sv["c1"]], [("T", dc1, dc1.shape[1])])
+        lins["c2"].bwd(dtok0, 512, Ms, [sv["c1"]], [("T", dc1, dc1.shape[1])], bias_done=True)
         dc0a = self.act_bwd(sv["c0a"], dc1, Ms, self.Cd, L.ACT_RELU)
         lins["c0"].bwd(dc0a, dc0a.shape[1], Ms, [sv["cin"]], [None])
         self.sv = None

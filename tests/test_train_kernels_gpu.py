@@ -235,6 +235,20 @@ def test_row_block_forward_and_backward_vs_torch_autograd(compute, case):
                              d_film=d_film[:, 1024:], dfilm_ld=2048, partials=part, chunks=chunks, **common))
     gb, glg, glb, gng, gnb = (torch.zeros(512, device=DEV) for _ in range(5))
     K.row_param_reduce(part, chunks * nseq, gb, glg, glb, gng, gnb)
+    # the same sums added straight into the gradients (what the training engine uses: no partials, no second launch)
+    g2 = [torch.full((512,), 0.5, device=DEV) for _ in range(5)]
+    d_film2 = torch.zeros(nseq, 2048, device=DEV)
+    K.row_bwd(dt, K.row_args(d_xn=dev(d_xn), d_h=dev(d_h) if f & L.ROWF_STORE_H else None,
+                             d_rot=dev(d_r) if f & L.ROWF_STORE_ROT else None, d_z=torch.empty_like(d_z),
+                             d_xres=torch.empty_like(d_xres), d_film=d_film2[:, 1024:], dfilm_ld=2048, chunks=2, g_bias=g2[0],
+                             g_ln_g=g2[1] if f & L.ROWF_LN_POST else None, g_ln_b=g2[2] if f & L.ROWF_LN_POST else None,
+                             g_nln_g=g2[3] if f & L.ROWF_NEXT_LN else None, g_nln_b=g2[4] if f & L.ROWF_NEXT_LN else None,
+                             **common))
+    for k, (got, ref_) in enumerate(zip(g2, (gb, glg, glb, gng, gnb))):
+        on = k == 0 or (k in (1, 2) and f & L.ROWF_LN_POST) or (k in (3, 4) and f & L.ROWF_NEXT_LN)
+        want_k = ref_ + 0.5 if on else torch.full_like(ref_, 0.5)
+        assert float((got - want_k).abs().max()) <= 1e-5 * max(1.0, float(ref_.abs().max())), k
+    assert rel(d_film2, d_film) < 1e-5 or float(d_film.abs().max()) == 0.0
     gtol = max(tol, 5e-6)
     assert rel(d_z, zr.grad) < gtol
     if f & L.ROWF_RES:
@@ -259,7 +273,10 @@ def _images(x, Lp, T):
 
 
 @pytest.mark.parametrize("compute", ["f32", "bf16"])
-@pytest.mark.parametrize("Lq,Lk,p", [(120, 120, 0.1), (120, 62, 0.1), (450, 152, 0.0), (70, 130, 0.1)])
+# 450 / 300-row shapes take the operand-resident bf16 kernels (attn_res.h, attn_bwd_*_res_kernel), the others -- and every f32
+# case -- the streaming ones
+@pytest.mark.parametrize("Lq,Lk,p", [(120, 120, 0.1), (120, 62, 0.1), (450, 152, 0.0), (70, 130, 0.1), (450, 450, 0.1),
+                                     (450, 152, 0.1), (300, 450, 0.1), (257, 33, 0.1)])
 def test_attention_train_forward_and_backward_vs_torch_autograd(compute, Lq, Lk, p):
     dt, T, tol = mode(compute)
     n, H = 2, 8

@@ -33,3 +33,15 @@ for C in (512, 1024, 1536):
     X = torch.randn(M, C, device=dev).to(bf); Xt = torch.empty(C, M, device=dev, dtype=bf)
     us = t(lambda: K.cast_transpose(L.DT_BF16, X, M, C, C, dstT=Xt, ld_dstT=M, rows_pad=M))
     print(f"  C={C:5d}: {us:6.1f} us  {2*M*C*2/us/1e3:7.1f} GB/s")
+
+print("library reference (torch.mm -> hipBLASLt / rocBLAS), same shapes: what a tuned vendor kernel reaches here")
+for N, Kd in ((512, 512), (1536, 512), (1024, 512), (512, 1024)):
+    A = torch.randn(M, Kd, device=dev).to(bf); W = torch.randn(N, Kd, device=dev).to(bf)
+    Wt = W.t()
+    out = torch.empty(M, N, device=dev, dtype=bf)
+    us = t(lambda: torch.mm(A, Wt, out=out))
+    print(f"  fwd   N={N:5d} K={Kd:5d}: {us:7.1f} us  {2.0*M*N*Kd/us/1e6:7.1f} TFLOP/s")
+    dY = torch.randn(M, N, device=dev).to(bf)
+    dW = torch.empty(N, Kd, device=dev, dtype=bf)
+    us = t(lambda: torch.mm(dY.t(), A, out=dW))
+    print(f"  wgrad N={N:5d} K={Kd:5d}: {us:7.1f} us  {2.0*M*N*Kd/us/1e6:7.1f} TFLOP/s")
