@@ -443,9 +443,9 @@ __global__ __launch_bounds__(256) void row_fwd_kernel(tcdiff_row_args a) {
 }
 
 // grid = (chunks, M / L): a block works inside ONE sequence, so its FiLM gradient goes to one row of d_film.  Eight waves
-// per block and up to 16 blocks per sequence: a wave walks its rows serially (each row is a chain of loads and two wave
-// reductions), so the launch needs waves, not work per wave -- with 4 waves x 8 blocks per sequence (one wave per SIMD at
-// 32 sequences) it ran at a quarter of the HBM rate.
+// per block: a wave walks its rows serially (each row is a chain of loads and two wave reductions), so the launch needs
+// waves, not work per wave -- with 4 waves x 8 blocks per sequence (one wave per SIMD at 32 sequences) it ran at a quarter
+// of the HBM rate.  196 VGPRs = two waves per SIMD = one block per CU; capped at 128 it spills 364 bytes per lane.
 constexpr int ROWB_WAVES = 8;
 template <class P>
 __global__ __launch_bounds__(64 * ROWB_WAVES) void row_bwd_kernel(tcdiff_row_args a) {

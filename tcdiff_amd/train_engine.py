@@ -31,6 +31,11 @@ from . import _lib as L
 from . import kernels as K
 
 DEAD = ("traj_Modulation", "traj_embedding", "embeddings_table")      # parameters the forward never uses (model/model.py:346-355,371,557)
+import os as _os
+# row_bwd blocks per sequence.  The kernel holds 196 VGPRs (7 column accumulators + a row in flight), i.e. two waves per SIMD =
+# ONE 8-wave block per CU: at 32 sequences 8 blocks each are exactly one resident round, and every further block only adds
+# adders to the gradient atomics (batch 32, ms per step in row_bwd: 4 blocks 2.06, 8: 1.46, 16: 1.80, 32: 2.25).
+_ROWB_CHUNKS = int(_os.environ.get("TCDIFF_ROWB_CHUNKS", "8"))
 _ALLOW_CPU = False          # tools/dryrun_train.py only: host-side dry run of the schedule against a stub library
 
 
@@ -335,7 +340,7 @@ class TrainEngine:
         """tcdiff_row_bwd with its parameter gradients added straight into the flat gradient buffer.
         ln / nln: parameter-name prefixes of the post / next LayerNorm; lin: key of the nn.Linear that produced z, whose bias
         gradient is the column sum of d_z (then that linear's bwd is called with bias_done=True)."""
-        chunks = max(1, min(16, L_ // 16))      # blocks per sequence (8 waves each): >= 4 waves per SIMD at 32 x 450 rows
+        chunks = max(1, min(_ROWB_CHUNKS, L_ // 16))
         g = {}
         if ln:
             g.update(g_ln_g=self.g(ln + ".weight"), g_ln_b=self.g(ln + ".bias"))
