@@ -64,6 +64,15 @@ typedef struct {
     int tok_off;       /* QKV: added to the token index  */
     int seq_off;       /* QKV: added to the sequence index */
     int k_splits;      /* TC_EPI_ATOMIC_F32: workgroups per output tile (set by tcdiff_gemm_splitk; 0 elsewhere) */
+    /* Training step, TC_EPI_STORE_T with act == NONE and N, ldc multiples of the 16-byte chunk: the activation (+ nn.Dropout)
+     * that follows / precedes the nn.Linear in the same pass (model/model.py:244,399-400,490-494,522-528 and their autograd).
+     *   out2 != NULL   : out = a = T(acc + bias) (kept for the backward), out2[m][n] = T(dropout(act2(a)))
+     *   act_src != NULL: the GEMM is the input gradient of the NEXT linear, out = T(T(acc) * mask / (1 - p) * act2'(act_src[m][n]))
+     * dropout: counter hash of (drop_seed (DEVICE int[2] or NULL), drop_site, m * N + n); drop_thr = 0 disables it. */
+    void* out2; int ldc2;
+    const void* act_src; int ld_src;
+    int act2;
+    const int* drop_seed; int drop_site; uint32_t drop_thr; float drop_scale;
 } tcdiff_tile_epi;
 
 /* C[M,N] = A[M,K] * W[N,K]^T with epilogue.  If A2 != NULL, output columns >= split_n (a multiple of 128)

@@ -24,7 +24,9 @@ _vp, _i, _f, _l = C.c_void_p, C.c_int, C.c_float, C.c_long
 class TileEpi(C.Structure):
     _fields_ = [("mode", _i), ("act", _i), ("scale_q", _f), ("bias", _vp), ("out", _vp), ("out_k", _vp),
                 ("out_v", _vp), ("ldc", _i), ("L", _i), ("Lp", _i), ("H", _i), ("n_q", _i), ("n_k", _i),
-                ("tok_off", _i), ("seq_off", _i), ("k_splits", _i)]
+                ("tok_off", _i), ("seq_off", _i), ("k_splits", _i), ("out2", _vp), ("ldc2", _i), ("act_src", _vp),
+                ("ld_src", _i), ("act2", _i), ("drop_seed", _vp), ("drop_site", _i), ("drop_thr", C.c_uint32),
+                ("drop_scale", _f)]
 
 
 class RowEpi(C.Structure):

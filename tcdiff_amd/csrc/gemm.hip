@@ -35,6 +35,7 @@
 //   gemm_rowln dumps its fp32 64x512 tile to LDS and finishes LayerNorm/FiLM/residual/rotary in a row-wise pass
 //   (one wave per row, 16-byte loads/stores, wave-wide shuffle reductions) exactly like ops.hip::ln_rot.
 #include "attn_common.h"      // v_frag: transposed MFMA fragments of a staged [k][64 columns] tile (the TN form)
+#include "train_common.h"     // counter-hash dropout, activation derivatives (the fused activation epilogues of the training step)
 #include "tcdiff_hip.h"
 
 #ifdef TC_STAMP
@@ -59,6 +60,34 @@ extern "C" int tcdiff_debug_stamp_buffer(void* p) {
 // outside the decoder layers (FiLM stack, input / fusion / final projection: 152-228 tiles, K up to 1536).  With two
 // stages every k-tile waits out what is left of a ~1.2 us DMA round trip after 0.25 us of MFMA work (25 us for K =
 // 1536); with four the DMA of tile kt + 3 is issued while tile kt is computed.
+// a 16-byte chunk of T <-> floats
+template <class P>
+DEVINL void unpack_chunk(const u32x4& c, float (&v)[16 / sizeof(typename P::elem_t)]) {
+    if (P::IS_BF16) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[2 * j] = bf2f((uint16_t)(c[j] & 0xffffu));
+            v[2 * j + 1] = bf2f((uint16_t)(c[j] >> 16));
+        }
+    } else {
+        const f32x4_t f = __builtin_bit_cast(f32x4_t, c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = f[j];
+    }
+}
+template <class P>
+DEVINL u32x4 pack_chunk(const float (&v)[16 / sizeof(typename P::elem_t)]) {
+    u32x4 c;
+    if (P::IS_BF16) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[j] = pack_bf2(v[2 * j], v[2 * j + 1]);
+    } else {
+        const f32x4_t f = {v[0], v[1], v[2], v[3]};
+        c = __builtin_bit_cast(u32x4, f);
+    }
+    return c;
+}
+
 // TN = true: out[m][n] = sum_k A[k][m] W[k][n] -- BOTH operands row-major over the contraction index (the weight gradient
 // dW = dY^T X straight from the token-major dY and X: no transposed copies).  A k-tile is staged as [KT rows of k][128
 // columns] in 128-byte column blocks (the layout of attention's V tile), and every fragment is the transposed read of
@@ -309,7 +338,62 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(const char* __restrict__
                 T* base = reinterpret_cast<T*>(which == 0 ? e.out : (which == 1 ? e.out_k : e.out_v));
                 dst = base + (((long)seq * e.H + head) * e.Lp + tok) * 64 + d;
             }
-            if (n + EPC <= N && (qkv || ((long)e.ldc * ES) % 16 == 0)) {
+            if (!qkv && (e.out2 || e.act_src)) {
+                // training step, fused activation (the launcher guarantees whole aligned chunks).  Forward (out2): `out` keeps the
+                // pre-activation a (T) for the backward, out2 = T(dropout(act2(a))) -- nn.Linear + activation + nn.Dropout of
+                // model/model.py:399-400,244,522-528 in one pass.  Backward (act_src): the tile is dY of the activation's output;
+                // out = T(dY * mask / (1 - p) * act2'(a)) with a read from act_src.  Both on the T-rounded values, as the separate
+                // tcdiff_act_drop(_bwd) kernels do; dropout index = m * N + n (train_common.h).
+                const DropCtx dc = drop_ctx(e.drop_seed, e.drop_site, e.drop_thr, e.drop_scale);
+                u32x4 src = val;
+                if (e.act_src) src = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(e.act_src) + (long)m * e.ld_src + n);
+                else *reinterpret_cast<u32x4*>(dst) = val;
+                float x[EPC], y[EPC];
+                unpack_chunk<P>(src, x);
+                if (e.act_src) unpack_chunk<P>(val, y);
+                // the activation is chosen by WAVE-UNIFORM branches around whole loops: a per-element switch is if-converted
+                // and every lane then evaluates erf, tanh, log1p and exp for every element (common.h, act_ct)
+                float f[EPC];
+                const float sc = e.drop_thr ? e.drop_scale : 1.0f;
+                if (e.act_src) {
+#pragma unroll
+                    for (int t = 0; t < EPC; ++t) y[t] *= sc;          // (dY * scale) * act'(a): the rounding order of tcdiff_act_drop_bwd
+                    if (e.act2 == ACT_GELU) {
+#pragma unroll
+                        for (int t = 0; t < EPC; ++t) f[t] = y[t] * gelu_grad(x[t]);
+                    } else if (e.act2 == ACT_RELU) {
+#pragma unroll
+                        for (int t = 0; t < EPC; ++t) f[t] = x[t] > 0.0f ? y[t] : 0.0f;
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < EPC; ++t) f[t] = y[t] * act_grad(x[t], e.act2);
+                    }
+                } else {
+                    if (e.act2 == ACT_GELU) {
+#pragma unroll
+                        for (int t = 0; t < EPC; ++t) f[t] = gelu_erf(x[t]);
+                    } else if (e.act2 == ACT_RELU) {
+#pragma unroll
+                        for (int t = 0; t < EPC; ++t) f[t] = fmaxf(x[t], 0.0f);
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < EPC; ++t) f[t] = apply_act(x[t], e.act2);
+                    }
+                }
+                if (!e.act_src) {
+#pragma unroll
+                    for (int t = 0; t < EPC; ++t) f[t] *= sc;
+                }
+                if (e.drop_thr) {
+#pragma unroll
+                    for (int t = 0; t < EPC; ++t)
+                        f[t] = drop_keep(dc, (uint32_t)m * (uint32_t)N + (uint32_t)(n + t)) ? f[t] : 0.0f;
+                }
+#pragma unroll
+                for (int t = 0; t < EPC; ++t) y[t] = f[t];
+                T* d2 = e.act_src ? dst : reinterpret_cast<T*>(e.out2) + (long)m * e.ldc2 + n;
+                *reinterpret_cast<u32x4*>(d2) = pack_chunk<P>(y);
+            } else if (n + EPC <= N && (qkv || ((long)e.ldc * ES) % 16 == 0)) {
                 *reinterpret_cast<u32x4*>(dst) = val;
             } else {
                 const T* sv = reinterpret_cast<const T*>(smem + row * RS + ch * 16);
@@ -558,6 +642,13 @@ static int launch_tile(int dtype, const void* A, const void* A2, int split_n, co
     } else {
         if (!epi->out) return TC_ERR_ARG;
         if (!aligned16(epi->out)) return TC_ERR_ALIGN;
+    }
+    if (epi->out2 || epi->act_src) {            // fused activation epilogues (training step): whole aligned chunks only
+        const int epc = 16 / es;
+        if (epi->mode != TC_EPI_STORE_T || (epi->out2 && epi->act_src) || epi->act != TC_ACT_NONE) return TC_ERR_ARG;
+        if (epi->act2 < TC_ACT_NONE || epi->act2 > TC_ACT_SILU || N % epc || epi->ldc % epc) return TC_ERR_ARG;
+        if (epi->out2 && (epi->ldc2 < N || epi->ldc2 % epc || !aligned16(epi->out2))) return TC_ERR_ARG;
+        if (epi->act_src && (epi->ld_src < N || epi->ld_src % epc || !aligned16(epi->act_src))) return TC_ERR_ARG;
     }
     tcdiff_tile_epi e = *epi;
     if (e.mode == TC_EPI_ATOMIC_F32) {

@@ -85,10 +85,24 @@ class _Lin:
             self.bias = eng.params[self.bnames[0]].detach()
 
     # ---- forward ---------------------------------------------------------------------------------------------------
-    def fwd(self, A, M, *, A2=None, out=None, f32=False, ldc=None, heads=None, rows=None):
+    def fwd(self, A, M, *, A2=None, out=None, f32=False, ldc=None, heads=None, rows=None, act=None):
         """out[M, N] = A W^T + b.  f32: fp32 output, else T.  heads = dict(out, out_k, out_v, scale_q, Lseq, Lp, n_q, n_k):
-        scatter to head-major images.  rows = (lo, hi): only that slice of the stacked outputs."""
+        scatter to head-major images.  rows = (lo, hi): only that slice of the stacked outputs.
+        act = (TC_ACT_*, dropout site or None): the activation (+ nn.Dropout) that follows, in the GEMM's epilogue -- returns
+        (out, act_out); shapes the epilogue does not take run tcdiff_act_drop as a second launch."""
         eng = self.eng
+        if act is not None:
+            kind, site = act
+            thr, sc = (eng.thr, eng.dscale) if site is not None else (0, 1.0)
+            y = eng.e(M, out.shape[1])
+            ld = ldc if ldc else self.N
+            if self.N % (16 // out.element_size()) == 0 and ld == out.shape[1] and not eng.no_fuse:
+                K.gemm_tile(eng.dt, A, self.Wf, M, self.N, self.Kp, bias=self.bias, mode=L.EPI_STORE_T, out=out, ldc=ld, out2=y,
+                            ldc2=ld, act2=kind, seed=eng.seed, site=site or 0, thr=thr, drop_scale=sc)
+            else:
+                K.gemm_tile(eng.dt, A, self.Wf, M, self.N, self.Kp, bias=self.bias, mode=L.EPI_STORE_T, out=out, ldc=ld)
+                K.act_drop(eng.dt, out, out.shape[1], y, y.shape[1], M, self.N, kind, eng.seed, site or 0, thr, sc)
+            return out, y
         lo, hi = rows if rows else (0, self.N)
         W = self.Wf[lo:hi]
         bias = self.bias[lo:hi] if self.bias is not None else None
@@ -137,6 +151,17 @@ class _Lin:
                 A = dYT.view(-1)[lo:]
                 if w[0] == "HEADS":
                     K.gemm_tile(dt, A, self.WbT[gi], M, self.K, ngp, lda=Np, mode=L.EPI_QKV_HEADS, H=eng.H, **w[1])
+                elif w[0] == "ACT":                             # ("ACT", da, ld, a, TC_ACT_*, site): through the activation's backward
+                    _, da, ld, a_src, kind, site = w
+                    thr, sc = (eng.thr, eng.dscale) if site is not None else (0, 1.0)
+                    if self.K % (16 // da.element_size()) == 0 and a_src.dtype == eng.T and da.dtype == eng.T and not eng.no_fuse:
+                        K.gemm_tile(dt, A, self.WbT[gi], M, self.K, ngp, lda=Np, mode=L.EPI_STORE_T, out=da, ldc=ld,
+                                    act_src=a_src, ld_src=a_src.shape[1], act2=kind, seed=eng.seed, site=site or 0, thr=thr,
+                                    drop_scale=sc)
+                    else:
+                        dy = eng.e(M, ld)
+                        K.gemm_tile(dt, A, self.WbT[gi], M, self.K, ngp, lda=Np, mode=L.EPI_STORE_T, out=dy, ldc=ld)
+                        K.act_drop_bwd(dt, a_src, a_src.shape[1], dy, ld, da, M, self.K, kind, eng.seed, site or 0, thr, sc)
                 else:
                     K.gemm_tile(dt, A, self.WbT[gi], M, self.K, ngp, lda=Np,
                                 mode=L.EPI_STORE_F32 if w[0] == "F32" else L.EPI_STORE_T, out=w[1], ldc=w[2])
@@ -310,6 +335,7 @@ class TrainEngine:
     def z(self, *shape, dtype=None):
         return torch.zeros(*shape, device=self.dev, dtype=self.T if dtype is None else dtype)
 
+    no_fuse = bool(int(_os.environ.get("TCDIFF_TRAIN_NOFUSE", "0")))     # A/B: activations as separate launches
     poison = False      # tests: fill every "empty" workspace with NaN, so that a kernel reading what nothing wrote shows up
 
     def pz(self, key, *shape, dtype=None):
@@ -419,9 +445,7 @@ class TrainEngine:
             self.row_fwd(flags=L.ROWF_DROP_PRE | L.ROWF_RES | L.ROWF_STORE_X | L.ROWF_NEXT_LN | L.ROWF_STORE_H, M=Ms, L=S,
                          z=zo, xres=tok, xout=x2, nln_g=P(q + "norm2.weight"), nln_b=P(q + "norm2.bias"), nln_eps=1e-5,
                          hout=h2, site_pre=4 * i + 1)
-            a = e(Ms, 1024)
-            lins[f"e{i}.l1"].fwd(h2, Ms, out=a)
-            f = self.act_fwd(a, Ms, 1024, L.ACT_GELU, site=4 * i + 2)
+            a, f = lins[f"e{i}.l1"].fwd(h2, Ms, out=e(Ms, 1024), act=(L.ACT_GELU, 4 * i + 2))
             zf = e(Ms, 512, dtype=f32)
             lins[f"e{i}.l2"].fwd(f, Ms, out=zf, f32=True)
             x3 = e(Ms, 512, dtype=f32)
@@ -487,12 +511,8 @@ class TrainEngine:
         xp = e(M, 512)
         lins["in"].fwd(xin, M, out=xp)
         xpf = xp.view(Ms, 512 * dn)
-        f1a = e(Ms, 1024)
-        lins["f1"].fwd(xpf, Ms, out=f1a)
-        f1 = self.act_fwd(f1a, Ms, 1024, L.ACT_RELU)
-        f2a = e(Ms, 1024)
-        lins["f2"].fwd(f1, Ms, out=f2a)
-        f2 = self.act_fwd(f2a, Ms, 1024, L.ACT_RELU)
+        f1a, f1 = lins["f1"].fwd(xpf, Ms, out=e(Ms, 1024), act=(L.ACT_RELU, None))
+        f2a, f2 = lins["f2"].fwd(f1, Ms, out=e(Ms, 1024), act=(L.ACT_RELU, None))
         xs = e(Ms, 512 * dn, dtype=f32)
         lins["f3"].fwd(f2, Ms, out=xs, f32=True)
         xs = xs.view(M, 512)
@@ -534,9 +554,7 @@ class TrainEngine:
                          ln_b=P(q + "multihead_attn.layer_norm.bias"), ln_eps=1e-6, film=film[:, (3 * l + 1) * 1024:],
                          film_ld=nfilm, xres=x2, xout=x3, nln_g=P(q + "norm3.weight"), nln_b=P(q + "norm3.bias"), nln_eps=1e-5,
                          hout=h3, site_pre=sd + 4, site_post=sd + 5)
-            a = e(M, 1024)
-            lins[f"l{l}.ff1"].fwd(h3, M, out=a)
-            f = self.act_fwd(a, M, 1024, L.ACT_GELU, site=sd + 6)
+            a, f = lins[f"l{l}.ff1"].fwd(h3, M, out=e(M, 1024), act=(L.ACT_GELU, sd + 6))
             z3 = e(M, 512, dtype=f32)
             lins[f"l{l}.ff2"].fwd(f, M, out=z3, f32=True)
             h4 = e(M, 512)
@@ -622,9 +640,8 @@ class TrainEngine:
                          z=s["z3"], film=sv["film"][:, (3 * l + 2) * 1024:], film_ld=nfilm, xres=s["x3"],
                          nln_g=P(q + "norm4.weight"), nln_b=P(q + "norm4.bias"), nln_eps=1e-5, site_pre=sd + 7, d_h=dh4, d_z=dz3,
                          d_xres=gx3, d_film=dfilm[:, (3 * l + 2) * 1024:], dfilm_ld=nfilm)
-            df = e(M, 1024)
-            lins[f"l{l}.ff2"].bwd(dz3, 512, M, [s["f"]], [("T", df, 1024)], bias_done=True)
-            da = self.act_bwd(s["a"], df, M, 1024, L.ACT_GELU, site=sd + 6)
+            da = e(M, 1024)
+            lins[f"l{l}.ff2"].bwd(dz3, 512, M, [s["f"]], [("ACT", da, 1024, s["a"], L.ACT_GELU, sd + 6)], bias_done=True)
             dh3 = e(M, 512)
             lins[f"l{l}.ff1"].bwd(da, 1024, M, [s["h3"]], [("T", dh3, 512)])
             # cross-attention block
@@ -668,12 +685,9 @@ class TrainEngine:
         self.row_bwd(M=M, L_=Lq, nln=st + "0.norm1", flags=L.ROWF_NEXT_LN | L.ROWF_STORE_H | L.ROWF_STORE_ROT, z=sv["xs"],
                      nln_g=P(st + "0.norm1.weight"), nln_b=P(st + "0.norm1.bias"), nln_eps=1e-5, rope=self.rope, pos_mod=Lq,
                      d_xn=g_x, d_h=g_h, d_rot=g_r, d_z=dxs)
-        df2 = e(Ms, 1024)
-        lins["f3"].bwd(dxs.view(Ms, 512 * dn), 512 * dn, Ms, [sv["f2"]], [("T", df2, 1024)])
-        df2a = self.act_bwd(sv["f2a"], df2, Ms, 1024, L.ACT_RELU)
-        df1 = e(Ms, 1024)
-        lins["f2"].bwd(df2a, 1024, Ms, [sv["f1"]], [("T", df1, 1024)])
-        df1a = self.act_bwd(sv["f1a"], df1, Ms, 1024, L.ACT_RELU)
+        df2a, df1a = e(Ms, 1024), e(Ms, 1024)
+        lins["f3"].bwd(dxs.view(Ms, 512 * dn), 512 * dn, Ms, [sv["f2"]], [("ACT", df2a, 1024, sv["f2a"], L.ACT_RELU, None)])
+        lins["f2"].bwd(df2a, 1024, Ms, [sv["f1"]], [("ACT", df1a, 1024, sv["f1a"], L.ACT_RELU, None)])
         dxp = e(Ms, 512 * dn)
         lins["f1"].bwd(df1a, 1024, Ms, [sv["xpf"]], [("T", dxp, 512 * dn)])
         lins["in"].bwd(dxp.view(M, 512), 512, M, [sv["xin"]], [None])
@@ -729,9 +743,8 @@ class TrainEngine:
             else:
                 self.row_bwd(M=Ms, L_=S, lin=f"e{i}.l2", flags=fl, z=s["zf"], xres=s["x2"], site_pre=4 * i + 3, d_xn=g_tok,
                              d_z=dzf, d_xres=gx2)
-            df = e(Ms, 1024)
-            lins[f"e{i}.l2"].bwd(dzf, 512, Ms, [s["f"]], [("T", df, 1024)], bias_done=True)
-            da = self.act_bwd(s["a"], df, Ms, 1024, L.ACT_GELU, site=4 * i + 2)
+            da = e(Ms, 1024)
+            lins[f"e{i}.l2"].bwd(dzf, 512, Ms, [s["f"]], [("ACT", da, 1024, s["a"], L.ACT_GELU, 4 * i + 2)], bias_done=True)
             dh2 = e(Ms, 512)
             lins[f"e{i}.l1"].bwd(da, 1024, Ms, [s["h2"]], [("T", dh2, 512)])
             dzo, gx1 = e(Ms, 512), e(Ms, 512, dtype=f32)

@@ -96,6 +96,43 @@ def test_gemm_tn_weight_gradient_from_token_major_operands(compute):
 
 
 @pytest.mark.parametrize("compute", ["f32", "bf16"])
+@pytest.mark.parametrize("act,p", [(L.ACT_GELU, 0.1), (L.ACT_RELU, 0.0), (L.ACT_SILU, 0.1)])
+def test_gemm_tile_fused_activation_epilogues_equal_the_separate_launches(compute, act, p):
+    """nn.Linear + activation + nn.Dropout in one launch (out = pre-activation, out2 = its activated, dropped image) and the
+    input-gradient GEMM with the activation's backward in its epilogue: bit-identical to gemm_tile followed by act_drop(_bwd)."""
+    dt, T, tol = mode(compute)
+    M, N, Kd = 300, 1024, 512
+    g = torch.Generator().manual_seed(14)
+    A = torch.randn(M, Kd, generator=g).to(T).to(DEV)
+    W = (torch.randn(N, Kd, generator=g) * 0.05).to(T).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    thr, sc = K.drop_params(p)
+    site = 22
+    a1, y1 = torch.empty(M, N, device=DEV, dtype=T), torch.empty(M, N, device=DEV, dtype=T)
+    K.gemm_tile(dt, A, W, M, N, Kd, bias=bias, out=a1, ldc=N)
+    K.act_drop(dt, a1, N, y1, N, M, N, act, seed_dev(), site, thr, sc)
+    a2, y2 = torch.empty(M, N, device=DEV, dtype=T), torch.empty(M, N, device=DEV, dtype=T)
+    K.gemm_tile(dt, A, W, M, N, Kd, bias=bias, out=a2, ldc=N, out2=y2, ldc2=N, act2=act, seed=seed_dev(), site=site, thr=thr,
+                drop_scale=sc)
+    assert torch.equal(a1, a2) and torch.equal(y1, y2)
+    if p > 0:
+        frac = float((y2 == 0).float().mean())
+        assert 0.05 < frac < 0.6                                  # the mask is live (GELU / SiLU outputs are almost never exactly 0)
+    # backward: dX = dY W2^T through the activation; dY [M, 512], W2T [1024 (k_in), 512]
+    dY = torch.randn(M, 512, generator=g).to(T).to(DEV)
+    W2T = (torch.randn(N, 512, generator=g) * 0.05).to(T).to(DEV)
+    d1, da1 = torch.empty(M, N, device=DEV, dtype=T), torch.empty(M, N, device=DEV, dtype=T)
+    K.gemm_tile(dt, dY, W2T, M, N, 512, out=d1, ldc=N)
+    K.act_drop_bwd(dt, a1, N, d1, N, da1, M, N, act, seed_dev(), site, thr, sc)
+    da2 = torch.empty(M, N, device=DEV, dtype=T)
+    K.gemm_tile(dt, dY, W2T, M, N, 512, out=da2, ldc=N, act_src=a1, ld_src=N, act2=act, seed=seed_dev(), site=site, thr=thr,
+                drop_scale=sc)
+    assert torch.equal(da1, da2)
+    with pytest.raises(L.TcdiffError):                            # ragged widths are refused (the engine launches act_drop instead)
+        K.gemm_tile(dt, A, W, M, 438, Kd, out=a2, ldc=N, out2=y2, ldc2=N, act2=act)
+
+
+@pytest.mark.parametrize("compute", ["f32", "bf16"])
 def test_cast_transpose_multi_equals_the_single_launches(compute):
     dt, T, tol = mode(compute)
     g = torch.Generator().manual_seed(13)
