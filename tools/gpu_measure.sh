@@ -6,7 +6,7 @@ mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 python -m pytest tests -q -m gpu 2>&1 | tail -3
 python -m pytest tests/test_parity_gpu.py -m gpu -s -q -k "c2 or bf16 or drift" > gpurun_out/${R}_parity_at_benchmarked_config.log 2>&1; tail -2 gpurun_out/${R}_parity_at_benchmarked_config.log
-python -m pytest tests/test_train_step_gpu.py -m gpu -s -q 2>&1 | grep -E "^\[f32\]|^\[bf16\]|passed|failed" > gpurun_out/${R}_train_step_parity.log; tail -3 gpurun_out/${R}_train_step_parity.log
+python -m pytest tests/test_train_step_gpu.py -m gpu -s -q 2>&1 | grep -E "\[f32\]|\[bf16\]|passed|failed" > gpurun_out/${R}_train_step_parity.log; tail -3 gpurun_out/${R}_train_step_parity.log
 python bench.py 2>gpurun_out/bench_default_err.log > gpurun_out/${R}_bench_full_1000steps.json; tail -c 2500 gpurun_out/${R}_bench_full_1000steps.json
 python tools/chain_bench.py 2>/dev/null | grep "chain B" > gpurun_out/${R}_chain_block_scaling.txt; cat gpurun_out/${R}_chain_block_scaling.txt
 for b in 4 32; do python tools/train_bench.py --batch $b --iters 8 --kernels 2>/dev/null | tail -1; done > gpurun_out/${R}_train_step.jsonl; cut -c1-400 gpurun_out/${R}_train_step.jsonl
