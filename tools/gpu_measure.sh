@@ -31,3 +31,7 @@ rm -rf gpurun_out/prof_train
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_train -- python3 tools/train_bench.py --batch 32 --iters 4 > gpurun_out/prof_train.log 2>&1
 f=$(find gpurun_out/prof_train -name "*kernel_stats.csv" | head -1); cp "$f" gpurun_out/${R}_kernel_stats_train_step_b32.csv; head -12 "$f" | cut -c1-160
 rm -rf gpurun_out/prof_train
+# per-call-site / per-shape tables of the training step
+python tools/train_shapes.py --batch 32 --top 60 2>/dev/null | grep -v amdgpu.ids > gpurun_out/${R}_train_shapes_b32.log
+python tools/gemm_shapes.py 2>/dev/null | grep -v amdgpu.ids > gpurun_out/${R}_gemm_shapes.log
+python tools/attn_bench.py 2>/dev/null | grep -v amdgpu.ids > gpurun_out/${R}_attn_bench.log
