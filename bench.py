@@ -50,6 +50,7 @@ def parse(argv=None):
     p.add_argument("--no-kernel-profile", action="store_true", help="skip the in-sampler per-kernel timing pass")
     p.add_argument("--cpu-seconds", type=float, default=30.0, help="total CPU-baseline budget (three samples of a third each)")
     p.add_argument("--no-train-step", action="store_true", help="skip the secondary config-5 training-step timing")
+    p.add_argument("--no-other-configs", action="store_true", help="skip the config-1 / config-4 sampling lines")
     p.add_argument("--train-batch", type=int, default=32, help="clips per GPU of the training step (BASELINE config 5: 32)")
     p.add_argument("--stub", action="store_true",
                    help="rank plumbing only (process group, shard ranges, all-reduce, JSON relay); no GPU work: "
@@ -437,6 +438,13 @@ def rank_main(a):
             del d32
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(dn, S, T, a.cpu_seconds)
+        if world == 1 and not a.no_other_configs and (dn, S, T) == (3, 150, 1000):
+            # BASELINE.json's other single-GPU sampling configurations, one timed job each after a warm-up job (they are
+            # parity-test cases, not the metric: reported so that a driver run sees what DESIGN.md section 5 quotes)
+            try:
+                res["other_configs"] = other_configs(a, dev)
+            except Exception as e:
+                res["other_configs_error"] = repr(e)[:300]
     # ---- secondary: the training step (BASELINE config 5: batch 32 per GPU, Adan, data-parallel over the job's ranks) ----------
     ts = None
     if not a.no_train_step:
@@ -448,6 +456,36 @@ def rank_main(a):
     D.barrier()
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
+
+
+def other_configs(a, dev):
+    import torch
+    import torch.nn.functional as F
+    from tcdiff_amd import DanceDecoder, GaussianDiffusion
+    from tcdiff_amd import weights as W
+    out = {}
+    for name, dn, S, T, nb in (("config1_1clip_2x60_T100", 2, 60, 100, 1), ("config4_5x300_T1000_batch4", 5, 300, 1000, 4)):
+        model = DanceDecoder(nfeats=151, seq_len=S, latent_dim=512, ff_size=1024, num_layers=8, num_heads=8, dropout=0.1,
+                             cond_feature_dim=438, activation=F.gelu, required_dancer_num=dn, compute_dtype=a.dtype)
+        model.load_state_dict(W.synth_state_dict_like(model))
+        diff = GaussianDiffusion(model.eval(), S, 151, None, schedule="cosine", n_timestep=T, predict_epsilon=False,
+                                 loss_type="l2", use_p2=False, cond_drop_prob=0.25, guidance_weight=2, seq_len=S).to(dev).eval()
+        Lq = dn * S
+        cond = torch.stack([W.synth_cond(c, S) for c in range(nb)]).to(dev)
+        xT = torch.stack([W.synth_xT(c, Lq) for c in range(nb)]).to(dev)
+        diff.p_sample_loop((nb, Lq, 151), cond, noise=xT, seed=1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        x = diff.p_sample_loop((nb, Lq, 151), cond, noise=xT, seed=1)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert bool(torch.isfinite(x).all())
+        gf = GFLOP_PER_CLIP_STEP.get((dn, S))
+        out[name] = {"value": round(nb / dt, 4), "unit": "clips/s", "clips": nb, "dancers": dn, "frames": S, "ddpm_steps": T,
+                     "dtype": a.dtype, "ms_per_job": round(dt * 1e3, 1),
+                     "mfma_frac": round(nb / dt * gf * T / 1e3 / PEAK_BF16_TFLOPS, 4) if (gf and a.dtype == "bf16") else None}
+        del diff, model
+    return out
 
 
 def train_step_bench(a, D, dev, world, dn, S, iters=8, warm=3):

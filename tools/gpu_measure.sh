@@ -10,7 +10,7 @@ python -m pytest tests/test_train_step_gpu.py -m gpu -s -q 2>&1 | grep -E "\[f32
 python bench.py 2>gpurun_out/bench_default_err.log > gpurun_out/${R}_bench_full_1000steps.json; tail -c 2500 gpurun_out/${R}_bench_full_1000steps.json
 python tools/chain_bench.py 2>/dev/null | grep "chain B" > gpurun_out/${R}_chain_block_scaling.txt; cat gpurun_out/${R}_chain_block_scaling.txt
 for b in 4 32; do python tools/train_bench.py --batch $b --iters 8 --kernels 2>/dev/null | tail -1; done > gpurun_out/${R}_train_step.jsonl; cut -c1-400 gpurun_out/${R}_train_step.jsonl
-ARGS="bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-profile --no-parity-mode --no-train-step"
+ARGS="bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-profile --no-parity-mode --no-train-step --no-other-configs"
 rm -rf gpurun_out/prof_trace
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_trace -- python3 $ARGS --ddpm-steps 200 > gpurun_out/prof_trace.log 2>&1
 echo "trace rc=$?"
