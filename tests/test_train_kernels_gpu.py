@@ -313,7 +313,7 @@ def _images(x, Lp, T):
 # 450 / 300-row shapes take the operand-resident bf16 kernels (attn_res.h, attn_bwd_*_res_kernel), the others -- and every f32
 # case -- the streaming ones
 @pytest.mark.parametrize("Lq,Lk,p", [(120, 120, 0.1), (120, 62, 0.1), (450, 152, 0.0), (70, 130, 0.1), (450, 450, 0.1),
-                                     (450, 152, 0.1), (300, 450, 0.1), (257, 33, 0.1)])
+                                     (450, 152, 0.1), (300, 450, 0.1), (257, 33, 0.1), (600, 600, 0.1)])      # 600: two key chunks
 def test_attention_train_forward_and_backward_vs_torch_autograd(compute, Lq, Lk, p):
     dt, T, tol = mode(compute)
     n, H = 2, 8
