@@ -443,6 +443,23 @@ int tcdiff_gemm_splitk(int dtype, const void* A, const void* W, int M, int N, in
 int tcdiff_gemm_tn(int dtype, const void* A, const void* B, int M, int N, int K, int lda, int ldb, float* out, int ldc,
                    int splits, hipStream_t stream);
 
+/* Several weight gradients in ONE launch: out_i[m][n] += sum_k A_i[k][m] B_i[k][n] for i < n_prob <= TC_TN_MAX_PROB, each
+ * with tcdiff_gemm_tn's shape rules.  The (tile, k-tile) work units of all problems are cut into equal contiguous shares,
+ * one workgroup per CU: every CU runs the same number of k-tiles and a tile is added (fp32 atomics) once per share that
+ * touches it.  `probs` is a HOST array (copied into the kernel arguments); fill A .. ldc, the rest is the launcher's.
+ * The backward of a decoder layer queues its seven weight gradients and flushes them here (train_engine.py). */
+#define TC_TN_MAX_PROB 16
+typedef struct {
+    const void* A; const void* B; float* out;      /* A [K][lda] (dY), B [K][ldb] (X), out [M][ldc] fp32 */
+    int M, N, K, lda, ldb, ldc;
+    int nk, unit0;                                  /* set by tcdiff_gemm_tn_grouped */
+} tcdiff_tn_problem;
+typedef struct {
+    int n_prob, total_units, units_per_wg, kc;      /* kc: k-tiles per chunk of the unit order */
+    tcdiff_tn_problem p[TC_TN_MAX_PROB];
+} tcdiff_tn_group;
+int tcdiff_gemm_tn_grouped(int dtype, const tcdiff_tn_problem* probs, int n_prob, hipStream_t stream);
+
 /* y = T(dropout(act(a)))  /  da = dy * mask / (1 - p) * act'(a).  a, da: fp32 (a_f32 != 0) or T [rows][ld_a]; y, dy:
  * T [rows][ld_y]; columns >= cols of y / da are written as zeros up to the leading dimension.  Hash index = r * cols + c.
  * Replaces the activations + nn.Dropout of model/model.py:244,400 (GELU), :490-494,522-528 (ReLU), :454-458,157 (Mish),

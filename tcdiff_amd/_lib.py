@@ -72,6 +72,14 @@ class CtDesc(C.Structure):
                 ("cols_pad", _i), ("ld_dstT", _i), ("rows_pad", _i), ("tile0", _i), ("tiles_x", _i), ("vec", _i)]
 
 
+class TnProblem(C.Structure):
+    """tcdiff_tn_problem (include/tcdiff_hip.h): one weight gradient of tcdiff_gemm_tn_grouped."""
+    _fields_ = [("A", _vp), ("B", _vp), ("out", _vp), ("M", _i), ("N", _i), ("K", _i), ("lda", _i), ("ldb", _i), ("ldc", _i),
+                ("nk", _i), ("unit0", _i)]
+
+
+TN_MAX_PROB = 16
+
 ROWF_BIAS, ROWF_DROP_PRE, ROWF_LN_POST, ROWF_DROP_POST, ROWF_FILM, ROWF_RES, ROWF_STORE_X, ROWF_NEXT_LN, ROWF_STORE_H, \
     ROWF_STORE_ROT = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
 
@@ -112,6 +120,7 @@ _SIGS = {
     "tcdiff_cast_transpose": [_i, _i, _vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp, _vp],
     "tcdiff_gemm_splitk": [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp],
     "tcdiff_gemm_tn": [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp],
+    "tcdiff_gemm_tn_grouped": [_i, C.POINTER(TnProblem), _i, _vp],
     "tcdiff_ct_desc_init": [_i, C.POINTER(CtDesc)],
     "tcdiff_cast_transpose_multi": [_i, _vp, _i, _i, _vp],
     "tcdiff_act_drop": [_i, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, C.c_uint32, _f, _vp],

@@ -407,6 +407,126 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(const char* __restrict__
 }
 
 // =================================================================================================
+// gemm_tn_grouped: the weight gradients of SEVERAL nn.Linears in one launch, work split evenly over the CUs
+// =================================================================================================
+// A weight gradient is a small output (512 x 512 ... 1024 x 1536) over a long contraction (14 400 token rows): one launch
+// per linear needs ~16 workgroups per tile to fill the chip, and then each of them runs 14 k-tiles and adds a 64-KB tile
+// with atomics -- the launch is two thirds prologue + atomics (512 x 512: 30 us for 9 us of k-loop; the memory-side adders
+// take ~1 MB per us).  The backward of a decoder layer produces seven such gradients whose operands all exist by the end
+// of the layer, so they are done together: the (tile, k-tile) work units of all problems form one list, cut into equal
+// contiguous shares, one per workgroup (one workgroup per CU).  A share crosses at most a few tile boundaries; per tile
+// segment the workgroup runs the TN k-loop of gemm_tile_kernel over its k-range and adds the tile once.  Atomic volume drops
+// from (16 splits x tiles) to (~1.5 x tiles), every CU has the same number of k-tiles.
+template <class P>
+__global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(tcdiff_tn_group g) {
+    typedef typename P::elem_t T;
+    typedef AttnCfg<P> C;
+    constexpr int ES = sizeof(T), NS = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    constexpr int STAGE = 2 * 128 * TC_ROWB, WOFF = 128 * TC_ROWB;
+    // Unit order = (problem, k-chunk of g.kc k-tiles, tile, k-tile inside the chunk), shares handed out so that an XCD owns a
+    // contiguous range of them: at any moment the 32 CUs of an XCD work on neighbouring tiles of the SAME chunk of token rows,
+    // i.e. on the same few column blocks of dY and X, which then come out of that XCD's L2.  (Tile-major order over the whole
+    // contraction -- neighbours at unrelated token rows -- ran at HBM speed: 196 us for a decoder layer's group, 6.6 TB/s.)
+    int u = xcd_remap(blockIdx.x, gridDim.x) * g.units_per_wg;
+    const int u_end = min(u + g.units_per_wg, g.total_units);
+    while (u < u_end) {
+        int pi = 0;
+        while (pi + 1 < g.n_prob && g.p[pi + 1].unit0 <= u) ++pi;            // wave-uniform scan over <= 16 problems
+        const tcdiff_tn_problem pr = g.p[pi];
+        const int tiles_n = pr.N / 128, tiles = (pr.M / 128) * tiles_n;
+        const int lu = u - pr.unit0;
+        int ch = lu / (tiles * g.kc);
+        const int nch = (pr.nk + g.kc - 1) / g.kc;
+        ch = ch < nch ? ch : nch - 1;
+        const int clen = min(g.kc, pr.nk - ch * g.kc);                       // k-tiles in this chunk
+        const int local = lu - ch * tiles * g.kc;
+        const int tile = local / clen, kin = local - tile * clen;
+        const int kt0 = ch * g.kc + kin;
+        const int nk = min(clen - kin, u_end - u);
+        const int m0 = (tile / tiles_n) * 128, n0 = (tile % tiles_n) * 128;
+        const char* A = reinterpret_cast<const char*>(pr.A);
+        const char* B = reinterpret_cast<const char*>(pr.B);
+        const long lda_b = (long)pr.lda * ES, ldb_b = (long)pr.ldb * ES;
+        const int Kt = pr.nk * P::KT;
+        f32x16_t acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.0f;
+        auto issue = [&](int t) {
+            const int tt = kt0 + (t < nk ? t : nk - 1);
+            char* dst = smem + (t % NS) * STAGE;
+#pragma unroll
+            for (int c = 0; c < ES; ++c) {
+                stage_glds<P::KT, 4>(dst + c * (P::KT * TC_ROWB), A + (long)m0 * ES + c * TC_ROWB, lda_b, tt * P::KT, Kt, 0, wave, lane);
+                stage_glds<P::KT, 4>(dst + WOFF + c * (P::KT * TC_ROWB), B + (long)n0 * ES + c * TC_ROWB, ldb_b, tt * P::KT, Kt, 0,
+                                     wave, lane);
+            }
+        };
+#pragma unroll
+        for (int t = 0; t < NS - 1; ++t) issue(t);
+        for (int kt = 0; kt < nk; ++kt) {
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // tile kt landed: all but the 8 (NS - 2) younger DMAs of this wave
+            __syncthreads();
+            issue(kt + NS - 1);
+            const int cur = kt % NS;
+            const char* ta = smem + cur * STAGE + (wm * 64) * TC_ROWB;
+            const char* tw = smem + cur * STAGE + WOFF + (wn * 64) * TC_ROWB;
+#pragma unroll
+            for (int k32 = 0; k32 < C::NKT; ++k32)
+#pragma unroll
+                for (int st = 0; st < C::PV_STEPS; ++st) {
+                    u32x4 fa[2], fw[2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) fa[i] = v_frag<P>(ta, i, k32, st, lane);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) fw[j] = v_frag<P>(tw, j, k32, st, lane);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) P::mma(acc[i][j], fw[j], fa[i]);
+                }
+        }
+        sync_dma();          // the re-issued tail DMAs have landed, every wave is out of the last tile: smem becomes the output stage
+        // out[m][n] += acc through LDS: 64 consecutive floats per atomic wave-instruction (gemm_tile_kernel, TC_EPI_ATOMIC_F32)
+        constexpr int RSF = 128 * 4 + 16;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            if (wm == pass) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int ml = i * 32 + r;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4) {
+                            const int nl = wn * 64 + j * 32 + 8 * q4 + 4 * h;
+                            const f32x4_t pk = {acc[i][j][4 * q4 + 0], acc[i][j][4 * q4 + 1], acc[i][j][4 * q4 + 2], acc[i][j][4 * q4 + 3]};
+                            *reinterpret_cast<f32x4_t*>(smem + ml * RSF + nl * 4) = pk;
+                        }
+                }
+            }
+            __syncthreads();
+#pragma unroll 4
+            for (int c = tid; c < 64 * 128; c += 256) {
+                const int row = c >> 7, col = c & 127;
+                unsafeAtomicAdd(pr.out + (long)(m0 + pass * 64 + row) * pr.ldc + n0 + col,
+                                *reinterpret_cast<const float*>(smem + row * RSF + col * 4));
+            }
+            __syncthreads();          // the stage is reused: by the second pass, then by the next segment's DMA
+        }
+        u += nk;
+    }
+}
+
+// =================================================================================================
 // gemm_rowln: 64 x 512 tiles, 512 threads; row-complete epilogue
 // =================================================================================================
 #define ROWLN_SMEM (2 * (64 + 512) * TC_ROWB)
@@ -754,6 +874,58 @@ extern "C" int tcdiff_gemm_tn(int dtype, const void* A, const void* B, int M, in
         if (deep) TC_LAUNCH_TN(MmaF32, 4); else TC_LAUNCH_TN(MmaF32, 2);
     }
 #undef TC_LAUNCH_TN
+    TC_CHECK_LAUNCH();
+    return TC_OK;
+}
+
+// several weight gradients in one evenly split launch (include/tcdiff_hip.h)
+extern "C" int tcdiff_gemm_tn_grouped(int dtype, const tcdiff_tn_problem* probs, int n_prob, hipStream_t stream) {
+    if (!probs || n_prob <= 0 || n_prob > TC_TN_MAX_PROB) return TC_ERR_ARG;
+    if (dtype != TC_DTYPE_BF16 && dtype != TC_DTYPE_F32) return TC_ERR_ARG;
+    const int es = dtype == TC_DTYPE_BF16 ? 2 : 4;
+    const int kt = dtype == TC_DTYPE_BF16 ? 64 : 32;
+    tcdiff_tn_group g = {};
+    g.n_prob = n_prob;
+    long units = 0;
+    for (int i = 0; i < n_prob; ++i) {
+        tcdiff_tn_problem p = probs[i];
+        if (!p.A || !p.B || !p.out || p.M <= 0 || p.N <= 0 || p.K <= 0 || p.ldc < p.N || p.lda < p.M || p.ldb < p.N) return TC_ERR_ARG;
+        if (p.M % 128 || p.N % 128 || p.K % kt) return TC_ERR_UNSUPPORTED;
+        if (!aligned16(p.A) || !aligned16(p.B) || !aligned16(p.out) || ((long)p.lda * es) % 16 || ((long)p.ldb * es) % 16)
+            return TC_ERR_ALIGN;
+        if ((long)p.K * p.lda * es >= (1L << 32) || (long)p.K * p.ldb * es >= (1L << 32)) return TC_ERR_ARG;
+        p.nk = p.K / kt;
+        p.unit0 = (int)units;
+        units += (long)(p.M / 128) * (p.N / 128) * p.nk;
+        if (units >= (1L << 31)) return TC_ERR_ARG;
+        g.p[i] = p;
+    }
+    static tc_dev_state dev_state;
+    const int n_cu = tc_device_once(dev_state, [](int) {
+        hipError_t a = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_grouped_kernel<MmaBF16>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 128 * TC_ROWB);
+        hipError_t b = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_grouped_kernel<MmaF32>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 128 * TC_ROWB);
+        return a != hipSuccess ? a : b;
+    });
+    if (n_cu < 0) return n_cu;
+    g.total_units = (int)units;
+    // one workgroup per CU (128 KB of LDS each); shares of at least 4 k-tiles so that tiny groups do not pay a prologue per unit
+    long per = (units + n_cu - 1) / n_cu;
+    if (per < 4) per = 4;
+    g.units_per_wg = (int)per;
+    // chunk of the contraction a tile is accumulated over before it is added = one share: a workgroup then flushes one or two
+    // tiles, and the 32 workgroups of an XCD sit on 32 neighbouring tiles of the same token rows.  Measured on a decoder
+    // layer's eight gradients (14 400 tokens, 155 k-tiles per share): chunk = share 126 us, half a share 131 us, a quarter
+    // 147 us (more atomics), the whole contraction (tile-major, no sharing in L2) 196 us.
+    // (chunk != share makes every share straddle two segments: a lone 512 x 512 problem 85 us instead of 27)
+    long kc = per;
+    g.kc = (int)kc;
+    const unsigned grid = (unsigned)((units + per - 1) / per);
+    if (dtype == TC_DTYPE_BF16)
+        hipLaunchKernelGGL(gemm_tn_grouped_kernel<MmaBF16>, dim3(grid), dim3(256), 4 * 2 * 128 * TC_ROWB, stream, g);
+    else
+        hipLaunchKernelGGL(gemm_tn_grouped_kernel<MmaF32>, dim3(grid), dim3(256), 4 * 2 * 128 * TC_ROWB, stream, g);
     TC_CHECK_LAUNCH();
     return TC_OK;
 }

@@ -260,6 +260,17 @@ def gemm_tn(dt, A, B, M, N, K, lda, ldb, out, ldc, splits):
     L.check(L.load().tcdiff_gemm_tn(dt, _p(A), _p(B), M, N, K, lda, ldb, _p(out), ldc, splits, stream()), "tcdiff_gemm_tn")
 
 
+def gemm_tn_grouped(dt, problems):
+    """problems: list of (A, B, M, N, K, lda, ldb, out, ldc) as gemm_tn takes them, at most L.TN_MAX_PROB: all of them in ONE
+    launch with the work split evenly over the CUs (the weight gradients a decoder layer's backward has queued)."""
+    n = len(problems)
+    arr = (L.TnProblem * n)()
+    for d, (A, B, M, N, K, lda, ldb, out, ldc) in zip(arr, problems):
+        d.A, d.B, d.out = _p(A), _p(B), _p(out)
+        d.M, d.N, d.K, d.lda, d.ldb, d.ldc = M, N, K, lda, ldb, ldc
+    L.check(L.load().tcdiff_gemm_tn_grouped(dt, arr, n, stream()), "tcdiff_gemm_tn_grouped")
+
+
 def ct_table(dt, entries, device):
     """Device table for cast_transpose_multi.  entries: dicts with src (fp32 tensor view), rows, cols, ld_src and dst /
     ld_dst / cols_pad and / or dstT / ld_dstT / rows_pad.  Returns (table tensor, n_desc, n_tiles); the table holds raw

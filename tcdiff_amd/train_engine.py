@@ -170,7 +170,10 @@ class _Lin:
             # one workgroup per CU: measured (tools/gemm_shapes.py, 14 400 rows) 512x512: 16 splits 29 us, 32 splits 40 us, 1: 149 us
             splits = max(1, min(256 // tiles, Mp // kt, 64))
             if tn:
-                K.gemm_tn(dt, dY.view(-1)[lo:], X, ng, self.K, M, ld_dy, X.shape[1], gW[lo * self.K:], self.K, splits)
+                if eng.group_wgrad:       # queued: all weight gradients of the layer go out as one evenly split launch
+                    eng.queue_wgrad((dY.view(-1)[lo:], X, ng, self.K, M, ld_dy, X.shape[1], gW[lo * self.K:], self.K))
+                else:
+                    K.gemm_tn(dt, dY.view(-1)[lo:], X, ng, self.K, M, ld_dy, X.shape[1], gW[lo * self.K:], self.K, splits)
                 continue
             Xt = eng.e(self.K, Mp)
             K.cast_transpose(dt, X, M, self.K, X.shape[1], dstT=Xt, ld_dstT=Mp, rows_pad=Mp)
@@ -206,6 +209,7 @@ class TrainEngine:
         self.seed = torch.zeros(2, device=self.dev, dtype=torch.int32)
         self.packed_version = None
         self._ct = self._ct_ptrs = self._ct_keep = None
+        self._wq = []
         self.sv = None
         self._pz = {}
         self._define()
@@ -361,6 +365,19 @@ class TrainEngine:
 
     def row_fwd(self, **kw):
         K.row_fwd(self.dt, self._row(**kw))
+
+    group_wgrad = not bool(int(_os.environ.get("TCDIFF_TRAIN_NOGROUP", "0")))      # A/B: one tcdiff_gemm_tn launch per linear
+
+    def queue_wgrad(self, prob):
+        """prob = gemm_tn's arguments; the operand tensors stay referenced (alive) until the flush."""
+        self._wq.append(prob)
+        if len(self._wq) == L.TN_MAX_PROB:
+            self.flush_wgrad()
+
+    def flush_wgrad(self):
+        if self._wq:
+            K.gemm_tn_grouped(self.dt, self._wq)
+            self._wq = []
 
     def row_bwd(self, *, M, L_, ln=None, nln=None, lin=None, **kw):
         """tcdiff_row_bwd with its parameter gradients added straight into the flat gradient buffer.
@@ -678,6 +695,7 @@ class TrainEngine:
             g_r, g_h = e(M, 512), e(M, 512)
             lins[f"l{l}.qkv"].bwd(dQKV, 1536, M, [s["r1"], s["h1"]], [("T", g_r, 512), ("T", g_h, 512)])
             g_x = gx1
+            self.flush_wgrad()                            # the layer's seven weight gradients: one evenly split launch
             if sync is not None:                          # this layer's linears are complete: average them across the ranks now
                 sync.ready(self.flat, *self.layer_range[l])
         # ---- front: layer 0's norm1 / rotary on the fusion projection's output, then the fusion MLP -----------------------------
@@ -771,6 +789,7 @@ class TrainEngine:
         lins["c2"].bwd(dtok0, 512, Ms, [sv["c1"]], [("T", dc1, dc1.shape[1])], bias_done=True)
         dc0a = self.act_bwd(sv["c0a"], dc1, Ms, self.Cd, L.ACT_RELU)
         lins["c0"].bwd(dc0a, dc0a.shape[1], Ms, [sv["cin"]], [None])
+        self.flush_wgrad()
         self.sv = None
         if sync is not None:                              # everything outside the decoder layers, then wait for all of it
             sync.ready(self.flat, 0, self.layer_range[0][0])

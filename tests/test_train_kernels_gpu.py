@@ -96,6 +96,36 @@ def test_gemm_tn_weight_gradient_from_token_major_operands(compute):
 
 
 @pytest.mark.parametrize("compute", ["f32", "bf16"])
+def test_gemm_tn_grouped_adds_every_weight_gradient_of_the_group(compute):
+    """several dW_i += dY_i^T X_i in one launch whose (tile, k-tile) units are cut into equal shares: shares cross tile AND
+    problem boundaries (different shapes, different token counts), every output still gets exactly its own sum"""
+    dt, T, tol = mode(compute)
+    g = torch.Generator().manual_seed(15)
+    shapes = [(256, 128, 1344), (128, 384, 1344), (512, 512, 704), (128, 128, 64), (384, 256, 2112)]     # (n_out, n_in, tokens)
+    probs, checks, dYs, Xs = [], [], [], []
+    for n_out, n_in, rows in shapes:
+        ld_dy, ldx = n_out + 128, n_in
+        dY = torch.randn(rows, ld_dy, generator=g).to(T)
+        X = torch.randn(rows, ldx, generator=g).to(T)
+        init = torch.randn(n_out, n_in, generator=g)
+        out = init.clone().to(DEV)
+        want = init.double() + dY[:, 64:64 + n_out].double().t() @ X.double()
+        dYd, Xd = dY.to(DEV), X.to(DEV)
+        dYs.append(dY)
+        Xs.append(X)
+        probs.append((dYd.view(-1)[64:], Xd, n_out, n_in, rows, ld_dy, ldx, out, n_in))
+        checks.append((out, want))
+    K.gemm_tn_grouped(dt, probs)
+    for i, (out, want) in enumerate(checks):
+        assert rel(out, want) < (1e-6 if compute == "f32" else 1e-5), i
+    K.gemm_tn_grouped(dt, probs[:1])                       # a group of one accumulates on top: init + 2 x product
+    prod = dYs[0][:, 64:64 + shapes[0][0]].double().t() @ Xs[0].double()
+    assert rel(checks[0][0], checks[0][1] + prod) < (1e-6 if compute == "f32" else 1e-5)
+    with pytest.raises(L.TcdiffError):
+        K.gemm_tn_grouped(dt, [(probs[0][0], probs[0][1], 200, 128, 1344, probs[0][5], probs[0][6], probs[0][7], 128)])
+
+
+@pytest.mark.parametrize("compute", ["f32", "bf16"])
 @pytest.mark.parametrize("act,p", [(L.ACT_GELU, 0.1), (L.ACT_RELU, 0.0), (L.ACT_SILU, 0.1)])
 def test_gemm_tile_fused_activation_epilogues_equal_the_separate_launches(compute, act, p):
     """nn.Linear + activation + nn.Dropout in one launch (out = pre-activation, out2 = its activated, dropped image) and the
