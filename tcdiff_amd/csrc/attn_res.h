@@ -143,19 +143,23 @@ __global__ __launch_bounds__(512) void attention_res_kernel(const char* __restri
                     for (int q = 0; q < 16; q += 2) {
                         const f32x2_t x = __builtin_elementwise_fma(f32x2_t{s[g][kt][q], s[g][kt][q + 1]}, l2, nm);
                         const f32x2_t p = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
-                        rs2 += p;                               // the softmax denominator is taken BEFORE the dropout
-                        if constexpr (TRAIN) {
-                            if (ta.thr) {
-                                const uint32_t x = ((uint32_t)(seq * H + head) * (uint32_t)Lq + (uint32_t)(qbase + g * 32 + r)) *
-                                                       (uint32_t)Lk + (uint32_t)(kv0 + kt * 32);
-                                s[g][kt][q] = drop_apply(dc, x + (uint32_t)acc_row(q, h), p[0]);
-                                s[g][kt][q + 1] = drop_apply(dc, x + (uint32_t)acc_row(q + 1, h), p[1]);
-                                continue;
-                            }
-                        }
                         s[g][kt][q] = p[0];
                         s[g][kt][q + 1] = p[1];
+                        rs2 += p;                               // the softmax denominator is taken BEFORE the dropout
                     }
+                if constexpr (TRAIN) {
+                    // dropout as its own pass over the registers, under ONE wave-uniform branch: inside the exp loop it broke that
+                    // loop's packed-math schedule (p = 0: 37 us against the sampler's 28 us for the same work)
+                    if (ta.thr) {
+                        const uint32_t x0 = ((uint32_t)(seq * H + head) * (uint32_t)Lq + (uint32_t)(qbase + g * 32 + r)) * (uint32_t)Lk +
+                                            (uint32_t)kv0;
+#pragma unroll
+                        for (int kt = 0; kt < NS; ++kt)
+#pragma unroll
+                            for (int q = 0; q < 16; ++q)
+                                s[g][kt][q] = drop_apply(dc, x0 + (uint32_t)(kt * 32 + acc_row(q, h)), s[g][kt][q]);
+                    }
+                }
                 float rs = rs2[0] + rs2[1];
                 rs += other_half(rs);
                 if (__builtin_amdgcn_ballot_w64(m_new > m_run[g]) != 0) {
