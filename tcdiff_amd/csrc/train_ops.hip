@@ -446,6 +446,8 @@ __global__ __launch_bounds__(256) void row_fwd_kernel(tcdiff_row_args a) {
 // per block: a wave walks its rows serially (each row is a chain of loads and two wave reductions), so the launch needs
 // waves, not work per wave -- with 4 waves x 8 blocks per sequence (one wave per SIMD at 32 sequences) it ran at a quarter
 // of the HBM rate.  196 VGPRs = two waves per SIMD = one block per CU; capped at 128 it spills 364 bytes per lane.
+// (Tried: the seven column sums and three constants in LDS with ds_add_f32 per element -- 120 VGPRs, but LDS float atomics
+// retire under one lane per clock: 168 us per launch instead of 37.)
 constexpr int ROWB_WAVES = 8;
 template <class P>
 __global__ __launch_bounds__(64 * ROWB_WAVES) void row_bwd_kernel(tcdiff_row_args a) {
