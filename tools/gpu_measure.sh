@@ -35,3 +35,4 @@ rm -rf gpurun_out/prof_train
 python tools/train_shapes.py --batch 32 --top 60 2>/dev/null | grep -v amdgpu.ids > gpurun_out/${R}_train_shapes_b32.log
 python tools/gemm_shapes.py 2>/dev/null | grep -v amdgpu.ids > gpurun_out/${R}_gemm_shapes.log
 python tools/attn_bench.py 2>/dev/null | grep -v amdgpu.ids > gpurun_out/${R}_attn_bench.log
+python tools/tn_probe.py 2>/dev/null | grep -v amdgpu.ids > gpurun_out/${R}_tn_probe.log
