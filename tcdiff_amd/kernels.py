@@ -30,7 +30,8 @@ def stream() -> int:
 
 
 def _p(t):
-    return None if t is None else C.c_void_p(t.data_ptr())
+    """device address for a c_void_p argument / struct field (a plain int converts as well as a c_void_p object and costs a third)"""
+    return None if t is None else t.data_ptr()
 
 
 def gemm_tile(dt, A, W, M, N, K, *, lda=None, ldw=None, A2=None, split_n=0, a_mod=0, mode=L.EPI_STORE_T,
@@ -311,10 +312,7 @@ def act_drop_bwd(dt, a, ld_a, dy, ld_y, da, rows, cols, act, seed=None, site=0, 
 
 
 def row_args(**kw) -> "L.RowArgs":
-    a = L.RowArgs()
-    for k, v in kw.items():
-        setattr(a, k, v.data_ptr() if isinstance(v, torch.Tensor) else v)
-    return a
+    return L.RowArgs(**{k: (v.data_ptr() if isinstance(v, torch.Tensor) else v) for k, v in kw.items()})
 
 
 def row_fwd(dt, a):

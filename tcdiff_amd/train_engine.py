@@ -210,6 +210,7 @@ class TrainEngine:
         self.packed_version = None
         self._ct = self._ct_ptrs = self._ct_keep = None
         self._wq = []
+        self._graphs, self._pool, self._graph_broken = {}, None, None
         self.sv = None
         self._pz = {}
         self._define()
@@ -366,6 +367,11 @@ class TrainEngine:
     def row_fwd(self, **kw):
         K.row_fwd(self.dt, self._row(**kw))
 
+    # TCDIFF_TRAIN_GRAPH=1: replay forward / backward as hipGraphs from the third step with the same shapes on.  OFF by default:
+    # measured on MI355X, batch 32 (device time 12.2 ms): eager 12.4-13.1 ms per step over the boxes (the host, ~10-12 ms of
+    # Python + launch calls, runs ahead of the device and the kernels queue back to back), captured 14.4 ms -- the ~550 kernel
+    # nodes of the two graphs are dispatched with a gap each.  Batch 4 (device 9.5 ms, host-bound when eager): 13.2 -> 10.7 ms.
+    use_graphs = bool(int(_os.environ.get("TCDIFF_TRAIN_GRAPH", "0")))
     group_wgrad = not bool(int(_os.environ.get("TCDIFF_TRAIN_NOGROUP", "0")))      # A/B: one tcdiff_gemm_tn launch per linear
 
     def queue_wgrad(self, prob):
@@ -410,25 +416,63 @@ class TrainEngine:
     # ------------------------------------------------------------------------------------------------------------------
     def forward(self, x, cond, times, keep, seed: Tuple[int, int], p_drop: float):
         """x (B, Lq, nf) fp32, cond (B, 2S(+1), Cd), times (B,) long, keep (B,) bool -> out (B, Lq, nf) fp32.
-        model/model.py:548-624 with train-mode dropout (probability p_drop; 0 = the eval-mode arithmetic)."""
-        if self.sv is not None and self.sv.get("pending"):
-            pass        # a forward without its backward (e.g. a validation pass with gradients enabled): simply overwritten
+        model/model.py:548-624 with train-mode dropout (probability p_drop; 0 = the eval-mode arithmetic).
+        Host part (dropout parameters, seed words to device memory, weight repack when a parameter changed, input conversion),
+        then the launch schedule `_fwd` -- directly, or from the third call with the same shapes on as a replayed hipGraph
+        (the ~250 launches of the forward cost ~5 ms of Python / ctypes time per step, the ~300 of the backward ~8 ms: more than
+        their device time on a slow host)."""
+        B = x.shape[0]
+        self.thr, self.dscale = K.drop_params(p_drop)
+        self.seed.copy_(torch.tensor([seed[0] & 0x7FFFFFFF, seed[1] & 0x7FFFFFFF], dtype=torch.int32))
+        self.repack()
+        x = x.reshape(B, self.Lq, self.nf).to(device=self.dev, dtype=torch.float32).contiguous()
+        cond = cond.to(device=self.dev, dtype=torch.float32).contiguous()
+        if cond.shape[1] // 2 != self.S:
+            raise L.TcdiffError(f"cond length {cond.shape[1]} does not pair into seq_len={self.S} tokens (model/model.py:572-589)")
+        times = times.to(device=self.dev, dtype=torch.int32).contiguous()
+        keep = keep.to(device=self.dev, dtype=torch.uint8).contiguous()
+        if not self.use_graphs or self.poison or self._graph_broken:
+            return self._fwd(x, cond, times, keep)
+        key = (B, cond.shape[1], float(p_drop))
+        st = self._graphs.setdefault(key, {"n": 0, "fwd": None, "bwd": None})
+        st["n"] += 1
+        if st["fwd"] is None:
+            if st["n"] < 3:
+                return self._fwd(x, cond, times, keep)
+            try:
+                if self._pool is None:
+                    self._pool = torch.cuda.graph_pool_handle()
+                st["x"], st["cond"], st["t"], st["keep"] = x.clone(), cond.clone(), times.clone(), keep.clone()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=self._pool, capture_error_mode="thread_local"):
+                    out = self._fwd(st["x"], st["cond"], st["t"], st["keep"])
+                st["fwd"], st["out"], st["sv"] = g, out, self.sv
+                st["sv"]["graph"] = st
+            except Exception as ex:                       # noqa: BLE001  -- never let the optimisation take the step down
+                self._graph_broken = f"{type(ex).__name__}: {ex}"
+                st["fwd"] = None
+                return self._fwd(x, cond, times, keep)
+        else:
+            st["x"].copy_(x)
+            st["cond"].copy_(cond)
+            st["t"].copy_(times)
+            st["keep"].copy_(keep)
+        st["fwd"].replay()
+        self.sv = st["sv"]
+        self.sv["pending"] = True
+        return st["out"].view(B, self.Lq, self.nf)
+
+    def _fwd(self, x, cond, times, keep_u8):
+        """the forward's launches; x (B, Lq, nf) fp32, cond (B, clen, Cd) fp32, times int32, keep uint8: device, contiguous"""
         dt, lins = self.dt, self.lins
         B = x.shape[0]
         S, dn, Lq, nf, H, NL, Cd = self.S, self.dn, self.Lq, self.nf, self.H, self.NL, self.Cd
         M, Ms, Mc = B * Lq, B * S, B * (S + 2)
-        self.thr, self.dscale = K.drop_params(p_drop)
-        self.seed.copy_(torch.tensor([seed[0] & 0x7FFFFFFF, seed[1] & 0x7FFFFFFF], dtype=torch.int32))
-        self.repack()
         sv = dict(B=B, pending=True)
         P, e, z = self.P, self.e, self.z
         f32 = torch.float32
-        x = x.reshape(M, nf).float().contiguous()
-        cond = cond.to(self.dev).float().contiguous()
+        x = x.view(M, nf)
         clen = cond.shape[1]
-        if clen // 2 != S:
-            raise L.TcdiffError(f"cond length {clen} does not pair into seq_len={S} tokens (model/model.py:572-589)")
-        keep_u8 = keep.to(device=self.dev, dtype=torch.uint8).contiguous()
         sv["keep"] = keep_u8
 
         # ---- music branch: cond_projection, two encoder layers (model/model.py:572-583,211-245) -------------------------
@@ -496,7 +540,7 @@ class TrainEngine:
         sv.update(pooled=pooled, ph=ph, pa=pa, pb=pb)
         # ---- time path (model/model.py:601-612) and the FiLM generators (:154-168) ----------------------------------------
         emb = e(B, 512)
-        K.sinusoidal(dt, times.to(device=self.dev, dtype=torch.int32).contiguous(), B, self.sin_freq, emb)
+        K.sinusoidal(dt, times, B, self.sin_freq, emb)
         ta = e(B, 2048)
         lins["t1"].fwd(emb, B, out=ta)
         th = self.act_fwd(ta, B, 2048, L.ACT_MISH)
@@ -607,6 +651,47 @@ class TrainEngine:
         if sv is None or not sv.get("pending"):
             raise L.TcdiffError("backward without a matching train-mode forward (one forward may be outstanding per model)")
         sv["pending"] = False
+        # a parameter's .grad may still alias the previous step's flat buffer (the caller accumulates across calls
+        # instead of zero_grad): never overwrite gradients somebody still holds
+        p_first = self.params[next(iter(self.slot))]
+        aliased = p_first.grad is not None and \
+            p_first.grad.untyped_storage().data_ptr() == self.flat.untyped_storage().data_ptr()
+        if aliased:
+            self._new_flat()
+            for st in self._graphs.values():              # captured backwards write the buffer that was just given away
+                st["bwd"] = None
+        sync = None
+        if self.grad_sync is not False:
+            from .dist import FlatGradientAllReducer
+            if FlatGradientAllReducer.active():
+                sync = self.grad_sync = self.grad_sync or FlatGradientAllReducer()
+        B = sv["B"]
+        d_out = d_out.reshape(B * self.Lq, self.nf).to(dtype=torch.float32).contiguous()
+        st = sv.get("graph")
+        if st is None or sync is not None or self.poison or self._graph_broken:
+            self._bwd(sv, d_out, sync, zero=not aliased)
+            return self.grad_views()
+        if st["bwd"] is None:
+            try:
+                st["dout"] = d_out.clone()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=self._pool, capture_error_mode="thread_local"):
+                    self._bwd(sv, st["dout"], None, zero=True)
+                st["bwd"] = g
+            except Exception as ex:                       # noqa: BLE001
+                self._graph_broken = f"{type(ex).__name__}: {ex}"
+                st["bwd"] = None
+                self._wq = []
+                self._bwd(sv, d_out, None, zero=True)
+                return self.grad_views()
+        else:
+            st["dout"].copy_(d_out)
+        st["bwd"].replay()
+        self.sv = None
+        return self.grad_views()
+
+    def _bwd(self, sv, d_out, sync, zero=True):
+        """the backward's launches; d_out (M, nf) fp32 contiguous; gradients accumulate into self.flat (zeroed first)"""
         dt, lins = self.dt, self.lins
         B = sv["B"]
         S, dn, Lq, nf, H, NL = self.S, self.dn, self.Lq, self.nf, self.H, self.NL
@@ -615,19 +700,8 @@ class TrainEngine:
         e, z, P = self.e, self.z, self.P
         f32 = torch.float32
         st = "seqTransDecoder.stack."
-        # a parameter's .grad may still alias the previous step's flat buffer (the caller accumulates across calls
-        # instead of zero_grad): never overwrite gradients somebody still holds
-        p_first = self.params[next(iter(self.slot))]
-        if p_first.grad is not None and p_first.grad.untyped_storage().data_ptr() == self.flat.untyped_storage().data_ptr():
-            self._new_flat()
-        else:
+        if zero:
             self.flat.zero_()
-        sync = None
-        if self.grad_sync is not False:
-            from .dist import FlatGradientAllReducer
-            if FlatGradientAllReducer.active():
-                sync = self.grad_sync = self.grad_sync or FlatGradientAllReducer()
-        d_out = d_out.reshape(M, nf).float().contiguous()
         nfilm = NL * 3 * 1024
         dfilm = z(B, nfilm, dtype=f32)
         nk = 512 * NL
@@ -795,7 +869,6 @@ class TrainEngine:
             sync.ready(self.flat, 0, self.layer_range[0][0])
             sync.ready(self.flat, self.layer_range[-1][1], self.n_grad)
             sync.finish()
-        return self.grad_views()
 
 
 class _DenoiserTrainFn(torch.autograd.Function):

@@ -230,6 +230,40 @@ def test_reference_training_loop_runs_unchanged():
     assert float((p.grad - 2 * g1).abs().max()) <= 1e-3 * float(g1.abs().max())
 
 
+def test_captured_step_equals_the_eager_schedule():
+    """TCDIFF_TRAIN_GRAPH=1 (off by default, see train_engine.py): from the third step with the same shapes on, forward and
+    backward are replayed hipGraphs.  Same launches, so the same numbers: the forward bit for bit, the gradients up to the
+    summation order of the fp32 atomics -- checked step by step against the eager schedule on the same parameters."""
+    x_start, cond, _ = step_inputs(0, 10)
+    torch.manual_seed(5)
+    sd, diff = build("f32")
+    diff.train()
+    eng = diff.model.train_engine()
+    optim = Adan(diff.model.parameters(), lr=1e-4, weight_decay=0.0)
+    named = dict(diff.model.named_parameters())
+
+    def grads(graphs, step):
+        eng.use_graphs = graphs
+        diff.model.train_seed = (11, step)
+        t = torch.tensor([3 + step, 30, 60 + step], device=DEV)
+        tot, _ = diff.p_losses(x_start.to(DEV), cond.to(DEV), t, noise=torch.zeros(B, S, DN, 151, device=DEV),
+                               keep_mask=torch.tensor([True, step % 2 == 0, False], device=DEV))
+        optim.zero_grad()
+        tot.backward()
+        return float(tot), {n: p.grad.detach().clone() for n, p in named.items() if p.grad is not None}
+
+    for step in range(6):
+        le, ge = grads(False, step)
+        lg, gg = grads(True, step)
+        assert eng._graph_broken is None, eng._graph_broken
+        assert le == lg, (step, le, lg)                                   # the forward has no atomics
+        worst = max(rel(gg[n].cpu().numpy(), ge[n].cpu().numpy()) for n in ge)
+        assert set(gg) == set(ge) and worst < 2e-5, (step, worst)
+        optim.step()                                                      # on the captured path's gradients
+    st = [v for v in eng._graphs.values() if v["fwd"] is not None and v["bwd"] is not None]
+    assert len(st) == 1 and st[0]["n"] == 6
+
+
 def test_inference_after_training_sees_the_updated_weights():
     sd, diff = build("f32")
     diff.train()

@@ -19,6 +19,7 @@ class _Stub:
 L._lib = _Stub()
 K.stream = lambda: 0
 TE._ALLOW_CPU = True
+TE.TrainEngine.use_graphs = False      # no device, no capture
 from tcdiff_amd.model import DanceDecoder
 from tcdiff_amd.diffusion import GaussianDiffusion
 
@@ -39,3 +40,27 @@ n_grad = sum(p.grad is not None for p in model.parameters())
 print("backward ok; parameters with grad:", n_grad, "of", len(list(model.parameters())), "flat", eng.n_grad)
 shapes_ok = all(p.grad.shape == p.shape for p in model.parameters() if p.grad is not None)
 print("grad shapes ok:", shapes_ok)
+
+# host cost of one forward + backward of the schedule (stub launchers: pure Python / ctypes / allocator time)
+import time
+import cProfile, pstats
+for p in model.parameters():
+    p.grad = None
+t0 = time.perf_counter()
+N = 5
+for _ in range(N):
+    out = TE.denoiser_train(model, x, cond, t, keep, (1, 2), 0.1)
+    out.sum().backward()
+    for p in model.parameters():
+        p.grad = None
+print(f"host time per forward + backward: {(time.perf_counter() - t0) / N * 1e3:.2f} ms")
+if "--profile" in sys.argv:
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(3):
+        out = TE.denoiser_train(model, x, cond, t, keep, (1, 2), 0.1)
+        out.sum().backward()
+        for p in model.parameters():
+            p.grad = None
+    pr.disable()
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
