@@ -488,7 +488,7 @@ def other_configs(a, dev):
     return out
 
 
-def train_step_bench(a, D, dev, world, dn, S, iters=8, warm=3):
+def train_step_bench(a, D, dev, world, dn, S, iters=10, warm=5):
     """TCDiff.train_loop's body (TCDiff.py:227-245) on every rank: diffusion(x, cond) in train mode (dropout live), zero_grad,
     backward (gradients averaged over the ranks by RCCL all-reduces launched layer by layer under the backward), fused Adan,
     fused EMA.  `value` = whole-job steps per second of the data-parallel job = 1 / (max-over-ranks time per step)."""

@@ -73,6 +73,10 @@ typedef struct {
     const void* act_src; int ld_src;
     int act2;
     const int* drop_seed; int drop_site; uint32_t drop_thr; float drop_scale;
+    /* TC_EPI_QKV_HEADS: hgroup > 0 -- the columns of one of Q / K / V hold several images of hgroup heads each (all eight
+     * decoder layers' cross-attention K, or V: model/model.py:394-396 evaluated for every layer in one GEMM); image g starts
+     * hgroup_stride elements after image g - 1. */
+    int hgroup; long hgroup_stride;
 } tcdiff_tile_epi;
 
 /* C[M,N] = A[M,K] * W[N,K]^T with epilogue.  If A2 != NULL, output columns >= split_n (a multiple of 128)

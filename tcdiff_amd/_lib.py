@@ -26,7 +26,7 @@ class TileEpi(C.Structure):
                 ("out_v", _vp), ("ldc", _i), ("L", _i), ("Lp", _i), ("H", _i), ("n_q", _i), ("n_k", _i),
                 ("tok_off", _i), ("seq_off", _i), ("k_splits", _i), ("out2", _vp), ("ldc2", _i), ("act_src", _vp),
                 ("ld_src", _i), ("act2", _i), ("drop_seed", _vp), ("drop_site", _i), ("drop_thr", C.c_uint32),
-                ("drop_scale", _f)]
+                ("drop_scale", _f), ("hgroup", _i), ("hgroup_stride", _l)]
 
 
 class RowEpi(C.Structure):
@@ -149,11 +149,31 @@ class TcdiffError(RuntimeError):
     pass
 
 
+_rec = None          # a list while train_engine records a command list: every launcher call is appended as (function, arguments)
+
+
+class _Recorder:
+    """Stands in for the library while a step is being recorded: calls go through unchanged and are remembered."""
+
+    def __init__(self, lib, out):
+        self._lib, self._out = lib, out
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        out = self._out
+
+        def call(*args):
+            rc = fn(*args)
+            out.append((fn, args))
+            return rc
+        return call
+
+
 def load():
     """Load the HIP library; raises if it has not been built (no CPU fallback exists)."""
     global _lib
     if _lib is not None:
-        return _lib
+        return _lib if _rec is None else _Recorder(_lib, _rec)
     if not os.path.exists(LIB_PATH):
         raise TcdiffError(f"{LIB_PATH} not found: build it with `python -m tcdiff_amd.build` "
                           "(the MI355X path has no CPU fallback)")

@@ -333,9 +333,14 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(const char* __restrict__
                 // column n -> (Q | K | V, head, d); row m -> (sequence, token): head-major images for attention
                 const int which = n < e.n_q ? 0 : (n < e.n_q + e.n_k ? 1 : 2);
                 const int nn = n - (which == 0 ? 0 : (which == 1 ? e.n_q : e.n_q + e.n_k));
-                const int head = nn >> 6, d = nn & 63;
+                int head = nn >> 6;
+                const int d = nn & 63;
                 const int seq = m / e.L + e.seq_off, tok = m % e.L + e.tok_off;
                 T* base = reinterpret_cast<T*>(which == 0 ? e.out : (which == 1 ? e.out_k : e.out_v));
+                if (e.hgroup > 0) {          // several images side by side in the columns (the K / V of all decoder layers' cross-attention)
+                    base += (long)(head / e.hgroup) * e.hgroup_stride;
+                    head = head % e.hgroup;
+                }
                 dst = base + (((long)seq * e.H + head) * e.Lp + tok) * 64 + d;
             }
             if (!qkv && (e.out2 || e.act_src)) {

@@ -367,12 +367,35 @@ class TrainEngine:
     def row_fwd(self, **kw):
         K.row_fwd(self.dt, self._row(**kw))
 
-    # TCDIFF_TRAIN_GRAPH=1: replay forward / backward as hipGraphs from the third step with the same shapes on.  OFF by default:
-    # measured on MI355X, batch 32 (device time 12.2 ms): eager 12.4-13.1 ms per step over the boxes (the host, ~10-12 ms of
-    # Python + launch calls, runs ahead of the device and the kernels queue back to back), captured 14.4 ms -- the ~550 kernel
-    # nodes of the two graphs are dispatched with a gap each.  Batch 4 (device 9.5 ms, host-bound when eager): 13.2 -> 10.7 ms.
-    use_graphs = bool(int(_os.environ.get("TCDIFF_TRAIN_GRAPH", "0")))
+    # From the third step with the same shapes on, forward and backward are REPLAYED: the first two steps run the Python schedule,
+    # the third runs it once more under a stream capture (its private memory pool makes every workspace address permanent), which
+    # yields one hipGraph each for the ~250 launches of the forward and the ~300 of the backward, and -- recorded on the way -- the
+    # list of launcher calls (function + ctypes arguments) and torch copies.  Later steps copy the inputs into the captured input
+    # tensors and replay.  Why: the Python schedule costs 10-13 ms of host time per step (ctypes, allocator, argument structs)
+    # against 12.0 ms of device time at batch 32, so on a slow host the GPU waits for launches (13.6-14.8 ms per step measured on
+    # such boxes, 11.9 ms at batch 4 where the device needs 9.5); replayed, the step is device-bound everywhere (12.7 / 9.6 ms).
+    #   TCDIFF_TRAIN_GRAPH=2 (default) hipGraph replay; =1 the recorded command list as ordinary launches (same time, ~3 us of
+    #   host per launch); =0 never capture.  Data-parallel runs (gradient all-reduces inside the backward) always run eagerly.
+    use_graphs = int(_os.environ.get("TCDIFF_TRAIN_GRAPH", "2"))
     group_wgrad = not bool(int(_os.environ.get("TCDIFF_TRAIN_NOGROUP", "0")))      # A/B: one tcdiff_gemm_tn launch per linear
+
+    def tt(self, fn):
+        """a torch op of the schedule (a copy / fill on tensors that stay put): run it and, while recording, remember it"""
+        fn()
+        if L._rec is not None:
+            L._rec.append((None, fn))
+
+    @staticmethod
+    def _replay(cmds):
+        """the recorded launches again, on the current stream (every launcher's last argument is the stream)"""
+        s = K.stream()
+        for fn, args in cmds:
+            if fn is None:
+                args()
+            else:
+                rc = fn(*args[:-1], s)
+                if rc != 0:
+                    L.check(rc, "replayed launch")
 
     def queue_wgrad(self, prob):
         """prob = gemm_tn's arguments; the operand tensors stay referenced (alive) until the flush."""
@@ -423,7 +446,10 @@ class TrainEngine:
         their device time on a slow host)."""
         B = x.shape[0]
         self.thr, self.dscale = K.drop_params(p_drop)
-        self.seed.copy_(torch.tensor([seed[0] & 0x7FFFFFFF, seed[1] & 0x7FFFFFFF], dtype=torch.int32))
+        # two scalar fills, not a copy from a host tensor: a pageable host-to-device copy blocks the host until everything queued
+        # before it has run -- one full device sync per step, after which the GPU idled while Python queued the next forward
+        self.seed[0].fill_(seed[0] & 0x7FFFFFFF)
+        self.seed[1].fill_(seed[1] & 0x7FFFFFFF)
         self.repack()
         x = x.reshape(B, self.Lq, self.nf).to(device=self.dev, dtype=torch.float32).contiguous()
         cond = cond.to(device=self.dev, dtype=torch.float32).contiguous()
@@ -444,9 +470,13 @@ class TrainEngine:
                     self._pool = torch.cuda.graph_pool_handle()
                 st["x"], st["cond"], st["t"], st["keep"] = x.clone(), cond.clone(), times.clone(), keep.clone()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=self._pool, capture_error_mode="thread_local"):
-                    out = self._fwd(st["x"], st["cond"], st["t"], st["keep"])
-                st["fwd"], st["out"], st["sv"] = g, out, self.sv
+                L._rec = cmds = []
+                try:
+                    with torch.cuda.graph(g, pool=self._pool, capture_error_mode="thread_local"):
+                        out = self._fwd(st["x"], st["cond"], st["t"], st["keep"])
+                finally:
+                    L._rec = None
+                st["fwd"], st["out"], st["sv"], st["fwd_cmds"] = g, out, self.sv, cmds
                 st["sv"]["graph"] = st
             except Exception as ex:                       # noqa: BLE001  -- never let the optimisation take the step down
                 self._graph_broken = f"{type(ex).__name__}: {ex}"
@@ -457,7 +487,10 @@ class TrainEngine:
             st["cond"].copy_(cond)
             st["t"].copy_(times)
             st["keep"].copy_(keep)
-        st["fwd"].replay()
+        if self.use_graphs == 2:
+            st["fwd"].replay()
+        else:
+            self._replay(st["fwd_cmds"])
         self.sv = st["sv"]
         self.sv["pending"] = True
         return st["out"].view(B, self.Lq, self.nf)
@@ -554,17 +587,19 @@ class TrainEngine:
         lins["film"].fwd(fin, B, out=film, f32=True)
         sv.update(emb=emb, ta=ta, th=th, pre=pre, fin=fin, film=film)
         # ---- memory = norm_cond(cat(tokens, time tokens)) and every layer's cross-attention K / V (:615-616,386-396) --------
-        memin = torch.cat([sel_tok.view(B, S, 512), tcat[:, 512:].reshape(B, 2, 512)], 1).contiguous()   # copies only
+        memin = e(B, S + 2, 512, dtype=f32)                # cat(tokens, the two time tokens): copies only
+        self.tt(lambda: memin[:, :S].copy_(sel_tok.view(B, S, 512)))
+        self.tt(lambda: memin[:, S:].copy_(tcat[:, 512:].unflatten(1, (2, 512))))
         mem_h, mem_rot = e(Mc, 512), e(Mc, 512)
         self.row_fwd(flags=L.ROWF_NEXT_LN | L.ROWF_STORE_H | L.ROWF_STORE_ROT, M=Mc, L=S + 2, z=memin.view(Mc, 512),
                      nln_g=P("norm_cond.weight"), nln_b=P("norm_cond.bias"), nln_eps=1e-5, hout=mem_h, rout=mem_rot,
                      rope=self.rope, pos_mod=S + 2)
         Kc, Vc = self.pz("Kc", NL, B, H, self.Lpc, 64), self.pz("Vc", NL, B, H, self.Lpc, 64)
         nk = 512 * NL
-        for l in range(NL):
-            hd = dict(out=None, scale_q=1.0, Lseq=S + 2, Lp=self.Lpc, n_q=0)
-            lins["ckv"].fwd(mem_rot, Mc, heads=dict(out_k=Kc[l], out_v=None, n_k=512, **hd), rows=(512 * l, 512 * l + 512))
-            lins["ckv"].fwd(mem_h, Mc, heads=dict(out_k=None, out_v=Vc[l], n_k=0, **hd), rows=(nk + 512 * l, nk + 512 * l + 512))
+        # all layers' w_ks(rot(memory)) and w_vs(memory) as ONE GEMM: columns [0, nk) take rot(memory), [nk, 2 nk) memory; the
+        # epilogue scatters layer l's eight heads into the image Kc[l] / Vc[l]
+        lins["ckv"].fwd(mem_rot, Mc, A2=mem_h, heads=dict(out=None, out_k=Kc, out_v=Vc, scale_q=1.0, Lseq=S + 2, Lp=self.Lpc, n_q=0,
+                                                          n_k=nk, hgroup=H, hgroup_stride=B * H * self.Lpc * 64))
         sv.update(memin=memin, mem_h=mem_h, mem_rot=mem_rot, Kc=Kc, Vc=Vc)
         # ---- motion: input projection + fusion projection (model/model.py:560-561) --------------------------------------------
         xin = self.pz("xin", M, lins["in"].Kp)
@@ -675,9 +710,13 @@ class TrainEngine:
             try:
                 st["dout"] = d_out.clone()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=self._pool, capture_error_mode="thread_local"):
-                    self._bwd(sv, st["dout"], None, zero=True)
-                st["bwd"] = g
+                L._rec = cmds = []
+                try:
+                    with torch.cuda.graph(g, pool=self._pool, capture_error_mode="thread_local"):
+                        self._bwd(sv, st["dout"], None, zero=True)
+                finally:
+                    L._rec = None
+                st["bwd"], st["bwd_cmds"] = g, cmds
             except Exception as ex:                       # noqa: BLE001
                 self._graph_broken = f"{type(ex).__name__}: {ex}"
                 st["bwd"] = None
@@ -686,7 +725,10 @@ class TrainEngine:
                 return self.grad_views()
         else:
             st["dout"].copy_(d_out)
-        st["bwd"].replay()
+        if self.use_graphs == 2:
+            st["bwd"].replay()
+        else:
+            self._replay(st["bwd_cmds"])
         self.sv = None
         return self.grad_views()
 
@@ -701,9 +743,10 @@ class TrainEngine:
         f32 = torch.float32
         st = "seqTransDecoder.stack."
         if zero:
-            self.flat.zero_()
+            self.tt(lambda: self.flat.zero_())
         nfilm = NL * 3 * 1024
-        dfilm = z(B, nfilm, dtype=f32)
+        dfilm = e(B, nfilm, dtype=f32)
+        self.tt(lambda: dfilm.zero_())
         nk = 512 * NL
         dKV = e(Mc, 2 * nk)                              # [dK of layer 0..NL-1 | dV of layer 0..NL-1], token-major
 
@@ -791,14 +834,15 @@ class TrainEngine:
                      z=sv["memin"].view(Mc, 512), nln_g=P("norm_cond.weight"), nln_b=P("norm_cond.bias"), nln_eps=1e-5,
                      rope=self.rope, pos_mod=S + 2, d_h=d_mh, d_rot=d_mrot, d_z=d_memin, dz_f32=1)
         d_memin = d_memin.view(B, S + 2, 512)
-        g_tok_mem = d_memin[:, :S].contiguous()            # copies only
+        g_tok_mem = e(B, S, 512, dtype=f32)                # copies only
+        self.tt(lambda: g_tok_mem.copy_(d_memin[:, :S]))
         # ---- FiLM generators and the time path ------------------------------------------------------------------------------------------
         dfin = e(B, 512)
         lins["film"].bwd(dfilm, nfilm, B, [sv["fin"]], [("T", dfin, 512)])
         d_pre = self.act_bwd(sv["pre"], dfin, B, 512, L.ACT_MISH)          # fp32: = d t_base = d cond_hidden
         d_tcat = e(B, 1536, dtype=f32)
-        d_tcat[:, :512].copy_(d_pre)
-        d_tcat[:, 512:].copy_(d_memin[:, S:].reshape(B, 1024))
+        self.tt(lambda: d_tcat[:, :512].copy_(d_pre))
+        self.tt(lambda: d_tcat[:, 512:].unflatten(1, (2, 512)).copy_(d_memin[:, S:]))
         dth = e(B, 2048)
         lins["tct"].bwd(d_tcat, 1536, B, [sv["th"]], [("T", dth, 2048)])
         dta = self.act_bwd(sv["ta"], dth, B, 2048, L.ACT_MISH)

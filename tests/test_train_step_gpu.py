@@ -230,10 +230,11 @@ def test_reference_training_loop_runs_unchanged():
     assert float((p.grad - 2 * g1).abs().max()) <= 1e-3 * float(g1.abs().max())
 
 
-def test_captured_step_equals_the_eager_schedule():
-    """TCDIFF_TRAIN_GRAPH=1 (off by default, see train_engine.py): from the third step with the same shapes on, forward and
-    backward are replayed hipGraphs.  Same launches, so the same numbers: the forward bit for bit, the gradients up to the
-    summation order of the fp32 atomics -- checked step by step against the eager schedule on the same parameters."""
+@pytest.mark.parametrize("mode", [2, 1])
+def test_captured_step_equals_the_eager_schedule(mode):
+    """From the third step with the same shapes on, forward and backward are replayed (train_engine.py: 2 = the captured
+    hipGraphs, 1 = the recorded launcher calls).  Same launches, so the same numbers: the forward bit for bit, the gradients up
+    to the summation order of the fp32 atomics -- checked step by step against the eager schedule on the same parameters."""
     x_start, cond, _ = step_inputs(0, 10)
     torch.manual_seed(5)
     sd, diff = build("f32")
@@ -243,7 +244,7 @@ def test_captured_step_equals_the_eager_schedule():
     named = dict(diff.model.named_parameters())
 
     def grads(graphs, step):
-        eng.use_graphs = graphs
+        eng.use_graphs = mode if graphs else 0
         diff.model.train_seed = (11, step)
         t = torch.tensor([3 + step, 30, 60 + step], device=DEV)
         tot, _ = diff.p_losses(x_start.to(DEV), cond.to(DEV), t, noise=torch.zeros(B, S, DN, 151, device=DEV),
