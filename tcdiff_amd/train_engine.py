@@ -211,6 +211,7 @@ class TrainEngine:
         self._ct = self._ct_ptrs = self._ct_keep = None
         self._wq = []
         self._graphs, self._pool, self._graph_broken = {}, None, None
+        self._gv = self._gv_flat = None
         self.sv = None
         self._pz = {}
         self._define()
@@ -315,6 +316,24 @@ class TrainEngine:
             else:
                 out.append(None)
         return out
+
+    def deliver_grads(self) -> List[Optional[torch.Tensor]]:
+        """What the autograd node returns for the parameters.  Normally nothing: every live parameter's .grad is SET here to a
+        persistent view of the flat buffer (or added to, if the caller kept gradients from an earlier backward) -- the 310
+        AccumulateGrad nodes and 310 fresh view tensors per step cost ~1.5 ms of host time between the end of the backward and
+        the optimizer's launch, during which the GPU idled.  A parameter with tensor hooks gets its gradient through autograd."""
+        if any(p._backward_hooks or getattr(p, "_post_accumulate_grad_hooks", None) for p in self.params.values()):
+            return self.grad_views()
+        if self._gv is None or self._gv_flat is not self.flat:
+            self._gv = [(self.params[n], self.flat[o:o + cnt].view(self.params[n].shape)) for n, (o, cnt) in self.slot.items()]
+            self._gv_flat = self.flat
+        for p, v in self._gv:
+            g = p.grad
+            if g is None:
+                p.grad = v
+            else:
+                g.add_(v)
+        return [None] * len(self.order)
 
     def repack(self):
         """W / W^T operand packs of every linear from the fp32 masters, when a parameter changed (once per optimizer step):
@@ -705,7 +724,7 @@ class TrainEngine:
         st = sv.get("graph")
         if st is None or sync is not None or self.poison or self._graph_broken:
             self._bwd(sv, d_out, sync, zero=not aliased)
-            return self.grad_views()
+            return self.deliver_grads()
         if st["bwd"] is None:
             try:
                 st["dout"] = d_out.clone()
@@ -722,7 +741,7 @@ class TrainEngine:
                 st["bwd"] = None
                 self._wq = []
                 self._bwd(sv, d_out, None, zero=True)
-                return self.grad_views()
+                return self.deliver_grads()
         else:
             st["dout"].copy_(d_out)
         if self.use_graphs == 2:
@@ -730,7 +749,7 @@ class TrainEngine:
         else:
             self._replay(st["bwd_cmds"])
         self.sv = None
-        return self.grad_views()
+        return self.deliver_grads()
 
     def _bwd(self, sv, d_out, sync, zero=True):
         """the backward's launches; d_out (M, nf) fp32 contiguous; gradients accumulate into self.flat (zeroed first)"""
