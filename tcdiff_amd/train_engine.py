@@ -7,13 +7,18 @@ The reference trains with torch autograd over ``DanceDecoder.forward`` (model/mo
 the kernels below and keeps the activations the reverse pass needs, and whose backward walks the same graph in reverse:
 
   nn.Linear            forward  tcdiff_gemm_tile;  dgrad = tcdiff_gemm_tile against the transposed weight pack;
-                       wgrad = tcdiff_gemm_splitk over the token rows (dY^T and X^T repacked by tcdiff_cast_transpose,
-                       which also yields the bias gradient)
+                       wgrad = dY^T X straight from the token-major dY and X: queued per decoder layer and flushed as ONE
+                       evenly split launch (tcdiff_gemm_tn_grouped); shapes that form does not take are repacked by
+                       tcdiff_cast_transpose for tcdiff_gemm_splitk
   attention            tcdiff_attention_train / tcdiff_attention_bwd (weights recomputed, dropout bits regenerated)
-  everything between   tcdiff_row_fwd / tcdiff_row_bwd (bias, dropout, LayerNorms, FiLM, residual, rotary) and
-                       tcdiff_act_drop(_bwd); the conditioning path's selects / pool / adds have their own adjoints
+  everything between   tcdiff_row_fwd / tcdiff_row_bwd (bias, dropout, LayerNorms, FiLM, residual, rotary; the backward adds the
+                       LayerNorm / FiLM / bias gradients itself); activations (+ dropout) ride in the neighbouring GEMMs'
+                       epilogues; the conditioning path's selects / pool / adds have their own adjoints
 
-Gradients land in ONE flat fp32 buffer (fused linears contiguous) of which every parameter's ``.grad`` is a view: the
+From the third step with the same shapes on, forward and backward are replayed hipGraphs captured from this very schedule
+(``TrainEngine.use_graphs``): the ~550 launches cost more host time through Python than device time on a slow host.
+
+Gradients land in ONE flat fp32 buffer (fused linears contiguous) of which every parameter's ``.grad`` is set to a view: the
 data-parallel all-reduce (tcdiff_amd/dist.py) runs on slices of that buffer without a copy.  torch contributes device
 memory, the stream and the autograd hook -- no arithmetic.  There is no CPU path: off-GPU this module raises.
 
