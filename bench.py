@@ -446,12 +446,17 @@ def rank_main(a):
             except Exception as e:
                 res["other_configs_error"] = repr(e)[:300]
     # ---- secondary: the training step (BASELINE config 5: batch 32 per GPU, Adan, data-parallel over the job's ranks) ----------
-    ts = None
+    ts, ts_err = None, None
     if not a.no_train_step:
-        ts = train_step_bench(a, D, dev, world, dn, S)
+        try:
+            ts = train_step_bench(a, D, dev, world, dn, S)
+        except Exception as e:           # the headline line must not depend on the secondary measurement
+            ts_err = repr(e)[:300]
     if rank == 0:
         if ts is not None:
             res["train_step"] = ts
+        if ts_err is not None:
+            res["train_step_error"] = ts_err
         print(json.dumps(res), flush=True)
     D.barrier()
     if torch.distributed.is_initialized():
