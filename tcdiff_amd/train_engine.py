@@ -490,6 +490,15 @@ class TrainEngine:
             if st["n"] < 3:
                 return self._fwd(x, cond, times, keep)
             try:
+                # a captured shape pins its whole activation set (5.7 GB at batch 32): at most three shapes stay captured
+                live = [k for k, v in self._graphs.items() if v["fwd"] is not None]
+                for k in live[:max(0, len(live) - 2)]:
+                    old = self._graphs.pop(k)
+                    if old.get("sv") is not None:
+                        old["sv"].pop("graph", None)
+                    if self.sv is old.get("sv"):
+                        self.sv = None
+                    old.clear()
                 if self._pool is None:
                     self._pool = torch.cuda.graph_pool_handle()
                 st["x"], st["cond"], st["t"], st["keep"] = x.clone(), cond.clone(), times.clone(), keep.clone()

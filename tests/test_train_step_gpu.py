@@ -296,6 +296,27 @@ def test_training_on_a_fixed_batch_reduces_the_loss(compute):
     assert diff.model.train_engine()._graph_broken is None
 
 
+def test_changing_batch_sizes_keep_at_most_three_captured_shapes():
+    """every new batch shape runs eagerly twice, is captured at its third step, and the oldest captured shape is dropped when a
+    fourth arrives (a captured shape pins its activations); going back to an evicted shape simply starts over"""
+    torch.manual_seed(2)
+    sd, diff = build("bf16")
+    diff.train()
+    eng = diff.model.train_engine()
+    optim = Adan(diff.model.parameters(), lr=1e-4, weight_decay=0.0)
+    for b in (1, 2, 3, 4, 1):
+        x = torch.stack([O.synth_motion(c, DN * S).reshape(S, DN, 151).permute(1, 0, 2) for c in range(b)]).to(DEV)
+        cond = torch.stack([O.synth_cond(c, S) for c in range(b)]).to(DEV)
+        for _ in range(4):
+            total, _ = diff(x, cond)
+            optim.zero_grad()
+            total.backward()
+            optim.step()
+            assert bool(torch.isfinite(total))
+        captured = [k for k, v in eng._graphs.items() if v.get("fwd") is not None]
+        assert eng._graph_broken is None and 1 <= len(captured) <= 3 and captured[-1][0] == b, (b, captured)
+
+
 def test_inference_after_training_sees_the_updated_weights():
     sd, diff = build("f32")
     diff.train()
