@@ -167,6 +167,15 @@ class _Lin:
                         dy = eng.e(M, ld)
                         K.gemm_tile(dt, A, self.WbT[gi], M, self.K, ngp, lda=Np, mode=L.EPI_STORE_T, out=dy, ldc=ld)
                         K.act_drop_bwd(dt, a_src, a_src.shape[1], dy, ld, da, M, self.K, kind, eng.seed, site or 0, thr, sc)
+                elif M <= 128 and ngp >= 4096 and w[2] == self.K:
+                    # one row panel over a long contraction (the 24 FiLM generators' input gradient: 32 rows x 24 576): as a plain
+                    # tile GEMM four workgroups walk 384 k-tiles each (242 us); split over the contraction with fp32 atomics
+                    # every CU takes six (then one small cast for a T-typed consumer)
+                    acc = w[1] if w[0] == "F32" else eng.e(M, self.K, dtype=torch.float32)
+                    eng.tt(lambda acc=acc: acc.zero_())
+                    K.gemm_splitk(dt, A, self.WbT[gi], M, self.K, ngp, Np, ngp, acc, self.K, max(1, min(64, ngp // kt)))
+                    if w[0] != "F32":
+                        K.cast_transpose(dt, acc, M, self.K, self.K, dst=w[1], ld_dst=w[2], cols_pad=self.K)
                 else:
                     K.gemm_tile(dt, A, self.WbT[gi], M, self.K, ngp, lda=Np,
                                 mode=L.EPI_STORE_F32 if w[0] == "F32" else L.EPI_STORE_T, out=w[1], ldc=w[2])
