@@ -28,6 +28,7 @@ TCDiff.train_loop does (TCDiff.py:227-234).
 from __future__ import annotations
 
 import math
+import warnings
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -522,6 +523,7 @@ class TrainEngine:
                 st["sv"]["graph"] = st
             except Exception as ex:                       # noqa: BLE001  -- never let the optimisation take the step down
                 self._graph_broken = f"{type(ex).__name__}: {ex}"
+                warnings.warn(f"tcdiff_amd: capturing the training step failed ({self._graph_broken}); continuing with the eager schedule")
                 st["fwd"] = None
                 return self._fwd(x, cond, times, keep)
         else:
@@ -761,6 +763,7 @@ class TrainEngine:
                 st["bwd"], st["bwd_cmds"] = g, cmds
             except Exception as ex:                       # noqa: BLE001
                 self._graph_broken = f"{type(ex).__name__}: {ex}"
+                warnings.warn(f"tcdiff_amd: capturing the training step failed ({self._graph_broken}); continuing with the eager schedule")
                 st["bwd"] = None
                 self._wq = []
                 self._bwd(sv, d_out, None, zero=True)
