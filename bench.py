@@ -22,6 +22,7 @@ N = 1, `cpu_baseline` (the CPU oracle -- a port of the reference's PyTorch path 
 import argparse
 import importlib.util
 import json
+import re
 import os
 import sys
 import time
@@ -52,6 +53,7 @@ def parse(argv=None):
     p.add_argument("--no-train-step", action="store_true", help="skip the secondary config-5 training-step timing")
     p.add_argument("--no-other-configs", action="store_true", help="skip the config-1 / config-4 sampling lines")
     p.add_argument("--train-batch", type=int, default=32, help="clips per GPU of the training step (BASELINE config 5: 32)")
+    p.add_argument("--dump-samples", default=None, help="rank 0 saves the gathered samples of the last job here (tests)")
     p.add_argument("--stub", action="store_true",
                    help="rank plumbing only (process group, shard ranges, all-reduce, JSON relay); no GPU work: "
                         "what tests/test_launch_cpu.py runs over gloo")
@@ -163,6 +165,15 @@ def insampler_kernel_times(diff, shape, cond, xT, n_steps=40):
     return out, n_steps
 
 
+def kernel_source_sha() -> str:
+    """content hash of the sampler's kernel sources: a PMC file belongs to the build it was measured on"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("chain.hip", "attention.hip", "attn_res.h", "gemm.hip", "ops.hip", "common.h"):
+        h.update(open(os.path.join(ROOT, "tcdiff_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:12]
+
+
 def kernel_roofline(times, n_steps, B_launch, streams, dn, S, dtype):
     """Fold profiler records into families; the dominant family's achieved rate = its algorithmic FLOPs per DDPM step /
     its device time per DDPM step."""
@@ -200,21 +211,31 @@ def kernel_roofline(times, n_steps, B_launch, streams, dn, S, dtype):
                 hbm=dict(algorithmic_gbps=d["algo_gbps"], peak=PEAK_HBM_GBPS, frac=d["hbm_frac"],
                          algorithmic_mb_per_ddpm_step=round(nbytes[dom] / 1e6, 1)))
     if dom == "chain":
-        # What actually bounds this launch (profiles/r03_chain_block_scaling.txt): every row block pulls the
-        # layer's weights out of its XCD's L2 (a CU cannot hold more than ~64 of the 14 400 rows), and the launch takes
-        # (blocks per XCD x bytes per block) / the rate an L2 delivers them at.  Reported beside the MFMA figure.
+        # The launch streams every row block's weights L2 -> CU (a CU cannot hold more than ~64 of the 14 400 rows).  Round 4
+        # measured what that costs and what it does not (profiles/r04_chain_experiments.txt): with pure loads EVERY CU streams
+        # the same 5.5 MB at 113-117 GB/s (26-29 TB/s chip-wide) at 1, 225 and 256 blocks -- the per-CU vector-memory return
+        # path, not the L2, is the ceiling of the stream -- and the chain launch's slow-down from 1 to 225 blocks is the shader
+        # clock (2.39 -> 1.9-2.0 GHz at the power limit), not contention.  Reported beside the MFMA figure.
         n_blk = (2 * B * dn * S + 63) // 64
-        per_step = (7 * 5.5 + 4.0) * 1024 * 1024 * n_blk + 160 * 2048 * 8 * ((B * S + 63) // 64) * dn
-        roof["l2_weight_stream"] = dict(
-            bytes_per_ddpm_step=int(per_step), achieved_gbps=round(per_step / (d["device_ms_per_ddpm_step"] * 1e-3) / 1e9, 1),
-            channel_peak_gbps=17200.0, measured_saturation_gbps=11600.0,
-            frac_of_measured_saturation=round(per_step / (d["device_ms_per_ddpm_step"] * 1e-3) / 1e9 / 11600.0, 3),
-            note="L2 -> CU weight bytes of the chain launches (row blocks x stream bytes) / their device time; channel peak = 8 XCDs x "
-                 "16 channels x 64 B x 2.1 GHz; saturation = what the same launch reaches at 32 blocks per XCD (chain_bench)")
-    # HBM-side bytes from the committed rocprofv3 PMC passes of this command (never measured by this run: labelled)
-    for pm_name in ("r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):
+        per_step = (7 * 176 + 128) * 4096 * 8 * n_blk + 80 * 4096 * 8 * ((B * S + 63) // 64) * dn
+        gbps = per_step / (d["device_ms_per_ddpm_step"] * 1e-3) / 1e9
+        roof["weight_stream"] = dict(
+            bytes_per_ddpm_step=int(per_step), achieved_gbps=round(gbps, 1), achieved_gbps_per_cu=round(gbps / n_blk, 1),
+            probe_ceiling_gbps_per_cu=115.0, frac_of_probe_ceiling=round(gbps / n_blk / 115.0, 3),
+            note="L2 -> CU weight bytes of the chain launches (row blocks x stream bytes) / their device time, epilogues included; "
+                 "ceiling = tools/probe/l2_alias_probe.hip, pure loads of the same stream by 225 / 256 CUs at once "
+                 "(profiles/r04_chain_experiments.txt)")
+    # HBM-side bytes from the committed rocprofv3 PMC passes of this command (never measured by this run: labelled), and only
+    # while that file was measured on THIS build of the dominant kernel's source (content hash recorded by make_pmc_json.py)
+    src_sha = kernel_source_sha()
+    for pm_name in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if re.fullmatch(r"r\d+_pmc\.json", f)), reverse=True):
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", pm_name)))
+            if pm.get("source_sha") != src_sha:
+                roof["traffic_from"] = (f"none: profiles/{pm_name} was measured on another build of the kernels "
+                                        f"(source hash {pm.get('source_sha')} != {src_sha}); re-run tools/gpu_measure.sh")
+                sys.stderr.write(f"bench.py: WARNING: {roof['traffic_from']}\n")
+                break
             roof["traffic"] = pm[dom]["bytes_per_launch"]
             roof["traffic_from"] = f"profiles/{pm_name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, committed)"
             if "bytes_per_ddpm_step" in pm:
@@ -305,6 +326,8 @@ def rank_facts(D, n_total, rank, world, dev):
     lo, hi = D.shard_range(n_total, rank, world)
     if world == 1:
         return 1, [[lo, hi]]
+    if dist.get_backend() == "gloo":
+        dev = "cpu"
     one = torch.ones(1, device=dev, dtype=torch.int32)
     dist.all_reduce(one)
     mine = torch.tensor([lo, hi], device=dev, dtype=torch.int32)
@@ -335,8 +358,13 @@ def rank_main(a):
     import torch
     import torch.nn.functional as F
     from tcdiff_amd import dist as D
-    rank, world, local = D.init_from_env()
+    # TCDIFF_BENCH_ONE_DEVICE=1 (tests): every rank runs on GPU 0 and the collectives go through gloo -- the rank plumbing of a
+    # multi-GPU run (sharding, clip offsets, gather, max-over-ranks timing) on a one-GPU box; RCCL refuses duplicate devices
+    one_dev = os.environ.get("TCDIFF_BENCH_ONE_DEVICE", "0") == "1"
+    rank, world, local = D.init_from_env("gloo" if one_dev else None)
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
+    if one_dev:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     from tcdiff_amd import DanceDecoder, GaussianDiffusion
@@ -377,14 +405,14 @@ def rank_main(a):
     D.barrier()
     dt = D.max_over_ranks(time.perf_counter() - t0, dev)
     assert out.shape == (n_total, Lq, 151) and bool(torch.isfinite(out).all())
+    if a.dump_samples and rank == 0:
+        torch.save(out.cpu(), a.dump_samples)
 
     if rank == 0:
         clips_per_s = n_total * a.steps / dt
         gf = GFLOP_PER_CLIP_STEP.get((dn, S))
         nb = hi - lo
-        streams = diff.dual_parts if diff.dual_stream else 1
-        while streams > 1 and nb // streams < 2:
-            streams -= 1
+        streams = 1
         res = {
             "metric": "sampled clips/sec (3 dancers x 150 frames, 1000 DDPM steps)",
             "value": round(clips_per_s, 4), "unit": "clips/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -509,6 +537,8 @@ def train_step_bench(a, D, dev, world, dn, S, iters=10, warm=5):
                              loss_type="l2", use_p2=False, cond_drop_prob=0.25, guidance_weight=2, seq_len=S).to(dev)
     diff.train()
     optim = Adan(model.parameters(), lr=5e-5, weight_decay=0.02)
+    if world > 1:
+        model.train_engine().enable_grad_sync()            # data-parallel gradient averaging is opt-in (dist.FlatGradientAllReducer)
     g = torch.Generator().manual_seed(4242 + int(os.environ.get("RANK", "0")))
     x = (torch.rand(b, dn, S, 151, generator=g) * 2 - 1).to(dev)
     cond = torch.randn(b, 2 * S + 1, 438, generator=g).to(dev)

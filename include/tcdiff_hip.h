@@ -181,18 +181,19 @@ int tcdiff_adan_step(const tcdiff_adan_chunk* chunks, int n_chunks, const tcdiff
  *                     next layer's norm1 (+rotary) ; w_qs / w_ks / w_vs --> Q, K, V images
  *                     replaces model/model.py:103-106,334,338-339,344,399-401 and the next layer's :326,374-383,78-80
  *   TC_CHAIN_B_LAST : the same up to linear3, whose bf16 rows feed the final projection (model/model.py:623)
- * `wstream`: the chain's weights as ONE linear stream per wave in consumption order, [8 waves][n_stages][2048 B]; a
- * stage is the MFMA fragment image of the 64 (512-wide GEMMs: [n-tile 2][half][32 weight rows][16 B] of one 16-deep
- * k-step) or 32 (linear1 chunk: [k-step 2][half][32 rows][16 B]) weight rows wave w consumes; order: fc (32 stages), then for
- * chain A w_qs (32); for chain B four times {linear1 rows 256c+32w.. (16 stages), linear2 k-slice 256c.. (16)}, then
- * linear3 (32), w_qs, w_ks, w_vs of the NEXT layer (32 each).  n_stages = 64 / 288 / 192.  tcdiff_amd/engine.py packs it.
+ * `wstream`: the chain's weights as ONE linear stream per wave in consumption order, [8 waves][n_stages][4096 B]; a
+ * stage is the v_mfma_f32_16x16x32_bf16 A-fragment image of one 32-deep k-step of the 64 (512-wide GEMMs: [n-tile 4][lane
+ * group g 4][16 weight rows][16 B], lane group g holding k = 32 ks + 8 PI[g] .. +7 with PI = (0, 3, 1, 2)) or of two k-steps of
+ * the 32 (linear1 chunk: [k-step 2][n-tile 2][g][16 rows][16 B]) weight rows wave w consumes; order: fc (16 stages), then for
+ * chain A w_qs (16); for chain B four times {linear1 rows 256c+32w.. (8 stages), linear2 k-slice 256c.. (8)}, then
+ * linear3 (16), w_qs, w_ks, w_vs of the NEXT layer (16 each).  n_stages = 32 / 144 / 96.  tcdiff_amd/engine.py packs it.
  * Rows: M token rows, L tokens per sequence; FiLM row = m / L, rotary position = m % L; head-major images as
  * TC_EPI_QKV_HEADS (H must be 8).  a_mod / xres_mod > 0: input / residual row = m % mod (layer 0 shares them between
  * the CFG branches).  The fp32 residual stream between chain launches is column-blocked (see the struct).
  *   TC_CHAIN_FULL / TC_CHAIN_FULL_LAST : chain A, then the CROSS-ATTENTION itself (head w on wave w, K / V from the
  *                     fragment-ordered cache images written by tcdiff_pack_kv_frags), then chain B / B_LAST, in one launch:
  *                     per layer the step is  self-attention -> one chain launch.  Stream: chain A's stages followed by
- *                     chain B's (352 / 256 stages); the first fc block uses ln_g.., film, n2_*, the second lnb_*, filmb,
+ *                     chain B's (176 / 128 stages); the first fc block uses ln_g.., film, n2_*, the second lnb_*, filmb,
  *                     n3_*; xres / xres_mod feed the first, xout carries x in between. */
 #define TC_CHAIN_A 0
 #define TC_CHAIN_B 1
@@ -200,10 +201,10 @@ int tcdiff_adan_step(const tcdiff_adan_chunk* chunks, int n_chunks, const tcdiff
 #define TC_CHAIN_FULL 3
 #define TC_CHAIN_FULL_LAST 4
 #define TC_CHAIN_FRONT 5 /* last fusion linear of one dancer over a block of 64 FRAMES (A = bf16 [M frames][1024], weights
-                            rows [512 d, 512 d + 512) of relative_projection_layer.4, K = 1024: 64 stages) -> layer 0's
+                            rows [512 d, 512 d + 512) of relative_projection_layer.4, K = 1024: 32 stages) -> layer 0's
                             residual input xout (token row = frame dn + d, column-blocked with M dn rows); then layer 0's
-                            norm1 (nn_g, nn_b) + rotary and w_qs / w_ks / w_vs (32 stages each) -> Q, K, V images.  M =
-                            frames, L = TOKENS per sequence, b3 = all 512 dn biases; wstream = [dn][8 waves][160 stages];
+                            norm1 (nn_g, nn_b) + rotary and w_qs / w_ks / w_vs (16 stages each) -> Q, K, V images.  M =
+                            frames, L = TOKENS per sequence, b3 = all 512 dn biases; wstream = [dn][8 waves][80 stages];
                             grid = blocks x dn.  Replaces model/model.py:526-528,561 and layer 0's :326,374-383,78-80. */
 
 typedef struct {
@@ -257,9 +258,11 @@ int tcdiff_chain(const tcdiff_chain_args* args, hipStream_t stream);
 
 /* Fragment-ordered images of the cross-attention K / V caches for TC_CHAIN_FULL (bf16): for keys key_lo <= key < key_hi
  * of every (slot, head) of Kc / Vc (T[n_slots][H][Lp][64], natural [key][d] rows),
- *   Kf[slot][head][key / 32][d / 16][half * 32 + key % 32][j]  with d % 16 = 8 (j / 4) + 4 half + j % 4
- *   Vf[slot][head][key / 32][(key % 32) / 16][d / 32][half * 32 + d % 32][j]  with key % 16 = 8 (j / 4) + 4 half + j % 4
- * i.e. each 1-KB piece is the 64 lanes' 16-byte MFMA A-operand fragments of one (key tile, k-step).  Keys >= Lk inside
+ *   Kf[slot][head][key / 32][(key % 32) / 16][d / 32][16 g + key % 16][jj]  with d % 32 = 16 (jj / 4) + 4 g + jj % 4
+ *   Vf[slot][head][key / 32][d / 16][16 g + d % 16][jj]                     with key % 32 = 16 (jj / 4) + 4 g + jj % 4
+ * i.e. each 1-KB piece is the 64 lanes' 16-byte v_mfma_f32_16x16x32_bf16 A-operand fragments of one (16-key tile, 32-deep
+ * d-step) of K, or (16-d tile, 32-key step) of V^T, in the k order in which the chain kernel's accumulator tiles hold Q^T
+ * and P^T (two 16-row tiles, rows 4 g + j of each).  Keys >= Lk inside
  * the last tile must hold finite values (zero).  Run once over [0, Lk) when a cache slot is filled and over the two
  * time-token keys every step. */
 int tcdiff_pack_kv_frags(const void* Kc, const void* Vc, void* Kf, void* Vf, int n_slots, int H, int Lp, int nkt,

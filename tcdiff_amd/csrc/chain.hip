@@ -12,76 +12,75 @@
 //             --linear2--> FiLM, +x --norm4--> [LDS] --linear3--> x' (fp32, HBM) --norm1', rotary--> [LDS]
 //             --w_qs / w_ks--> Q, K images ; norm1' --> [LDS] --w_vs--> V image        (last layer: stops after linear3)
 //   FULL    : chain A, then the cross-attention itself (head w on wave w; K / V from fragment-ordered cache images, the
-//             Q^T accumulator tile is the B operand of the score MFMA), then chain B: ONE launch per decoder layer.
+//             Q^T accumulator tiles are the B operand of the score MFMA), then chain B: ONE launch per decoder layer.
 //             This is the production path; A and B alone are the reference it is tested against.
 //
 // Only the weights stream.  Structure:
 //   * 8 waves, wave w owns output columns [64 w, 64 w + 64) of every 512-wide GEMM (= head w of Q / K / V) for all 64
-//     rows; MFMA operand roles are swapped (A operand = weight rows, B operand = activation rows), so a lane holds 4
-//     consecutive columns of ONE row per register quad: LayerNorm statistics are in-register sums + one cross-half
-//     swap + an 8-wave exchange through LDS, and FiLM / residual / rotary / bf16 packing need no transposition.
+//     rows.  Round 4: the products are v_mfma_f32_16x16x32_bf16 (round 1-3: 32x32x16).  Same cycles per FLOP, but every
+//     accumulator register is read and written once per 32 deep k-step instead of once per 16, and the chip -- which this
+//     launch holds at its power limit (225 busy CUs: 1.88-1.91 GHz against 2.39 GHz for a lone block, measured with
+//     s_memtime) -- keeps a 7 % higher clock on it: the same launch took 100.4 instead of 111.0 us in the timing experiment
+//     that led here (profiles/r04_chain_experiments.txt; cdna_hip_programming.md section 5.4 rule 28).
+//   * MFMA operand roles are swapped (A operand = weight rows, B operand = activation rows): the accumulator tile
+//     acc[nt][mt] holds, in lane l = 16 g + c, element j: column n = 64 w + 16 nt + 4 g + j of row m = 16 mt + c.  A lane
+//     has 4 consecutive columns of 4 rows: LayerNorm statistics are in-register sums + a 3-swap reduce-scatter over the
+//     four lane groups (v_permlane16_swap / v_permlane32_swap) + an 8-wave exchange through LDS, and FiLM / residual /
+//     rotary / bf16 packing need no transposition.
 //   * the weights of a chain are packed ON THE HOST (engine.py, once per checkpoint) into one linear stream per wave in
-//     consumption order, in 2-KB stages that are already the MFMA fragment image ([n-tile][half][row][16 B]).  A wave
-//     consumes only fragments of its OWN columns, so weights never touch LDS: a stage is two coalesced 1-KB global
-//     loads straight into registers, 8 stages (16 KB per wave, 128 KB per CU) are in flight in a register ring whose
+//     consumption order, in 4-KB stages that are already the MFMA fragment image ([n-tile 4][lane 64][16 B] of one 32-deep
+//     k-step).  A wave consumes only fragments of its OWN columns, so weights never touch LDS: a stage is four coalesced
+//     1-KB loads straight into registers, 4 stages (16 KB per wave, 128 KB per CU) are in flight in a register ring whose
 //     slots are compile-time indices, and the GEMM phases (fully unrolled) have NO workgroup barrier and no
-//     hand-written waits.  The stream runs ahead across GEMM and epilogue boundaries (the next GEMM's first stages land
-//     during the LayerNorm in front of it).
-//   * activations live in LDS as [k-tile][64 rows][128 B] with the XOR chunk swizzle of common.h (tile_off).
-//   * every global access of an epilogue is a contiguous kilobyte per wave instruction: the fp32 residual stream and the
+//     hand-written waits.  The stream runs ahead across GEMM and epilogue boundaries.
+//   * activations live in LDS as [k-tile][64 rows][128 B] with the XOR chunk swizzle of common.h (tile_off).  Lane group g
+//     of a B fragment takes the 16-byte chunk PI(g) = (0, 3, 1, 2)[g] of its 32-deep k-step (and the weight fragments are
+//     packed with the same k order): with the natural order the two row sets a ds_read_b128 serves together ({0-3, 12-15}
+//     of one chunk, {4-11} of the next) land on the same bank slots under the swizzle; chunks that differ by XOR 3 do not.
+//   * every global access of an epilogue is made of contiguous 512-byte pieces: the fp32 residual stream and the
 //     rotary table are column-blocked (RowPipe below), head-major images leave through wave-private LDS staging
-//     (store_heads).  With the accumulator layout the natural "my 16 bytes of my row" access is 32 separate line
-//     requests per instruction; those passes cost 30 us of a 130-us launch before.
-// Barriers: one pair per LayerNorm (statistics exchange) and one per activation hand-off.
+//     (store_heads).
+// Barriers: one per LayerNorm statistics exchange and one per activation hand-off.
 #include "common.h"
 #include "tcdiff_hip.h"
 
 // LDS map.  The small constant areas come first so that their reads are `base VGPR + 16-bit immediate`.
-#define CH_FILM 0            //  8 KB  FiLM (scale | shift) rows of the <= 2 sequences this block touches, for the next epilogue
+#define CH_FILM 0            //  8 KB  FiLM (scale + 1 | shift) rows of the <= 2 sequences this block touches, for the next epilogue
 #define CH_VEC 8192          // 12 KB  six 512-float vectors (LayerNorm weights, biases) of the next epilogue(s)
-#define CH_SCR 20480         //  8 KB  LayerNorm statistics exchange: 2 x [2][8 waves][64 rows] floats
+#define CH_SCR 20480         //  8 KB  LayerNorm statistics exchange: 2 x [8 waves][64 rows] float2
 #define CH_ABUF 28672        // 64 KB  activation block [8 k-tiles][64][128 B]
 #define CH_H1C 94208         // 32 KB  GELU(linear1) chunk [4 k-tiles][64][128 B]
 #define CH_ABUF2 94208       // 64 KB  second activation block (un-rotated norm1 image for V); overlays the dead h1 chunk
 #define CH_STG7 159744       //  4 KB  eighth staging slot of store_heads (slots 0-6: the first 28 KB)
 #define CH_SMEM 163840
-#ifndef CH_D
-#define CH_D 8               // weight stages in flight per wave (registers): 8 x 2 KB x 8 waves = 128 KB per CU
-#endif
-#define CH_R 16              // ring slots inside a GEMM phase: a phase tops the CH_D resident stages up to CH_R in flight
-#ifndef CH_QKV_R
-#define CH_QKV_R CH_D        // ring depth of the Q / K / V GEMMs at the end of the launch
-#endif
-#ifndef CH_XP
-#define CH_XP 0              // K / V register sets of the pipelined in-kernel cross-attention for a 5-tile memory (0: off).
-                             // Measured with 2 and 3 sets: the launch takes the same time (115.1 / 116.5 vs 115.7 / 114.3 us,
-                             // same box): the cross-attention streams 640 KB of K / V per block and is bound by that, like
-                             // the weight stream, not by the round trip per tile.  Kept as a build option (-DCH_XP=3).
-#endif
-#define CH_STAGE 2048
+#define CH_D 4               // weight stages in flight per wave (registers): 4 x 4 KB x 8 waves = 128 KB per CU
+#define CH_STAGE 4096
 
 typedef const float* fptr;
+typedef f32x4_t acc_t[4][4];          // [n-tile][m-tile]
+
+DEVINL void mma16(f32x4_t& acc, const u32x4& a, const u32x4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+}
 
 // A wave's weight stream.  The fragments of a stage are private to the wave (it owns the output columns they produce),
-// so they never need LDS: a stage is two coalesced 1-KB global loads straight into the registers the MFMAs read, and
+// so they never need LDS: a stage is four coalesced 1-KB global loads straight into the registers the MFMAs read, and
 // the ring of CH_D stages in flight is a register array indexed at compile time (every loop over it is unrolled).
 // The compiler counts vmcnt for these loads itself.  Past the end of the stream the last stage is re-read (never used).
 struct WStream {
     __amdgpu_buffer_rsrc_t rsrc;   // this wave's stream as a raw buffer: a stage address is SGPR descriptor + SGPR stage
-    unsigned voff;                 // offset + this one VGPR (lane * 16); as 64-bit global addresses every stage load
-                                   // cost a v_lshl_add_u64 and a VGPR pair (760 VALU instructions per launch and wave)
+    unsigned voff;                 // offset + this one VGPR (lane * 16)
     unsigned pos;      // stages consumed so far (wave-uniform)
     unsigned last;     // index of the last stage
-    u32x4 a[CH_R], b[CH_R];   // slots 0 .. CH_D-1 live across phases, the rest only inside a GEMM phase
+    u32x4 w[CH_D][4];
 };
 DEVINL void ws_load(WStream& ws, int slot, unsigned stage) {
     const unsigned st = stage < ws.last ? stage : ws.last;
     const unsigned so = st * CH_STAGE;                       // scalar
-    ws.a[slot] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ws.rsrc, ws.voff, so, 0));
-    ws.b[slot] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ws.rsrc, ws.voff + 1024u, so, 0));
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        ws.w[slot][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ws.rsrc, ws.voff + 1024u * i, so, 0));
 }
-#define CH_MMA(acc, w, a) MmaBF16::mma(acc, w, a)
-#define CH_FRAG(at, row, ch) lds_frag(at, row, ch)
 // IR-level fence for memory operations + machine-scheduler fence for everything: keeps an unrolled epilogue loop one
 // iteration at a time (see the fc epilogue)
 #define CH_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -89,8 +88,8 @@ DEVINL void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" :::
 
 // Fresh copies of the lane / wave index that the compiler cannot relate to earlier ones: every phase derives its LDS
 // and global addresses from its own copy, so address arithmetic is recomputed per phase (a few VALU ops) instead of
-// being hoisted to the top of the kernel and kept alive across it -- which, with 64 accumulator + 32 ring registers
-// resident, spilled ~150 VGPRs, and every scratch reload in an epilogue is a full memory round trip.
+// being hoisted to the top of the kernel and kept alive across it -- which, with 64 accumulator + 64 ring registers
+// resident, spills, and every scratch reload in an epilogue is a full memory round trip.
 DEVINL int fresh_v(int x) {
     asm volatile("" : "+v"(x));
     return x;
@@ -101,262 +100,378 @@ DEVINL int fresh_s(int x) {
 }
 
 DEVINL f32x4_t ld4(const float* p) { return *reinterpret_cast<const f32x4_t*>(p); }
-DEVINL void zero(f32x16_t& v) {
-    const f32x16_t z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    v = z;
+DEVINL void zero(acc_t& a) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) a[nt][mt] = f32x4_t{0, 0, 0, 0};
 }
 
-// acc[mi][ni] (rows 32 mi + r, columns 64 wave + 32 ni + ..) += act[64 x 16 NST] (k-steps 0.. of `abuf`) * W stages;
-// a stage = one 16-deep k-step of the wave's 64 weight rows: fragment ni = weight rows 32 ni + r.  NST % CH_D == 0.
+// ---- lane-group exchanges (the four 16-lane groups g of a wave hold different columns of the same rows) -----------------
+// v_permlane16_swap vdst, src: lanes 16-31 / 48-63 of vdst swap with lanes 0-15 / 32-47 of src;
+// v_permlane32_swap vdst, src: lanes 32-63 of vdst swap with lanes 0-31 of src (cdna_hip_programming.md T21).
+DEVINL void swap16(float& a, float& b) {
+    auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+    a = __builtin_bit_cast(float, (unsigned)r[0]);
+    b = __builtin_bit_cast(float, (unsigned)r[1]);
+}
+DEVINL void swap32(float& a, float& b) {
+    auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+    a = __builtin_bit_cast(float, (unsigned)r[0]);
+    b = __builtin_bit_cast(float, (unsigned)r[1]);
+}
+// reduce-scatter: a[t] = this lane's partial of row tile t (over its lane group's columns) -> the sum over the four lane
+// groups of row tile g, in lane group g (3 swaps + 3 adds for 4 values)
+DEVINL float rs4_sum(float a0, float a1, float a2, float a3) {
+    swap16(a0, a1);          // a0 = [a0.g0, a1.g0, a0.g2, a1.g2], a1 = [a0.g1, a1.g1, a0.g3, a1.g3]
+    swap16(a2, a3);
+    float p01 = a0 + a1, p23 = a2 + a3;      // p01 = [a0(g0+g1), a1(g0+g1), a0(g2+g3), a1(g2+g3)]
+    swap32(p01, p23);        // p01 = [a0(g0+g1), a1(g0+g1), a2(g0+g1), a3(g0+g1)], p23 = the (g2+g3) halves
+    return p01 + p23;
+}
+// all-gather: v = the value of row tile g in lane group g -> out[t] = row tile t's value, in every lane group
+DEVINL void ag4(float v, float (&out)[4]) {
+    float r0 = v, r1 = v;
+    swap16(r0, r1);          // r0 = [v.g0, v.g0, v.g2, v.g2], r1 = [v.g1, v.g1, v.g3, v.g3]
+    float q0 = r0, q2 = r0, q1 = r1, q3 = r1;
+    swap32(q0, q2);          // q0 = v.g0 everywhere, q2 = v.g2 everywhere
+    swap32(q1, q3);
+    out[0] = q0; out[1] = q1; out[2] = q2; out[3] = q3;
+}
+// maximum over the four lane groups, in every lane
+DEVINL float ar4_max(float v) {
+    float a = v, b = v;
+    swap16(a, b);
+    v = fmaxf(a, b);
+    a = v; b = v;
+    swap32(a, b);
+    return fmaxf(a, b);
+}
+DEVINL float ar4_sum(float v) {
+    float a = v, b = v;
+    swap16(a, b);
+    v = a + b;
+    a = v; b = v;
+    swap32(a, b);
+    return a + b;
+}
+
+// every accumulator tile through an (empty) asm statement: orders the MFMAs in front of it before everything behind it
+DEVINL void acc_fence(acc_t& a) {
+#pragma unroll
+    for (int nt = 0; nt < 4; nt += 2)
+        asm volatile("" : "+v"(a[nt][0]), "+v"(a[nt][1]), "+v"(a[nt][2]), "+v"(a[nt][3]), "+v"(a[nt + 1][0]), "+v"(a[nt + 1][1]),
+                     "+v"(a[nt + 1][2]), "+v"(a[nt + 1][3]));
+}
+
+// LDS addresses of this lane's B fragments: row 16 mt + c of a [64][128 B] k-tile, chunk 4 (ks & 1) + PI(g) of k-step ks.
+// The two bases (even / odd k-step) INCLUDE the activation block's LDS address and are opaque to the compiler, so that every
+// fragment read is `base VGPR + 16-bit immediate` ((ks >> 1) * 8192 + mt * 2048 <= 63488): folded into the immediate, the
+// block's own offset (28 KB ..) pushes the later k-tiles past 65535 and every one of them costs an address VGPR.
+typedef const __attribute__((address_space(3))) u32x4 lds_u32x4;
+struct FragOff { unsigned e, o; };
+DEVINL FragOff frag_off(const char* abuf, int lane) {
+    const int c = lane & 15, g = lane >> 4;
+    const int pg = (0x9C >> (2 * g)) & 3;                   // PI = (0, 3, 1, 2)
+    const int sw = tile_swz(c);                             // (row >> 1) & 7 of row 16 mt + c does not depend on mt
+    const unsigned base = (unsigned)reinterpret_cast<uintptr_t>(abuf);      // the low half of a generic LDS pointer is the LDS address
+    FragOff f;
+    f.e = base + c * TC_ROWB + ((pg ^ sw) << 4);
+    f.o = base + c * TC_ROWB + (((4 + pg) ^ sw) << 4);
+    asm volatile("" : "+v"(f.e), "+v"(f.o));
+    return f;
+}
+DEVINL u32x4 frag_rd(const FragOff& f, int ks, int mt) {
+    return *reinterpret_cast<lds_u32x4*>((uintptr_t)(((ks & 1) ? f.o : f.e) + (unsigned)((ks >> 1) * 8192 + mt * 2048)));
+}
+
+// acc[nt][mt] (rows 16 mt + c, columns 64 wave + 16 nt + ..) += act[64 x 32 NST] (k-steps 0.. of `abuf`) * W stages;
+// a stage = one 32-deep k-step of the wave's 64 weight rows: fragment nt = weight rows 16 nt + c.  NST % CH_D == 0.
 // Fully unrolled (NST <= 32 stage bodies): a rolled loop carries the ring through a phi, and hipcc placed a register
 // copy of the most recently loaded slot at the loop header -- i.e. `s_waitcnt vmcnt(0)`, a full drain of the wave's
 // weight stream, every CH_D stages.  The activation fragments of stage ks + 1 are read before the MFMAs of stage ks.
-// (Tried: the two waves of a SIMD taking turns at issue priority every few stages (s_setprio), because with the
-// default oldest-first arbitration waves 0-3 finish every barrier-free stretch ~2 us before waves 4-7.  It balances
-// them, and the stretch takes exactly as long: the pair is bound by what the CU gets from L2, not by arbitration.)
 // TAIL: the launch's last phase -- its last CH_D stages refill nothing (there is nothing behind them).
-template <int NST, bool TAIL = false, int R = CH_D>
-DEVINL void phase_n512(f32x16_t (&acc)[2][2], const char* abuf, WStream& ws, int lane) {
-    static_assert(NST % R == 0, "a phase starts and ends at ring slot 0");
+template <int NST, bool TAIL = false>
+DEVINL void phase_n512(acc_t& acc, const char* abuf, WStream& ws, int lane) {
+    static_assert(NST % CH_D == 0, "a phase starts and ends at ring slot 0");
     lane = fresh_v(lane);
-    const int r = lane & 31, h = lane >> 5;
-    u32x4 a0 = CH_FRAG(abuf, r, h), a1 = CH_FRAG(abuf, 32 + r, h);
-    // Between phases CH_D stages are in flight (64 VGPRs, all the epilogues can spare).  Inside a phase the accumulators
-    // and the ring are all that is live, so the phase opens by topping the ring up to CH_R stages: the weight stream of
-    // a CU is latency-bound (bytes in flight / ~1.7 us), and the deeper ring is what the register file allows HERE.
-    // Relative stage j lives in slot j % CH_R; nothing past the next phase's first CH_D stages is loaded, so the phase
-    // ends as it began: stages NST .. NST + CH_D - 1 in slots 0 .. CH_D - 1.
-    const unsigned base = ws.pos;
+    const FragOff fo = frag_off(abuf, lane);
+    u32x4 b[4];
 #pragma unroll
-    for (int j = CH_D; j < R; ++j)
-        if (!(TAIL && j >= NST)) ws_load(ws, j, base + j);
+    for (int mt = 0; mt < 4; ++mt) b[mt] = frag_rd(fo, 0, mt);
+    const unsigned base = ws.pos;
+    FragOff fo2 = fo;                  // K = 1024 (TC_CHAIN_FRONT): k-tiles 8 .. 15 from a second pair of bases
+    if (NST > 16) {
+        fo2.e += 65536u;
+        fo2.o += 65536u;
+        asm volatile("" : "+v"(fo2.e), "+v"(fo2.o));
+    }
 #pragma unroll
     for (int ks = 0; ks < NST; ++ks) {
-        const int i = ks % R;
-        const u32x4 w0 = ws.a[i], w1 = ws.b[i];
-#ifdef CH_NO_TAIL
-        if (ks + R < NST + CH_D) ws_load(ws, i, base + ks + R);
-#else
-        if (ks + R < NST + CH_D && !(TAIL && ks + R >= NST)) ws_load(ws, i, base + ks + R);
-#endif
-        u32x4 n0 = a0, n1 = a1;
+        const int i = ks % CH_D;
+        const u32x4 w0 = ws.w[i][0], w1 = ws.w[i][1], w2 = ws.w[i][2], w3 = ws.w[i][3];
+        if (!(TAIL && ks + CH_D >= NST)) ws_load(ws, i, base + ks + CH_D);
+        u32x4 n0 = b[0], n1 = b[1], n2 = b[2], n3 = b[3];
         if (ks + 1 < NST) {
-            const char* at = abuf + ((ks + 1) >> 2) * 8192;
-            const int ch = 2 * ((ks + 1) & 3) + h;
-            n0 = CH_FRAG(at, r, ch);
-            n1 = CH_FRAG(at, 32 + r, ch);
+            const FragOff& fn = ks + 1 < 16 ? fo : fo2;
+            const int kl = (ks + 1) & 15;
+            n0 = frag_rd(fn, kl, 0);
+            n1 = frag_rd(fn, kl, 1);
+            n2 = frag_rd(fn, kl, 2);
+            n3 = frag_rd(fn, kl, 3);
         }
-        // Stage order: the next stage's two LDS reads and the refill are ISSUED, then this stage's MFMAs run (the
-        // ~100 cycles of LDS latency pass under them even when the wave is alone on its SIMD), then the fence.  Left to
-        // itself hipcc schedules read, wait, use, and a wave whose SIMD mate is parked at a barrier exposes the whole
-        // LDS latency in every stage.
+        // Stage order: the next stage's LDS reads and the refill are ISSUED, then this stage's MFMAs run (the ~100
+        // cycles of LDS latency pass under them even when the wave is alone on its SIMD), then the fence.  Left to
+        // itself hipcc schedules read, wait, use.
         __builtin_amdgcn_sched_barrier(0);
-        CH_MMA(acc[0][0], w0, a0);
-        CH_MMA(acc[0][1], w1, a0);
-        CH_MMA(acc[1][0], w0, a1);
-        CH_MMA(acc[1][1], w1, a1);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            mma16(acc[0][mt], w0, b[mt]);
+            mma16(acc[1][mt], w1, b[mt]);
+            mma16(acc[2][mt], w2, b[mt]);
+            mma16(acc[3][mt], w3, b[mt]);
+        }
         __builtin_amdgcn_sched_barrier(0);   // ... and the MFMAs do not sink below the next stage's reads either
         // Stage fence.  Memory clobber: the refill stays in its own stage, the stream never drains.  The next stage's
-        // fragments pass THROUGH it, so the next stage's MFMAs cannot be pulled up to right behind their reads.
-        asm volatile("" : "+v"(n0), "+v"(n1) : : "memory");
-        a0 = n0;
-        a1 = n1;
+        // fragments pass THROUGH it, so the next stage's MFMAs cannot be pulled up to right behind their reads; the
+        // accumulators pass through it too: an MFMA has no side effect, and instruction selection otherwise defers whole
+        // stages of them past the following stages' loads (seen in the listing: empty stages, then 40 MFMAs in a row with
+        // three stages of fragments and refills live -- 232 VGPRs and four ring slots spilled behind `s_waitcnt vmcnt(0)`).
+        acc_fence(acc);
+        asm volatile("" : "+v"(n0), "+v"(n1), "+v"(n2), "+v"(n3) : : "memory");
+        b[0] = n0; b[1] = n1; b[2] = n2; b[3] = n3;
     }
     ws.pos = base + NST;
 }
-// The rolled form (one CH_D-stage body, looped): kept for TC_CHAIN_A alone, whose fully unrolled build hipcc spills
-// (277 VGPRs); that mode is the reference the fused launch is tested against, not the production path.
-DEVINL void phase_n512_rolled(f32x16_t (&acc)[2][2], const char* abuf, int nst, WStream& ws, int lane) {
+// linear1 chunk: a1[nt][mt] (columns 32 wave + 16 nt + ..) += act[64 x 512] * W1 chunk; a stage = 2 k-steps of the wave's
+// 32 rows: fragments [k-step 2][n-tile 2]
+DEVINL void phase_ff1(f32x4_t (&a1)[2][4], const char* abuf, WStream& ws, int lane) {
     lane = fresh_v(lane);
-    const int r = lane & 31, h = lane >> 5;
-#pragma unroll 1
-    for (int s0 = 0; s0 < nst; s0 += CH_D) {
+    const FragOff fo = frag_off(abuf, lane);
+    u32x4 b[4];
 #pragma unroll
-        for (int i = 0; i < CH_D; ++i) {
-            const u32x4 w0 = ws.a[i], w1 = ws.b[i];
-            ws_load(ws, i, ws.pos + CH_D);
-            ws.pos++;
-            const int ks = s0 + i;
-            const char* at = abuf + (ks >> 2) * 8192;
-            const int ch = 2 * (ks & 3) + h;
-            const u32x4 a0 = CH_FRAG(at, r, ch), a1 = CH_FRAG(at, 32 + r, ch);
-            CH_MMA(acc[0][0], w0, a0);
-            CH_MMA(acc[0][1], w1, a0);
-            CH_MMA(acc[1][0], w0, a1);
-            CH_MMA(acc[1][1], w1, a1);
-            asm volatile("" ::: "memory");
-        }
-    }
-}
-// linear1 chunk: acc[mi] (columns 32 wave + ..) += act[64 x 512] * W1 chunk; a stage = 2 k-steps of the wave's 32 rows
-DEVINL void phase_ff1(f32x16_t (&acc)[2], const char* abuf, WStream& ws, int lane) {
-    lane = fresh_v(lane);
-    const int r = lane & 31, h = lane >> 5;
-    u32x4 a0 = CH_FRAG(abuf, r, h), a1 = CH_FRAG(abuf, 32 + r, h);
+    for (int mt = 0; mt < 4; ++mt) b[mt] = frag_rd(fo, 0, mt);
     const unsigned base = ws.pos;
-    // (CH_D deep only: two accumulator sets are live in the feed-forward loop)
 #pragma unroll
-    for (int st = 0; st < 16; ++st) {
+    for (int st = 0; st < 8; ++st) {
         const int i = st % CH_D;
-        const u32x4 wk[2] = {ws.a[i], ws.b[i]};
+        const u32x4 wk[4] = {ws.w[i][0], ws.w[i][1], ws.w[i][2], ws.w[i][3]};
         ws_load(ws, i, base + st + CH_D);
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
             const int ks = 2 * st + k2;
-            u32x4 n0 = a0, n1 = a1;
-            if (ks + 1 < 32) {
-                const char* at = abuf + ((ks + 1) >> 2) * 8192;
-                const int ch = 2 * ((ks + 1) & 3) + h;
-                n0 = CH_FRAG(at, r, ch);
-                n1 = CH_FRAG(at, 32 + r, ch);
+            u32x4 n0 = b[0], n1 = b[1], n2 = b[2], n3 = b[3];
+            if (ks + 1 < 16) {
+                n0 = frag_rd(fo, ks + 1, 0);
+                n1 = frag_rd(fo, ks + 1, 1);
+                n2 = frag_rd(fo, ks + 1, 2);
+                n3 = frag_rd(fo, ks + 1, 3);
             }
             __builtin_amdgcn_sched_barrier(0);   // see phase_n512
-            CH_MMA(acc[0], wk[k2], a0);
-            CH_MMA(acc[1], wk[k2], a1);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                mma16(a1[0][mt], wk[2 * k2], b[mt]);
+                mma16(a1[1][mt], wk[2 * k2 + 1], b[mt]);
+            }
             __builtin_amdgcn_sched_barrier(0);
-            asm volatile("" : "+v"(n0), "+v"(n1) : : "memory");
-            a0 = n0;
-            a1 = n1;
+            asm volatile("" : "+v"(a1[0][0]), "+v"(a1[0][1]), "+v"(a1[0][2]), "+v"(a1[0][3]), "+v"(a1[1][0]), "+v"(a1[1][1]),
+                         "+v"(a1[1][2]), "+v"(a1[1][3]));
+            asm volatile("" : "+v"(n0), "+v"(n1), "+v"(n2), "+v"(n3) : : "memory");
+            b[0] = n0; b[1] = n1; b[2] = n2; b[3] = n3;
         }
     }
-    ws.pos = base + 16;
+    ws.pos = base + 8;
 }
 
-// LayerNorm statistics of the 64 rows over all 512 columns: this lane's rows are 32 mi + r.  One exchange: every wave
+// LayerNorm statistics of the 64 rows over all 512 columns: this lane's rows are 16 mt + c.  One exchange: every wave
 // publishes (sum, sum of squares) of its 64 columns, var = E[v^2] - mean^2 in fp32 (|mean| is of the order of the
 // standard deviation for these activations: the cancellation costs ~1e-7 relative, far below the bf16 operands).
 // Returns rstd and nmr = -mean * rstd: the normalised value is fma(v, rstd, nmr), one op per element instead of two.
-// The sums run on float2 accumulators (v_pk_add_f32 / v_pk_fma_f32: 64 instructions for the 64 values, not 128).
-DEVINL void row_stats(const f32x16_t (&acc)[2][2], float* scr, int wave, int lane, float eps, float (&nmr)[2],
-                      float (&rstd)[2]) {
+// Lane l finishes row l of the block (reduce-scatter over the lane groups, then the 8 waves' pairs in wave order: the
+// sums are deterministic), and the four lane groups exchange their rows' (rstd, nmr) by swaps.
+DEVINL void row_stats(const acc_t& acc, float* scr, int wave, int lane, float eps, float (&nmr)[4], float (&rstd)[4]) {
     lane = fresh_v(lane);
     wave = fresh_s(wave);
-    const int r = lane & 31;
-    float s[2], s2[2];
+    float s[4], s2[4];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
+    for (int mt = 0; mt < 4; ++mt) {
         f32x2_t t = {0.0f, 0.0f}, t2 = {0.0f, 0.0f};
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-            for (int q = 0; q < 16; q += 2) {
-                const f32x2_t v = {acc[mi][ni][q], acc[mi][ni][q + 1]};
+            for (int q = 0; q < 4; q += 2) {
+                const f32x2_t v = {acc[nt][mt][q], acc[nt][mt][q + 1]};
                 t += v;
                 t2 = __builtin_elementwise_fma(v, v, t2);
             }
-        const float ts = t[0] + t[1], t2s = t2[0] + t2[1];
-        s[mi] = ts + other_half(ts);
-        s2[mi] = t2s + other_half(t2s);
+        s[mt] = t[0] + t[1];
+        s2[mt] = t2[0] + t2[1];
     }
-    if (lane < 32) {
-        scr[wave * 64 + r] = s[0];
-        scr[wave * 64 + 32 + r] = s[1];
-        scr[512 + wave * 64 + r] = s2[0];
-        scr[512 + wave * 64 + 32 + r] = s2[1];
-    }
+    f32x2_t mine;
+    mine[0] = rs4_sum(s[0], s[1], s[2], s[3]);
+    mine[1] = rs4_sum(s2[0], s2[1], s2[2], s2[3]);
+    *reinterpret_cast<f32x2_t*>(scr + (wave * 64 + lane) * 2) = mine;       // row `lane` of the block, this wave's columns
     lds_barrier();
+    f32x2_t tot = {0.0f, 0.0f};
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-        float t = 0.0f, t2 = 0.0f;
-#pragma unroll
-        for (int w = 0; w < 8; ++w) {
-            t += scr[w * 64 + 32 * mi + r];
-            t2 += scr[512 + w * 64 + 32 * mi + r];
-        }
-        const float mean = t * (1.0f / 512.0f);
-        const float var = fmaxf(t2 * (1.0f / 512.0f) - mean * mean, 0.0f);
-        rstd[mi] = rsqrtf(var + eps);
-        nmr[mi] = -mean * rstd[mi];
-    }
+    for (int w = 0; w < 8; ++w) tot += *reinterpret_cast<const f32x2_t*>(scr + (w * 64 + lane) * 2);
+    const float mean = tot[0] * (1.0f / 512.0f);
+    const float var = fmaxf(tot[1] * (1.0f / 512.0f) - mean * mean, 0.0f);
+    const float rs = rsqrtf(var + eps);
+    ag4(rs, rstd);
+    ag4(-mean * rs, nmr);
 }
 
-// constants of an epilogue come from LDS (staged by stage_consts): no long-latency loads, no long-lived registers
-// Byte offset of this lane's first column (64 wave + 4 h) in a 512-float LDS vector, as a value the compiler cannot take
-// apart: the per-iteration column offsets then fold into the ds_read immediates instead of being recomputed (under
-// register pressure hipcc rematerialised ~2 VALU adds per constant read: 90 per epilogue).
-DEVINL int col_base_bytes(int wave, int h) {
-    int v = (64 * wave + 4 * h) * 4;
-    asm volatile("" : "+v"(v));
-    return v;
-}
 DEVINL f32x4_t lds4b(const char* base, int byte_off) {
     return *reinterpret_cast<const f32x4_t*>(base + byte_off);
 }
 DEVINL f32x4_t lds4(const char* base, int float_index) {
     return *reinterpret_cast<const f32x4_t*>(base + float_index * 4);
 }
+// Byte offset of this lane's first column (64 wave + 4 g) in a 512-float LDS vector, as a value the compiler cannot take
+// apart: the per-iteration column offsets (64 nt bytes) then fold into the ds_read immediates.
+DEVINL int col_base_bytes(int wave, int g) {
+    int v = (64 * wave + 4 * g) * 4;
+    asm volatile("" : "+v"(v));
+    return v;
+}
 
-// This lane's two rows of a [rows, 512] fp32 matrix (residual stream, rotary table), 8 column groups each: a register
-// pipeline 4 groups deep (32 VGPRs; all 16 float4 at once would not fit beside accumulators and weight ring).
-// Layouts.  Row-major [row][512]: a load instruction then touches 32 rows x 32 bytes = 32 separate line requests, and
-// five such passes plus three store passes cost ~17 us of a 130-us launch (measured by ablation).  COLUMN-BLOCKED
-// [64 groups of 8 columns][rows][8 floats]: the 32 rows of a lane half are consecutive, so an instruction reads ONE
-// contiguous kilobyte.  The residual stream between chain launches and the rotary table handed to them are
-// column-blocked; only layer 0's input (written by gemm_rowln) is row-major (`xres_rowmajor`).
+// This lane's four rows of a [rows, 512] fp32 matrix (residual stream, rotary table), 4 column quads each (one per
+// n-tile): a register pipeline 2 n-tiles deep (32 VGPRs).
+// Layouts.  Row-major [row][512]: a load instruction then touches 16 rows x 64 bytes.  COLUMN-BLOCKED
+// [64 groups of 8 columns][rows][8 floats]: the 16 rows of two lane groups are consecutive, so an instruction reads two
+// contiguous half kilobytes.  The residual stream between chain launches and the rotary table handed to them are
+// column-blocked; only layer 0's input when written by gemm_rowln is row-major (`xres_rowmajor`).
 struct RowPipe {
-    __amdgpu_buffer_rsrc_t rsrc;   // the matrix as a raw buffer: address = SGPR descriptor + SGPR (column group) + VGPR (row)
-    unsigned voff[2];              // byte offset of this lane's 16 bytes of its row inside a column group
-    unsigned soff, its;            // byte offset of column group 8 wave, bytes between column groups (wave-uniform)
-    f32x4_t q[4][2];               // [group & 3][row tile]
+    __amdgpu_buffer_rsrc_t rsrc;   // the matrix as a raw buffer: address = SGPR descriptor + SGPR (n-tile) + VGPR (row, lane group)
+    unsigned voff[4];              // byte offset of this lane's 16 bytes of row tile mt inside the wave's first column group
+    unsigned soff, its;            // byte offset of the wave's first column group, bytes per n-tile step (wave-uniform)
+    f32x4_t q[2][4];               // [n-tile & 1][row tile]
 };
 DEVINL __amdgpu_buffer_rsrc_t f32_buffer(const float* base, long n_floats) {
     const long bytes = n_floats * 4;
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes < 0xFFFFFFFFl ? (int)bytes : -1, 0x00020000);
 }
-DEVINL void rp_issue(RowPipe& rp, int it) {
-#ifdef CH_ABLATE_XLOAD
+DEVINL void rp_issue(RowPipe& rp, int nt) {
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) rp.q[it & 3][mi] = f32x4_t{0.5f, 0.25f, 0.5f, 0.25f};
-#else
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-        rp.q[it & 3][mi] = __builtin_bit_cast(
-            f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rp.rsrc, rp.voff[mi], rp.soff + (unsigned)it * rp.its, 0));
-#endif
+    for (int mt = 0; mt < 4; ++mt)
+        rp.q[nt & 1][mt] = __builtin_bit_cast(
+            f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rp.rsrc, rp.voff[mt], rp.soff + (unsigned)nt * rp.its, 0));
 }
 // rows: row count of the column-blocked matrix, or 0 for a row-major one (`total_rows` rows of 512 floats)
-DEVINL void rp_start(RowPipe& rp, const float* base, const int (&row)[2], long rows, long total_rows, int wave, int h) {
+DEVINL void rp_start(RowPipe& rp, const float* base, const int (&row)[4], long rows, long total_rows, int wave, int g) {
     rp.rsrc = f32_buffer(base, total_rows * 512);
-    rp.its = rows > 0 ? (unsigned)rows * 32u : 32u;
-    rp.soff = rows > 0 ? (unsigned)wave * 8u * rp.its : (unsigned)wave * 256u;
+    const unsigned grp = rows > 0 ? (unsigned)rows * 32u : 0u;       // bytes per column group of 8
+    rp.its = rows > 0 ? 2u * grp : 64u;
+    rp.soff = rows > 0 ? (unsigned)wave * 8u * grp : (unsigned)wave * 256u;
+    const unsigned gterm = rows > 0 ? (unsigned)(g >> 1) * grp + 16u * (g & 1) : 16u * g;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-        rp.voff[mi] = rows > 0 ? (unsigned)row[mi] * 32u + 16u * h : (unsigned)row[mi] * 2048u + 16u * h;
-#pragma unroll
-    for (int it = 0; it < 4; ++it) rp_issue(rp, it);
+    for (int mt = 0; mt < 4; ++mt)
+        rp.voff[mt] = (rows > 0 ? (unsigned)row[mt] * 32u : (unsigned)row[mt] * 2048u) + gterm;
+    rp_issue(rp, 0);
+    rp_issue(rp, 1);
 }
-// store this lane's 16 bytes of column group 8 wave + it of a column-blocked matrix of `rows` rows
-DEVINL void cb_store(__amdgpu_buffer_rsrc_t rsrc, long rows, int wave, int it, int row, int h, f32x4_t v) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, (unsigned)row * 32u + 16u * h,
-                                           (unsigned)(wave * 8 + it) * ((unsigned)rows * 32u), 0);
+// store this lane's 16 bytes (columns 64 wave + 16 nt + 4 g ..) of row `row` of a column-blocked matrix of `rows` rows
+DEVINL void cb_store(__amdgpu_buffer_rsrc_t rsrc, long rows, int wave, int nt, int row, int g, f32x4_t v) {
+    const unsigned grp = (unsigned)rows * 32u;
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc,
+                                           (unsigned)row * 32u + (unsigned)(g >> 1) * grp + 16u * (g & 1),
+                                           (unsigned)(wave * 8 + 2 * nt) * grp, 0);
 }
 
-// u = LayerNorm(acc) (optionally rotated) -> bf16 -> activation block in LDS (k = column); g, b: LDS vectors;
+// LDS byte offset of this lane's 8 bytes (4 bf16: columns 16 nt + 4 g .. of the wave's k-tile) of row 16 mt + c in a
+// [64][128 B] activation tile: + mt * 2048; the chunk is 2 nt + (g >> 1) (+ 4 for the odd half of a 32-column owner)
+DEVINL int act_wr_off(int lane, int nt, int chunk0 = 0) {
+    const int c = lane & 15, g = lane >> 4;
+    return c * TC_ROWB + (((chunk0 + 2 * nt + (g >> 1)) ^ tile_swz(c)) << 4) + 8 * (g & 1);
+}
+
+// linear2 over one 256-column chunk of h1 (8 stages, as phase_n512<8>) with the bias + GELU + bf16 packing of the NEXT chunk's
+// linear1 accumulators a1 issued one tile per stage behind that stage's MFMAs: the VALU work (exact-erf polynomial, ~45
+// instructions per tile) runs while the matrix pipe executes, instead of between two GEMM phases with the matrix pipe idle
+// (round 3: 2.5-3.6 us per chunk between linear1 and linear2).  hbw: the h1 buffer of the next chunk; bias1: b1 + its first column.
+DEVINL void phase_ff2_gelu(acc_t& acc, const char* hbr, WStream& ws, int lane, const f32x4_t (&a1)[2][4], char* hbw,
+                           const char* bias1, int wave) {
+    lane = fresh_v(lane);
+    const FragOff fo = frag_off(hbr, lane);
+    const int g = lane >> 4;
+    unsigned wo[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)     // chunk column 32 wave + 16 nt + 4 g: k-tile wave / 2, 16-byte chunk 4 (wave & 1) + 2 nt + (g >> 1)
+        wo[nt] = (unsigned)reinterpret_cast<uintptr_t>(hbw) + (wave >> 1) * 8192 + act_wr_off(lane, nt, 4 * (wave & 1));
+    asm volatile("" : "+v"(wo[0]), "+v"(wo[1]));
+    int bo = (32 * wave + 4 * g) * 4;
+    asm volatile("" : "+v"(bo));
+    u32x4 b[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) b[mt] = frag_rd(fo, 0, mt);
+    const unsigned base = ws.pos;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        const int i = ks % CH_D;
+        const u32x4 w0 = ws.w[i][0], w1 = ws.w[i][1], w2 = ws.w[i][2], w3 = ws.w[i][3];
+        ws_load(ws, i, base + ks + CH_D);
+        u32x4 n0 = b[0], n1 = b[1], n2 = b[2], n3 = b[3];
+        if (ks + 1 < 8) {
+            n0 = frag_rd(fo, ks + 1, 0);
+            n1 = frag_rd(fo, ks + 1, 1);
+            n2 = frag_rd(fo, ks + 1, 2);
+            n3 = frag_rd(fo, ks + 1, 3);
+        }
+        const int nt = ks >> 2, mt = ks & 3;           // the a1 tile of this stage
+        const f32x4_t b4 = lds4b(bias1 + bo, 64 * nt);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m2 = 0; m2 < 4; ++m2) {
+            mma16(acc[0][m2], w0, b[m2]);
+            mma16(acc[1][m2], w1, b[m2]);
+            mma16(acc[2][m2], w2, b[m2]);
+            mma16(acc[3][m2], w3, b[m2]);
+        }
+        {
+            float v[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[t] = a1[nt][mt][t] + b4[t];
+            act4_ct<ACT_GELU>(v, ACT_GELU);
+            typedef __attribute__((ext_vector_type(2))) uint32_t u32x2v;
+            typedef __attribute__((address_space(3))) u32x2v lds_u32x2;
+            const u32x2v pk = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+            *reinterpret_cast<lds_u32x2*>((uintptr_t)(wo[nt] + (unsigned)(mt * 2048))) = pk;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc_fence(acc);
+        asm volatile("" : "+v"(n0), "+v"(n1), "+v"(n2), "+v"(n3) : : "memory");
+        b[0] = n0; b[1] = n1; b[2] = n2; b[3] = n3;
+    }
+    ws.pos = base + 8;
+}
+
+// u = LayerNorm(acc) (optionally rotated) -> bf16 -> activation block in LDS (k = column); gv, bv: LDS vectors;
 // rp: the rotary rows (cos0 sin0 cos1 sin1 per column quad), started by the caller before the statistics exchange
 template <bool ROT>
-DEVINL void norm_to_lds(const f32x16_t (&acc)[2][2], const float (&nmr)[2], const float (&rstd)[2], const char* g,
-                        const char* b, RowPipe& rp, char* abuf, int wave, int lane, char* plain) {
+DEVINL void norm_to_lds(const acc_t& acc, const float (&nmr)[4], const float (&rstd)[4], const char* gv, const char* bv,
+                        RowPipe& rp, char* abuf, int wave, int lane, char* plain) {
     lane = fresh_v(lane);
     wave = fresh_s(wave);
-    const int r = lane & 31, h = lane >> 5;
-    const int cb0 = col_base_bytes(wave, h);
+    const int g = lane >> 4;
+    const int cb0 = col_base_bytes(wave, g);
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const int ni = it >> 2, gq = it & 3;
-        const f32x4_t g4 = lds4b(g + cb0, 32 * it), b4 = lds4b(b + cb0, 32 * it);
+    for (int nt = 0; nt < 4; ++nt) {
+        const f32x4_t g4 = lds4b(gv + cb0, 64 * nt), b4 = lds4b(bv + cb0, 64 * nt);
+        const int wo = wave * 8192 + act_wr_off(lane, nt);
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
+        for (int mt = 0; mt < 4; ++mt) {
             float u[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) u[t] = fmaf(fmaf(acc[mi][ni][4 * gq + t], rstd[mi], nmr[mi]), g4[t], b4[t]);
+            for (int t = 0; t < 4; ++t) u[t] = fmaf(fmaf(acc[nt][mt][t], rstd[mt], nmr[mt]), g4[t], b4[t]);
             if (plain) {   // the un-rotated image too (V = norm1(x) W_v)
                 uint2 pk;
                 pk.x = pack_bf2(u[0], u[1]);
                 pk.y = pack_bf2(u[2], u[3]);
-                *reinterpret_cast<uint2*>(plain + wave * 8192 + tile_off(32 * mi + r, 4 * ni + gq) + 8 * h) = pk;
+                *reinterpret_cast<uint2*>(plain + wo + mt * 2048) = pk;
             }
             if (ROT) {
-                const f32x4_t q = rp.q[it & 3][mi];   // cos0 sin0 cos1 sin1
+                const f32x4_t q = rp.q[nt & 1][mt];   // cos0 sin0 cos1 sin1
                 const float y0 = u[0] * q[0] - u[1] * q[1], y1 = u[1] * q[0] + u[0] * q[1];
                 const float y2 = u[2] * q[2] - u[3] * q[3], y3 = u[3] * q[2] + u[2] * q[3];
                 u[0] = y0; u[1] = y1; u[2] = y2; u[3] = y3;
@@ -364,21 +479,21 @@ DEVINL void norm_to_lds(const f32x16_t (&acc)[2][2], const float (&nmr)[2], cons
             uint2 pk;
             pk.x = pack_bf2(u[0], u[1]);
             pk.y = pack_bf2(u[2], u[3]);
-            *reinterpret_cast<uint2*>(abuf + wave * 8192 + tile_off(32 * mi + r, 4 * ni + gq) + 8 * h) = pk;
+            *reinterpret_cast<uint2*>(abuf + wo + mt * 2048) = pk;
         }
-        if (ROT && it + 4 < 8) rp_issue(rp, it + 4);
-        CH_FENCE();   // one column group at a time (see the fc epilogue)
+        if (ROT && nt + 2 < 4) rp_issue(rp, nt + 2);
+        CH_FENCE();   // one n-tile at a time (see the fc epilogue)
     }
 }
 
 // head-major scatter of a 512-wide projection (wave = head): model/model.py:78-80,92-95.  The accumulator layout gives a
-// lane 8 bytes of a row at a time; written like that every store instruction makes 32 sixteen-byte write requests, and
-// the three scatters of the next layer's Q, K, V cost 13 us of a 130-us launch.  Instead each 32-row half of the wave's
-// [64 rows][64 columns] tile goes through 4 KB of the (by now idle) constants area -- wave-private, XOR-swizzled by
-// (row >> 1) & 7 (the 64 banks hold two 128-byte rows), no barrier -- and leaves as 16 bytes per lane, 8 lanes per 128-byte row: 8 full lines per instruction.
+// lane 8 bytes of a row at a time; written like that every store instruction makes 16 thirty-two-byte write requests.
+// Instead each 32-row half of the wave's [64 rows][64 columns] tile goes through 4 KB of the (by now idle) constants area
+// -- wave-private, XOR-swizzled by (row >> 1) & 7 (the 64 banks hold two 128-byte rows), no barrier -- and leaves as 16
+// bytes per lane, 8 lanes per 128-byte row: 8 full lines per instruction.
 DEVINL char* stage_area(char* smem, int wave) { return smem + (wave < 7 ? wave * 4096 : CH_STG7); }
 template <bool SCALE>   // Q carries 1 / sqrt(d_k); K and V are stored as they are
-DEVINL void store_heads(const f32x16_t (&acc)[2][2], void* base, float scale, int L, int Lp, int H, int m0, int M,
+DEVINL void store_heads(const acc_t& acc, void* base, float scale, int L, int Lp, int H, int m0, int M,
                         int wave, int lane, char* smem, int dn = 1, int dancer = 0) {
     // rows are FRAMES m0 .. of dancer `dancer` (token = frame dn + dancer; dn = 1: rows are tokens); L tokens per sequence
 #ifdef CH_ABLATE_STORES   // timing experiment only: how much of the Q / K / V tail is the head-major scatter?
@@ -386,29 +501,38 @@ DEVINL void store_heads(const f32x16_t (&acc)[2][2], void* base, float scale, in
 #endif
     lane = fresh_v(lane);
     wave = fresh_s(wave);
-    const int r = lane & 31, h = lane >> 5;
+    const int c = lane & 15, g = lane >> 4;
     char* stg = stage_area(smem, wave);
     const int row0 = lane >> 3, ch = lane & 7;      // read side: row row0 + 8 k, 16-byte chunk ch
     const int Lf = L / dn;                          // frames per sequence
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
+    for (int hf = 0; hf < 2; ++hf) {
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ml = 0; ml < 2; ++ml) {
+            const int rl = 16 * ml + c;             // row of the 32-row staging tile
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
+            for (int nt = 0; nt < 4; ++nt) {
+                const f32x4_t v = acc[nt][2 * hf + ml];
                 uint2 pk;
                 if (SCALE) {
-                    pk.x = pack_bf2(acc[mi][ni][4 * gq + 0] * scale, acc[mi][ni][4 * gq + 1] * scale);
-                    pk.y = pack_bf2(acc[mi][ni][4 * gq + 2] * scale, acc[mi][ni][4 * gq + 3] * scale);
+                    pk.x = pack_bf2(v[0] * scale, v[1] * scale);
+                    pk.y = pack_bf2(v[2] * scale, v[3] * scale);
                 } else {
-                    pk.x = pack_bf2(acc[mi][ni][4 * gq + 0], acc[mi][ni][4 * gq + 1]);
-                    pk.y = pack_bf2(acc[mi][ni][4 * gq + 2], acc[mi][ni][4 * gq + 3]);
+                    pk.x = pack_bf2(v[0], v[1]);
+                    pk.y = pack_bf2(v[2], v[3]);
                 }
-                *reinterpret_cast<uint2*>(stg + r * 128 + (((4 * ni + gq) ^ ((r >> 1) & 7)) << 4) + 8 * h) = pk;
+                *reinterpret_cast<uint2*>(stg + rl * 128 + (((2 * nt + (g >> 1)) ^ ((rl >> 1) & 7)) << 4) + 8 * (g & 1)) = pk;
             }
+        }
         // the LDS queue of a wave is in order: its reads below see its writes above
-        int m = m0 + 32 * mi + row0;
-        const int seq = m / Lf;
+        int m = m0 + 32 * hf + row0;
+        int seq;
+        if (dn == 1) {                 // rows are tokens: the block starts in sequence m0 / L (scalar) and crosses at most once
+            const int sq0 = m0 / L;
+            seq = m >= (sq0 + 1) * L ? sq0 + 1 : sq0;
+        } else {
+            seq = m / Lf;
+        }
         int tokf = m - seq * Lf;
         // destination of (sequence, head = wave, token, chunk): +8 frames = +8 dn tokens of 128 bytes; past the end of a
         // sequence the next one starts (H * Lp - L) rows further
@@ -432,249 +556,144 @@ DEVINL void store_heads(const f32x16_t (&acc)[2][2], void* base, float scale, in
 
 // Cross-attention of this wave's head inside the chain (model/model.py:386-396,97-102 with cached K / V): the wave owns
 // head `wave` of all 64 rows.  qacc = (rot W_q^T)^T tiles straight from the projection GEMM (lane = row, registers = d):
-// scaled and packed they ARE the B operand of S^T = K Q^T, with d in the order the accumulator holds it -- the K / V
-// caches are kept in a second, fragment-ordered image (tcdiff_pack_kv_frags) whose 1-KB pieces load straight into the
-// A operands.  Online softmax over 32-key tiles exactly as csrc/attention.hip; O^T = V^T P^T with P^T fed from the S^T
-// accumulator registers.  A 32-row tile that straddles two sequences runs once per sequence and every lane keeps the
-// result of its own row's sequence.  Output: bf16 O rows into the activation block (columns 64 wave ..).
-DEVINL void cross_attention(const f32x16_t (&qacc)[2][2], const tcdiff_chain_args& a, int m0, char* abuf, int wave,
-                            int lane) {
+// scaled and packed, the pairs (nt = 2 s, 2 s + 1) ARE the B operand of S^T = K Q^T for the 32-deep d-step s, with d in the
+// order the accumulators hold it (slot 8 g + jj <-> d = 32 s + 16 (jj >> 2) + 4 g + (jj & 3)) -- the K / V caches are kept
+// in a second, fragment-ordered image (tcdiff_pack_kv_frags) whose 1-KB pieces load straight into the A operands with the
+// same order.  Online softmax over 32-key tiles (two 16-key score tiles); O^T = V^T P^T with P^T fed from the S^T
+// accumulator registers (key slot 8 g + jj <-> key 16 (jj >> 2) + 4 g + (jj & 3) of the tile).  The row sum stays a per-lane
+// partial until the end; only the row maximum crosses the lane groups per tile.  Two passes of 32 rows (two row tiles each:
+// the O accumulators of all four would not fit beside the weight ring); a pass whose rows straddle two sequences runs
+// once per sequence and every lane keeps the result of its own row's sequence.
+// Output: bf16 O rows into the activation block (columns 64 wave ..).
+DEVINL void cross_attention(const acc_t& qacc, const tcdiff_chain_args& a, int m0, char* abuf, int wave, int lane) {
     lane = fresh_v(lane);
     wave = fresh_s(wave);
-    const int r = lane & 31, h = lane >> 5;
+    const int c = lane & 15, g = lane >> 4;
     const int M = a.M, L = a.L, nkt = a.nkt;
-    u32x4 qf[2][4];
+    u32x4 qf[4][2];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int s16 = 0; s16 < 4; ++s16) {
-            const int ni = s16 >> 1, o8 = 8 * (s16 & 1);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                qf[mi][s16][j] = pack_bf2(qacc[mi][ni][o8 + 2 * j] * a.scale_q, qacc[mi][ni][o8 + 2 * j + 1] * a.scale_q);
-        }
-    constexpr float LOG2E = 1.4426950408889634f;
-    const long head_bytes = (long)nkt * 4096;
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-        int ra = m0 + 32 * mi, rb = ra + 31;
-        ra = ra < M ? ra : M - 1;
-        rb = rb < M ? rb : M - 1;
-        const int sa = ra / L, sb = rb / L;                 // wave-uniform
-        int mrow = m0 + 32 * mi + r;
-        mrow = mrow < M ? mrow : M - 1;
-        const int my_seq = mrow / L;
-#pragma unroll 1
-        for (int seq = sa; seq <= sb; ++seq) {
-            const int kv = seq < a.n_shared ? 0 : seq - a.n_shared + (a.n_shared > 0 ? 1 : 0);
-            const u32x4* Kp = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(a.kf) +
-                                                              ((long)kv * a.H + wave) * head_bytes) + lane;
-            const u32x4* Vp = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(a.vf) +
-                                                              ((long)kv * a.H + wave) * head_bytes) + lane;
-            f32x16_t o[2];
-            zero(o[0]);
-            zero(o[1]);
-            float m_run = -INFINITY, l_run = 0.0f;
-            u32x4 kn[4];                                           // K fragments run one tile ahead
-#pragma unroll
-            for (int i = 0; i < 4; ++i) kn[i] = Kp[i * 64];
-#pragma unroll 1
-            for (int kt = 0; kt < nkt; ++kt) {
-                u32x4 kc[4], vc[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    kc[i] = kn[i];
-                    vc[i] = Vp[(kt * 4 + i) * 64];                 // V of this tile: in flight under QK^T and the softmax
-                }
-                const int nx = kt + 1 < nkt ? kt + 1 : kt;       // the last iteration re-reads its own tile (unused)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) kn[i] = Kp[(nx * 4 + i) * 64];
-                f32x16_t s;
-                zero(s);
-#pragma unroll
-                for (int s16 = 0; s16 < 4; ++s16) MmaBF16::mma(s, kc[s16], qf[mi][s16]);
-                if (kt * 32 + 32 > a.Lk) {
-#pragma unroll
-                    for (int q = 0; q < 16; ++q)
-                        if (kt * 32 + acc_row(q, h) >= a.Lk) s[q] = -INFINITY;
-                }
-                float mx = s[0];
-#pragma unroll
-                for (int q = 1; q < 16; ++q) mx = fmaxf(mx, s[q]);
-                mx = fmaxf(mx, other_half(mx)) * LOG2E;
-                const float m_new = fmaxf(m_run, mx);
-                // x = s log2(e) - m and the row sum as float2 ops (v_pk_fma_f32 / v_pk_add_f32); exp2 stays scalar
-                f32x2_t rs2 = {0.0f, 0.0f};
-                const f32x2_t l2 = {LOG2E, LOG2E}, nm = {-m_new, -m_new};
-#pragma unroll
-                for (int q = 0; q < 16; q += 2) {
-                    const f32x2_t x = __builtin_elementwise_fma(f32x2_t{s[q], s[q + 1]}, l2, nm);
-                    const f32x2_t pp = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
-                    s[q] = pp[0];
-                    s[q + 1] = pp[1];
-                    rs2 += pp;
-                }
-                float rs = rs2[0] + rs2[1];
-                rs += other_half(rs);
-                // the running maximum moves in the first tile or two; afterwards the whole wave skips the rescale
-                if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {
-                    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // first tile: exp2(-inf) = 0, o is 0
-                    l_run *= alpha;
-#pragma unroll
-                    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                        for (int q = 0; q < 16; ++q) o[dt][q] *= alpha;
-                    m_run = m_new;
-                }
-                l_run += rs;
-#pragma unroll
-                for (int sp = 0; sp < 2; ++sp) {
-                    u32x4 pf;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) pf[j] = pack_bf2(s[8 * sp + 2 * j], s[8 * sp + 2 * j + 1]);
-#pragma unroll
-                    for (int dt = 0; dt < 2; ++dt) MmaBF16::mma(o[dt], vc[sp * 2 + dt], pf);
-                }
-            }
-            if (my_seq == seq) {
-                const float inv = 1.0f / l_run;
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) {
-                        uint2 pk;
-                        pk.x = pack_bf2(o[dt][4 * gq + 0] * inv, o[dt][4 * gq + 1] * inv);
-                        pk.y = pack_bf2(o[dt][4 * gq + 2] * inv, o[dt][4 * gq + 3] * inv);
-                        *reinterpret_cast<uint2*>(abuf + wave * 8192 + tile_off(32 * mi + r, 4 * dt + gq) + 8 * h) = pk;
-                    }
-            }
-        }
-    }
-}
-
-// The same cross-attention with the K / V fragment loads of later tiles in flight while a tile is computed, for a memory of
-// exactly NKT tiles (the benchmark's 150 + 2 keys: NKT = 5).  The loop above exposes one L2 round trip per tile (a dependent
-// chain K -> S -> softmax -> P -> V of ~0.3 us of work per ~1 us of latency, 10 tiles per wave).  Here the (<= 2 NKT) tiles
-// of a row tile are straight-line code over NSET register sets (a rolled loop would carry them through phis, and a copy
-// of a set in flight is a vmcnt drain), addressed through a raw buffer (SGPR descriptor + SGPR tile offset).  The sets
-// need the weight ring's registers: the caller runs the GEMM in front without refilling the ring and re-primes it behind.
-template <int NKT, int NSET>
-DEVINL void cross_attention_p(const f32x16_t (&qacc)[2][2], const tcdiff_chain_args& a, int m0, char* abuf, int wave,
-                              int lane) {
-    static_assert(NSET == 2 || NSET == 3, "two or three K / V register sets");
-    lane = fresh_v(lane);
-    wave = fresh_s(wave);
-    const int r = lane & 31, h = lane >> 5;
-    const int M = a.M, L = a.L;
-    u32x4 qf[2][4];
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int s16 = 0; s16 < 4; ++s16) {
-            const int ni = s16 >> 1, o8 = 8 * (s16 & 1);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                qf[mi][s16][j] = pack_bf2(qacc[mi][ni][o8 + 2 * j] * a.scale_q, qacc[mi][ni][o8 + 2 * j + 1] * a.scale_q);
+        for (int s = 0; s < 2; ++s) {
+            const f32x4_t lo = qacc[2 * s][mt], hi = qacc[2 * s + 1][mt];
+            qf[mt][s][0] = pack_bf2(lo[0] * a.scale_q, lo[1] * a.scale_q);
+            qf[mt][s][1] = pack_bf2(lo[2] * a.scale_q, lo[3] * a.scale_q);
+            qf[mt][s][2] = pack_bf2(hi[0] * a.scale_q, hi[1] * a.scale_q);
+            qf[mt][s][3] = pack_bf2(hi[2] * a.scale_q, hi[3] * a.scale_q);
         }
     constexpr float LOG2E = 1.4426950408889634f;
     const unsigned voff = (unsigned)lane * 16u;
     const __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.kf), 0, -1, 0x00020000);
     const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.vf), 0, -1, 0x00020000);
+    auto ld_tile = [&](const __amdgpu_buffer_rsrc_t& r, unsigned so, u32x4 (&f)[4]) {
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-        int ra = m0 + 32 * mi, rb = ra + 31;
+        for (int i = 0; i < 4; ++i) f[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff + 1024u * i, so, 0));
+    };
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {               // rows 32 ps .. 32 ps + 31 = row tiles 2 ps, 2 ps + 1
+        int ra = m0 + 32 * ps, rb = ra + 31;
         ra = ra < M ? ra : M - 1;
         rb = rb < M ? rb : M - 1;
-        const int sa = ra / L, sb = rb / L;                 // wave-uniform; sb - sa is 0 or 1
-        int mrow = m0 + 32 * mi + r;
-        mrow = mrow < M ? mrow : M - 1;
-        const int my_seq = mrow / L;
-        const int J = (sb - sa + 1) * NKT;                  // tiles of this row tile
-        auto fetch = [&](int j, u32x4 (&kc)[4], u32x4 (&vc)[4]) {   // tile j = (sequence sa + j / NKT, key tile j % NKT)
-            const int seq = sa + (j >= NKT ? 1 : 0), kt = j >= NKT ? j - NKT : j;
+        const int sa = ra / L, sb = rb / L;                 // wave-uniform
+        int my_seq[2];
+#pragma unroll
+        for (int ml = 0; ml < 2; ++ml) {
+            int mrow = m0 + 32 * ps + 16 * ml + c;
+            mrow = mrow < M ? mrow : M - 1;
+            my_seq[ml] = mrow / L;
+        }
+#pragma unroll 1
+        for (int seq = sa; seq <= sb; ++seq) {
             const int kv = seq < a.n_shared ? 0 : seq - a.n_shared + (a.n_shared > 0 ? 1 : 0);
-            const unsigned so = (unsigned)(((kv * a.H + wave) * NKT + kt) * 4096);
+            const unsigned so0 = (unsigned)((kv * a.H + wave) * nkt) * 4096u;      // this (slot, head)'s image (< 4 GB: launcher)
+            f32x4_t o[4][2];                                // [d tile][row tile of the pass]
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                kc[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(kr, voff + 1024u * i, so, 0));
-                vc[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(vr, voff + 1024u * i, so, 0));
-            }
-        };
-        f32x16_t o[2];
-        float m_run = -INFINITY, l_run = 0.0f;
-        auto tile = [&](int j, const u32x4 (&kc)[4], const u32x4 (&vc)[4]) {
-            const int kt = j >= NKT ? j - NKT : j;
-            if (kt == 0) {
-                zero(o[0]);
-                zero(o[1]);
-                m_run = -INFINITY;
-                l_run = 0.0f;
-            }
-            f32x16_t s;
-            zero(s);
+            for (int dt = 0; dt < 4; ++dt) o[dt][0] = o[dt][1] = f32x4_t{0, 0, 0, 0};
+            float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.0f, 0.0f};
+            u32x4 kn[4];                                           // K fragments run one tile ahead
+            ld_tile(kr, so0, kn);
+#pragma unroll 1
+            for (int kt = 0; kt < nkt; ++kt) {
+                u32x4 kc[4], vc[4];
 #pragma unroll
-            for (int s16 = 0; s16 < 4; ++s16) MmaBF16::mma(s, kc[s16], qf[mi][s16]);
-            if (kt * 32 + 32 > a.Lk) {
+                for (int i = 0; i < 4; ++i) kc[i] = kn[i];
+                ld_tile(vr, so0 + (unsigned)kt * 4096u, vc);       // V of this tile: in flight under QK^T and the softmax
+                const int nx = kt + 1 < nkt ? kt + 1 : kt;       // the last iteration re-reads its own tile (unused)
+                ld_tile(kr, so0 + (unsigned)nx * 4096u, kn);
+                // the two row tiles of the pass are independent chains in ONE basic block (no per-tile branch between them)
+                f32x4_t s0[2], s1[2];                              // keys 4 g + j and 16 + 4 g + j of the tile
 #pragma unroll
-                for (int q = 0; q < 16; ++q)
-                    if (kt * 32 + acc_row(q, h) >= a.Lk) s[q] = -INFINITY;
-            }
-            float mx = s[0];
+                for (int ml = 0; ml < 2; ++ml) {
+                    const int mt = 2 * ps + ml;
+                    s0[ml] = s1[ml] = f32x4_t{0, 0, 0, 0};
+                    mma16(s0[ml], kc[0], qf[mt][0]);
+                    mma16(s1[ml], kc[2], qf[mt][0]);
+                    mma16(s0[ml], kc[1], qf[mt][1]);
+                    mma16(s1[ml], kc[3], qf[mt][1]);
+                }
+                if (kt * 32 + 32 > a.Lk) {
 #pragma unroll
-            for (int q = 1; q < 16; ++q) mx = fmaxf(mx, s[q]);
-            mx = fmaxf(mx, other_half(mx)) * LOG2E;
-            const float m_new = fmaxf(m_run, mx);
-            f32x2_t rs2 = {0.0f, 0.0f};
-            const f32x2_t l2 = {LOG2E, LOG2E}, nm = {-m_new, -m_new};
+                    for (int ml = 0; ml < 2; ++ml)
 #pragma unroll
-            for (int q = 0; q < 16; q += 2) {
-                const f32x2_t x = __builtin_elementwise_fma(f32x2_t{s[q], s[q + 1]}, l2, nm);
-                const f32x2_t pp = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
-                s[q] = pp[0];
-                s[q + 1] = pp[1];
-                rs2 += pp;
-            }
-            float rs = rs2[0] + rs2[1];
-            rs += other_half(rs);
-            if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {
-                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-                l_run *= alpha;
+                        for (int j = 0; j < 4; ++j) {
+                            if (kt * 32 + 4 * g + j >= a.Lk) s0[ml][j] = -INFINITY;
+                            if (kt * 32 + 16 + 4 * g + j >= a.Lk) s1[ml][j] = -INFINITY;
+                        }
+                }
+                float m_new[2];
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt)
+                for (int ml = 0; ml < 2; ++ml) {
+                    float mx = fmaxf(fmaxf(fmaxf(s0[ml][0], s0[ml][1]), fmaxf(s0[ml][2], s0[ml][3])),
+                                     fmaxf(fmaxf(s1[ml][0], s1[ml][1]), fmaxf(s1[ml][2], s1[ml][3])));
+                    mx = ar4_max(mx) * LOG2E;
+                    m_new[ml] = fmaxf(m_run[ml], mx);
+                }
+                // the running maximum moves in the first tile or two; afterwards the whole wave skips the rescale
+                if (__builtin_amdgcn_ballot_w64(m_new[0] > m_run[0] || m_new[1] > m_run[1]) != 0) {
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) o[dt][q] *= alpha;
-                m_run = m_new;
-            }
-            l_run += rs;
+                    for (int ml = 0; ml < 2; ++ml) {
+                        const float alpha = __builtin_amdgcn_exp2f(m_run[ml] - m_new[ml]);   // first tile: exp2(-inf) = 0, o is 0
+                        l_run[ml] *= alpha;
 #pragma unroll
-            for (int sp = 0; sp < 2; ++sp) {
-                u32x4 pf;
+                        for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) pf[jj] = pack_bf2(s[8 * sp + 2 * jj], s[8 * sp + 2 * jj + 1]);
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) MmaBF16::mma(o[dt], vc[sp * 2 + dt], pf);
-            }
-            if (kt == NKT - 1 && my_seq == sa + (j >= NKT ? 1 : 0)) {   // this sequence is done: rows that belong to it
-                const float inv = 1.0f / l_run;
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) {
-                        uint2 pk;
-                        pk.x = pack_bf2(o[dt][4 * gq + 0] * inv, o[dt][4 * gq + 1] * inv);
-                        pk.y = pack_bf2(o[dt][4 * gq + 2] * inv, o[dt][4 * gq + 3] * inv);
-                        *reinterpret_cast<uint2*>(abuf + wave * 8192 + tile_off(32 * mi + r, 4 * dt + gq) + 8 * h) = pk;
+                            for (int j = 0; j < 4; ++j) o[dt][ml][j] *= alpha;
+                        m_run[ml] = m_new[ml];
                     }
+                }
+#pragma unroll
+                for (int ml = 0; ml < 2; ++ml) {
+                    float rs = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        s0[ml][j] = __builtin_amdgcn_exp2f(fmaf(s0[ml][j], LOG2E, -m_new[ml]));
+                        s1[ml][j] = __builtin_amdgcn_exp2f(fmaf(s1[ml][j], LOG2E, -m_new[ml]));
+                        rs += s0[ml][j] + s1[ml][j];
+                    }
+                    l_run[ml] += rs;
+                    u32x4 pf;
+                    pf[0] = pack_bf2(s0[ml][0], s0[ml][1]);
+                    pf[1] = pack_bf2(s0[ml][2], s0[ml][3]);
+                    pf[2] = pack_bf2(s1[ml][0], s1[ml][1]);
+                    pf[3] = pack_bf2(s1[ml][2], s1[ml][3]);
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) mma16(o[dt][ml], vc[dt], pf);
+                }
             }
-        };
-        u32x4 kk[NSET][4], vv[NSET][4];
 #pragma unroll
-        for (int p = 0; p < NSET - 1; ++p) fetch(p, kk[p], vv[p]);     // NKT >= NSET - 1
+            for (int ml = 0; ml < 2; ++ml) {
+                const float lsum = ar4_sum(l_run[ml]);
+                if (my_seq[ml] == seq) {
+                    const float inv = __builtin_amdgcn_rcpf(lsum);    // 1 ulp; the quotient is rounded to bf16 next
+                    const int mt = 2 * ps + ml;
 #pragma unroll
-        for (int j = 0; j < 2 * NKT; ++j) {                  // straight-line: tiles beyond J are skipped (wave-uniform)
-            if (j < J) {
-                if (j + NSET - 1 < J) fetch(j + NSET - 1, kk[(j + NSET - 1) % NSET], vv[(j + NSET - 1) % NSET]);
-                tile(j, kk[j % NSET], vv[j % NSET]);
+                    for (int dt = 0; dt < 4; ++dt) {
+                        uint2 pk;
+                        pk.x = pack_bf2(o[dt][ml][0] * inv, o[dt][ml][1] * inv);
+                        pk.y = pack_bf2(o[dt][ml][2] * inv, o[dt][ml][3] * inv);
+                        *reinterpret_cast<uint2*>(abuf + wave * 8192 + act_wr_off(lane, dt) + mt * 2048) = pk;
+                    }
+                }
             }
         }
     }
@@ -694,8 +713,7 @@ DEVINL void cross_attention_p(const f32x16_t (&qacc)[2][2], const tcdiff_chain_a
 #define CH_T(i) do { } while (0)
 #endif
 
-// XP > 0: the pipelined in-kernel cross-attention with XP register sets (memory of exactly 5 key tiles), see cross_attention_p
-template <int MODE, int XP = 0>
+template <int MODE>
 __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     constexpr bool HAS_A = MODE == TC_CHAIN_A || MODE == TC_CHAIN_FULL || MODE == TC_CHAIN_FULL_LAST;   // fc + norm2 + w_qs
     constexpr bool FULL = MODE == TC_CHAIN_FULL || MODE == TC_CHAIN_FULL_LAST;                          // + cross-attention
@@ -707,7 +725,7 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31, h = lane >> 5;
+    const int c = lane & 15, g = lane >> 4;
     const int dn = FRONT ? a.dn : 1;
     const int dancer = FRONT ? (int)(blockIdx.x % (unsigned)dn) : 0;
     const int m0 = FRONT ? (int)(blockIdx.x / (unsigned)dn) * 64 : xcd_remap(blockIdx.x, gridDim.x) * 64;
@@ -717,22 +735,36 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     char* abuf = smem + CH_ABUF;
     char* h1c = smem + CH_H1C;
     float* scr = reinterpret_cast<float*>(smem + CH_SCR);
-    char* cfilm = smem + CH_FILM;      // [2 sequences][scale 512 | shift 512] floats
+    char* cfilm = smem + CH_FILM;      // [2 sequences][scale + 1: 512 | shift: 512] floats
     char* cvec = smem + CH_VEC;        // six vectors of 512 floats
 
-    // rows of this lane (both row tiles), clamped: rows past M recompute row M - 1 (their inputs are clamped to it)
-    int mc[2], sidx[2];
+    // rows of this lane (four row tiles), clamped: rows past M recompute row M - 1 (their inputs are clamped to it).
+    // Every phase recomputes what it needs of them from a fresh copy of the lane index (a few VALU ops) -- kept as arrays
+    // they are 16 registers alive across the whole kernel.
     const int seq0 = (m0 < M ? m0 : M - 1) / L;
     const int seq_last = (M - 1) / L;
+    const int seqb = (seq0 + 1) * L;   // first row of the block's second sequence (L >= 64 rows per sequence: launcher)
+    struct Rows { int mc[4], sidx[4]; };
+    auto rows = [&]() {
+        Rows r;
+        const int cc = fresh_v(c);
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-        const int m = m0 + 32 * mi + r;
-        mc[mi] = m < M ? m : M - 1;
-        sidx[mi] = mc[mi] / L - seq0;          // 0 or 1: L >= 64 rows per sequence (checked by the launcher)
-    }
+        for (int mt = 0; mt < 4; ++mt) {
+            const int m = m0 + 16 * mt + cc;
+            r.mc[mt] = m < M ? m : M - 1;
+            r.sidx[mt] = r.mc[mt] >= seqb ? 1 : 0;
+        }
+        return r;
+    };
+    // rotary position of the rows: FRONT rows are frames of one dancer (token = frame dn + dancer)
+    auto positions = [&](const Rows& r, int (&pos)[4]) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+            pos[mt] = FRONT ? (r.mc[mt] * dn + dancer) % L : r.mc[mt] - (r.sidx[mt] ? seqb : seqb - L);
+    };
     // Epilogue constants go through LDS.  Thread t carries one float4 of the FiLM rows and up to two of the vectors
     // from global memory to LDS; they are fetched early (latency hidden behind a GEMM) and stored once the previous
-    // epilogue no longer reads the area.
+    // epilogue no longer reads the area.  The FiLM scale is stored as scale + 1 (featurewise_affine, model/model.py:171-173).
     struct Consts { f32x4_t f, v0, v1; };
     auto fetch_consts = [&](const float* film, const float* const (&vec)[6]) {
         Consts k;
@@ -746,7 +778,8 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
         return k;
     };
     auto store_consts = [&](const Consts& k) {
-        *reinterpret_cast<f32x4_t*>(cfilm + tid * 16) = k.f;
+        const float one = (fresh_v(tid) & 255) < 128 ? 1.0f : 0.0f;    // floats 0..511 of a FiLM row are the scale
+        *reinterpret_cast<f32x4_t*>(cfilm + tid * 16) = k.f + one;
         *reinterpret_cast<f32x4_t*>(cvec + tid * 16) = k.v0;
         if (tid < 256) *reinterpret_cast<f32x4_t*>(cvec + 8192 + tid * 16) = k.v1;
     };
@@ -785,85 +818,88 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     __syncthreads();
     CH_T(1);
 
-    f32x16_t acc[2][2];
-    auto clear = [&]() {
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) zero(acc[mi][ni]);
-    };
-    float nmr[2], rstd[2];             // LayerNorm of the current rows: u = fma(v, rstd, nmr)
+    acc_t acc;
+    float nmr[4], rstd[4];             // LayerNorm of the current rows: u = fma(v, rstd, nmr)
     RowPipe rp;                        // residual rows, later rotary rows, of this lane
-    // token row of this lane's rows in the residual stream, and its position in its sequence
-    const int trow[2] = {mc[0] * dn + dancer, mc[1] * dn + dancer};
     const long xrows = (long)M * dn;
     const __amdgpu_buffer_rsrc_t xo = f32_buffer(a.xout, xrows * 512);     // the residual stream out
-    int pos[2] = {trow[0] % L, trow[1] % L};
     Consts nxt;
 
     // fc epilogue: LayerNorm(eps), FiLM, residual -> x in the accumulators and in xout (model/model.py:103-106,171-173,
-    // 327 / 334); constants in vector slots 0, 1 and the FiLM area; the residual rows were started by the caller
+    // 327 / 334); constants in vector slots 0, 1 and the FiLM area; the residual rows were started by the caller.  The
+    // barrier inside the statistics exchange is also the one that says every wave has left the GEMM.
     auto fc_epilogue = [&](float eps, int stamp) {
-        lds_barrier();                 // every wave is out of the GEMM: the activation block may be overwritten
         CH_T(stamp);
         row_stats(acc, scr, wave, lane, eps, nmr, rstd);
         CH_T(stamp + 1);
         // fresh copies: the two inlined instances of this epilogue must not share (and keep alive) their addresses
-        const int hh = fresh_v(h), wv = fresh_s(wave);
-        const int mcl[2] = {fresh_v(mc[0]), fresh_v(mc[1])};
-        const int cb0 = col_base_bytes(wv, hh);
-        // FiLM rows of this lane's two rows: sequence 0 or 1 of the block (4 KB apart), as opaque byte offsets too
-        int fb[2] = {sidx[0] * 4096 + cb0, sidx[1] * 4096 + cb0};
-        asm volatile("" : "+v"(fb[0]), "+v"(fb[1]));
+        const int gg = fresh_v(g), wv = fresh_s(wave);
+        const Rows rw = rows();
+        int fb[4];
+        const int cb0 = col_base_bytes(wv, gg);
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int ni = it >> 2, gq = it & 3;
-            const f32x4_t g4 = lds4b(vecp(0) + cb0, 32 * it), b4 = lds4b(vecp(1) + cb0, 32 * it);
+        for (int mt = 0; mt < 4; ++mt) {
+            fb[mt] = rw.sidx[mt] * 4096 + cb0;    // FiLM rows of this lane's rows: sequence 0 or 1 of the block (4 KB apart)
+            asm volatile("" : "+v"(fb[mt]));
+        }
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-                const f32x4_t sc = lds4b(cfilm + fb[mi], 32 * it), sh = lds4b(cfilm + fb[mi], 2048 + 32 * it);
-                const f32x4_t x4 = rp.q[it & 3][mi];
+        for (int nt = 0; nt < 4; ++nt) {
+            const f32x4_t g4 = lds4b(vecp(0) + cb0, 64 * nt), b4 = lds4b(vecp(1) + cb0, 64 * nt);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const f32x4_t sc = lds4b(cfilm + fb[mt], 64 * nt), sh = lds4b(cfilm + fb[mt], 2048 + 64 * nt);
+                const f32x4_t x4 = rp.q[nt & 1][mt];
                 f32x4_t o;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    float v = fmaf(fmaf(acc[mi][ni][4 * gq + t], rstd[mi], nmr[mi]), g4[t], b4[t]);
-                    v = (sc[t] + 1.0f) * v + sh[t];
+                    float v = fmaf(fmaf(acc[nt][mt][t], rstd[mt], nmr[mt]), g4[t], b4[t]);
+                    v = fmaf(sc[t], v, sh[t]);
                     v = x4[t] + v;
-                    acc[mi][ni][4 * gq + t] = v;
+                    acc[nt][mt][t] = v;
                     o[t] = v;
                 }
                 // unguarded: rows past M rewrite row M - 1 with the SAME values (same inputs; every load of this column
                 // group, in place or not, was issued before this store)
-                cb_store(xo, M, wv, it, mcl[mi], hh, o);
+                cb_store(xo, M, wv, nt, rw.mc[mt], gg, o);
             }
-            if (it + 4 < 8) rp_issue(rp, it + 4);
-            // one column group at a time: without a fence hipcc hoists the loads of ALL eight groups (row pipeline
-            // refills and LDS constants) above the arithmetic, needs ~100 more registers and spills them
+            if (nt + 2 < 4) rp_issue(rp, nt + 2);
+            // one n-tile at a time: without a fence hipcc hoists the loads of ALL of them (row pipeline refills and LDS
+            // constants) above the arithmetic, needs ~100 more registers and spills them
             CH_FENCE();
         }
+    };
+    auto xres_start = [&]() {
+        const Rows rw = rows();
+        int rr[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) rr[mt] = a.xres_mod > 0 ? rw.mc[mt] % a.xres_mod : rw.mc[mt];
+        rp_start(rp, a.xres, rr, a.xres_rowmajor ? 0 : (a.xres_mod > 0 ? a.xres_mod : M), a.xres_mod > 0 ? a.xres_mod : M, wave,
+                 fresh_v(g));
+    };
+    auto xout_start = [&]() {          // the x this lane stored in an earlier epilogue of this launch
+        const Rows rw = rows();
+        rp_start(rp, a.xout, rw.mc, M, M, wave, fresh_v(g));
+    };
+    auto rope_start = [&]() {
+        const Rows rw = rows();
+        int pos[4];
+        positions(rw, pos);
+        rp_start(rp, a.rope, pos, a.rope_rows, a.rope_rows, wave, fresh_v(g));
     };
 
     if (HAS_A) {
         // ================= self-attention block tail: fc + LayerNorm(1e-6) + FiLM + residual, norm2 + rotary, w_qs
-        clear();
-        if (FULL)
-            phase_n512<32>(acc, abuf, ws, lane);
-        else
-            phase_n512_rolled(acc, abuf, 32, ws, lane);
+        zero(acc);
+        phase_n512<16>(acc, abuf, ws, lane);
         CH_T(2);
-        {
-            int rr[2];
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi) rr[mi] = a.xres_mod > 0 ? mc[mi] % a.xres_mod : mc[mi];
-            rp_start(rp, a.xres, rr, a.xres_rowmajor ? 0 : (a.xres_mod > 0 ? a.xres_mod : M), a.xres_mod > 0 ? a.xres_mod : M, wave, h);   // in flight during the statistics exchange
-        }
+        xres_start();                  // in flight during the statistics exchange
         fc_epilogue(a.ln_eps, 40);
         CH_T(3);
         if (FULL) {
             const float* const v[6] = {fcb_g, fcb_b, n3_g, n3_b, nullptr, nullptr};
             nxt = fetch_consts(fcb_film, v);
         }
-        rp_start(rp, a.rope, pos, a.rope_rows, a.rope_rows, wave, h);
+        rope_start();
         row_stats(acc, scr + 1024, wave, lane, a.n2_eps, nmr, rstd);
         CH_T(4);
         // norm2 + rotary (model/model.py:332,387) -> LDS -> Q = rot W_q^T / 8 (model/model.py:78,97)
@@ -871,43 +907,29 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
         lds_barrier();
         CH_T(34);
         if (FULL) store_consts(nxt);   // the cross-attention fc block's constants: read two barriers from here
-        clear();
+        zero(acc);
+        phase_n512<16>(acc, abuf, ws, lane);
         if (!FULL) {
-            phase_n512_rolled(acc, abuf, 32, ws, lane);
             store_heads<true>(acc, a.q_out, a.scale_q, L, a.Lp, a.H, m0, M, wave, lane, smem);
             return;
         }
         // ================= cross-attention in place (the Q image never leaves the registers)
-        if constexpr (XP > 0) {
-            // pipelined form: the weight ring is left empty behind the w_qs GEMM (its registers hold K / V tiles in the
-            // cross-attention) and re-primed with the next GEMM's first stages afterwards
-            phase_n512<32, true>(acc, abuf, ws, lane);
-            CH_T(35);
-            lds_barrier();             // every wave is out of the w_qs GEMM: the activation block becomes O
-            cross_attention_p<5, XP>(acc, a, m0, abuf, wave, lane);
-#pragma unroll
-            for (int i = 0; i < CH_D; ++i) ws_load(ws, i, ws.pos + i);
-        } else {
-            phase_n512<32>(acc, abuf, ws, lane);
-            CH_T(35);
-            lds_barrier();             // every wave is out of the w_qs GEMM: the activation block becomes O
-            cross_attention(acc, a, m0, abuf, wave, lane);
-        }
+        CH_T(35);
+        lds_barrier();                 // every wave is out of the w_qs GEMM: the activation block becomes O
+#ifndef CH_ABLATE_XATTN   // (timing experiment)
+        cross_attention(acc, a, m0, abuf, wave, lane);
+#endif
         CH_T(36);
         lds_barrier();
     }
     if constexpr (!FRONT) {
     // ================= cross-attention block tail: fc + LayerNorm(1e-6) + FiLM + residual (model/model.py:334)
-    clear();
-    phase_n512<32>(acc, abuf, ws, lane);
-    if (FULL) {
-        rp_start(rp, a.xout, mc, M, M, wave, h);    // the x this lane stored in the first fc epilogue
-    } else {
-        int rr[2];
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) rr[mi] = a.xres_mod > 0 ? mc[mi] % a.xres_mod : mc[mi];
-        rp_start(rp, a.xres, rr, a.xres_rowmajor ? 0 : (a.xres_mod > 0 ? a.xres_mod : M), a.xres_mod > 0 ? a.xres_mod : M, wave, h);
-    }
+    zero(acc);
+    phase_n512<16>(acc, abuf, ws, lane);
+    if (FULL)
+        xout_start();                  // the x this lane stored in the first fc epilogue
+    else
+        xres_start();
     CH_T(37);
     fc_epilogue(a.ln_eps, 42);
     CH_T(38);
@@ -923,76 +945,97 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     store_consts(nxt);
     lds_barrier();                     // ... and everybody sees the feed-forward constants
     CH_T(5);
-    clear();   // acc = linear2 accumulator
-#pragma unroll 1
-    for (int c = 0; c < 4; ++c) {
-        f32x16_t a1[2];
-        zero(a1[0]);
-        zero(a1[1]);
+    zero(acc);   // acc = linear2 accumulator
+    // Chunks of 256 h1 columns, software-pipelined: linear1(0), GELU(0) | linear1(c), { linear2(c - 1) with GELU(c) behind its
+    // MFMAs } for c = 1..3 | linear2(3).  The weight stream is packed in this order (engine._build_chain_streams).  Two h1
+    // buffers: linear2(c - 1) reads buffer (c - 1) & 1 while GELU(c) fills buffer c & 1, whose last readers (linear2(c - 2))
+    // finished before the barrier in between.
+    {
+        f32x4_t a1[2][4];
+        auto zero1 = [&]() {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) a1[nt][mt] = f32x4_t{0, 0, 0, 0};
+        };
+        zero1();
         phase_ff1(a1, abuf, ws, lane);
-        CH_T(6 + 4 * c);
-        // two h1 buffers: chunk c - 2's linear2 reads of this one finished before the barrier of chunk c - 1
-        char* hb = h1c + (c & 1) * 32768;
-        CH_T(7 + 4 * c);
+        CH_T(6);
         {
-            const int nb = 256 * c + 32 * wave;
+            const int nb = 32 * wave + 4 * g;               // b1 occupies vector slots 0 and 1
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const f32x4_t b4 = lds4(cvec, nb + 8 * gq + 4 * h);      // b1 occupies vector slots 0 and 1
+            for (int nt = 0; nt < 2; ++nt) {
+                const f32x4_t b4 = lds4(cvec, nb + 16 * nt);
+                // chunk column 32 wave + 16 nt + 4 g: k-tile wave / 2, 16-byte chunk 4 (wave & 1) + 2 nt + (g >> 1)
+                const int wo = (wave >> 1) * 8192 + act_wr_off(lane, nt, 4 * (wave & 1));
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi) {
+                for (int mt = 0; mt < 4; ++mt) {
                     float v[4];
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) v[t] = a1[mi][4 * gq + t] + b4[t];
+                    for (int t = 0; t < 4; ++t) v[t] = a1[nt][mt][t] + b4[t];
+#ifndef CH_ABLATE_GELU   // (timing experiment: how much of the launch is the GELU's VALU work?)
                     act4_ct<ACT_GELU>(v, ACT_GELU);
+#endif
                     uint2 pk;
                     pk.x = pack_bf2(v[0], v[1]);
                     pk.y = pack_bf2(v[2], v[3]);
-                    // chunk column 32 wave + 8 gq + 4 h: k-tile wave / 2, 16-byte chunk 4 (wave & 1) + gq
-                    *reinterpret_cast<uint2*>(hb + (wave >> 1) * 8192 + tile_off(32 * mi + r, 4 * (wave & 1) + gq) +
-                                              8 * h) = pk;
+                    *reinterpret_cast<uint2*>(h1c + wo + mt * 2048) = pk;
                 }
             }
         }
         lds_barrier();
-        CH_T(8 + 4 * c);
-        phase_n512<16>(acc, hb, ws, lane);
-        CH_T(9 + 4 * c);
+        CH_T(8);
+#pragma unroll
+        for (int ch = 1; ch < 4; ++ch) {
+            zero1();
+            phase_ff1(a1, abuf, ws, lane);
+            CH_T(6 + 4 * ch);
+            phase_ff2_gelu(acc, h1c + ((ch - 1) & 1) * 32768, ws, lane, a1, h1c + (ch & 1) * 32768, cvec + 1024 * ch, wave);
+            CH_T(7 + 4 * ch);
+            lds_barrier();
+            CH_T(8 + 4 * ch);
+        }
+        phase_n512<8>(acc, h1c + 32768, ws, lane);
+        CH_T(21);
     }
     // linear2 bias, FiLM, residual (the x this lane stored above), norm4 -> LDS
-    rp_start(rp, a.xout, mc, M, M, wave, h);
-    const int cb2 = col_base_bytes(fresh_s(wave), fresh_v(h));
-    int fb2[2] = {sidx[0] * 4096 + cb2, sidx[1] * 4096 + cb2};
-    asm volatile("" : "+v"(fb2[0]), "+v"(fb2[1]));
+    xout_start();
+    {
+        const int cb2 = col_base_bytes(fresh_s(wave), fresh_v(g));
+        const Rows rw = rows();
+        int fb2[4];
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const int ni = it >> 2, gq = it & 3;
-        const f32x4_t b4 = lds4b(vecp(2) + cb2, 32 * it);
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-            const f32x4_t sc = lds4b(cfilm + fb2[mi], 32 * it), sh = lds4b(cfilm + fb2[mi], 2048 + 32 * it);
-            const f32x4_t x4 = rp.q[it & 3][mi];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                float v = acc[mi][ni][4 * gq + t] + b4[t];
-                v = (sc[t] + 1.0f) * v + sh[t];
-                acc[mi][ni][4 * gq + t] = x4[t] + v;
-            }
-            // nothing in this iteration touches memory after its loads, so the arithmetic is free to sink below the
-            // loads of all later iterations (whose operands then all have to be kept): pin it to this iteration
-            asm volatile("" ::"v"(acc[mi][ni][4 * gq + 0]), "v"(acc[mi][ni][4 * gq + 1]), "v"(acc[mi][ni][4 * gq + 2]),
-                         "v"(acc[mi][ni][4 * gq + 3]));
+        for (int mt = 0; mt < 4; ++mt) {
+            fb2[mt] = rw.sidx[mt] * 4096 + cb2;
+            asm volatile("" : "+v"(fb2[mt]));
         }
-        if (it + 4 < 8) rp_issue(rp, it + 4);
-        CH_FENCE();
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const f32x4_t b4 = lds4b(vecp(2) + cb2, 64 * nt);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const f32x4_t sc = lds4b(cfilm + fb2[mt], 64 * nt), sh = lds4b(cfilm + fb2[mt], 2048 + 64 * nt);
+                const f32x4_t x4 = rp.q[nt & 1][mt];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    float v = acc[nt][mt][t] + b4[t];
+                    v = fmaf(sc[t], v, sh[t]);
+                    acc[nt][mt][t] = x4[t] + v;
+                }
+                // nothing in this iteration touches memory after its loads, so the arithmetic is free to sink below the
+                // loads of all later iterations (whose operands then all have to be kept): pin it to this iteration
+                asm volatile("" ::"v"(acc[nt][mt][0]), "v"(acc[nt][mt][1]), "v"(acc[nt][mt][2]), "v"(acc[nt][mt][3]));
+            }
+            if (nt + 2 < 4) rp_issue(rp, nt + 2);
+            CH_FENCE();
+        }
     }
     CH_T(22);
     {
         const float* const v[6] = {a.b3, a.nn_g, a.nn_b, nullptr, nullptr, nullptr};
         nxt = fetch_consts(nullptr, v);
     }
-    lds_barrier();                     // every wave is out of the last linear2 chunk (and of its constants' first use)
-    row_stats(acc, scr, wave, lane, a.n4_eps, nmr, rstd);
+    row_stats(acc, scr, wave, lane, a.n4_eps, nmr, rstd);      // (its barrier: every wave is out of the last linear2 chunk)
     CH_T(23);
     norm_to_lds<false>(acc, nmr, rstd, vecp(3), vecp(4), rp, abuf, wave, lane, nullptr);
     lds_barrier();
@@ -1001,66 +1044,68 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     // ================= x' = linear3(norm4(x)) + b3, no residual (model/model.py:344); FRONT: the last fusion linear of this
     // block's dancer over K = 1024 (model/model.py:526-528), whose output is layer 0's residual input
     CH_T(24);
-    clear();
+    zero(acc);
     if (FRONT)
-        phase_n512<64>(acc, abuf, ws, lane);
-    else if (LAST)
-        phase_n512<32, true>(acc, abuf, ws, lane);
-    else
         phase_n512<32>(acc, abuf, ws, lane);
+    else if (LAST)
+        phase_n512<16, true>(acc, abuf, ws, lane);
+    else
+        phase_n512<16>(acc, abuf, ws, lane);
     CH_T(25);
     lds_barrier();
-    const int cb3 = col_base_bytes(fresh_s(wave), fresh_v(h));
+    {
+        const int g3 = fresh_v(g);
+        const int cb3 = col_base_bytes(fresh_s(wave), g3);
+        const Rows rw = rows();
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
+        for (int nt = 0; nt < 4; ++nt) {
+            const int n = 64 * wave + 16 * nt + 4 * g3;
+            const f32x4_t b4 = lds4b(vecp(0) + cb3, 64 * nt);
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            const int n = 64 * wave + 32 * ni + 8 * gq + 4 * h;
-            const f32x4_t b4 = lds4b(vecp(0) + cb3, 32 * (4 * ni + gq));
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
+            for (int mt = 0; mt < 4; ++mt) {
                 f32x4_t o;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    acc[mi][ni][4 * gq + t] += b4[t];
-                    o[t] = acc[mi][ni][4 * gq + t];
+                    acc[nt][mt][t] += b4[t];
+                    o[t] = acc[nt][mt][t];
                 }
                 if (LAST && a.out_ld > 0) {
                     // linear3 carries the final projection folded into it (engine.py: W_final W_3, two linear maps
                     // with nothing in between, model/model.py:344,623): columns [0, out_ld) ARE the network output
                     if (n < a.out_ld)
-                        *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(a.h_out) + (long)mc[mi] * a.out_ld + n) = o;
+                        *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(a.h_out) + (long)rw.mc[mt] * a.out_ld + n) = o;
                 } else if (LAST) {   // a separate final projection reads bf16 rows (model/model.py:623)
                     uint2 pk;
                     pk.x = pack_bf2(o[0], o[1]);
                     pk.y = pack_bf2(o[2], o[3]);
-                    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.h_out) + (long)mc[mi] * 512 + n) = pk;
+                    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.h_out) + (long)rw.mc[mt] * 512 + n) = pk;
                 } else {
-                    cb_store(xo, xrows, wave, 4 * ni + gq, trow[mi], h, o);
+                    cb_store(xo, xrows, wave, nt, rw.mc[mt] * dn + dancer, g3, o);
                 }
             }
             CH_FENCE();
         }
+    }
     if (LAST) return;
     // ================= next layer: norm1 + rotary -> Q, K ; norm1 -> V (model/model.py:326,374-383,78-80)
     CH_T(26);
-    rp_start(rp, a.rope, pos, a.rope_rows, a.rope_rows, wave, h);
+    rope_start();
     row_stats(acc, scr, wave, lane, a.nn_eps, nmr, rstd);
     CH_T(27);
     norm_to_lds<true>(acc, nmr, rstd, vecp(1), vecp(2), rp, abuf, wave, lane, smem + CH_ABUF2);
     lds_barrier();
     CH_T(28);
-    clear();
-    phase_n512<32, false, CH_QKV_R>(acc, abuf, ws, lane);
+    zero(acc);
+    phase_n512<16>(acc, abuf, ws, lane);
     CH_T(29);
     store_heads<true>(acc, a.q_out, a.scale_q, L, a.Lp, a.H, m0, M, wave, lane, smem, dn, dancer);
-    clear();
-    phase_n512<32, false, CH_QKV_R>(acc, abuf, ws, lane);
+    zero(acc);
+    phase_n512<16>(acc, abuf, ws, lane);
     CH_T(30);
     store_heads<false>(acc, a.k_out, 1.0f, L, a.Lp, a.H, m0, M, wave, lane, smem, dn, dancer);
     CH_T(31);
-    clear();
-    phase_n512<32, true, CH_QKV_R>(acc, smem + CH_ABUF2, ws, lane);
+    zero(acc);
+    phase_n512<16, true>(acc, smem + CH_ABUF2, ws, lane);
     CH_T(32);
     store_heads<false>(acc, a.v_out, 1.0f, L, a.Lp, a.H, m0, M, wave, lane, smem, dn, dancer);
     CH_T(33);
@@ -1073,8 +1118,8 @@ extern "C" int tcdiff_chain(const tcdiff_chain_args* a, hipStream_t stream) {
     if (!a || a->M <= 0 || a->L <= 0 || !a->A || !a->wstream) return TC_ERR_ARG;
     const bool front = a->mode == TC_CHAIN_FRONT;
     if (!front && a->L < 64) return TC_ERR_UNSUPPORTED;   // a 64-row block must touch at most two sequences
-    const int want = a->mode == TC_CHAIN_A ? 64 : a->mode == TC_CHAIN_B ? 288 : a->mode == TC_CHAIN_B_LAST ? 192 :
-                     a->mode == TC_CHAIN_FULL ? 352 : a->mode == TC_CHAIN_FULL_LAST ? 256 : front ? 160 : -1;
+    const int want = a->mode == TC_CHAIN_A ? 32 : a->mode == TC_CHAIN_B ? 144 : a->mode == TC_CHAIN_B_LAST ? 96 :
+                     a->mode == TC_CHAIN_FULL ? 176 : a->mode == TC_CHAIN_FULL_LAST ? 128 : front ? 80 : -1;
     if (want < 0 || a->n_stages != want) return TC_ERR_ARG;
     if (a->out_ld < 0 || a->out_ld % 4 || a->out_ld > 512) return TC_ERR_ARG;
     const void* ptrs[] = {a->A, a->wstream, a->ln_g, a->ln_b, a->film, a->xres, a->xout, a->n2_g, a->n2_b, a->rope,
@@ -1108,15 +1153,6 @@ extern "C" int tcdiff_chain(const tcdiff_chain_args* a, hipStream_t stream) {
         return TC_ERR_ARG;
     static tc_dev_state dev_state;
     const int n_cu = tc_device_once(dev_state, [](int) {
-#if CH_XP > 0
-        {
-            const void* xf[2] = {reinterpret_cast<const void*>(chain_kernel<TC_CHAIN_FULL, CH_XP>),
-                                 reinterpret_cast<const void*>(chain_kernel<TC_CHAIN_FULL_LAST, CH_XP>)};
-            for (const void* f : xf)
-                if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, CH_SMEM) != hipSuccess)
-                    return hipErrorInvalidValue;
-        }
-#endif
         const void* fns[6] = {reinterpret_cast<const void*>(chain_kernel<TC_CHAIN_A>),
                               reinterpret_cast<const void*>(chain_kernel<TC_CHAIN_B>),
                               reinterpret_cast<const void*>(chain_kernel<TC_CHAIN_B_LAST>),
@@ -1136,19 +1172,8 @@ extern "C" int tcdiff_chain(const tcdiff_chain_args* a, hipStream_t stream) {
         case TC_CHAIN_A: hipLaunchKernelGGL(chain_kernel<TC_CHAIN_A>, grid, dim3(512), CH_SMEM, stream, *a); break;
         case TC_CHAIN_B: hipLaunchKernelGGL(chain_kernel<TC_CHAIN_B>, grid, dim3(512), CH_SMEM, stream, *a); break;
         case TC_CHAIN_B_LAST: hipLaunchKernelGGL(chain_kernel<TC_CHAIN_B_LAST>, grid, dim3(512), CH_SMEM, stream, *a); break;
-#if CH_XP > 0
-        case TC_CHAIN_FULL:
-            if (a->nkt == 5) hipLaunchKernelGGL((chain_kernel<TC_CHAIN_FULL, CH_XP>), grid, dim3(512), CH_SMEM, stream, *a);
-            else hipLaunchKernelGGL(chain_kernel<TC_CHAIN_FULL>, grid, dim3(512), CH_SMEM, stream, *a);
-            break;
-        default:
-            if (a->nkt == 5) hipLaunchKernelGGL((chain_kernel<TC_CHAIN_FULL_LAST, CH_XP>), grid, dim3(512), CH_SMEM, stream, *a);
-            else hipLaunchKernelGGL(chain_kernel<TC_CHAIN_FULL_LAST>, grid, dim3(512), CH_SMEM, stream, *a);
-            break;
-#else
         case TC_CHAIN_FULL: hipLaunchKernelGGL(chain_kernel<TC_CHAIN_FULL>, grid, dim3(512), CH_SMEM, stream, *a); break;
         default: hipLaunchKernelGGL(chain_kernel<TC_CHAIN_FULL_LAST>, grid, dim3(512), CH_SMEM, stream, *a); break;
-#endif
     }
     TC_CHECK_LAUNCH();
     return TC_OK;

@@ -4,6 +4,23 @@
 #include "common.h"
 #include "tcdiff_hip.h"
 
+// ---- fragment-ordered K / V cache images for the in-chain cross-attention (csrc/chain.hip cross_attention) -----------
+// Element index of K[key][d] / V[key][d] inside the image of one (slot, head): 4 KB per 32-key tile, each 1-KB piece the 64
+// lanes' 16-byte A-operand fragments of one v_mfma_f32_16x16x32_bf16 (lane = 16 g + c, 8 elements jj), in the k order in which
+// the chain kernel's ACCUMULATORS hold the other operand (include/tcdiff_hip.h, tcdiff_pack_kv_frags):
+//   K: piece (key % 32) / 16 * 2 + d / 32, c = key % 16, slot 8 g + jj <-> d % 32 = 16 (jj / 4) + 4 g + jj % 4
+//   V: piece d / 16,                      c = d % 16,   slot 8 g + jj <-> key % 32 = 16 (jj / 4) + 4 g + jj % 4
+DEVINL long kf_index(int key, int d) {
+    const int kt = key >> 5, k32 = key & 31, d32 = d & 31;
+    const int g = (d32 & 15) >> 2, jj = 4 * (d32 >> 4) + (d32 & 3);
+    return ((long)((kt * 2 + (k32 >> 4)) * 2 + (d >> 5)) * 64 + g * 16 + (k32 & 15)) * 8 + jj;
+}
+DEVINL long vf_index(int key, int d) {
+    const int kt = key >> 5, k32 = key & 31;
+    const int g = (k32 & 15) >> 2, jj = 4 * (k32 >> 4) + (k32 & 3);
+    return ((long)(kt * 4 + (d >> 4)) * 64 + g * 16 + (d & 15)) * 8 + jj;
+}
+
 // =================================================================================================
 // LayerNorm (+ rotary): one wave per 512-wide row; lane l owns columns [4l, 4l+4) and [256+4l, 256+4l+4),
 // so every rotary pair (2j, 2j+1) is inside one lane's float4 -- no cross-lane traffic for the rotation.
@@ -321,14 +338,8 @@ __global__ __launch_bounds__(256) void step_prologue_kernel(tcdiff_step_prologue
             if (a.Kc) ((E*)(c < 512 ? a.Kc : a.Vc))[(sh * a.Lp + tok) * 64 + d] = v;
             if (a.Kf) {  // same element maps as pack_kv_frags_kernel
                 const long base = sh * (long)a.nkt * 2048;
-                const int kt = tok >> 5, k32 = tok & 31;
-                if (c < 512) {
-                    const int s16 = d >> 4, dd = d & 15, hh = (dd & 7) >> 2, j = 4 * (dd >> 3) + (dd & 3);
-                    ((E*)a.Kf)[base + ((long)(kt * 4 + s16) * 64 + hh * 32 + k32) * 8 + j] = v;
-                } else {
-                    const int sp = k32 >> 4, kk = k32 & 15, hh = (kk & 7) >> 2, j = 4 * (kk >> 3) + (kk & 3);
-                    ((E*)a.Vf)[base + ((long)((kt * 2 + sp) * 2 + (d >> 5)) * 64 + hh * 32 + (d & 31)) * 8 + j] = v;
-                }
+                if (c < 512) ((E*)a.Kf)[base + kf_index(tok, d)] = v;
+                else ((E*)a.Vf)[base + vf_index(tok, d)] = v;
             }
         } else {
             const long k = i - n_film - n_kv;
@@ -477,7 +488,6 @@ extern "C" int tcdiff_window_couple(float* x, int b, int seq_len, int row_elems,
     return TC_OK;
 }
 
-// ---- fragment-ordered K / V cache images for the in-chain cross-attention (csrc/chain.hip cross_attention) -----------
 __global__ void pack_kv_frags_kernel(const uint16_t* __restrict__ Kc, const uint16_t* __restrict__ Vc,
                                      uint16_t* __restrict__ Kf, uint16_t* __restrict__ Vf, long n_sh, int Lp, int nkt,
                                      int key_lo, int nkeys) {
@@ -489,15 +499,8 @@ __global__ void pack_kv_frags_kernel(const uint16_t* __restrict__ Kc, const uint
     const long sh = r2 / nkeys;
     const long src = (sh * Lp + key) * 64 + d;
     const long base = sh * (long)nkt * 2048;                              // elements per (slot, head) image
-    const int kt = key >> 5, k32 = key & 31;
-    {   // K: [kt][d / 16][half][key % 32][j],  d % 16 = 8 (j / 4) + 4 half + j % 4
-        const int s16 = d >> 4, dd = d & 15, hh = (dd & 7) >> 2, j = 4 * (dd >> 3) + (dd & 3);
-        Kf[base + ((long)(kt * 4 + s16) * 64 + hh * 32 + k32) * 8 + j] = Kc[src];
-    }
-    {   // V: [kt][(key % 32) / 16][d / 32][half][d % 32][j],  key % 16 = 8 (j / 4) + 4 half + j % 4
-        const int sp = k32 >> 4, kk = k32 & 15, hh = (kk & 7) >> 2, j = 4 * (kk >> 3) + (kk & 3);
-        Vf[base + ((long)((kt * 2 + sp) * 2 + (d >> 5)) * 64 + hh * 32 + (d & 31)) * 8 + j] = Vc[src];
-    }
+    Kf[base + kf_index(key, d)] = Kc[src];
+    Vf[base + vf_index(key, d)] = Vc[src];
 }
 
 extern "C" int tcdiff_pack_kv_frags(const void* Kc, const void* Vc, void* Kf, void* Vf, int n_slots, int H, int Lp,

@@ -80,25 +80,6 @@ class EMA:
         return new if old is None else old * self.beta + (1 - self.beta) * new
 
 
-_SLEEP_CAL = {}
-
-
-def _sleep_cycles_per_us(device) -> float:
-    """torch.cuda._sleep counts cycles of a device timer; calibrated once per device against HIP events instead of assuming a
-    clock (the skew of the optional two-stream sampler used to hard-code 2 100 cycles per microsecond)."""
-    key = torch.device(device).index
-    if key not in _SLEEP_CAL:
-        with torch.cuda.device(device):
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            torch.cuda._sleep(100_000)
-            s.record()
-            torch.cuda._sleep(4_000_000)
-            e.record()
-            e.synchronize()
-            _SLEEP_CAL[key] = 4_000_000 / max(s.elapsed_time(e) * 1e3, 1.0)
-    return _SLEEP_CAL[key]
-
-
 class _LossFn(torch.autograd.Function):
     """total = 0.636 recon + 2.964 velocity + 0.646 fk + 10.942 foot (reference model/diffusion.py:668-741) of the denoiser
     output, forward and backward in HIP kernels (csrc/train.hip, csrc/train_ops.hip): 6-D rotations -> axis-angle ->
@@ -233,16 +214,6 @@ class GaussianDiffusion(nn.Module):
         row_of = {t: i for i, t in enumerate(uniq)}
         return eng, [row_of[int(t)] for t in tseq]
 
-    # Two-stream sampling: the batch is split into two halves that run as parallel branches of the captured graph.
-    # Every kernel of the step alternates between a DMA/MFMA-bound main loop and an HBM-bound epilogue; two
-    # independent half-size launch chains let one half's memory-bound phases overlap the other's compute phases.
-    # Clips are independent (and the noise is keyed by the global clip index), so the samples are bit-identical.
-    # Default OFF since the row-block chain kernels (one workgroup per CU for a whole 16-clip launch): 9.2 clips/s single
-    # stream against 9.06 with two half-batch streams (profiles/README.md); the op-by-op f32 mode still gains ~4 % from it.
-    dual_stream = os.environ.get("TCDIFF_DUAL", "0") != "0"
-    dual_parts = int(os.environ.get("TCDIFF_DUAL_PARTS", "2"))
-    dual_skew_us = float(os.environ.get("TCDIFF_DUAL_SKEW_US", "40"))   # < 0: lock-step halves inside one graph
-
     def _run(self, mode: int, shape, cond, x: torch.Tensor, tseq, params: torch.Tensor, *, traj=None,
              step_noise: Optional[Callable] = None, seed: Optional[int] = None, clip_offset: int = 0,
              after_step: Optional[Callable] = None, use_graph: bool = True, collect=None, constrain=None, couple=None):
@@ -254,162 +225,83 @@ class GaussianDiffusion(nn.Module):
         samplers replay one graph per step like the plain ones; `after_step` remains for callers' own hooks."""
         B, Lq, nf = shape
         n = len(tseq)
-        nparts = self.dual_parts if (self.dual_stream and use_graph and after_step is None and couple is None
-                                     and n > 2) else 1
-        while nparts > 1 and B // nparts < 2:
-            nparts -= 1
-        cuts = [(k * B) // nparts for k in range(nparts + 1)]        # near-equal contiguous sub-batches
-        bounds = [(cuts[k], cuts[k + 1]) for k in range(nparts)]
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         w_eff = params[:, 0].tolist()
         x = x.reshape(B, Lq, nf)
-        parts = []
-        for k, (lo, hi) in enumerate(bounds):
-            Bp = hi - lo
-            eng, rows = self._prepare(Bp, cond[lo:hi], tseq, slot=k)
-            st = eng.sampler_state(n, Bp * Lq, nf)
-            st["x"].copy_(x[lo:hi].reshape(Bp * Lq, nf))
-            st["counter"].zero_()
-            st["rows"][:n] = torch.tensor(rows, dtype=torch.int32)
-            st["tseq"][:n] = torch.tensor([int(t) for t in tseq], dtype=torch.int32)
-            st["params"][:n] = params.to(torch.float32)
-            if traj is not None:
-                st["traj"].copy_(traj.reshape(B, Lq, 3)[lo:hi].reshape(Bp * Lq, 3))
-            cm = 0
-            if constrain is not None:
-                st["cval"].copy_(constrain["value"].reshape(B, Lq, nf)[lo:hi].reshape(Bp * Lq, nf))
-                m = constrain["mask"].to(st["x"].device, torch.float32).reshape(-1, nf)
-                cm = Lq if m.shape[0] == Lq else Bp * Lq      # one [L, nfeat] mask for every clip, or a full one
-                st["cmask"][:cm].copy_(m if m.shape[0] == Lq else m.reshape(B, Lq, nf)[lo:hi].reshape(Bp * Lq, nf))
-            # the seed lives in device memory (counter[1..2]) so that a captured graph can be re-seeded
-            st["counter"][1:3] = torch.tensor([seed & 0x7FFFFFFF, (seed >> 31) & 0x7FFFFFFF], dtype=torch.int32)
-            parts.append(dict(eng=eng, st=st, B=Bp, lo=lo, hi=hi, mask_rows=cm))
+        # one stream, one launch chain: with one resident-block kernel per layer the chip is full, and two half-batch chains on
+        # two streams measured 3 % slower (rounds 1-3 kept that as a default-off option; removed in round 4)
+        eng, rows = self._prepare(B, cond, tseq, slot=0)
+        st = eng.sampler_state(n, B * Lq, nf)
+        st["x"].copy_(x.reshape(B * Lq, nf))
+        st["counter"].zero_()
+        st["rows"][:n] = torch.tensor(rows, dtype=torch.int32)
+        st["tseq"][:n] = torch.tensor([int(t) for t in tseq], dtype=torch.int32)
+        st["params"][:n] = params.to(torch.float32)
+        if traj is not None:
+            st["traj"].copy_(traj.reshape(B * Lq, 3))
+        mask_rows = 0
+        if constrain is not None:
+            st["cval"].copy_(constrain["value"].reshape(B * Lq, nf))
+            m = constrain["mask"].to(st["x"].device, torch.float32).reshape(-1, nf)
+            mask_rows = Lq if m.shape[0] == Lq else B * Lq      # one [L, nfeat] mask for every clip, or a full one
+            st["cmask"][:mask_rows].copy_(m)
+        # the seed lives in device memory (counter[1..2]) so that a captured graph can be re-seeded
+        st["counter"][1:3] = torch.tensor([seed & 0x7FFFFFFF, (seed >> 31) & 0x7FFFFFFF], dtype=torch.int32)
 
-        def step_part(p, branches: int):
-            eng, st, Bp = p["eng"], p["st"], p["B"]
-            b = eng.b
-            eng.step_prologue(st, 2 * Bp, st["x"], Bp * Lq)
+        def step(branches: int):
+            eng.step_prologue(st, 2 * B, st["x"], B * Lq)
             if branches == 2:
-                out = eng.network(st["x"], Bp, 2, 0, Bp, 0, x_ready=True)
-                unc, con = out, out[Bp * Lq:]
+                out = eng.network(st["x"], B, 2, 0, B, 0, x_ready=True)
+                unc, con = out, out[B * Lq:]
             else:
-                out = eng.network(st["x"], Bp, 1, 1, 0, Bp, x_ready=True)
+                out = eng.network(st["x"], B, 1, 1, 0, B, x_ready=True)
                 unc, con = None, out
             K.sampler_update(mode | L.SAMPLER_ADVANCE, unc, con, 152, st["x"], st["eps"] if step_noise is not None else None,
-                             st["traj"] if traj is not None else None, None, Bp * Lq, nf, Lq, st["counter"],
-                             st["params"], st["tseq"], seed=0, clip0=clip_offset + p["lo"])
+                             st["traj"] if traj is not None else None, None, B * Lq, nf, Lq, st["counter"],
+                             st["params"], st["tseq"], seed=0, clip0=clip_offset)
             if constrain is not None:
-                K.sampler_constrain(constrain["kind"], st["x"], st["cmask"], p["mask_rows"], st["cval"],
-                                    st["qeps"] if constrain.get("q_noise") is not None else None, Bp * Lq, nf, Lq,
-                                    st["counter"], st["params"], st["tseq"], seed=0, clip0=clip_offset + p["lo"])
+                K.sampler_constrain(constrain["kind"], st["x"], st["cmask"], mask_rows, st["cval"],
+                                    st["qeps"] if constrain.get("q_noise") is not None else None, B * Lq, nf, Lq,
+                                    st["counter"], st["params"], st["tseq"], seed=0, clip0=clip_offset)
             if couple is not None:
-                K.window_couple_step(st["x"], Bp, couple[0], couple[1], st["counter"], st["params"])
-
-        def step(branches: int, parallel: bool):
-            if len(parts) == 1 or not parallel:
-                for p in parts:
-                    step_part(p, branches)
-                return
-            main = torch.cuda.current_stream()
-            for k in range(1, len(parts)):
-                sk = self._side_stream(main.device, k)
-                sk.wait_stream(main)
-                with torch.cuda.stream(sk):
-                    step_part(parts[k], branches)
-            step_part(parts[0], branches)
-            for k in range(1, len(parts)):
-                main.wait_stream(self._side_stream(main.device, k))
+                K.window_couple_step(st["x"], B, couple[0], couple[1], st["counter"], st["params"])
 
         graphs = self.__dict__.setdefault("_graphs", {})
-        gens = tuple(p["eng"].generation for p in parts)
-        full = lambda: torch.cat([p["st"]["x"].view(p["B"], Lq, nf) for p in parts], 0) if len(parts) > 1 \
-            else parts[0]["st"]["x"].view(B, Lq, nf)
-        # Free-running halves: each half replays its own step graph on its own stream with no per-step join, the second
-        # one started `dual_skew_us` late, so that the two launch chains stay out of phase (one half's HBM-bound
-        # epilogues beside the other's MFMA-bound main loops) instead of running the same kernel side by side.
+        gen = eng.generation
         q_noise = constrain.get("q_noise") if constrain is not None else None
-        skewed = len(parts) > 1 and self.dual_skew_us >= 0 and step_noise is None and collect is None and q_noise is None
-        sides = [self._side_stream(x.device, k) for k in range(1, len(parts))]
-        side_started = False
         for i, t in enumerate(tseq):
             branches = 1 if w_eff[i] == 1.0 else 2
             if step_noise is not None:
-                eps = step_noise(int(t), (B, Lq, nf))
-                for p in parts:
-                    p["st"]["eps"].copy_(eps[p["lo"]:p["hi"]].reshape(p["B"] * Lq, nf))
+                st["eps"].copy_(step_noise(int(t), (B, Lq, nf)).reshape(B * Lq, nf))
             if q_noise is not None:
-                qe = q_noise(int(t), (B, Lq, nf))
-                for p in parts:
-                    p["st"]["qeps"].copy_(qe[p["lo"]:p["hi"]].reshape(p["B"] * Lq, nf))
-            ckey = None if constrain is None else (constrain["kind"], q_noise is not None,
-                                                   tuple(p["mask_rows"] for p in parts))
-            gkey = (mode, branches, step_noise is not None, traj is not None, clip_offset, B, len(parts), gens, id(self.model),
-                    skewed, ckey, couple)
-            # Anything that is not a replay of the free-running per-part graphs launches work for EVERY part on the main
-            # stream: join the side streams first, or their queued replays race with it on the parts' buffers.
-            if side_started and not (use_graph and gkey in graphs):
-                for sk in sides:
-                    torch.cuda.current_stream().wait_stream(sk)
-                side_started = False
+                st["qeps"].copy_(q_noise(int(t), (B, Lq, nf)).reshape(B * Lq, nf))
+            ckey = None if constrain is None else (constrain["kind"], q_noise is not None, mask_rows)
+            gkey = (mode, branches, step_noise is not None, traj is not None, clip_offset, B, gen, id(self.model), ckey, couple)
             if not use_graph:
-                step(branches, False)
+                step(branches)
             elif gkey in graphs:
-                if not skewed:
-                    graphs[gkey].replay()
-                else:
-                    main = torch.cuda.current_stream()
-                    if not side_started:
-                        for k, sk in enumerate(sides):
-                            sk.wait_stream(main)
-                            with torch.cuda.stream(sk):
-                                torch.cuda._sleep(int(self.dual_skew_us * (k + 1) * _sleep_cycles_per_us(main.device)))
-                        side_started = True
-                    graphs[gkey][0].replay()
-                    for k, sk in enumerate(sides):
-                        with torch.cuda.stream(sk):
-                            graphs[gkey][k + 1].replay()
+                graphs[gkey].replay()
             elif ("warm", gkey) not in graphs:
-                step(branches, False)           # first visit: eager (loads code objects, sets kernel attributes)
+                step(branches)                  # first visit: eager (loads code objects, sets kernel attributes)
                 graphs[("warm", gkey)] = True
             else:                               # second visit: capture the step once, replay from now on
-                for k in [k for k in graphs if isinstance(k, tuple) and len(k) == 12 and k[8] == id(self.model) and k[7] != gens]:
+                for k in [k for k in graphs if isinstance(k, tuple) and len(k) == 10 and k[7] == id(self.model) and k[6] != gen]:
                     del graphs[k]               # graphs of engines whose buffers have moved
-                live = [k for k in graphs if isinstance(k, tuple) and len(k) == 12]
+                live = [k for k in graphs if isinstance(k, tuple) and len(k) == 10]
                 for k in live[:max(0, len(live) - 15)]:
                     del graphs[k]               # a bounded cache: at most 16 captured step graphs (oldest first) ...
                     graphs.pop(("warm", k), None)   # ... and their warm-up marks
-                if not skewed:
-                    graph = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(graph):
-                        step(branches, True)
-                    graphs[gkey] = graph
-                    graph.replay()
-                else:
-                    pair = []
-                    for p in parts:
-                        graph = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(graph):
-                            step_part(p, branches)
-                        graph.replay()
-                        pair.append(graph)
-                    graphs[gkey] = pair
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    step(branches)
+                graphs[gkey] = graph
+                graph.replay()
             if after_step is not None:
-                after_step(i, int(t), parts[0]["st"]["x"].view(B, Lq, nf))
+                after_step(i, int(t), st["x"].view(B, Lq, nf))
             if collect is not None:
-                collect.append(full().clone())
-        if side_started:
-            for sk in sides:
-                torch.cuda.current_stream().wait_stream(sk)
-        return full().clone()
-
-    def _side_stream(self, device, k: int = 1):
-        pool = self.__dict__.setdefault("_sides", {})
-        s = pool.get(k)
-        if s is None or s.device != device:
-            s = torch.cuda.Stream(device=device)
-            pool[k] = s
-        return s
+                collect.append(st["x"].view(B, Lq, nf).clone())
+        return st["x"].view(B, Lq, nf).clone()
 
     # ------------------------------------------------------------------------------------------
     # reference sampling API

@@ -49,8 +49,14 @@ def gather_samples(local: torch.Tensor, n_clips: int) -> torch.Tensor:
     if local.shape[0] < bmax:
         pad = torch.zeros(bmax - local.shape[0], *local.shape[1:], device=local.device, dtype=local.dtype)
         local = torch.cat([local, pad], 0)
-    out = torch.empty(world * bmax, *local.shape[1:], device=local.device, dtype=local.dtype)
-    dist.all_gather_into_tensor(out, local.contiguous())
+    if dist.get_backend() == "gloo" and local.is_cuda:
+        # test configuration only (several ranks sharing one GPU: RCCL refuses duplicate devices): gloo moves host memory
+        host = torch.empty(world * bmax, *local.shape[1:], dtype=local.dtype)
+        dist.all_gather_into_tensor(host, local.contiguous().cpu())
+        out = host.to(local.device)
+    else:
+        out = torch.empty(world * bmax, *local.shape[1:], device=local.device, dtype=local.dtype)
+        dist.all_gather_into_tensor(out, local.contiguous())
     out = out.view(world, bmax, *local.shape[1:])
     return torch.cat([out[r, : hi - lo] for r, (lo, hi) in enumerate(sizes)], 0)
 
@@ -58,7 +64,7 @@ def gather_samples(local: torch.Tensor, n_clips: int) -> torch.Tensor:
 def max_over_ranks(seconds: float, device) -> float:
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return seconds
-    t = torch.tensor([seconds], device=device, dtype=torch.float64)
+    t = torch.tensor([seconds], device="cpu" if dist.get_backend() == "gloo" else device, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -102,62 +108,6 @@ def long_ddim_sample_sharded(diff, n_windows: int, Lq: int, nfeat: int, cond_loc
     return gather_samples(out, n_windows)
 
 
-class GradientAllReducer:
-    """Data-parallel gradient averaging for the training step (the reference's intent: `accelerate launch` + DDP,
-    TCDiff.py:51-52,108-111,232 -- its own training loop bypasses the DDP wrapper).
-
-    Parameters are packed into a few LARGE flat fp32 buckets (default 64 MB: 53.9 M live-gradient parameters = 216 MB =
-    4 collectives) because xGMI is point-to-point: a ring all-reduce is bound by one ~153 GB/s link whatever the message
-    size, so the win is in few launches and full-size messages, not in NVSwitch-style 25 MB buckets.  Buckets are filled
-    in REVERSE parameter order (the order backward produces gradients in), `reduce()` averages every bucket whose
-    parameters have gradients; parameters without a gradient on this step (the 125 tensors the forward never uses,
-    model/model.py:346-355,371) are skipped -- they are unused on every rank alike, which is what the reference's
-    `find_unused_parameters=True` handles with an extra bitmap all-reduce.  `async_op` launches all collectives before
-    waiting, so they overlap each other and any compute still queued on other streams."""
-
-    def __init__(self, params, bucket_bytes: int = 64 << 20):
-        self.params = [p for p in params if p.requires_grad]
-        self.buckets, cur, size = [], [], 0
-        for p in reversed(self.params):
-            n = p.numel() * 4
-            if cur and size + n > bucket_bytes:
-                self.buckets.append(cur)
-                cur, size = [], 0
-            cur.append(p)
-            size += n
-        if cur:
-            self.buckets.append(cur)
-        self._flat = {}
-
-    def reduce(self) -> int:
-        """Average `.grad` over the process group in place; returns the number of collectives issued."""
-        if not dist.is_initialized() or dist.get_world_size() == 1:
-            return 0
-        world = dist.get_world_size()
-        work = []
-        for bi, bucket in enumerate(self.buckets):
-            ps = [p for p in bucket if p.grad is not None]
-            if not ps:
-                continue
-            n = sum(p.numel() for p in ps)
-            flat = self._flat.get(bi)
-            if flat is None or flat.numel() < n or flat.device != ps[0].grad.device:
-                flat = torch.empty(sum(p.numel() for p in bucket), device=ps[0].grad.device, dtype=torch.float32)
-                self._flat[bi] = flat
-            views, off = [], 0
-            for p in ps:
-                v = flat[off:off + p.numel()].view_as(p.grad)
-                v.copy_(p.grad)
-                views.append(v)
-                off += p.numel()
-            work.append((dist.all_reduce(flat[:n], op=dist.ReduceOp.SUM, async_op=True), ps, views))
-        for w, ps, views in work:
-            w.wait()
-            for p, v in zip(ps, views):
-                p.grad.copy_(v).div_(world)
-        return len(work)
-
-
 class FlatGradientAllReducer:
     """Gradient averaging of the HIP training step (tcdiff_amd/train_engine.py) across the ranks of the default process
     group: the reference's intent of `accelerate launch` + DDP (TCDiff.py:51-52,108-111,232).
@@ -172,27 +122,27 @@ class FlatGradientAllReducer:
     `finish()` makes the compute stream wait for all of them; with RCCL the averaging is the collective's own
     ReduceOp.AVG, with gloo (CPU tests) the sum is scaled afterwards."""
 
-    def __init__(self, bucket_bytes: int = 64 << 20):
+    def __init__(self, bucket_bytes: int = 64 << 20, group=None):
         self.bucket = max(1, bucket_bytes // 4)
+        self.group = group            # None: the default process group; bound by the trainer (TrainEngine.enable_grad_sync)
         self.work = []
         self.launched = 0
 
-    @staticmethod
-    def active() -> bool:
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    def active(self) -> bool:
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
 
     def ready(self, flat: torch.Tensor, lo: int, hi: int):
         if not self.active() or hi <= lo:
             return
-        avg = dist.get_backend() == "nccl"
+        avg = dist.get_backend(self.group) == "nccl"
         for a in range(lo, hi, self.bucket):
             piece = flat[a:min(hi, a + self.bucket)]
-            w = dist.all_reduce(piece, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, async_op=True)
+            w = dist.all_reduce(piece, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=self.group, async_op=True)
             self.work.append((w, None if avg else piece))
             self.launched += 1
 
     def finish(self) -> int:
-        world = dist.get_world_size() if self.active() else 1
+        world = dist.get_world_size(self.group) if self.active() else 1
         n = len(self.work)
         for w, piece in self.work:
             w.wait()

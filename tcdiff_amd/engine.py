@@ -106,40 +106,53 @@ class DenoiserEngine:
         return out.contiguous()
 
     # ---- weight streams of the chain kernels (include/tcdiff_hip.h, tcdiff_chain_args.wstream) -------------------
+    # A stage (4 KB) is the image of the four 1-KB loads a wave makes for one 32-deep k-step: [n-tile][lane = 16 g + c][8 k]
+    # with lane group g holding the 16-byte chunk PI[g] of the k-step (csrc/chain.hip: the activation fragments are read
+    # from LDS in that chunk order because it is bank-conflict-free under the tile swizzle).
+    _PI = (0, 3, 1, 2)
+
     @staticmethod
     def _stages_n512(W: torch.Tensor) -> torch.Tensor:
-        """[512, K] -> [8 waves][K/16 stages][1024]: stage = [n-tile 2][half][32 weight rows][8 k] of one 16-deep k-step
-        (the order in which the 64 lanes of the wave's two 1-KB loads pick up their MFMA fragments)."""
+        """[512, K] -> [8 waves][K/32 stages][2048]: stage = [n-tile 4][lane group 4][16 weight rows][8 k] of one 32-deep
+        k-step of the wave's 64 rows (wave w: rows 64 w ..; row 16 nt + c, k = 32 ks + 8 PI[g] + j)."""
         K_ = W.shape[1]
-        return W.reshape(8, 2, 32, K_ // 16, 2, 8).permute(0, 3, 1, 4, 2, 5).reshape(8, K_ // 16, 1024)
+        w6 = W.reshape(8, 4, 16, K_ // 32, 4, 8)[:, :, :, :, list(DenoiserEngine._PI), :]     # [w, nt, c, ks, g, j]
+        return w6.permute(0, 3, 1, 4, 2, 5).reshape(8, K_ // 32, 2048)
 
     @staticmethod
     def _stages_ff1(W1: torch.Tensor) -> torch.Tensor:
-        """[1024, 512] -> [4 chunks][8 waves][16 stages][1024]: stage = [k-step 2][half][32 rows][8 k]."""
-        return W1.reshape(4, 8, 32, 16, 2, 2, 8).permute(0, 1, 3, 4, 5, 2, 6).reshape(4, 8, 16, 1024)
+        """[1024, 512] -> [4 chunks][8 waves][8 stages][2048]: wave w owns rows 256 c + 32 w .. of chunk c; stage =
+        [k-step 2][n-tile 2][lane group 4][16 rows][8 k]."""
+        w8 = W1.reshape(4, 8, 2, 16, 8, 2, 4, 8)[:, :, :, :, :, :, list(DenoiserEngine._PI), :]   # [ch, w, nt, c, st, k2, g, j]
+        return w8.permute(0, 1, 4, 5, 2, 6, 3, 7).reshape(4, 8, 8, 2048)
 
     @staticmethod
     def _stages_ff2(W2: torch.Tensor) -> torch.Tensor:
-        """[512, 1024] -> [4 chunks][8 waves][16 stages][1024]: the k-slice [256 c, 256 c + 256) of every row."""
-        return W2.reshape(8, 2, 32, 4, 16, 2, 8).permute(3, 0, 4, 1, 5, 2, 6).reshape(4, 8, 16, 1024)
+        """[512, 1024] -> [4 chunks][8 waves][8 stages][2048]: the k-slice [256 c, 256 c + 256) of every row."""
+        w7 = W2.reshape(8, 4, 16, 4, 8, 4, 8)[:, :, :, :, :, list(DenoiserEngine._PI), :]       # [w, nt, c, ch, ks, g, j]
+        return w7.permute(3, 0, 4, 1, 5, 2, 6).reshape(4, 8, 8, 2048)
+
+    @staticmethod
+    def _ffn_order(f1, f2):
+        """the feed-forward stages in the order the kernel consumes them: linear1(0), then linear1(c), linear2(c - 1) for
+        c = 1..3, then linear2(3) (csrc/chain.hip: linear2(c - 1) runs with the GELU of chunk c behind its MFMAs)"""
+        return [f1[0], f1[1], f2[0], f1[2], f2[1], f1[3], f2[2], f2[3]]
 
     def _build_chain_streams(self):
         w = self.w
         if self.front:
-            # TC_CHAIN_FRONT: per dancer, the 512 rows of the last fusion linear it owns (K = 1024: 64 stages), then layer
-            # 0's w_qs / w_ks / w_vs (32 stages each)
+            # TC_CHAIN_FRONT: per dancer, the 512 rows of the last fusion linear it owns (K = 1024: 32 stages), then layer
+            # 0's w_qs / w_ks / w_vs (16 stages each)
             qkv = w["l0.qkv.w"]
             tail = [self._stages_n512(qkv[0:512]), self._stages_n512(qkv[512:1024]), self._stages_n512(qkv[1024:1536])]
             w["front"] = torch.stack([torch.cat([self._stages_n512(w["f3.w"][512 * d:512 * d + 512])] + tail, 1)
-                                      for d in range(self.dn)]).contiguous()          # [dn][8 waves][160][1024]
+                                      for d in range(self.dn)]).contiguous()          # [dn][8 waves][80][2048]
         for l in range(self.NL):
             p = f"l{l}."
             w[p + "chainA"] = torch.cat([self._stages_n512(w[p + "sfc.w"]), self._stages_n512(w[p + "cq.w"])],
                                         1).contiguous()
             f1, f2 = self._stages_ff1(w[p + "ff1.w"]), self._stages_ff2(w[p + "ff2.w"])
-            parts = [self._stages_n512(w[p + "cfc.w"])]
-            for c in range(4):
-                parts += [f1[c], f2[c]]
+            parts = [self._stages_n512(w[p + "cfc.w"])] + self._ffn_order(f1, f2)
             if l + 1 < self.NL or not self.fold_out:
                 parts.append(self._stages_n512(w[p + "l3.w"]))
             else:
@@ -469,7 +482,7 @@ class DenoiserEngine:
         if self.front:
             # ... as ONE chain launch per (64-frame block, dancer) that also runs layer 0's norm1, rotary and Q / K / V
             # projections; b["xs"] (layer 0's residual input) is then column-blocked like the rest of the stream
-            K.chain(L.CHAIN_FRONT, 160, B * S, Lq, b["f2"], w["front"], b3=w["f3.b"], nn_g=w["l0.norm1.g"],
+            K.chain(L.CHAIN_FRONT, B * S, Lq, b["f2"], w["front"], b3=w["f3.b"], nn_g=w["l0.norm1.g"],
                     nn_b=w["l0.norm1.b"], nn_eps=1e-5, rope=w["rope_cb"], xout=b["xs"], q_out=b["Q"], k_out=b["K"],
                     v_out=b["V"], scale_q=0.125, Lp=self.Lp, H=H, dn=dn)
         else:
@@ -555,13 +568,13 @@ class DenoiserEngine:
                     n2_b=w[p + "norm2.b"], n2_eps=1e-5, rope=rope)     # b["xa"] is COLUMN-BLOCKED on this path
         if self.use_full:
             # self-attention tail, cross-attention (K / V from the fragment-ordered caches) and feed-forward in ONE launch
-            K.chain(L.CHAIN_FULL_LAST if last else L.CHAIN_FULL, 256 if last else 352, R, Lq, b["O"], w[p + "chainF"],
+            K.chain(L.CHAIN_FULL_LAST if last else L.CHAIN_FULL, R, Lq, b["O"], w[p + "chainF"],
                     lnb_g=w[p + "cln.g"], lnb_b=w[p + "cln.b"], filmb=film0[:, (l * 3 + 1) * 1024:], n3_g=w[p + "norm3.g"],
                     n3_b=w[p + "norm3.b"], kf=b["Kf"][l, kv_slot0:], vf=b["Vf"][l, kv_slot0:], n_shared=n_shared,
                     nkt=self.nkt, Lk=S + 2, **head, **tail)
             return
-        K.chain(L.CHAIN_A, 64, R, Lq, b["O"], w[p + "chainA"], **head, q_out=b["Q"], scale_q=0.125, Lp=self.Lp, H=H)
+        K.chain(L.CHAIN_A, R, Lq, b["O"], w[p + "chainA"], **head, q_out=b["Q"], scale_q=0.125, Lp=self.Lp, H=H)
         K.attention(dt, b["Q"], Kc0[l], Vc0[l], b["O"], nseq, H, Lq, S + 2, self.Lp, self.Lpc, 512, n_shared=n_shared)
-        K.chain(L.CHAIN_B_LAST if last else L.CHAIN_B, 192 if last else 288, R, Lq, b["O"], w[p + "chainB"],
+        K.chain(L.CHAIN_B_LAST if last else L.CHAIN_B, R, Lq, b["O"], w[p + "chainB"],
                 ln_g=w[p + "cln.g"], ln_b=w[p + "cln.b"], ln_eps=1e-6, film=film0[:, (l * 3 + 1) * 1024:], film_ld=fld,
                 xres=b["xa"], xout=b["xa"], n2_g=w[p + "norm3.g"], n2_b=w[p + "norm3.b"], n2_eps=1e-5, rope=rope, **tail)

@@ -206,8 +206,16 @@ class DanceDecoder(nn.Module):
         from .train_engine import TrainEngine
         eng = self._train_engine
         dev = next(self.parameters()).device
+        if eng is not None and eng.param_ids != tuple(id(p) for p in self.parameters()):
+            # Parameter OBJECTS were replaced (load_state_dict(assign=True), a re-wrapped module): everything the engine
+            # captured or cached refers to the old ones
+            sync, eng = eng.grad_sync, None
+        else:
+            sync = None
         if eng is None or eng.dev != dev or eng.dt != K.dtype_id(self.compute_dtype):
             eng = TrainEngine(self, self.compute_dtype)
+            if sync is not None:
+                eng.grad_sync = sync
             self._train_engine = eng
         return eng
 

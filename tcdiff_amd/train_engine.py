@@ -203,6 +203,7 @@ class TrainEngine:
         L.load()
         self.model = model
         self.params: Dict[str, torch.nn.Parameter] = dict(model.named_parameters())
+        self.param_ids = tuple(id(p) for p in self.params.values())     # model.train_engine() rebuilds when objects are replaced
         p0 = next(iter(self.params.values()))
         if p0.device.type != "cuda" and not _ALLOW_CPU:
             raise L.TcdiffError("the training step runs on MI355X only (no CPU fallback; the CPU oracle is test-only)")
@@ -228,6 +229,7 @@ class TrainEngine:
         self._graphs, self._pool, self._graph_broken = {}, None, None
         self._gv = self._gv_flat = None
         self.sv = None
+        self._gen = 0
         self._pz = {}
         self._define()
         half = 256
@@ -305,8 +307,22 @@ class TrainEngine:
             lo = self.slot[first.wnames[0]][0]
             o, n = self.slot[(last.bnames or last.wnames)[-1]]
             self.layer_range.append((lo, o + n))
-        self.grad_sync = None         # None: average over the default process group when one with > 1 rank exists; False: never
+        # Data-parallel gradient averaging (dist.FlatGradientAllReducer) is OPT-IN and bound to a process group the trainer
+        # names (enable_grad_sync): a job that initialised torch.distributed for sharded sampling only and then fine-tunes on
+        # one rank would otherwise block in an all-reduce nobody else enters.  TCDIFF_GRAD_SYNC=1 restores
+        # "whenever a default group with more than one rank exists" for launchers that cannot call it.
+        self.grad_sync = None
+        if _os.environ.get("TCDIFF_GRAD_SYNC", "0") == "1":
+            self.enable_grad_sync()
         self._new_flat()
+
+    def enable_grad_sync(self, group=None, on: bool = True):
+        """Average gradients over `group` (None: the default process group) inside every backward from now on.  Every rank
+        of the group must run the same number of backward passes per step (use drop_last / equal shards: an uneven last
+        batch would pair collectives of different steps)."""
+        from .dist import FlatGradientAllReducer
+        self.grad_sync = FlatGradientAllReducer(group=group) if on else None
+        return self.grad_sync
 
     def _new_flat(self):
         self.flat = torch.zeros(self.n_grad, device=self.dev, dtype=torch.float32)
@@ -332,17 +348,26 @@ class TrainEngine:
                 out.append(None)
         return out
 
+    # True: hand every gradient back through autograd (AccumulateGrad nodes fire, so grad-accumulator hooks -- torch DDP /
+    # FSDP reducers, accelerate-prepared wrappers -- see them) instead of assigning .grad directly; ~1.5 ms of host time per
+    # step.  Hooks registered on the AccumulateGrad nodes are not visible from the Parameter, hence a switch and not a probe;
+    # such a wrapper does its own gradient averaging, so `enable_grad_sync` must stay off with it.
+    grads_through_autograd = False
+
     def deliver_grads(self) -> List[Optional[torch.Tensor]]:
         """What the autograd node returns for the parameters.  Normally nothing: every live parameter's .grad is SET here to a
         persistent view of the flat buffer (or added to, if the caller kept gradients from an earlier backward) -- the 310
         AccumulateGrad nodes and 310 fresh view tensors per step cost ~1.5 ms of host time between the end of the backward and
         the optimizer's launch, during which the GPU idled.  A parameter with tensor hooks gets its gradient through autograd."""
-        if any(p._backward_hooks or getattr(p, "_post_accumulate_grad_hooks", None) for p in self.params.values()):
-            return self.grad_views()
+        if self.grads_through_autograd or \
+                any(p._backward_hooks or getattr(p, "_post_accumulate_grad_hooks", None) for p in self.params.values()):
+            return [g if (g is not None and self.params[n].requires_grad) else None for n, g in zip(self.order, self.grad_views())]
         if self._gv is None or self._gv_flat is not self.flat:
             self._gv = [(self.params[n], self.flat[o:o + cnt].view(self.params[n].shape)) for n, (o, cnt) in self.slot.items()]
             self._gv_flat = self.flat
         for p, v in self._gv:
+            if not p.requires_grad:           # frozen layer: torch would not give it a gradient either
+                continue
             g = p.grad
             if g is None:
                 p.grad = v
@@ -358,6 +383,15 @@ class TrainEngine:
             return
         ptrs = tuple(p.data_ptr() for p in self.params.values())
         if self._ct is None or self._ct_ptrs != ptrs:              # parameters (re)allocated: the table holds raw pointers
+            if self._ct is not None:
+                # ... and so do the captured graphs (LayerNorm / null-embedding / bias pointers) and the cached .grad views
+                # (stale Parameter objects): drop them, the next steps recapture
+                for st in self._graphs.values():
+                    if st.get("sv") is not None:
+                        st["sv"].pop("graph", None)
+                    st.clear()
+                self._graphs = {}
+                self._gv = self._gv_flat = None
             ents = [d for lk in self.lins.values() for d in lk.pack_entries()]
             self._ct, self._ct_ptrs, self._ct_keep = K.ct_table(self.dt, ents, self.dev), ptrs, ents
         K.cast_transpose_multi(self.dt, self._ct)
@@ -537,6 +571,8 @@ class TrainEngine:
             self._replay(st["fwd_cmds"])
         self.sv = st["sv"]
         self.sv["pending"] = True
+        self._gen += 1
+        self.sv["gen"] = self._gen
         return st["out"].view(B, self.Lq, self.nf)
 
     def _fwd(self, x, cond, times, keep_u8):
@@ -545,7 +581,8 @@ class TrainEngine:
         B = x.shape[0]
         S, dn, Lq, nf, H, NL, Cd = self.S, self.dn, self.Lq, self.nf, self.H, self.NL, self.Cd
         M, Ms, Mc = B * Lq, B * S, B * (S + 2)
-        sv = dict(B=B, pending=True)
+        self._gen += 1
+        sv = dict(B=B, pending=True, gen=self._gen)
         P, e, z = self.P, self.e, self.z
         f32 = torch.float32
         x = x.view(M, nf)
@@ -725,10 +762,15 @@ class TrainEngine:
     # ------------------------------------------------------------------------------------------------------------------
     # backward
     # ------------------------------------------------------------------------------------------------------------------
-    def backward(self, d_out: torch.Tensor) -> List[Optional[torch.Tensor]]:
+    def backward(self, d_out: torch.Tensor, gen: Optional[int] = None) -> List[Optional[torch.Tensor]]:
         sv = self.sv
         if sv is None or not sv.get("pending"):
             raise L.TcdiffError("backward without a matching train-mode forward (one forward may be outstanding per model)")
+        if gen is not None and sv.get("gen") != gen:
+            # fwd(A), fwd(B), loss_A.backward(): the engine holds B's activations and dropout seed -- refuse instead of
+            # silently differentiating A through them
+            raise L.TcdiffError("backward of a train-mode forward that is no longer the most recent one: the engine keeps "
+                                "the activations of ONE forward per model (run forward -> backward in pairs)")
         sv["pending"] = False
         # a parameter's .grad may still alias the previous step's flat buffer (the caller accumulates across calls
         # instead of zero_grad): never overwrite gradients somebody still holds
@@ -739,11 +781,7 @@ class TrainEngine:
             self._new_flat()
             for st in self._graphs.values():              # captured backwards write the buffer that was just given away
                 st["bwd"] = None
-        sync = None
-        if self.grad_sync is not False:
-            from .dist import FlatGradientAllReducer
-            if FlatGradientAllReducer.active():
-                sync = self.grad_sync = self.grad_sync or FlatGradientAllReducer()
+        sync = self.grad_sync if (self.grad_sync is not None and self.grad_sync.active()) else None
         B = sv["B"]
         d_out = d_out.reshape(B * self.Lq, self.nf).to(dtype=torch.float32).contiguous()
         st = sv.get("graph")
@@ -964,11 +1002,13 @@ class _DenoiserTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, eng: TrainEngine, x, cond, times, keep, seed, p_drop, *params):
         ctx.eng = eng
-        return eng.forward(x, cond, times, keep, seed, p_drop)
+        out = eng.forward(x, cond, times, keep, seed, p_drop)
+        ctx.gen = eng.sv["gen"]       # the saved activations (and dropout seed) this node's backward has to find
+        return out
 
     @staticmethod
     def backward(ctx, d_out):
-        grads = ctx.eng.backward(d_out)
+        grads = ctx.eng.backward(d_out, gen=ctx.gen)
         return (None,) * 7 + tuple(grads)
 
 

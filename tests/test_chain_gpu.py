@@ -94,7 +94,7 @@ def test_chain_a_kernel_against_rowln_plus_tile():
     Q2 = torch.zeros_like(Q1)
     # the chain kernels take the rotary table and keep the residual stream COLUMN-BLOCKED ([64][rows][8]); layer 0's
     # residual input (gemm_rowln's output) is row-major
-    K.chain(L.CHAIN_A, 64, M, Lq, Oa, ws, a_mod=Rs, ln_g=g1, ln_b=b1, ln_eps=1e-6, film=film, film_ld=2048, xres=xres,
+    K.chain(L.CHAIN_A, M, Lq, Oa, ws, a_mod=Rs, ln_g=g1, ln_b=b1, ln_eps=1e-6, film=film, film_ld=2048, xres=xres,
             xres_mod=Rs, xres_rowmajor=True, xout=x2, n2_g=g2, n2_b=b2, n2_eps=1e-5, rope=K.to_cb(rope), q_out=Q2,
             scale_q=0.125, Lp=Lp, H=H)
     torch.cuda.synchronize()
@@ -150,15 +150,14 @@ def test_chain_b_kernel_against_op_by_op_sequence(last):
     E = DenoiserEngine
     f1, f2 = E._stages_ff1(W["ff1"]), E._stages_ff2(W["ff2"])
     parts = [E._stages_n512(W["cfc"])]
-    for c in range(4):
-        parts += [f1[c], f2[c]]
+    parts += E._ffn_order(f1, f2)
     parts.append(E._stages_n512(W["l3"]))
     if not last:
         parts += [E._stages_n512(W["qkv"][i * 512:(i + 1) * 512]) for i in range(3)]
     ws = torch.cat(parts, 1).contiguous()
     xb = K.to_cb(xres)                     # column-blocked residual stream, updated in place
     Q2, K2, V2, hl2 = z(nseq, H, Lp, 64), z(nseq, H, Lp, 64), z(nseq, H, Lp, 64), z(M, 512)
-    K.chain(L.CHAIN_B_LAST if last else L.CHAIN_B, ws.shape[1], M, Lq, Oa, ws, ln_g=g1, ln_b=b1, ln_eps=1e-6, film=film,
+    K.chain(L.CHAIN_B_LAST if last else L.CHAIN_B, M, Lq, Oa, ws, ln_g=g1, ln_b=b1, ln_eps=1e-6, film=film,
             film_ld=4096, xres=xb, xout=xb, n2_g=g3, n2_b=b3n, n2_eps=1e-5, rope=K.to_cb(rope), b1=bias1, b2=bias2,
             film3=film[:, 2048:], n4_g=g4, n4_b=b4, n4_eps=1e-5, b3=bias3, nn_g=None if last else gn,
             nn_b=None if last else bn, nn_eps=1e-5, q_out=None if last else Q2, k_out=None if last else K2,
@@ -211,8 +210,7 @@ def test_fused_layer_chain_against_chain_a_attention_chain_b(last, S):
     E = DenoiserEngine
     f1, f2 = E._stages_ff1(W["ff1"]), E._stages_ff2(W["ff2"])
     partsB = [E._stages_n512(W["cfc"])]
-    for c in range(4):
-        partsB += [f1[c], f2[c]]
+    partsB += E._ffn_order(f1, f2)
     partsB.append(E._stages_n512(W["l3"]))
     if not last:
         partsB += [E._stages_n512(W["qkv"][i * 512:(i + 1) * 512]) for i in range(3)]
@@ -224,11 +222,11 @@ def test_fused_layer_chain_against_chain_a_attention_chain_b(last, S):
     # ---- three launches
     x1 = K.to_cb(xres)
     Qc, O2 = z(nseq, H, Lp, 64), z(M, 512)
-    K.chain(L.CHAIN_A, 64, M, Lq, Oa, wsA, ln_g=gs[0], ln_b=gs[1], ln_eps=1e-6, film=film, film_ld=6144, xres=x1, xout=x1,
+    K.chain(L.CHAIN_A, M, Lq, Oa, wsA, ln_g=gs[0], ln_b=gs[1], ln_eps=1e-6, film=film, film_ld=6144, xres=x1, xout=x1,
             n2_g=gs[2], n2_b=gs[3], rope=rope, q_out=Qc, scale_q=0.125, Lp=Lp, H=H)
     K.attention(dt, Qc, Kc, Vc, O2, nseq, H, Lq, Lk, Lp, Lpc, 512, n_shared=n_shared)
     Q1, K1, V1, h1 = z(nseq, H, Lp, 64), z(nseq, H, Lp, 64), z(nseq, H, Lp, 64), z(M, 512)
-    K.chain(L.CHAIN_B_LAST if last else L.CHAIN_B, wsB.shape[1], M, Lq, O2, wsB, ln_g=gs[4], ln_b=gs[5], ln_eps=1e-6,
+    K.chain(L.CHAIN_B_LAST if last else L.CHAIN_B, M, Lq, O2, wsB, ln_g=gs[4], ln_b=gs[5], ln_eps=1e-6,
             film=film[:, 2048:], film_ld=6144, xres=x1, xout=x1, n2_g=gs[10], n2_b=gs[11], rope=rope,
             q_out=None if last else Q1, k_out=None if last else K1, v_out=None if last else V1,
             h_out=h1 if last else None, **tail)
@@ -237,7 +235,7 @@ def test_fused_layer_chain_against_chain_a_attention_chain_b(last, S):
     K.pack_kv_frags(Kc, Vc, Kf, Vf, n_kv, H, Lpc, nkt, 0, Lk)
     x2 = K.to_cb(xres)
     Q2, K2, V2, h2 = z(nseq, H, Lp, 64), z(nseq, H, Lp, 64), z(nseq, H, Lp, 64), z(M, 512)
-    K.chain(L.CHAIN_FULL_LAST if last else L.CHAIN_FULL, wsF.shape[1], M, Lq, Oa, wsF, ln_g=gs[0], ln_b=gs[1], ln_eps=1e-6,
+    K.chain(L.CHAIN_FULL_LAST if last else L.CHAIN_FULL, M, Lq, Oa, wsF, ln_g=gs[0], ln_b=gs[1], ln_eps=1e-6,
             film=film, film_ld=6144, xres=x2, xout=x2, n2_g=gs[2], n2_b=gs[3], rope=rope, lnb_g=gs[4], lnb_b=gs[5],
             filmb=film[:, 2048:], n3_g=gs[10], n3_b=gs[11], kf=Kf, vf=Vf, n_shared=n_shared, nkt=nkt, Lk=Lk,
             q_out=None if last else Q2, k_out=None if last else K2, v_out=None if last else V2,
@@ -281,10 +279,10 @@ def test_front_chain_against_rowln_plus_qkv_tile():
     E = DenoiserEngine
     tail = [E._stages_n512(Wqkv[i * 512:(i + 1) * 512]) for i in range(3)]
     ws = torch.stack([torch.cat([E._stages_n512(W3[512 * d:512 * d + 512])] + tail, 1) for d in range(dn)]).contiguous()
-    assert ws.shape == (dn, 8, 160, 1024)
+    assert ws.shape == (dn, 8, 80, 2048)
     xs2 = z(Rs, 512, dtype=torch.float32)
     Q2, K2, V2 = z(nseq, H, Lp, 64), z(nseq, H, Lp, 64), z(nseq, H, Lp, 64)
-    K.chain(L.CHAIN_FRONT, 160, Mf, Lq, f2, ws, b3=b3, nn_g=g1, nn_b=b1, nn_eps=1e-5, rope=K.to_cb(rope), xout=xs2, q_out=Q2,
+    K.chain(L.CHAIN_FRONT, Mf, Lq, f2, ws, b3=b3, nn_g=g1, nn_b=b1, nn_eps=1e-5, rope=K.to_cb(rope), xout=xs2, q_out=Q2,
             k_out=K2, v_out=V2, scale_q=0.125, Lp=Lp, H=H, dn=dn)
     torch.cuda.synchronize()
     md = lambda a_, b_: (float((a_.float() - b_.float()).abs().max()), float((a_.float() - b_.float()).abs().mean()))
@@ -327,8 +325,7 @@ def test_fused_layer_chain_against_a_torch_evaluation_of_the_layer_tail():
     E = DenoiserEngine
     f1, f2 = E._stages_ff1(W["ff1"]), E._stages_ff2(W["ff2"])
     parts = [E._stages_n512(W["sfc"]), E._stages_n512(W["cq"]), E._stages_n512(W["cfc"])]
-    for c in range(4):
-        parts += [f1[c], f2[c]]
+    parts += E._ffn_order(f1, f2)
     parts.append(E._stages_n512(W["l3"]))
     parts += [E._stages_n512(W["qkv"][i * 512:(i + 1) * 512]) for i in range(3)]
     wsF = torch.cat(parts, 1).contiguous()
@@ -336,7 +333,7 @@ def test_fused_layer_chain_against_a_torch_evaluation_of_the_layer_tail():
     K.pack_kv_frags(Kc, Vc, Kf, Vf, n_kv, H, Lpc, nkt, 0, Lk)
     x2 = K.to_cb(xres)
     Q2, K2, V2 = z(nseq, H, Lp, 64), z(nseq, H, Lp, 64), z(nseq, H, Lp, 64)
-    K.chain(L.CHAIN_FULL, wsF.shape[1], M, Lq, Oa, wsF, ln_g=gs[0], ln_b=gs[1], ln_eps=1e-6, film=film, film_ld=6144, xres=x2,
+    K.chain(L.CHAIN_FULL, M, Lq, Oa, wsF, ln_g=gs[0], ln_b=gs[1], ln_eps=1e-6, film=film, film_ld=6144, xres=x2,
             xout=x2, n2_g=gs[2], n2_b=gs[3], rope=K.to_cb(rope_rm), lnb_g=gs[4], lnb_b=gs[5], filmb=film[:, 2048:], n3_g=gs[10],
             n3_b=gs[11], kf=Kf, vf=Vf, n_shared=n_shared, nkt=nkt, Lk=Lk, q_out=Q2, k_out=K2, v_out=V2, b1=bias1, b2=bias2,
             film3=film[:, 4096:], n4_g=gs[6], n4_b=gs[7], b3=bias3, nn_g=gs[8], nn_b=gs[9], scale_q=0.125, Lp=Lp, H=H)

@@ -70,33 +70,37 @@ def test_shard_range_covers_everything():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
 
 
-def _grad_worker(rank, world, port, q):
+def _subgroup_worker(rank, world, port, q):
+    """gradient averaging bound to an explicit process group: rank 2 of 3 is outside the group and must neither take part
+    nor block (a default group that exists for sharded sampling must not pull a fine-tuning rank into collectives)"""
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
     D.init_from_env("gloo")
-    torch.manual_seed(0)
-    ps = [torch.nn.Parameter(torch.zeros(s)) for s in ((300, 7), (5,), (1000,), (64, 64), (3,))]
-    for i, p in enumerate(ps):
-        if i != 1:                                    # parameter 1 is "dead": no gradient on any rank
-            p.grad = torch.full(p.shape, float(rank + 1) * (i + 1))
-    red = D.GradientAllReducer(ps, bucket_bytes=8192)
-    n = red.reduce()
-    ok = ps[1].grad is None and all(torch.allclose(p.grad, torch.full(p.shape, 1.5 * (i + 1)))
-                                    for i, p in enumerate(ps) if i != 1)
-    q.put((rank, ok, n, len(red.buckets)))
+    grp = torch.distributed.new_group(ranks=[0, 1])
+    flat = torch.full((5000,), float(rank + 1))
+    if rank < 2:
+        red = D.FlatGradientAllReducer(bucket_bytes=4096, group=grp)
+        assert red.active()
+        red.ready(flat, 0, 3000)
+        red.ready(flat, 3000, 5000)
+        n = red.finish()
+    else:
+        n = 0                                          # trains nothing, enters no collective
+    q.put((rank, float(flat.min()), float(flat.max()), n))
+    torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
 
-def test_bucketed_gradient_allreduce_averages_over_ranks():
+def test_gradient_allreduce_is_bound_to_the_group_it_was_given():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    ps = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    ps = [ctx.Process(target=_subgroup_worker, args=(r, 3, port, q)) for r in range(3)]
     for p in ps:
         p.start()
     res = sorted(q.get(timeout=120) for _ in ps)
     for p in ps:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert all(r[1] for r in res)
-    assert res[0][2] == res[1][2] and res[0][3] >= 3          # several buckets, the same collectives on both ranks
+    assert res[0][1:3] == (1.5, 1.5) and res[1][1:3] == (1.5, 1.5) and res[2][1:3] == (3.0, 3.0)
+    assert res[0][3] == res[1][3] == 3 + 2 and res[2][3] == 0

@@ -215,22 +215,15 @@ def test_batch_independence_and_partition_invariance(c2):
 
 
 @pytest.mark.parametrize("compute", ["bf16", "f32"])
-def test_full_batch_properties_two_streams_partition_determinism(compute):
+def test_full_batch_properties_partition_determinism(compute):
     """BASELINE config 2 at its full batch (16 clips, 3 x 150), 24 DDPM steps across the guidance-clip boundary
     (t = 111..88: both CFG branches, then the conditional one only), in-kernel Philox noise.  Size-independent
-    properties, bit for bit: (1) the two free-running half-batch streams give the single-stream samples, (2) so do two
-    separate 8-clip calls with clip_offset (what two ranks would compute), (3) the same seed gives the same samples,
-    a different seed different ones."""
+    properties, bit for bit: (1) two separate 8-clip calls with clip_offset (what two ranks would compute) give the
+    16-clip call's samples, (2) the same seed gives the same samples, a different seed different ones."""
     _, _, diff = build(3, 150, 1000, compute)
     cond = torch.stack([O.synth_cond(c, 150) for c in range(16)])
     xT = torch.stack([O.synth_xT(c, 450) for c in range(16)])
-    diff.dual_stream = False
     single = diff.p_sample_loop((16, 450, 151), cond, noise=xT, start_point=112, seed=4242)
-    diff.dual_stream = True
-    for skew in (-1.0, 40.0):          # lock-step halves inside one graph / free-running halves
-        diff.dual_skew_us = skew
-        dual = diff.p_sample_loop((16, 450, 151), cond, noise=xT, start_point=112, seed=4242)
-        assert torch.equal(single, dual), f"two-stream sampling (skew {skew}) changed the samples"
     halves = [diff.p_sample_loop((8, 450, 151), cond[lo:lo + 8], noise=xT[lo:lo + 8], start_point=112, seed=4242,
                                  clip_offset=lo) for lo in (0, 8)]
     assert torch.equal(single, torch.cat(halves)), "a clip's sample depends on its shard"
@@ -449,20 +442,20 @@ def test_c2_bf16_vs_f32_drift_over_the_full_1000_steps():
     assert e < BF16_DRIFT_BOUND and mean < BF16_DRIFT_BOUND / 10
 
 
-def test_first_call_crosses_guidance_boundary_after_many_skewed_replays():
-    """on the FIRST call of a process the step at t < 0.1 T takes the eager warm-up branch for the
-    single-branch graph key while the side stream may still hold hundreds of free-running replays.  Cross the boundary
-    after 300 skewed replays on a fresh model and compare with the single-stream samples, bit for bit."""
+def test_first_call_crossing_the_guidance_boundary_equals_the_replayed_call():
+    """On the FIRST call of a process every step graph key is met eagerly once, then captured, then replayed -- and at
+    t < 0.1 T the key changes (single-branch steps) after hundreds of replays of the two-branch graph.  The first call on a
+    fresh model (eager warm-up + capture inside the loop) must give, bit for bit, what the all-replayed second call and the
+    never-captured schedule give."""
     cond = torch.stack([O.synth_cond(c, 150) for c in range(4)])
     xT = torch.stack([O.synth_xT(c, 450) for c in range(4)])
     _, _, fresh = build(3, 150, 1000, "bf16")
-    fresh.dual_stream = True
-    assert fresh.dual_skew_us >= 0
-    dual = fresh.p_sample_loop((4, 450, 151), cond, noise=xT, start_point=400, seed=31)     # first call: nothing captured
+    first = fresh.p_sample_loop((4, 450, 151), cond, noise=xT, start_point=400, seed=31)     # first call: nothing captured
+    again = fresh.p_sample_loop((4, 450, 151), cond, noise=xT, start_point=400, seed=31)     # every step replayed
+    assert torch.equal(first, again)
     _, _, ref = build(3, 150, 1000, "bf16")
-    ref.dual_stream = False
-    single = ref.p_sample_loop((4, 450, 151), cond, noise=xT, start_point=400, seed=31)
-    assert torch.equal(dual, single)
+    eager = ref.p_sample_loop((4, 450, 151), cond, noise=xT, start_point=400, seed=31, use_graph=False)
+    assert torch.equal(first, eager)
 
 
 def test_weights_written_by_fused_ema_and_adan_are_seen_by_the_next_forward():

@@ -70,6 +70,8 @@ def _engine_worker(rank, world, port, q):
     model = DanceDecoder(nfeats=151, seq_len=8, latent_dim=512, ff_size=1024, num_layers=2, num_heads=8, dropout=0.1,
                          cond_feature_dim=438, activation=F.gelu, required_dancer_num=2, compute_dtype="bf16")
     eng = model.train_engine()
+    assert eng.grad_sync is None              # a process group alone does NOT switch gradient averaging on (opt-in)
+    eng.enable_grad_sync(group=torch.distributed.group.WORLD)
     calls = []
     orig_ready = D.FlatGradientAllReducer.ready
 

@@ -35,6 +35,8 @@ diff = GaussianDiffusion(model, S, 151, None, schedule="cosine", n_timestep=T, p
                          use_p2=False, cond_drop_prob=0.25, guidance_weight=2, seq_len=S).to(DEV)
 diff.eval()                                                # dropout off: the global batch has a single-process equivalent
 optim = Adan(model.parameters(), lr=1e-4, weight_decay=0.02)
+if world > 1:
+    model.train_engine().enable_grad_sync()                # opt-in: bound to the default group by the trainer
 n_steps = 4
 def data(step, r):
     c0 = 10 * step + b * r

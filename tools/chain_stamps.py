@@ -23,7 +23,7 @@ for nblk in (1, 225):
     kf = rnd(nseq + 1, H, nkt * 2048, scale=0.5).to(bf); vf = rnd(nseq + 1, H, nkt * 2048, scale=0.5).to(bf)
     st = torch.zeros(8 * 64, device=dev, dtype=torch.int64)
     for _ in range(5):
-        K.chain(L.CHAIN_FULL, 352, M, Lq, Oa, wsF, ln_g=g[0], ln_b=g[1], ln_eps=1e-6, film=film, film_ld=6144, xres=x, xout=x,
+        K.chain(L.CHAIN_FULL, M, Lq, Oa, wsF, ln_g=g[0], ln_b=g[1], ln_eps=1e-6, film=film, film_ld=6144, xres=x, xout=x,
                 n2_g=g[2], n2_b=g[3], rope=rope, b1=b1, b2=b2, film3=film[:, 4096:], n4_g=g[4], n4_b=g[5], b3=b3, nn_g=g[6],
                 nn_b=g[7], q_out=Q, k_out=Kk, v_out=V, h_out=st, Lp=Lp, H=H, lnb_g=g[0], lnb_b=g[1], filmb=film[:, 2048:],
                 n3_g=g[2], n3_b=g[3], kf=kf, vf=vf, n_shared=nseq // 2, nkt=nkt, Lk=S_ + 2)
@@ -32,6 +32,7 @@ for nblk in (1, 225):
     t = tw[0]
     print(f"---- fused layer chain, {nblk} block(s): total {(t[33] - t[0]) / 100:.1f} us (100 MHz counter); per phase: wave 0's "
           f"duration, then every wave's arrival relative to wave 0 (us)")
+    print(f"  last wave ends at {(max(tw[w][33] for w in range(8)) - t[0]) / 100:.1f} us")
     print(f"  shader clock over the kernel (s_memtime / s_memrealtime): {(t[61] - t[60]) / max(1, t[33] - t[0]) * 100:.0f} MHz")
     prev = t[0]
     for i, name in order[1:]:
