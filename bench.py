@@ -389,6 +389,7 @@ def rank_main(a):
     cond = torch.stack([W.synth_cond(c, S) for c in range(lo, hi)]).to(dev)
     xT = torch.stack([W.synth_xT(c, Lq) for c in range(lo, hi)]).to(dev)
     ranks_seen, clip_ranges = rank_facts(D, n_total, rank, world, dev)
+    xT0, cond0 = W.synth_xT(0, Lq)[None].to(dev), W.synth_cond(0, S)[None].to(dev)       # clip 0 (the goldens' clip)
 
     def one_job():
         x = diff.p_sample_loop((hi - lo, Lq, 151), cond, noise=xT, seed=1234, clip_offset=lo)
@@ -464,6 +465,23 @@ def rank_main(a):
                                   "tolerance": "max-abs <= 1e-3 vs the reference on fp32 (tests/test_parity_gpu.py)",
                                   "mfma_frac_f32_peak": round(nb / d1 * gf * T / 1e3 / PEAK_F32_TFLOPS, 4) if gf else None}
             del d32
+        if world == 1 and (dn, S, T) == (3, 150, 1000):
+            # how far the BENCHMARKED arithmetic is from the reference: one guided evaluation of clip 0 at two timesteps against
+            # the committed outputs of the real reference on the same name-keyed synthetic weights and inputs
+            # (tests/golden/c2_forward.npz, made by tests/golden/make_golden.py); asserted in tests/test_parity_gpu.py
+            try:
+                import numpy as np
+                gz = np.load(os.path.join(ROOT, "tests", "golden", "c2_forward.npz"))
+                errs = {}
+                for t in (999, 37):
+                    y = diff.model.guided_forward(xT0[:1], cond0[:1], torch.full((1,), t, dtype=torch.long, device=dev), 2)
+                    errs[f"t{t}"] = float(np.abs(y.detach().cpu().double().numpy() - gz[f"guided_w2_t{t}"]).max())
+                res[f"{a.dtype}_vs_reference_maxabs"] = dict(
+                    guided_evaluation=round(max(errs.values()), 6), per_timestep={k: round(v, 6) for k, v in errs.items()},
+                    reference="real reference (fp32 CPU), clip 0, w = 2; outputs are O(1)",
+                    bound_in_tests=2.5e-2 if a.dtype == "bf16" else 5e-4)
+            except Exception as e:
+                res["vs_reference_error"] = repr(e)[:300]
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(dn, S, T, a.cpu_seconds)
         if world == 1 and not a.no_other_configs and (dn, S, T) == (3, 150, 1000):
@@ -497,7 +515,13 @@ def other_configs(a, dev):
     from tcdiff_amd import DanceDecoder, GaussianDiffusion
     from tcdiff_amd import weights as W
     out = {}
-    for name, dn, S, T, nb in (("config1_1clip_2x60_T100", 2, 60, 100, 1), ("config4_5x300_T1000_batch4", 5, 300, 1000, 4)):
+    # (name, dancers, frames, T, clips, sampler): config 1 and 4 of BASELINE.json with p_sample_loop, and what TCDiff.py
+    # itself calls when it renders -- ddim_sample, 50 steps, a handful of 3 x 150 clips with the trajectory in-painted
+    # (TCDiff.py:292-303, model/diffusion.py:386-442): the small-batch latency regime
+    for name, dn, S, T, nb, sampler in (("config1_1clip_2x60_T100", 2, 60, 100, 1, "ddpm"),
+                                        ("config4_5x300_T1000_batch4", 5, 300, 1000, 4, "ddpm"),
+                                        ("ddim50_3x150_1clip", 3, 150, 1000, 1, "ddim"),
+                                        ("ddim50_3x150_4clips", 3, 150, 1000, 4, "ddim")):
         model = DanceDecoder(nfeats=151, seq_len=S, latent_dim=512, ff_size=1024, num_layers=8, num_heads=8, dropout=0.1,
                              cond_feature_dim=438, activation=F.gelu, required_dancer_num=dn, compute_dtype=a.dtype)
         model.load_state_dict(W.synth_state_dict_like(model))
@@ -506,17 +530,24 @@ def other_configs(a, dev):
         Lq = dn * S
         cond = torch.stack([W.synth_cond(c, S) for c in range(nb)]).to(dev)
         xT = torch.stack([W.synth_xT(c, Lq) for c in range(nb)]).to(dev)
-        diff.p_sample_loop((nb, Lq, 151), cond, noise=xT, seed=1)
+        if sampler == "ddim":
+            x0 = torch.stack([W.synth_xT(100 + c, Lq, 3) for c in range(nb)]).clamp(-1, 1).to(dev)
+            job = lambda: diff.ddim_sample((nb, Lq, 151), cond, x_0=x0, init_noise=xT, seed=1)
+            steps = 50
+        else:
+            job = lambda: diff.p_sample_loop((nb, Lq, 151), cond, noise=xT, seed=1)
+            steps = T
+        job()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        x = diff.p_sample_loop((nb, Lq, 151), cond, noise=xT, seed=1)
+        x = job()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         assert bool(torch.isfinite(x).all())
         gf = GFLOP_PER_CLIP_STEP.get((dn, S))
-        out[name] = {"value": round(nb / dt, 4), "unit": "clips/s", "clips": nb, "dancers": dn, "frames": S, "ddpm_steps": T,
-                     "dtype": a.dtype, "ms_per_job": round(dt * 1e3, 1),
-                     "mfma_frac": round(nb / dt * gf * T / 1e3 / PEAK_BF16_TFLOPS, 4) if (gf and a.dtype == "bf16") else None}
+        out[name] = {"value": round(nb / dt, 4), "unit": "clips/s", "clips": nb, "dancers": dn, "frames": S, "sampler": sampler,
+                     "steps": steps, "dtype": a.dtype, "ms_per_job": round(dt * 1e3, 1), "ms_per_step": round(dt * 1e3 / steps, 4),
+                     "mfma_frac": round(nb / dt * gf * steps / 1e3 / PEAK_BF16_TFLOPS, 4) if (gf and a.dtype == "bf16") else None}
         del diff, model
     return out
 

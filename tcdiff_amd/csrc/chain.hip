@@ -386,66 +386,6 @@ DEVINL int act_wr_off(int lane, int nt, int chunk0 = 0) {
     return c * TC_ROWB + (((chunk0 + 2 * nt + (g >> 1)) ^ tile_swz(c)) << 4) + 8 * (g & 1);
 }
 
-// linear2 over one 256-column chunk of h1 (8 stages, as phase_n512<8>) with the bias + GELU + bf16 packing of the NEXT chunk's
-// linear1 accumulators a1 issued one tile per stage behind that stage's MFMAs: the VALU work (exact-erf polynomial, ~45
-// instructions per tile) runs while the matrix pipe executes, instead of between two GEMM phases with the matrix pipe idle
-// (round 3: 2.5-3.6 us per chunk between linear1 and linear2).  hbw: the h1 buffer of the next chunk; bias1: b1 + its first column.
-DEVINL void phase_ff2_gelu(acc_t& acc, const char* hbr, WStream& ws, int lane, const f32x4_t (&a1)[2][4], char* hbw,
-                           const char* bias1, int wave) {
-    lane = fresh_v(lane);
-    const FragOff fo = frag_off(hbr, lane);
-    const int g = lane >> 4;
-    unsigned wo[2];
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)     // chunk column 32 wave + 16 nt + 4 g: k-tile wave / 2, 16-byte chunk 4 (wave & 1) + 2 nt + (g >> 1)
-        wo[nt] = (unsigned)reinterpret_cast<uintptr_t>(hbw) + (wave >> 1) * 8192 + act_wr_off(lane, nt, 4 * (wave & 1));
-    asm volatile("" : "+v"(wo[0]), "+v"(wo[1]));
-    int bo = (32 * wave + 4 * g) * 4;
-    asm volatile("" : "+v"(bo));
-    u32x4 b[4];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) b[mt] = frag_rd(fo, 0, mt);
-    const unsigned base = ws.pos;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-        const int i = ks % CH_D;
-        const u32x4 w0 = ws.w[i][0], w1 = ws.w[i][1], w2 = ws.w[i][2], w3 = ws.w[i][3];
-        ws_load(ws, i, base + ks + CH_D);
-        u32x4 n0 = b[0], n1 = b[1], n2 = b[2], n3 = b[3];
-        if (ks + 1 < 8) {
-            n0 = frag_rd(fo, ks + 1, 0);
-            n1 = frag_rd(fo, ks + 1, 1);
-            n2 = frag_rd(fo, ks + 1, 2);
-            n3 = frag_rd(fo, ks + 1, 3);
-        }
-        const int nt = ks >> 2, mt = ks & 3;           // the a1 tile of this stage
-        const f32x4_t b4 = lds4b(bias1 + bo, 64 * nt);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int m2 = 0; m2 < 4; ++m2) {
-            mma16(acc[0][m2], w0, b[m2]);
-            mma16(acc[1][m2], w1, b[m2]);
-            mma16(acc[2][m2], w2, b[m2]);
-            mma16(acc[3][m2], w3, b[m2]);
-        }
-        {
-            float v[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) v[t] = a1[nt][mt][t] + b4[t];
-            act4_ct<ACT_GELU>(v, ACT_GELU);
-            typedef __attribute__((ext_vector_type(2))) uint32_t u32x2v;
-            typedef __attribute__((address_space(3))) u32x2v lds_u32x2;
-            const u32x2v pk = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-            *reinterpret_cast<lds_u32x2*>((uintptr_t)(wo[nt] + (unsigned)(mt * 2048))) = pk;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        acc_fence(acc);
-        asm volatile("" : "+v"(n0), "+v"(n1), "+v"(n2), "+v"(n3) : : "memory");
-        b[0] = n0; b[1] = n1; b[2] = n2; b[3] = n3;
-    }
-    ws.pos = base + 8;
-}
-
 // u = LayerNorm(acc) (optionally rotated) -> bf16 -> activation block in LDS (k = column); gv, bv: LDS vectors;
 // rp: the rotary rows (cos0 sin0 cos1 sin1 per column quad), started by the caller before the statistics exchange
 template <bool ROT>
@@ -561,9 +501,9 @@ DEVINL void store_heads(const acc_t& acc, void* base, float scale, int L, int Lp
 // in a second, fragment-ordered image (tcdiff_pack_kv_frags) whose 1-KB pieces load straight into the A operands with the
 // same order.  Online softmax over 32-key tiles (two 16-key score tiles); O^T = V^T P^T with P^T fed from the S^T
 // accumulator registers (key slot 8 g + jj <-> key 16 (jj >> 2) + 4 g + (jj & 3) of the tile).  The row sum stays a per-lane
-// partial until the end; only the row maximum crosses the lane groups per tile.  Two passes of 32 rows (two row tiles each:
-// the O accumulators of all four would not fit beside the weight ring); a pass whose rows straddle two sequences runs
-// once per sequence and every lane keeps the result of its own row's sequence.
+// partial until the end; only the row maximum crosses the lane groups per tile.  Every K / V tile is loaded once and serves all
+// four row tiles (the Q^T fragments wait in wave-private LDS meanwhile); a block whose rows straddle two sequences runs once
+// per sequence and every lane keeps the result of its own row's sequence.
 // Output: bf16 O rows into the activation block (columns 64 wave ..).
 DEVINL void cross_attention(const acc_t& qacc, const tcdiff_chain_args& a, int m0, char* abuf, int wave, int lane) {
     lane = fresh_v(lane);
@@ -908,11 +848,12 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
         CH_T(34);
         if (FULL) store_consts(nxt);   // the cross-attention fc block's constants: read two barriers from here
         zero(acc);
-        phase_n512<16>(acc, abuf, ws, lane);
         if (!FULL) {
+            phase_n512<16>(acc, abuf, ws, lane);
             store_heads<true>(acc, a.q_out, a.scale_q, L, a.Lp, a.H, m0, M, wave, lane, smem);
             return;
         }
+        phase_n512<16>(acc, abuf, ws, lane);
         // ================= cross-attention in place (the Q image never leaves the registers)
         CH_T(35);
         lds_barrier();                 // every wave is out of the w_qs GEMM: the activation block becomes O
@@ -946,23 +887,25 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     lds_barrier();                     // ... and everybody sees the feed-forward constants
     CH_T(5);
     zero(acc);   // acc = linear2 accumulator
-    // Chunks of 256 h1 columns, software-pipelined: linear1(0), GELU(0) | linear1(c), { linear2(c - 1) with GELU(c) behind its
-    // MFMAs } for c = 1..3 | linear2(3).  The weight stream is packed in this order (engine._build_chain_streams).  Two h1
-    // buffers: linear2(c - 1) reads buffer (c - 1) & 1 while GELU(c) fills buffer c & 1, whose last readers (linear2(c - 2))
-    // finished before the barrier in between.
-    {
+    // (Measured and dropped, round 4: the chunks as a software pipeline -- linear1(c), then linear2(c - 1) with the GELU of
+    // chunk c issued one tile per stage behind that stage's MFMAs, the weight stream packed in that order.  Same cycles per
+    // launch (208.8 k against 207.9 k shader cycles at 225 blocks): the SIMD's two waves already run half a phase apart --
+    // the older one takes the matrix pipe first -- so the leader's GELU sits under the follower's MFMAs as it is, and the
+    // fused phase is bound by VALU issue (~300 cycles of erf polynomial per 16 x 16 tile, two waves) instead.)
+#pragma unroll 1
+    for (int ch = 0; ch < 4; ++ch) {
         f32x4_t a1[2][4];
-        auto zero1 = [&]() {
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) a1[nt][mt] = f32x4_t{0, 0, 0, 0};
-        };
-        zero1();
+            for (int mt = 0; mt < 4; ++mt) a1[nt][mt] = f32x4_t{0, 0, 0, 0};
         phase_ff1(a1, abuf, ws, lane);
-        CH_T(6);
+        CH_T(6 + 4 * ch);
+        // two h1 buffers: chunk c - 2's linear2 reads of this one finished before the barrier of chunk c - 1
+        char* hb = h1c + (ch & 1) * 32768;
+        CH_T(7 + 4 * ch);
         {
-            const int nb = 32 * wave + 4 * g;               // b1 occupies vector slots 0 and 1
+            const int nb = 256 * ch + 32 * wave + 4 * g;        // b1 occupies vector slots 0 and 1
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 const f32x4_t b4 = lds4(cvec, nb + 16 * nt);
@@ -979,24 +922,14 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
                     uint2 pk;
                     pk.x = pack_bf2(v[0], v[1]);
                     pk.y = pack_bf2(v[2], v[3]);
-                    *reinterpret_cast<uint2*>(h1c + wo + mt * 2048) = pk;
+                    *reinterpret_cast<uint2*>(hb + wo + mt * 2048) = pk;
                 }
             }
         }
         lds_barrier();
-        CH_T(8);
-#pragma unroll
-        for (int ch = 1; ch < 4; ++ch) {
-            zero1();
-            phase_ff1(a1, abuf, ws, lane);
-            CH_T(6 + 4 * ch);
-            phase_ff2_gelu(acc, h1c + ((ch - 1) & 1) * 32768, ws, lane, a1, h1c + (ch & 1) * 32768, cvec + 1024 * ch, wave);
-            CH_T(7 + 4 * ch);
-            lds_barrier();
-            CH_T(8 + 4 * ch);
-        }
-        phase_n512<8>(acc, h1c + 32768, ws, lane);
-        CH_T(21);
+        CH_T(8 + 4 * ch);
+        phase_n512<8>(acc, hb, ws, lane);
+        CH_T(9 + 4 * ch);
     }
     // linear2 bias, FiLM, residual (the x this lane stored above), norm4 -> LDS
     xout_start();

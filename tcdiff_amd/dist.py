@@ -131,7 +131,9 @@ class FlatGradientAllReducer:
     def active(self) -> bool:
         return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
 
-    def ready(self, flat: torch.Tensor, lo: int, hi: int):
+    def ready(self, flat: torch.Tensor, lo: int, hi: int, more: bool = True):
+        """`more` (whether the backward has launches left behind this range) only matters to the capture stand-in of
+        train_engine._capture_bwd_segments, which shares this signature"""
         if not self.active() or hi <= lo:
             return
         avg = dist.get_backend(self.group) == "nccl"

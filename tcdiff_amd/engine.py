@@ -134,9 +134,8 @@ class DenoiserEngine:
 
     @staticmethod
     def _ffn_order(f1, f2):
-        """the feed-forward stages in the order the kernel consumes them: linear1(0), then linear1(c), linear2(c - 1) for
-        c = 1..3, then linear2(3) (csrc/chain.hip: linear2(c - 1) runs with the GELU of chunk c behind its MFMAs)"""
-        return [f1[0], f1[1], f2[0], f1[2], f2[1], f1[3], f2[2], f2[3]]
+        """the feed-forward stages in the order the kernel consumes them: linear1 chunk c, linear2 k-slice c, c = 0..3"""
+        return [f for c in range(4) for f in (f1[c], f2[c])]
 
     def _build_chain_streams(self):
         w = self.w

@@ -506,3 +506,54 @@ def test_c2_full_1000_step_loop_vs_reference_golden(golden_dir, compute, bound):
     errs["final"] = maxabs(x[:1], ref["final"])
     print(f"C2 full loop ({compute}) max-abs vs reference after steps:", {k: f"{v:.2e}" for k, v in errs.items()})
     assert max(errs.values()) < bound
+
+
+def test_bf16_error_attribution_by_switch(golden_dir):
+    """where does the bf16 mode's distance to the reference come from?  One guided evaluation of clip 0 at the
+    benchmarked shape against the REAL reference's output (tests/golden/c2_forward.npz), for the default bf16 path and with
+    one ingredient switched off at a time: the two weight folds (input_projection . fusion linear 1, linear3 . final_layer:
+    products taken in fp32 and rounded to bf16 ONCE), the front chain launch, the fused layer chain (A + B launches with the
+    op-by-op attention kernel between them) and all chains (op-by-op kernels: every intermediate rounded to bf16 in HBM).
+    Prints the table (profiles/r04_parity_at_benchmarked_config.log) and holds every variant to the stated bound; the f32
+    mode is the reference point that carries the <= 1e-3 claim."""
+    import importlib
+    ref = gold(golden_dir, "c2_forward")
+    cond = torch.stack([O.synth_cond(0, 150)]).to(DEV)
+    xT = torch.stack([O.synth_xT(0, 450)]).to(DEV)
+    variants = [("bf16 default", {}), ("bf16, no input fold", {"TCDIFF_FOLD_IN": "0"}), ("bf16, no output fold", {"TCDIFF_FOLD_OUT": "0"}),
+                ("bf16, no front chain", {"TCDIFF_FRONT": "0"}), ("bf16, chain A + B", {"TCDIFF_CHAIN": "1"}),
+                ("bf16, op-by-op", {"TCDIFF_CHAIN": "0"}), ("f32 parity mode", None)]
+    keys = ("TCDIFF_FOLD_IN", "TCDIFF_FOLD_OUT", "TCDIFF_FRONT", "TCDIFF_CHAIN")
+    saved = {k: os.environ.get(k) for k in keys}
+    rows = []
+    try:
+        for name, env in variants:
+            for k in keys:
+                os.environ.pop(k, None)
+            os.environ.update(env or {})
+            _, model, _ = build(3, 150, 1000, compute="f32" if env is None else "bf16")
+            errs = []
+            for t in (999, 37):
+                tt = torch.full((1,), t, dtype=torch.long, device=DEV)
+                y = model.guided_forward(xT, cond, tt, 2)
+                d = (y.detach().cpu().double().numpy() - ref[f"guided_w2_t{t}"])
+                errs.append((float(np.abs(d).max()), float(np.abs(d).mean())))
+            rows.append((name, errs))
+            del model
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+    print("\\nguided evaluation vs the real reference (clip 0, 3 x 150, w = 2): max-abs / mean-abs at t = 999 | t = 37")
+    for name, errs in rows:
+        print(f"  {name:24s} {errs[0][0]:.3e} / {errs[0][1]:.3e} | {errs[1][0]:.3e} / {errs[1][1]:.3e}")
+    worst = {name: max(e[0] for e in errs) for name, errs in rows}
+    assert worst["f32 parity mode"] < 5e-4
+    for name, e in worst.items():
+        if name != "f32 parity mode":
+            assert e < BF16_EVAL_BOUND, (name, e)
+    # no single ingredient of the default path costs more than half of its distance to the reference: the error is the bf16
+    # operand rounding of eight layers, not one of the folds
+    base = worst["bf16 default"]
+    assert all(base - e < 0.5 * base for n, e in worst.items() if n.startswith("bf16,")), worst

@@ -37,7 +37,7 @@ diff.eval()                                                # dropout off: the gl
 optim = Adan(model.parameters(), lr=1e-4, weight_decay=0.02)
 if world > 1:
     model.train_engine().enable_grad_sync()                # opt-in: bound to the default group by the trainer
-n_steps = 4
+n_steps = 5
 def data(step, r):
     c0 = 10 * step + b * r
     x = torch.stack([O.synth_motion(c0 + c, DN * S).reshape(S, DN, 151).permute(1, 0, 2) for c in range(b)])
@@ -66,6 +66,7 @@ out["collectives"] = eng.grad_sync.launched if eng.grad_sync else 0
 out["graph_broken"] = eng._graph_broken
 out["fwd_replayed"] = any(st["fwd"] is not None for st in eng._graphs.values())
 out["bwd_captured"] = any(st["bwd"] is not None for st in eng._graphs.values())
+out["bwd_segments"] = max([len(st["bwd_segs"]) for st in eng._graphs.values() if st.get("bwd_segs")] or [0])
 out["psum"] = {n: float(p.detach().double().sum()) for n, p in model.named_parameters()}
 print("RESULT " + json.dumps(out), flush=True)
 if world > 1:
@@ -112,11 +113,13 @@ def test_two_ranks_average_gradients_and_stay_identical():
     one = _run(1)[0]
     a, b = two
     assert a["world"] == b["world"] == 2 and one["world"] == 1
-    assert a["collectives"] == b["collectives"] and a["collectives"] >= 4 * 10         # >= 10 all-reduces per step, same on both
+    assert a["collectives"] == b["collectives"] and a["collectives"] >= 5 * 10         # >= 10 all-reduces per step, same on both
     assert a["graph_broken"] is None and b["graph_broken"] is None
-    assert a["fwd_replayed"] and not a["bwd_captured"]        # forward replayed from step 3 on, backward stays eager (collectives)
-    assert one["bwd_captured"]                                # ... and is replayed too without a process group
-    # identical parameters on both ranks after 4 steps (same averaged gradients, deterministic fused Adan)
+    # forward replayed from step 3 on; the data-parallel backward is replayed too, as one graph per decoder layer + the front,
+    # with the layer's all-reduce launched between two replays (steps 3 and 4 of this run: capture + replay, then replay)
+    assert a["fwd_replayed"] and not a["bwd_captured"] and a["bwd_segments"] == b["bwd_segments"] == 9
+    assert one["bwd_captured"] and one["bwd_segments"] == 0   # without a process group: ONE backward graph
+    # identical parameters on both ranks after 5 steps (same averaged gradients, deterministic fused Adan)
     worst = max(abs(a["psum"][n] - b["psum"][n]) for n in a["psum"])
     assert worst == 0.0, worst
     # step 0 (same parameters everywhere): the averaged gradient = the single-process gradient of the concatenated batch

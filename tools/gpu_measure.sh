@@ -1,7 +1,7 @@
 #!/bin/bash
-# round-3 measurement pass (one box visit): full GPU suite, parity log at the benchmarked config, default bench, rocprofv3 kernel
+# round-4 measurement pass (one box visit): full GPU suite, parity log at the benchmarked config, default bench, rocprofv3 kernel
 # stats (200 steps), FETCH/WRITE PMC passes (30 steps), SQ counters (20 steps), chain block-count scaling, training-step bench
-R=r03
+R=r04
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 python -m pytest tests -q -m gpu 2>&1 | tail -3
