@@ -193,7 +193,7 @@ int tcdiff_adan_step(const tcdiff_adan_chunk* chunks, int n_chunks, const tcdiff
  *   TC_CHAIN_FULL / TC_CHAIN_FULL_LAST : chain A, then the CROSS-ATTENTION itself (head w on wave w, K / V from the
  *                     fragment-ordered cache images written by tcdiff_pack_kv_frags), then chain B / B_LAST, in one launch:
  *                     per layer the step is  self-attention -> one chain launch.  Stream: chain A's stages followed by
- *                     chain B's (176 / 128 stages); the first fc block uses ln_g.., film, n2_*, the second lnb_*, filmb,
+ *                     chain B's (176 / 128 stages); the first fc block uses film, n2_*, the second filmb,
  *                     n3_*; xres / xres_mod feed the first, xout carries x in between. */
 #define TC_CHAIN_A 0
 #define TC_CHAIN_B 1
@@ -212,9 +212,11 @@ typedef struct {
     int M, L, a_mod, xres_mod, H, Lp;
     const void* A;        /* bf16 [*,512]: attention output rows */
     const void* wstream;
-    const float* ln_g;    /* SBI_MSA.layer_norm (eps ln_eps) */
-    const float* ln_b;
-    const float* film;    /* FiLM of the attention block: film[seq * film_ld + n] scale, +512 shift */
+    const float* film;    /* FiLM of the attention block, PRE-FOLDED with the post-LayerNorm (SBI_MSA.layer_norm, eps ln_eps)
+                             weights g, b in front of it: film[seq * film_ld + n] = g (scale + 1), +512: b (scale + 1) + shift,
+                             so that the block's epilogue is x += LN(z) * G + Bv (model/model.py:103-106,171-173,327,334).  The
+                             caller folds g, b into the DenseFiLM generator's weights (both rows are linear in its input):
+                             tcdiff_amd/engine.py load_weights */
     const float* xres;    /* fp32 residual in: column-blocked (below) with M (xres_mod > 0: xres_mod) rows, or, with
                              xres_rowmajor, plain [*,512] rows (layer 0: written by tcdiff_gemm_rowln) */
     float* xout;          /* fp32 residual out, column-blocked [64][M][8] (chain B: holds x between the blocks, then x') */
@@ -223,8 +225,8 @@ typedef struct {
     const float* rope;    /* cos/sin table of tcdiff_rope_table, column-blocked [64][rope_rows][8] */
     void* q_out;          /* Q image T[n_seq][8][Lp][64] (chain A: cross-attention Q; chain B: next layer's) */
     const float* b1;      /* linear1 bias [1024] */
-    const float* b2;      /* linear2 bias [512]  */
-    const float* film3;   /* FiLM of the feed-forward block */
+    const float* film3;   /* FiLM of the feed-forward block, pre-folded with linear2's bias b2: [scale + 1 | b2 (scale + 1) + shift]
+                             (model/model.py:339,399-401) */
     const float* n4_g;
     const float* n4_b;
     const float* b3;      /* linear3 bias */
@@ -236,9 +238,7 @@ typedef struct {
     int film_ld;
     float ln_eps, n2_eps, n4_eps, nn_eps, scale_q;
     /* TC_CHAIN_FULL*: the cross-attention block */
-    const float* lnb_g;   /* multihead_attn.layer_norm */
-    const float* lnb_b;
-    const float* filmb;   /* FiLM of the cross-attention block */
+    const float* filmb;   /* FiLM of the cross-attention block, pre-folded with multihead_attn.layer_norm like `film` */
     const float* n3_g;    /* norm3 */
     const float* n3_b;
     const void* kf;       /* fragment-ordered K cache of this layer: T[n_kv][8 heads][nkt][4][64 lanes][8] */
@@ -249,6 +249,8 @@ typedef struct {
     int xres_rowmajor;     /* 1: xres is a plain row-major [*,512] matrix */
     int rope_rows;         /* rows of the column-blocked rotary table (>= L) */
     int dn;                /* TC_CHAIN_FRONT: dancers */
+    int mt;                /* 16-row tiles per row block: 0 = chosen from M and the device's CU count (4 = 64-row blocks when that
+                              fills the chip, else 2 or 1: a small job runs on many small blocks), or 1 / 2 / 4 (tests) */
     int out_ld;            /* *_LAST modes: 0 -> h_out = bf16 [M,512] rows of linear3; > 0 -> h_out = fp32 [M][out_ld], the
                               first out_ld columns of linear3 (the caller folded final_layer into its weights and bias:
                               model/model.py:344,623); out_ld % 4 == 0 */

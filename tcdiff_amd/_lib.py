@@ -38,13 +38,13 @@ class RowEpi(C.Structure):
 
 class ChainArgs(C.Structure):
     _fields_ = [("mode", _i), ("n_stages", _i), ("M", _i), ("L", _i), ("a_mod", _i), ("xres_mod", _i), ("H", _i),
-                ("Lp", _i), ("A", _vp), ("wstream", _vp), ("ln_g", _vp), ("ln_b", _vp), ("film", _vp), ("xres", _vp),
-                ("xout", _vp), ("n2_g", _vp), ("n2_b", _vp), ("rope", _vp), ("q_out", _vp), ("b1", _vp), ("b2", _vp),
+                ("Lp", _i), ("A", _vp), ("wstream", _vp), ("film", _vp), ("xres", _vp),
+                ("xout", _vp), ("n2_g", _vp), ("n2_b", _vp), ("rope", _vp), ("q_out", _vp), ("b1", _vp),
                 ("film3", _vp), ("n4_g", _vp), ("n4_b", _vp), ("b3", _vp), ("nn_g", _vp), ("nn_b", _vp),
                 ("k_out", _vp), ("v_out", _vp), ("h_out", _vp), ("film_ld", _i), ("ln_eps", _f), ("n2_eps", _f),
-                ("n4_eps", _f), ("nn_eps", _f), ("scale_q", _f), ("lnb_g", _vp), ("lnb_b", _vp), ("filmb", _vp),
+                ("n4_eps", _f), ("nn_eps", _f), ("scale_q", _f), ("filmb", _vp),
                 ("n3_g", _vp), ("n3_b", _vp), ("kf", _vp), ("vf", _vp), ("n_shared", _i), ("nkt", _i), ("Lk", _i),
-                ("xres_rowmajor", _i), ("rope_rows", _i), ("dn", _i), ("out_ld", _i)]
+                ("xres_rowmajor", _i), ("rope_rows", _i), ("dn", _i), ("mt", _i), ("out_ld", _i)]
 
 
 class StepPrologueArgs(C.Structure):

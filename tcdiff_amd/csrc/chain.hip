@@ -57,7 +57,8 @@
 #define CH_STAGE 4096
 
 typedef const float* fptr;
-typedef f32x4_t acc_t[4][4];          // [n-tile][m-tile]
+// accumulators: f32x4_t acc[4 n-tiles][MT m-tiles of 16 rows]; MT = 4 (64-row blocks: the benchmark), 2 or 1 (small jobs:
+// more, smaller row blocks so that every CU gets one -- a block costs one pass over the layer's weights whatever its rows)
 
 DEVINL void mma16(f32x4_t& acc, const u32x4& a, const u32x4& b) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
@@ -100,11 +101,12 @@ DEVINL int fresh_s(int x) {
 }
 
 DEVINL f32x4_t ld4(const float* p) { return *reinterpret_cast<const f32x4_t*>(p); }
-DEVINL void zero(acc_t& a) {
+template <int MT>
+DEVINL void zero(f32x4_t (&a)[4][MT]) {
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) a[nt][mt] = f32x4_t{0, 0, 0, 0};
+        for (int mt = 0; mt < MT; ++mt) a[nt][mt] = f32x4_t{0, 0, 0, 0};
 }
 
 // ---- lane-group exchanges (the four 16-lane groups g of a wave hold different columns of the same rows) -----------------
@@ -157,11 +159,26 @@ DEVINL float ar4_sum(float v) {
 }
 
 // every accumulator tile through an (empty) asm statement: orders the MFMAs in front of it before everything behind it
-DEVINL void acc_fence(acc_t& a) {
+template <int MT>
+DEVINL void acc_fence(f32x4_t (&a)[4][MT]) {
+    if constexpr (MT == 4) {
 #pragma unroll
-    for (int nt = 0; nt < 4; nt += 2)
-        asm volatile("" : "+v"(a[nt][0]), "+v"(a[nt][1]), "+v"(a[nt][2]), "+v"(a[nt][3]), "+v"(a[nt + 1][0]), "+v"(a[nt + 1][1]),
-                     "+v"(a[nt + 1][2]), "+v"(a[nt + 1][3]));
+        for (int nt = 0; nt < 4; nt += 2)
+            asm volatile("" : "+v"(a[nt][0]), "+v"(a[nt][1]), "+v"(a[nt][2]), "+v"(a[nt][3]), "+v"(a[nt + 1][0]), "+v"(a[nt + 1][1]),
+                         "+v"(a[nt + 1][2]), "+v"(a[nt + 1][3]));
+    } else if constexpr (MT == 2) {
+        asm volatile("" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[2][0]), "+v"(a[2][1]), "+v"(a[3][0]),
+                     "+v"(a[3][1]));
+    } else {
+        asm volatile("" : "+v"(a[0][0]), "+v"(a[1][0]), "+v"(a[2][0]), "+v"(a[3][0]));
+    }
+}
+// the next stage's B fragments through the stage fence (see phase_n512)
+template <int MT>
+DEVINL void frag_fence(u32x4 (&n)[MT]) {
+    if constexpr (MT == 4) asm volatile("" : "+v"(n[0]), "+v"(n[1]), "+v"(n[2]), "+v"(n[3]) : : "memory");
+    else if constexpr (MT == 2) asm volatile("" : "+v"(n[0]), "+v"(n[1]) : : "memory");
+    else asm volatile("" : "+v"(n[0]) : : "memory");
 }
 
 // LDS addresses of this lane's B fragments: row 16 mt + c of a [64][128 B] k-tile, chunk 4 (ks & 1) + PI(g) of k-step ks.
@@ -191,14 +208,14 @@ DEVINL u32x4 frag_rd(const FragOff& f, int ks, int mt) {
 // copy of the most recently loaded slot at the loop header -- i.e. `s_waitcnt vmcnt(0)`, a full drain of the wave's
 // weight stream, every CH_D stages.  The activation fragments of stage ks + 1 are read before the MFMAs of stage ks.
 // TAIL: the launch's last phase -- its last CH_D stages refill nothing (there is nothing behind them).
-template <int NST, bool TAIL = false>
-DEVINL void phase_n512(acc_t& acc, const char* abuf, WStream& ws, int lane) {
+template <int NST, bool TAIL = false, int MT = 4>
+DEVINL void phase_n512(f32x4_t (&acc)[4][MT], const char* abuf, WStream& ws, int lane) {
     static_assert(NST % CH_D == 0, "a phase starts and ends at ring slot 0");
     lane = fresh_v(lane);
     const FragOff fo = frag_off(abuf, lane);
-    u32x4 b[4];
+    u32x4 b[MT];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) b[mt] = frag_rd(fo, 0, mt);
+    for (int mt = 0; mt < MT; ++mt) b[mt] = frag_rd(fo, 0, mt);
     const unsigned base = ws.pos;
     FragOff fo2 = fo;                  // K = 1024 (TC_CHAIN_FRONT): k-tiles 8 .. 15 from a second pair of bases
     if (NST > 16) {
@@ -211,21 +228,21 @@ DEVINL void phase_n512(acc_t& acc, const char* abuf, WStream& ws, int lane) {
         const int i = ks % CH_D;
         const u32x4 w0 = ws.w[i][0], w1 = ws.w[i][1], w2 = ws.w[i][2], w3 = ws.w[i][3];
         if (!(TAIL && ks + CH_D >= NST)) ws_load(ws, i, base + ks + CH_D);
-        u32x4 n0 = b[0], n1 = b[1], n2 = b[2], n3 = b[3];
+        u32x4 nb[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) nb[mt] = b[mt];
         if (ks + 1 < NST) {
             const FragOff& fn = ks + 1 < 16 ? fo : fo2;
             const int kl = (ks + 1) & 15;
-            n0 = frag_rd(fn, kl, 0);
-            n1 = frag_rd(fn, kl, 1);
-            n2 = frag_rd(fn, kl, 2);
-            n3 = frag_rd(fn, kl, 3);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) nb[mt] = frag_rd(fn, kl, mt);
         }
         // Stage order: the next stage's LDS reads and the refill are ISSUED, then this stage's MFMAs run (the ~100
         // cycles of LDS latency pass under them even when the wave is alone on its SIMD), then the fence.  Left to
         // itself hipcc schedules read, wait, use.
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
             mma16(acc[0][mt], w0, b[mt]);
             mma16(acc[1][mt], w1, b[mt]);
             mma16(acc[2][mt], w2, b[mt]);
@@ -238,19 +255,21 @@ DEVINL void phase_n512(acc_t& acc, const char* abuf, WStream& ws, int lane) {
         // stages of them past the following stages' loads (seen in the listing: empty stages, then 40 MFMAs in a row with
         // three stages of fragments and refills live -- 232 VGPRs and four ring slots spilled behind `s_waitcnt vmcnt(0)`).
         acc_fence(acc);
-        asm volatile("" : "+v"(n0), "+v"(n1), "+v"(n2), "+v"(n3) : : "memory");
-        b[0] = n0; b[1] = n1; b[2] = n2; b[3] = n3;
+        frag_fence(nb);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) b[mt] = nb[mt];
     }
     ws.pos = base + NST;
 }
 // linear1 chunk: a1[nt][mt] (columns 32 wave + 16 nt + ..) += act[64 x 512] * W1 chunk; a stage = 2 k-steps of the wave's
 // 32 rows: fragments [k-step 2][n-tile 2]
-DEVINL void phase_ff1(f32x4_t (&a1)[2][4], const char* abuf, WStream& ws, int lane) {
+template <int MT>
+DEVINL void phase_ff1(f32x4_t (&a1)[2][MT], const char* abuf, WStream& ws, int lane) {
     lane = fresh_v(lane);
     const FragOff fo = frag_off(abuf, lane);
-    u32x4 b[4];
+    u32x4 b[MT];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) b[mt] = frag_rd(fo, 0, mt);
+    for (int mt = 0; mt < MT; ++mt) b[mt] = frag_rd(fo, 0, mt);
     const unsigned base = ws.pos;
 #pragma unroll
     for (int st = 0; st < 8; ++st) {
@@ -260,24 +279,30 @@ DEVINL void phase_ff1(f32x4_t (&a1)[2][4], const char* abuf, WStream& ws, int la
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
             const int ks = 2 * st + k2;
-            u32x4 n0 = b[0], n1 = b[1], n2 = b[2], n3 = b[3];
+            u32x4 nb[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) nb[mt] = b[mt];
             if (ks + 1 < 16) {
-                n0 = frag_rd(fo, ks + 1, 0);
-                n1 = frag_rd(fo, ks + 1, 1);
-                n2 = frag_rd(fo, ks + 1, 2);
-                n3 = frag_rd(fo, ks + 1, 3);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) nb[mt] = frag_rd(fo, ks + 1, mt);
             }
             __builtin_amdgcn_sched_barrier(0);   // see phase_n512
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
+            for (int mt = 0; mt < MT; ++mt) {
                 mma16(a1[0][mt], wk[2 * k2], b[mt]);
                 mma16(a1[1][mt], wk[2 * k2 + 1], b[mt]);
             }
             __builtin_amdgcn_sched_barrier(0);
-            asm volatile("" : "+v"(a1[0][0]), "+v"(a1[0][1]), "+v"(a1[0][2]), "+v"(a1[0][3]), "+v"(a1[1][0]), "+v"(a1[1][1]),
-                         "+v"(a1[1][2]), "+v"(a1[1][3]));
-            asm volatile("" : "+v"(n0), "+v"(n1), "+v"(n2), "+v"(n3) : : "memory");
-            b[0] = n0; b[1] = n1; b[2] = n2; b[3] = n3;
+            if constexpr (MT == 4)
+                asm volatile("" : "+v"(a1[0][0]), "+v"(a1[0][1]), "+v"(a1[0][2]), "+v"(a1[0][3]), "+v"(a1[1][0]), "+v"(a1[1][1]),
+                             "+v"(a1[1][2]), "+v"(a1[1][3]));
+            else if constexpr (MT == 2)
+                asm volatile("" : "+v"(a1[0][0]), "+v"(a1[0][1]), "+v"(a1[1][0]), "+v"(a1[1][1]));
+            else
+                asm volatile("" : "+v"(a1[0][0]), "+v"(a1[1][0]));
+            frag_fence(nb);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) b[mt] = nb[mt];
         }
     }
     ws.pos = base + 8;
@@ -289,12 +314,13 @@ DEVINL void phase_ff1(f32x4_t (&a1)[2][4], const char* abuf, WStream& ws, int la
 // Returns rstd and nmr = -mean * rstd: the normalised value is fma(v, rstd, nmr), one op per element instead of two.
 // Lane l finishes row l of the block (reduce-scatter over the lane groups, then the 8 waves' pairs in wave order: the
 // sums are deterministic), and the four lane groups exchange their rows' (rstd, nmr) by swaps.
-DEVINL void row_stats(const acc_t& acc, float* scr, int wave, int lane, float eps, float (&nmr)[4], float (&rstd)[4]) {
+template <int MT>
+DEVINL void row_stats(const f32x4_t (&acc)[4][MT], float* scr, int wave, int lane, float eps, float (&nmr)[MT], float (&rstd)[MT]) {
     lane = fresh_v(lane);
     wave = fresh_s(wave);
-    float s[4], s2[4];
+    float s[MT], s2[MT];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
         f32x2_t t = {0.0f, 0.0f}, t2 = {0.0f, 0.0f};
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
@@ -307,19 +333,49 @@ DEVINL void row_stats(const acc_t& acc, float* scr, int wave, int lane, float ep
         s[mt] = t[0] + t[1];
         s2[mt] = t2[0] + t2[1];
     }
+    // lane -> the row of the block it finishes: MT = 4: row `lane` (row tile g); MT = 2: row 16 (g & 1) + c; MT = 1: row c
     f32x2_t mine;
-    mine[0] = rs4_sum(s[0], s[1], s[2], s[3]);
-    mine[1] = rs4_sum(s2[0], s2[1], s2[2], s2[3]);
-    *reinterpret_cast<f32x2_t*>(scr + (wave * 64 + lane) * 2) = mine;       // row `lane` of the block, this wave's columns
+    int row;
+    if constexpr (MT == 4) {
+        mine[0] = rs4_sum(s[0], s[1], s[2], s[3]);
+        mine[1] = rs4_sum(s2[0], s2[1], s2[2], s2[3]);
+        row = lane;
+    } else if constexpr (MT == 2) {
+        float a0 = s[0], a1 = s[1], b0 = s2[0], b1 = s2[1];
+        swap16(a0, a1);              // a0 = [s0.g0, s1.g0, s0.g2, s1.g2], a1 = [s0.g1, s1.g1, s0.g3, s1.g3]
+        swap16(b0, b1);
+        float p = a0 + a1, q = b0 + b1, p2 = p, q2 = q;          // p = [s0(g0+g1), s1(g0+g1), s0(g2+g3), s1(g2+g3)]
+        swap32(p, p2);               // p = lower half everywhere, p2 = upper half everywhere
+        swap32(q, q2);
+        mine[0] = p + p2;            // lane groups 0, 2: row tile 0; 1, 3: row tile 1
+        mine[1] = q + q2;
+        row = (lane & 15) + 16 * ((lane >> 4) & 1);
+    } else {
+        mine[0] = ar4_sum(s[0]);
+        mine[1] = ar4_sum(s2[0]);
+        row = lane & 15;
+    }
+    *reinterpret_cast<f32x2_t*>(scr + (wave * 64 + row) * 2) = mine;       // (MT < 4: lane groups write the same value twice / 4 x)
     lds_barrier();
     f32x2_t tot = {0.0f, 0.0f};
 #pragma unroll
-    for (int w = 0; w < 8; ++w) tot += *reinterpret_cast<const f32x2_t*>(scr + (w * 64 + lane) * 2);
+    for (int w = 0; w < 8; ++w) tot += *reinterpret_cast<const f32x2_t*>(scr + (w * 64 + row) * 2);
     const float mean = tot[0] * (1.0f / 512.0f);
     const float var = fmaxf(tot[1] * (1.0f / 512.0f) - mean * mean, 0.0f);
     const float rs = rsqrtf(var + eps);
-    ag4(rs, rstd);
-    ag4(-mean * rs, nmr);
+    const float nm = -mean * rs;
+    if constexpr (MT == 4) {
+        ag4(rs, rstd);
+        ag4(nm, nmr);
+    } else if constexpr (MT == 2) {
+        float r0 = rs, r1 = rs, n0 = nm, n1 = nm;
+        swap16(r0, r1);              // r0 = row tile 0's value in every lane group, r1 = row tile 1's
+        swap16(n0, n1);
+        rstd[0] = r0; rstd[1] = r1; nmr[0] = n0; nmr[1] = n1;
+    } else {
+        rstd[0] = rs;
+        nmr[0] = nm;
+    }
 }
 
 DEVINL f32x4_t lds4b(const char* base, int byte_off) {
@@ -342,31 +398,34 @@ DEVINL int col_base_bytes(int wave, int g) {
 // [64 groups of 8 columns][rows][8 floats]: the 16 rows of two lane groups are consecutive, so an instruction reads two
 // contiguous half kilobytes.  The residual stream between chain launches and the rotary table handed to them are
 // column-blocked; only layer 0's input when written by gemm_rowln is row-major (`xres_rowmajor`).
+template <int MT>
 struct RowPipe {
     __amdgpu_buffer_rsrc_t rsrc;   // the matrix as a raw buffer: address = SGPR descriptor + SGPR (n-tile) + VGPR (row, lane group)
-    unsigned voff[4];              // byte offset of this lane's 16 bytes of row tile mt inside the wave's first column group
+    unsigned voff[MT];             // byte offset of this lane's 16 bytes of row tile mt inside the wave's first column group
     unsigned soff, its;            // byte offset of the wave's first column group, bytes per n-tile step (wave-uniform)
-    f32x4_t q[2][4];               // [n-tile & 1][row tile]
+    f32x4_t q[2][MT];              // [n-tile & 1][row tile]
 };
 DEVINL __amdgpu_buffer_rsrc_t f32_buffer(const float* base, long n_floats) {
     const long bytes = n_floats * 4;
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes < 0xFFFFFFFFl ? (int)bytes : -1, 0x00020000);
 }
-DEVINL void rp_issue(RowPipe& rp, int nt) {
+template <int MT>
+DEVINL void rp_issue(RowPipe<MT>& rp, int nt) {
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
         rp.q[nt & 1][mt] = __builtin_bit_cast(
             f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rp.rsrc, rp.voff[mt], rp.soff + (unsigned)nt * rp.its, 0));
 }
 // rows: row count of the column-blocked matrix, or 0 for a row-major one (`total_rows` rows of 512 floats)
-DEVINL void rp_start(RowPipe& rp, const float* base, const int (&row)[4], long rows, long total_rows, int wave, int g) {
+template <int MT>
+DEVINL void rp_start(RowPipe<MT>& rp, const float* base, const int (&row)[MT], long rows, long total_rows, int wave, int g) {
     rp.rsrc = f32_buffer(base, total_rows * 512);
     const unsigned grp = rows > 0 ? (unsigned)rows * 32u : 0u;       // bytes per column group of 8
     rp.its = rows > 0 ? 2u * grp : 64u;
     rp.soff = rows > 0 ? (unsigned)wave * 8u * grp : (unsigned)wave * 256u;
     const unsigned gterm = rows > 0 ? (unsigned)(g >> 1) * grp + 16u * (g & 1) : 16u * g;
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
         rp.voff[mt] = (rows > 0 ? (unsigned)row[mt] * 32u : (unsigned)row[mt] * 2048u) + gterm;
     rp_issue(rp, 0);
     rp_issue(rp, 1);
@@ -388,9 +447,9 @@ DEVINL int act_wr_off(int lane, int nt, int chunk0 = 0) {
 
 // u = LayerNorm(acc) (optionally rotated) -> bf16 -> activation block in LDS (k = column); gv, bv: LDS vectors;
 // rp: the rotary rows (cos0 sin0 cos1 sin1 per column quad), started by the caller before the statistics exchange
-template <bool ROT>
-DEVINL void norm_to_lds(const acc_t& acc, const float (&nmr)[4], const float (&rstd)[4], const char* gv, const char* bv,
-                        RowPipe& rp, char* abuf, int wave, int lane, char* plain) {
+template <bool ROT, int MT>
+DEVINL void norm_to_lds(const f32x4_t (&acc)[4][MT], const float (&nmr)[MT], const float (&rstd)[MT], const char* gv,
+                        const char* bv, RowPipe<MT>& rp, char* abuf, int wave, int lane, char* plain) {
     lane = fresh_v(lane);
     wave = fresh_s(wave);
     const int g = lane >> 4;
@@ -400,7 +459,7 @@ DEVINL void norm_to_lds(const acc_t& acc, const float (&nmr)[4], const float (&r
         const f32x4_t g4 = lds4b(gv + cb0, 64 * nt), b4 = lds4b(bv + cb0, 64 * nt);
         const int wo = wave * 8192 + act_wr_off(lane, nt);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
             float u[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) u[t] = fmaf(fmaf(acc[nt][mt][t], rstd[mt], nmr[mt]), g4[t], b4[t]);
@@ -432,8 +491,8 @@ DEVINL void norm_to_lds(const acc_t& acc, const float (&nmr)[4], const float (&r
 // -- wave-private, XOR-swizzled by (row >> 1) & 7 (the 64 banks hold two 128-byte rows), no barrier -- and leaves as 16
 // bytes per lane, 8 lanes per 128-byte row: 8 full lines per instruction.
 DEVINL char* stage_area(char* smem, int wave) { return smem + (wave < 7 ? wave * 4096 : CH_STG7); }
-template <bool SCALE>   // Q carries 1 / sqrt(d_k); K and V are stored as they are
-DEVINL void store_heads(const acc_t& acc, void* base, float scale, int L, int Lp, int H, int m0, int M,
+template <bool SCALE, int MT>   // Q carries 1 / sqrt(d_k); K and V are stored as they are
+DEVINL void store_heads(const f32x4_t (&acc)[4][MT], void* base, float scale, int L, int Lp, int H, int m0, int M,
                         int wave, int lane, char* smem, int dn = 1, int dancer = 0) {
     // rows are FRAMES m0 .. of dancer `dancer` (token = frame dn + dancer; dn = 1: rows are tokens); L tokens per sequence
 #ifdef CH_ABLATE_STORES   // timing experiment only: how much of the Q / K / V tail is the head-major scatter?
@@ -445,10 +504,11 @@ DEVINL void store_heads(const acc_t& acc, void* base, float scale, int L, int Lp
     char* stg = stage_area(smem, wave);
     const int row0 = lane >> 3, ch = lane & 7;      // read side: row row0 + 8 k, 16-byte chunk ch
     const int Lf = L / dn;                          // frames per sequence
+    constexpr int NH = MT == 4 ? 2 : 1, NML = MT == 1 ? 1 : 2;      // 32-row halves of the block, row tiles per half
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
+    for (int hf = 0; hf < NH; ++hf) {
 #pragma unroll
-        for (int ml = 0; ml < 2; ++ml) {
+        for (int ml = 0; ml < NML; ++ml) {
             const int rl = 16 * ml + c;             // row of the 32-row staging tile
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
@@ -479,7 +539,7 @@ DEVINL void store_heads(const acc_t& acc, void* base, float scale, int L, int Lp
         uint16_t* dst = reinterpret_cast<uint16_t*>(base) + (((long)seq * H + wave) * Lp + tokf * dn + dancer) * 64 + ch * 8;
         const long wrap = ((long)H * Lp - L) * 64;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 2 * NML; ++k) {
             const int row = row0 + 8 * k;
             const u32x4 v = *reinterpret_cast<const u32x4*>(stg + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
             if (m < M) *reinterpret_cast<u32x4*>(dst) = v;
@@ -505,14 +565,16 @@ DEVINL void store_heads(const acc_t& acc, void* base, float scale, int L, int Lp
 // four row tiles (the Q^T fragments wait in wave-private LDS meanwhile); a block whose rows straddle two sequences runs once
 // per sequence and every lane keeps the result of its own row's sequence.
 // Output: bf16 O rows into the activation block (columns 64 wave ..).
-DEVINL void cross_attention(const acc_t& qacc, const tcdiff_chain_args& a, int m0, char* abuf, int wave, int lane) {
+template <int MT>
+DEVINL void cross_attention(const f32x4_t (&qacc)[4][MT], const tcdiff_chain_args& a, int m0, char* abuf, int wave, int lane) {
+    constexpr int NPS = MT == 4 ? 2 : 1, NML = MT == 1 ? 1 : 2;     // passes of 32 rows, row tiles (independent chains) per pass
     lane = fresh_v(lane);
     wave = fresh_s(wave);
     const int c = lane & 15, g = lane >> 4;
     const int M = a.M, L = a.L, nkt = a.nkt;
-    u32x4 qf[4][2];
+    u32x4 qf[MT][2];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const f32x4_t lo = qacc[2 * s][mt], hi = qacc[2 * s + 1][mt];
@@ -530,14 +592,14 @@ DEVINL void cross_attention(const acc_t& qacc, const tcdiff_chain_args& a, int m
         for (int i = 0; i < 4; ++i) f[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff + 1024u * i, so, 0));
     };
 #pragma unroll
-    for (int ps = 0; ps < 2; ++ps) {               // rows 32 ps .. 32 ps + 31 = row tiles 2 ps, 2 ps + 1
-        int ra = m0 + 32 * ps, rb = ra + 31;
+    for (int ps = 0; ps < NPS; ++ps) {             // rows 32 ps .. 32 ps + 31 = row tiles 2 ps, 2 ps + 1
+        int ra = m0 + 32 * ps, rb = ra + 16 * NML - 1;
         ra = ra < M ? ra : M - 1;
         rb = rb < M ? rb : M - 1;
         const int sa = ra / L, sb = rb / L;                 // wave-uniform
-        int my_seq[2];
+        int my_seq[NML];
 #pragma unroll
-        for (int ml = 0; ml < 2; ++ml) {
+        for (int ml = 0; ml < NML; ++ml) {
             int mrow = m0 + 32 * ps + 16 * ml + c;
             mrow = mrow < M ? mrow : M - 1;
             my_seq[ml] = mrow / L;
@@ -546,10 +608,17 @@ DEVINL void cross_attention(const acc_t& qacc, const tcdiff_chain_args& a, int m
         for (int seq = sa; seq <= sb; ++seq) {
             const int kv = seq < a.n_shared ? 0 : seq - a.n_shared + (a.n_shared > 0 ? 1 : 0);
             const unsigned so0 = (unsigned)((kv * a.H + wave) * nkt) * 4096u;      // this (slot, head)'s image (< 4 GB: launcher)
-            f32x4_t o[4][2];                                // [d tile][row tile of the pass]
+            f32x4_t o[4][NML];                              // [d tile][row tile of the pass]
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) o[dt][0] = o[dt][1] = f32x4_t{0, 0, 0, 0};
-            float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.0f, 0.0f};
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int ml = 0; ml < NML; ++ml) o[dt][ml] = f32x4_t{0, 0, 0, 0};
+            float m_run[NML], l_run[NML];
+#pragma unroll
+            for (int ml = 0; ml < NML; ++ml) {
+                m_run[ml] = -INFINITY;
+                l_run[ml] = 0.0f;
+            }
             u32x4 kn[4];                                           // K fragments run one tile ahead
             ld_tile(kr, so0, kn);
 #pragma unroll 1
@@ -561,9 +630,9 @@ DEVINL void cross_attention(const acc_t& qacc, const tcdiff_chain_args& a, int m
                 const int nx = kt + 1 < nkt ? kt + 1 : kt;       // the last iteration re-reads its own tile (unused)
                 ld_tile(kr, so0 + (unsigned)nx * 4096u, kn);
                 // the two row tiles of the pass are independent chains in ONE basic block (no per-tile branch between them)
-                f32x4_t s0[2], s1[2];                              // keys 4 g + j and 16 + 4 g + j of the tile
+                f32x4_t s0[NML], s1[NML];                              // keys 4 g + j and 16 + 4 g + j of the tile
 #pragma unroll
-                for (int ml = 0; ml < 2; ++ml) {
+                for (int ml = 0; ml < NML; ++ml) {
                     const int mt = 2 * ps + ml;
                     s0[ml] = s1[ml] = f32x4_t{0, 0, 0, 0};
                     mma16(s0[ml], kc[0], qf[mt][0]);
@@ -573,25 +642,27 @@ DEVINL void cross_attention(const acc_t& qacc, const tcdiff_chain_args& a, int m
                 }
                 if (kt * 32 + 32 > a.Lk) {
 #pragma unroll
-                    for (int ml = 0; ml < 2; ++ml)
+                    for (int ml = 0; ml < NML; ++ml)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             if (kt * 32 + 4 * g + j >= a.Lk) s0[ml][j] = -INFINITY;
                             if (kt * 32 + 16 + 4 * g + j >= a.Lk) s1[ml][j] = -INFINITY;
                         }
                 }
-                float m_new[2];
+                float m_new[NML];
 #pragma unroll
-                for (int ml = 0; ml < 2; ++ml) {
+                for (int ml = 0; ml < NML; ++ml) {
                     float mx = fmaxf(fmaxf(fmaxf(s0[ml][0], s0[ml][1]), fmaxf(s0[ml][2], s0[ml][3])),
                                      fmaxf(fmaxf(s1[ml][0], s1[ml][1]), fmaxf(s1[ml][2], s1[ml][3])));
                     mx = ar4_max(mx) * LOG2E;
                     m_new[ml] = fmaxf(m_run[ml], mx);
                 }
                 // the running maximum moves in the first tile or two; afterwards the whole wave skips the rescale
-                if (__builtin_amdgcn_ballot_w64(m_new[0] > m_run[0] || m_new[1] > m_run[1]) != 0) {
+                bool moved = m_new[0] > m_run[0];
+                if constexpr (NML == 2) moved = moved || m_new[1] > m_run[1];
+                if (__builtin_amdgcn_ballot_w64(moved) != 0) {
 #pragma unroll
-                    for (int ml = 0; ml < 2; ++ml) {
+                    for (int ml = 0; ml < NML; ++ml) {
                         const float alpha = __builtin_amdgcn_exp2f(m_run[ml] - m_new[ml]);   // first tile: exp2(-inf) = 0, o is 0
                         l_run[ml] *= alpha;
 #pragma unroll
@@ -602,7 +673,7 @@ DEVINL void cross_attention(const acc_t& qacc, const tcdiff_chain_args& a, int m
                     }
                 }
 #pragma unroll
-                for (int ml = 0; ml < 2; ++ml) {
+                for (int ml = 0; ml < NML; ++ml) {
                     float rs = 0.0f;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -621,7 +692,7 @@ DEVINL void cross_attention(const acc_t& qacc, const tcdiff_chain_args& a, int m
                 }
             }
 #pragma unroll
-            for (int ml = 0; ml < 2; ++ml) {
+            for (int ml = 0; ml < NML; ++ml) {
                 const float lsum = ar4_sum(l_run[ml]);
                 if (my_seq[ml] == seq) {
                     const float inv = __builtin_amdgcn_rcpf(lsum);    // 1 ulp; the quotient is rounded to bf16 next
@@ -653,8 +724,10 @@ DEVINL void cross_attention(const acc_t& qacc, const tcdiff_chain_args& a, int m
 #define CH_T(i) do { } while (0)
 #endif
 
-template <int MODE>
+// MT: 16-row tiles per block (4: 64-row blocks; 2, 1: small jobs, see tcdiff_chain)
+template <int MODE, int MT>
 __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
+    constexpr int BR = 16 * MT;        // rows per block
     constexpr bool HAS_A = MODE == TC_CHAIN_A || MODE == TC_CHAIN_FULL || MODE == TC_CHAIN_FULL_LAST;   // fc + norm2 + w_qs
     constexpr bool FULL = MODE == TC_CHAIN_FULL || MODE == TC_CHAIN_FULL_LAST;                          // + cross-attention
     constexpr bool LAST = MODE == TC_CHAIN_B_LAST || MODE == TC_CHAIN_FULL_LAST;
@@ -668,14 +741,14 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     const int c = lane & 15, g = lane >> 4;
     const int dn = FRONT ? a.dn : 1;
     const int dancer = FRONT ? (int)(blockIdx.x % (unsigned)dn) : 0;
-    const int m0 = FRONT ? (int)(blockIdx.x / (unsigned)dn) * 64 : xcd_remap(blockIdx.x, gridDim.x) * 64;
+    const int m0 = FRONT ? (int)(blockIdx.x / (unsigned)dn) * BR : xcd_remap(blockIdx.x, gridDim.x) * BR;
     CH_T(0);
     CH_TC(60);
     const int M = a.M, L = a.L;        // FRONT: M = frames, L = TOKENS per sequence
     char* abuf = smem + CH_ABUF;
     char* h1c = smem + CH_H1C;
     float* scr = reinterpret_cast<float*>(smem + CH_SCR);
-    char* cfilm = smem + CH_FILM;      // [2 sequences][scale + 1: 512 | shift: 512] floats
+    char* cfilm = smem + CH_FILM;      // [2 sequences][G: 512 | Bv: 512] floats
     char* cvec = smem + CH_VEC;        // six vectors of 512 floats
 
     // rows of this lane (four row tiles), clamped: rows past M recompute row M - 1 (their inputs are clamped to it).
@@ -684,12 +757,12 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     const int seq0 = (m0 < M ? m0 : M - 1) / L;
     const int seq_last = (M - 1) / L;
     const int seqb = (seq0 + 1) * L;   // first row of the block's second sequence (L >= 64 rows per sequence: launcher)
-    struct Rows { int mc[4], sidx[4]; };
+    struct Rows { int mc[MT], sidx[MT]; };
     auto rows = [&]() {
         Rows r;
         const int cc = fresh_v(c);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
             const int m = m0 + 16 * mt + cc;
             r.mc[mt] = m < M ? m : M - 1;
             r.sidx[mt] = r.mc[mt] >= seqb ? 1 : 0;
@@ -697,14 +770,16 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
         return r;
     };
     // rotary position of the rows: FRONT rows are frames of one dancer (token = frame dn + dancer)
-    auto positions = [&](const Rows& r, int (&pos)[4]) {
+    auto positions = [&](const Rows& r, int (&pos)[MT]) {
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
             pos[mt] = FRONT ? (r.mc[mt] * dn + dancer) % L : r.mc[mt] - (r.sidx[mt] ? seqb : seqb - L);
     };
     // Epilogue constants go through LDS.  Thread t carries one float4 of the FiLM rows and up to two of the vectors
     // from global memory to LDS; they are fetched early (latency hidden behind a GEMM) and stored once the previous
-    // epilogue no longer reads the area.  The FiLM scale is stored as scale + 1 (featurewise_affine, model/model.py:171-173).
+    // epilogue no longer reads the area.  The FiLM rows arrive PRE-FOLDED (tcdiff_chain_args.film): [G = g (scale + 1) |
+    // Bv = b (scale + 1) + shift] with g, b the LayerNorm weights in front of the FiLM (or 1, linear2's bias), so an epilogue is
+    // v = fma(u, G, Bv) + x (featurewise_affine, model/model.py:171-173, and the LayerNorm affine / bias in one step).
     struct Consts { f32x4_t f, v0, v1; };
     auto fetch_consts = [&](const float* film, const float* const (&vec)[6]) {
         Consts k;
@@ -718,24 +793,24 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
         return k;
     };
     auto store_consts = [&](const Consts& k) {
-        const float one = (fresh_v(tid) & 255) < 128 ? 1.0f : 0.0f;    // floats 0..511 of a FiLM row are the scale
-        *reinterpret_cast<f32x4_t*>(cfilm + tid * 16) = k.f + one;
+        *reinterpret_cast<f32x4_t*>(cfilm + tid * 16) = k.f;
         *reinterpret_cast<f32x4_t*>(cvec + tid * 16) = k.v0;
         if (tid < 256) *reinterpret_cast<f32x4_t*>(cvec + 8192 + tid * 16) = k.v1;
     };
     auto vecp = [&](int slot) { return cvec + slot * 2048; };
     // constants of the fc block that opens chain B: its own set when chain A ran in front of it in this launch
-    const float* fcb_g = FULL ? a.lnb_g : a.ln_g;
-    const float* fcb_b = FULL ? a.lnb_b : a.ln_b;
     const float* fcb_film = FULL ? a.filmb : a.film;
     const float* n3_g = FULL ? a.n3_g : a.n2_g;
     const float* n3_b = FULL ? a.n3_b : a.n2_b;
 
     // ---- the block's input rows (attention output) -> LDS, the first CH_D weight stages -> registers, constants -> LDS
+    // (the LDS image keeps the 64-row geometry -- 8 KB per k-tile -- whatever MT: rows 16 MT .. 63 are simply unused)
+    if (wave < 2 * MT) {
 #pragma unroll
-    for (int kt = 0; kt < (FRONT ? 16 : 8); ++kt)      // FRONT: 64 rows of 1024 = the activation block and its twin, contiguous
-        stage_glds<64, 8>(abuf + kt * 8192, reinterpret_cast<const char*>(a.A) + kt * TC_ROWB, FRONT ? 2048 : 1024, m0, M,
-                          a.a_mod, wave, lane);
+        for (int kt = 0; kt < (FRONT ? 16 : 8); ++kt)  // FRONT: rows of 1024 = the activation block and its twin, contiguous
+            stage_glds<BR, 2 * MT>(abuf + kt * 8192, reinterpret_cast<const char*>(a.A) + kt * TC_ROWB, FRONT ? 2048 : 1024, m0,
+                                   M, a.a_mod, wave, lane);
+    }
     WStream ws;
     ws.rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(reinterpret_cast<const char*>(a.wstream)) + ((long)dancer * 8 + wave) * a.n_stages * CH_STAGE, 0,
@@ -749,7 +824,7 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
         const float* const v[6] = {a.b3 + 512 * dancer, a.nn_g, a.nn_b, nullptr, nullptr, nullptr};
         store_consts(fetch_consts(nullptr, v));
     } else {
-        const float* const v[6] = {a.ln_g, a.ln_b, a.n2_g, a.n2_b, nullptr, nullptr};
+        const float* const v[6] = {nullptr, nullptr, a.n2_g, a.n2_b, nullptr, nullptr};
         store_consts(fetch_consts(a.film, v));
     }
     // a wait the compiler can SEE (an asm s_waitcnt is invisible to its vmcnt bookkeeping: it would then treat the
@@ -758,9 +833,9 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     __syncthreads();
     CH_T(1);
 
-    acc_t acc;
-    float nmr[4], rstd[4];             // LayerNorm of the current rows: u = fma(v, rstd, nmr)
-    RowPipe rp;                        // residual rows, later rotary rows, of this lane
+    f32x4_t acc[4][MT];
+    float nmr[MT], rstd[MT];             // LayerNorm of the current rows: u = fma(v, rstd, nmr)
+    RowPipe<MT> rp;                      // residual rows, later rotary rows, of this lane
     const long xrows = (long)M * dn;
     const __amdgpu_buffer_rsrc_t xo = f32_buffer(a.xout, xrows * 512);     // the residual stream out
     Consts nxt;
@@ -775,33 +850,35 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
         // fresh copies: the two inlined instances of this epilogue must not share (and keep alive) their addresses
         const int gg = fresh_v(g), wv = fresh_s(wave);
         const Rows rw = rows();
-        int fb[4];
         const int cb0 = col_base_bytes(wv, gg);
+        auto body = [&](int nt, int mt, const f32x4_t& G, const f32x4_t& Bv) {
+            const f32x4_t x4 = rp.q[nt & 1][mt];
+            f32x4_t o;
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
+            for (int t = 0; t < 4; ++t) {
+                float v = fmaf(fmaf(acc[nt][mt][t], rstd[mt], nmr[mt]), G[t], Bv[t]);
+                v = x4[t] + v;
+                acc[nt][mt][t] = v;
+                o[t] = v;
+            }
+            // unguarded: rows past M rewrite row M - 1 with the SAME values (same inputs; every load of this column
+            // group, in place or not, was issued before this store)
+            cb_store(xo, M, wv, nt, rw.mc[mt], gg, o);
+        };
+        // (Measured in the listing and dropped: a second code path for blocks that lie in ONE sequence -- constants read once
+        // per column quad instead of once per row tile.  The two paths raise the epilogue's register peak, hipcc spills ring
+        // slots across it, and the launch ends with its straddling blocks anyway.)
+        int fb[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
             fb[mt] = rw.sidx[mt] * 4096 + cb0;    // FiLM rows of this lane's rows: sequence 0 or 1 of the block (4 KB apart)
             asm volatile("" : "+v"(fb[mt]));
         }
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-            const f32x4_t g4 = lds4b(vecp(0) + cb0, 64 * nt), b4 = lds4b(vecp(1) + cb0, 64 * nt);
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const f32x4_t sc = lds4b(cfilm + fb[mt], 64 * nt), sh = lds4b(cfilm + fb[mt], 2048 + 64 * nt);
-                const f32x4_t x4 = rp.q[nt & 1][mt];
-                f32x4_t o;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    float v = fmaf(fmaf(acc[nt][mt][t], rstd[mt], nmr[mt]), g4[t], b4[t]);
-                    v = fmaf(sc[t], v, sh[t]);
-                    v = x4[t] + v;
-                    acc[nt][mt][t] = v;
-                    o[t] = v;
-                }
-                // unguarded: rows past M rewrite row M - 1 with the SAME values (same inputs; every load of this column
-                // group, in place or not, was issued before this store)
-                cb_store(xo, M, wv, nt, rw.mc[mt], gg, o);
-            }
+            for (int mt = 0; mt < MT; ++mt)
+                body(nt, mt, lds4b(cfilm + fb[mt], 64 * nt), lds4b(cfilm + fb[mt], 2048 + 64 * nt));
             if (nt + 2 < 4) rp_issue(rp, nt + 2);
             // one n-tile at a time: without a fence hipcc hoists the loads of ALL of them (row pipeline refills and LDS
             // constants) above the arithmetic, needs ~100 more registers and spills them
@@ -810,9 +887,9 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     };
     auto xres_start = [&]() {
         const Rows rw = rows();
-        int rr[4];
+        int rr[MT];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) rr[mt] = a.xres_mod > 0 ? rw.mc[mt] % a.xres_mod : rw.mc[mt];
+        for (int mt = 0; mt < MT; ++mt) rr[mt] = a.xres_mod > 0 ? rw.mc[mt] % a.xres_mod : rw.mc[mt];
         rp_start(rp, a.xres, rr, a.xres_rowmajor ? 0 : (a.xres_mod > 0 ? a.xres_mod : M), a.xres_mod > 0 ? a.xres_mod : M, wave,
                  fresh_v(g));
     };
@@ -822,7 +899,7 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     };
     auto rope_start = [&]() {
         const Rows rw = rows();
-        int pos[4];
+        int pos[MT];
         positions(rw, pos);
         rp_start(rp, a.rope, pos, a.rope_rows, a.rope_rows, wave, fresh_v(g));
     };
@@ -830,30 +907,30 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     if (HAS_A) {
         // ================= self-attention block tail: fc + LayerNorm(1e-6) + FiLM + residual, norm2 + rotary, w_qs
         zero(acc);
-        phase_n512<16>(acc, abuf, ws, lane);
+        phase_n512<16, false, MT>(acc, abuf, ws, lane);
         CH_T(2);
         xres_start();                  // in flight during the statistics exchange
         fc_epilogue(a.ln_eps, 40);
         CH_T(3);
         if (FULL) {
-            const float* const v[6] = {fcb_g, fcb_b, n3_g, n3_b, nullptr, nullptr};
+            const float* const v[6] = {nullptr, nullptr, n3_g, n3_b, nullptr, nullptr};
             nxt = fetch_consts(fcb_film, v);
         }
         rope_start();
         row_stats(acc, scr + 1024, wave, lane, a.n2_eps, nmr, rstd);
         CH_T(4);
         // norm2 + rotary (model/model.py:332,387) -> LDS -> Q = rot W_q^T / 8 (model/model.py:78,97)
-        norm_to_lds<true>(acc, nmr, rstd, vecp(2), vecp(3), rp, abuf, wave, lane, nullptr);
+        norm_to_lds<true, MT>(acc, nmr, rstd, vecp(2), vecp(3), rp, abuf, wave, lane, nullptr);
         lds_barrier();
         CH_T(34);
         if (FULL) store_consts(nxt);   // the cross-attention fc block's constants: read two barriers from here
         zero(acc);
         if (!FULL) {
-            phase_n512<16>(acc, abuf, ws, lane);
-            store_heads<true>(acc, a.q_out, a.scale_q, L, a.Lp, a.H, m0, M, wave, lane, smem);
+            phase_n512<16, false, MT>(acc, abuf, ws, lane);
+            store_heads<true, MT>(acc, a.q_out, a.scale_q, L, a.Lp, a.H, m0, M, wave, lane, smem);
             return;
         }
-        phase_n512<16>(acc, abuf, ws, lane);
+        phase_n512<16, false, MT>(acc, abuf, ws, lane);
         // ================= cross-attention in place (the Q image never leaves the registers)
         CH_T(35);
         lds_barrier();                 // every wave is out of the w_qs GEMM: the activation block becomes O
@@ -866,7 +943,7 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     if constexpr (!FRONT) {
     // ================= cross-attention block tail: fc + LayerNorm(1e-6) + FiLM + residual (model/model.py:334)
     zero(acc);
-    phase_n512<16>(acc, abuf, ws, lane);
+    phase_n512<16, false, MT>(acc, abuf, ws, lane);
     if (FULL)
         xout_start();                  // the x this lane stored in the first fc epilogue
     else
@@ -878,10 +955,10 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     CH_T(39);
     // ================= feed-forward (model/model.py:338-339,399-401): norm3 -> LDS
     {
-        const float* const v[6] = {a.b1, a.b1 + 512, a.b2, a.n4_g, a.n4_b, nullptr};
+        const float* const v[6] = {a.b1, a.b1 + 512, nullptr, a.n4_g, a.n4_b, nullptr};
         nxt = fetch_consts(a.film3, v);
     }
-    norm_to_lds<false>(acc, nmr, rstd, vecp(2), vecp(3), rp, abuf, wave, lane, nullptr);
+    norm_to_lds<false, MT>(acc, nmr, rstd, vecp(2), vecp(3), rp, abuf, wave, lane, nullptr);
     lds_barrier();                     // nobody reads the fc constants any more
     store_consts(nxt);
     lds_barrier();                     // ... and everybody sees the feed-forward constants
@@ -894,11 +971,11 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     // fused phase is bound by VALU issue (~300 cycles of erf polynomial per 16 x 16 tile, two waves) instead.)
 #pragma unroll 1
     for (int ch = 0; ch < 4; ++ch) {
-        f32x4_t a1[2][4];
+        f32x4_t a1[2][MT];
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) a1[nt][mt] = f32x4_t{0, 0, 0, 0};
+            for (int mt = 0; mt < MT; ++mt) a1[nt][mt] = f32x4_t{0, 0, 0, 0};
         phase_ff1(a1, abuf, ws, lane);
         CH_T(6 + 4 * ch);
         // two h1 buffers: chunk c - 2's linear2 reads of this one finished before the barrier of chunk c - 1
@@ -912,7 +989,7 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
                 // chunk column 32 wave + 16 nt + 4 g: k-tile wave / 2, 16-byte chunk 4 (wave & 1) + 2 nt + (g >> 1)
                 const int wo = (wave >> 1) * 8192 + act_wr_off(lane, nt, 4 * (wave & 1));
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
+                for (int mt = 0; mt < MT; ++mt) {
                     float v[4];
 #pragma unroll
                     for (int t = 0; t < 4; ++t) v[t] = a1[nt][mt][t] + b4[t];
@@ -928,7 +1005,7 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
         }
         lds_barrier();
         CH_T(8 + 4 * ch);
-        phase_n512<8>(acc, hb, ws, lane);
+        phase_n512<8, false, MT>(acc, hb, ws, lane);
         CH_T(9 + 4 * ch);
     }
     // linear2 bias, FiLM, residual (the x this lane stored above), norm4 -> LDS
@@ -936,29 +1013,25 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     {
         const int cb2 = col_base_bytes(fresh_s(wave), fresh_v(g));
         const Rows rw = rows();
-        int fb2[4];
+        auto body2 = [&](int nt, int mt, const f32x4_t& G, const f32x4_t& Bv) {
+            const f32x4_t x4 = rp.q[nt & 1][mt];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
+            for (int t = 0; t < 4; ++t) acc[nt][mt][t] = x4[t] + fmaf(acc[nt][mt][t], G[t], Bv[t]);     // linear2's bias is in Bv
+            // nothing in this iteration touches memory after its loads, so the arithmetic is free to sink below the
+            // loads of all later iterations (whose operands then all have to be kept): pin it to this iteration
+            asm volatile("" ::"v"(acc[nt][mt][0]), "v"(acc[nt][mt][1]), "v"(acc[nt][mt][2]), "v"(acc[nt][mt][3]));
+        };
+        int fb2[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
             fb2[mt] = rw.sidx[mt] * 4096 + cb2;
             asm volatile("" : "+v"(fb2[mt]));
         }
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-            const f32x4_t b4 = lds4b(vecp(2) + cb2, 64 * nt);
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const f32x4_t sc = lds4b(cfilm + fb2[mt], 64 * nt), sh = lds4b(cfilm + fb2[mt], 2048 + 64 * nt);
-                const f32x4_t x4 = rp.q[nt & 1][mt];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    float v = acc[nt][mt][t] + b4[t];
-                    v = fmaf(sc[t], v, sh[t]);
-                    acc[nt][mt][t] = x4[t] + v;
-                }
-                // nothing in this iteration touches memory after its loads, so the arithmetic is free to sink below the
-                // loads of all later iterations (whose operands then all have to be kept): pin it to this iteration
-                asm volatile("" ::"v"(acc[nt][mt][0]), "v"(acc[nt][mt][1]), "v"(acc[nt][mt][2]), "v"(acc[nt][mt][3]));
-            }
+            for (int mt = 0; mt < MT; ++mt)
+                body2(nt, mt, lds4b(cfilm + fb2[mt], 64 * nt), lds4b(cfilm + fb2[mt], 2048 + 64 * nt));
             if (nt + 2 < 4) rp_issue(rp, nt + 2);
             CH_FENCE();
         }
@@ -970,7 +1043,7 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     }
     row_stats(acc, scr, wave, lane, a.n4_eps, nmr, rstd);      // (its barrier: every wave is out of the last linear2 chunk)
     CH_T(23);
-    norm_to_lds<false>(acc, nmr, rstd, vecp(3), vecp(4), rp, abuf, wave, lane, nullptr);
+    norm_to_lds<false, MT>(acc, nmr, rstd, vecp(3), vecp(4), rp, abuf, wave, lane, nullptr);
     lds_barrier();
     store_consts(nxt);                 // b3, norm1': read after the barrier that follows linear3
     }   // !FRONT
@@ -979,11 +1052,11 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     CH_T(24);
     zero(acc);
     if (FRONT)
-        phase_n512<32>(acc, abuf, ws, lane);
+        phase_n512<32, false, MT>(acc, abuf, ws, lane);
     else if (LAST)
-        phase_n512<16, true>(acc, abuf, ws, lane);
+        phase_n512<16, true, MT>(acc, abuf, ws, lane);
     else
-        phase_n512<16>(acc, abuf, ws, lane);
+        phase_n512<16, false, MT>(acc, abuf, ws, lane);
     CH_T(25);
     lds_barrier();
     {
@@ -995,7 +1068,7 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
             const int n = 64 * wave + 16 * nt + 4 * g3;
             const f32x4_t b4 = lds4b(vecp(0) + cb3, 64 * nt);
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
+            for (int mt = 0; mt < MT; ++mt) {
                 f32x4_t o;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
@@ -1025,22 +1098,22 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     rope_start();
     row_stats(acc, scr, wave, lane, a.nn_eps, nmr, rstd);
     CH_T(27);
-    norm_to_lds<true>(acc, nmr, rstd, vecp(1), vecp(2), rp, abuf, wave, lane, smem + CH_ABUF2);
+    norm_to_lds<true, MT>(acc, nmr, rstd, vecp(1), vecp(2), rp, abuf, wave, lane, smem + CH_ABUF2);
     lds_barrier();
     CH_T(28);
     zero(acc);
-    phase_n512<16>(acc, abuf, ws, lane);
+    phase_n512<16, false, MT>(acc, abuf, ws, lane);
     CH_T(29);
-    store_heads<true>(acc, a.q_out, a.scale_q, L, a.Lp, a.H, m0, M, wave, lane, smem, dn, dancer);
+    store_heads<true, MT>(acc, a.q_out, a.scale_q, L, a.Lp, a.H, m0, M, wave, lane, smem, dn, dancer);
     zero(acc);
-    phase_n512<16>(acc, abuf, ws, lane);
+    phase_n512<16, false, MT>(acc, abuf, ws, lane);
     CH_T(30);
-    store_heads<false>(acc, a.k_out, 1.0f, L, a.Lp, a.H, m0, M, wave, lane, smem, dn, dancer);
+    store_heads<false, MT>(acc, a.k_out, 1.0f, L, a.Lp, a.H, m0, M, wave, lane, smem, dn, dancer);
     CH_T(31);
     zero(acc);
-    phase_n512<16, true>(acc, smem + CH_ABUF2, ws, lane);
+    phase_n512<16, true, MT>(acc, smem + CH_ABUF2, ws, lane);
     CH_T(32);
-    store_heads<false>(acc, a.v_out, 1.0f, L, a.Lp, a.H, m0, M, wave, lane, smem, dn, dancer);
+    store_heads<false, MT>(acc, a.v_out, 1.0f, L, a.Lp, a.H, m0, M, wave, lane, smem, dn, dancer);
     CH_T(33);
     CH_TC(61);
 }
@@ -1055,9 +1128,9 @@ extern "C" int tcdiff_chain(const tcdiff_chain_args* a, hipStream_t stream) {
                      a->mode == TC_CHAIN_FULL ? 176 : a->mode == TC_CHAIN_FULL_LAST ? 128 : front ? 80 : -1;
     if (want < 0 || a->n_stages != want) return TC_ERR_ARG;
     if (a->out_ld < 0 || a->out_ld % 4 || a->out_ld > 512) return TC_ERR_ARG;
-    const void* ptrs[] = {a->A, a->wstream, a->ln_g, a->ln_b, a->film, a->xres, a->xout, a->n2_g, a->n2_b, a->rope,
-                          a->q_out, a->b1, a->b2, a->film3, a->n4_g, a->n4_b, a->b3, a->nn_g, a->nn_b, a->k_out,
-                          a->v_out, a->h_out, a->lnb_g, a->lnb_b, a->filmb, a->n3_g, a->n3_b, a->kf, a->vf};
+    const void* ptrs[] = {a->A, a->wstream, a->film, a->xres, a->xout, a->n2_g, a->n2_b, a->rope,
+                          a->q_out, a->b1, a->film3, a->n4_g, a->n4_b, a->b3, a->nn_g, a->nn_b, a->k_out,
+                          a->v_out, a->h_out, a->filmb, a->n3_g, a->n3_b, a->kf, a->vf};
     for (const void* p : ptrs)
         if (p && !al16(p)) return TC_ERR_ALIGN;
     if (front) {
@@ -1067,7 +1140,7 @@ extern "C" int tcdiff_chain(const tcdiff_chain_args* a, hipStream_t stream) {
             return TC_ERR_ARG;
         if ((long)a->M * 2048 >= (1L << 32)) return TC_ERR_ARG;
     } else {
-        if (!a->ln_g || !a->ln_b || !a->film || a->film_ld % 4 || !a->xres || !a->xout || !a->n2_g || !a->n2_b) return TC_ERR_ARG;
+        if (!a->film || a->film_ld % 4 || !a->xres || !a->xout || !a->n2_g || !a->n2_b) return TC_ERR_ARG;
         if ((long)(a->a_mod > 0 ? a->a_mod : a->M) * 1024 >= (1L << 32)) return TC_ERR_ARG;
     }
     const bool has_a = a->mode == TC_CHAIN_A || a->mode == TC_CHAIN_FULL || a->mode == TC_CHAIN_FULL_LAST;
@@ -1076,22 +1149,21 @@ extern "C" int tcdiff_chain(const tcdiff_chain_args* a, hipStream_t stream) {
     const bool last = a->mode == TC_CHAIN_B_LAST || a->mode == TC_CHAIN_FULL_LAST;
     if (has_a && (!a->rope || a->H != 8)) return TC_ERR_ARG;
     if (a->mode == TC_CHAIN_A && (!a->q_out || a->Lp <= 0)) return TC_ERR_ARG;
-    if (has_b && (!a->b1 || !a->b2 || !a->film3 || !a->n4_g || !a->n4_b || !a->b3)) return TC_ERR_ARG;
+    if (has_b && (!a->b1 || !a->film3 || !a->n4_g || !a->n4_b || !a->b3)) return TC_ERR_ARG;
     if (has_b && !last &&
         (!a->rope || !a->nn_g || !a->nn_b || !a->q_out || !a->k_out || !a->v_out || a->H != 8 || a->Lp <= 0))
         return TC_ERR_ARG;
     if (last && !a->h_out) return TC_ERR_ARG;
-    if (full && (!a->lnb_g || !a->lnb_b || !a->filmb || !a->n3_g || !a->n3_b || !a->kf || !a->vf || a->nkt <= 0 ||
+    if (full && (!a->filmb || !a->n3_g || !a->n3_b || !a->kf || !a->vf || a->nkt <= 0 ||
                  a->Lk <= 0 || a->Lk > 32 * a->nkt || a->n_shared < 0))
         return TC_ERR_ARG;
     static tc_dev_state dev_state;
     const int n_cu = tc_device_once(dev_state, [](int) {
-        const void* fns[6] = {reinterpret_cast<const void*>(chain_kernel<TC_CHAIN_A>),
-                              reinterpret_cast<const void*>(chain_kernel<TC_CHAIN_B>),
-                              reinterpret_cast<const void*>(chain_kernel<TC_CHAIN_B_LAST>),
-                              reinterpret_cast<const void*>(chain_kernel<TC_CHAIN_FULL>),
-                              reinterpret_cast<const void*>(chain_kernel<TC_CHAIN_FULL_LAST>),
-                              reinterpret_cast<const void*>(chain_kernel<TC_CHAIN_FRONT>)};
+#define CH_FN(M_) reinterpret_cast<const void*>(chain_kernel<M_, 4>), reinterpret_cast<const void*>(chain_kernel<M_, 2>), \
+                   reinterpret_cast<const void*>(chain_kernel<M_, 1>)
+        const void* fns[18] = {CH_FN(TC_CHAIN_A), CH_FN(TC_CHAIN_B), CH_FN(TC_CHAIN_B_LAST), CH_FN(TC_CHAIN_FULL),
+                               CH_FN(TC_CHAIN_FULL_LAST), CH_FN(TC_CHAIN_FRONT)};
+#undef CH_FN
         for (const void* f : fns) {
             hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, CH_SMEM);
             if (e != hipSuccess) return e;
@@ -1099,15 +1171,30 @@ extern "C" int tcdiff_chain(const tcdiff_chain_args* a, hipStream_t stream) {
         return hipSuccess;
     });
     if (n_cu < 0) return n_cu;
-    dim3 grid(((a->M + 63) / 64) * (front ? a->dn : 1));
+    // Rows per block: 64 when that gives the chip enough blocks, else 32 or 16 -- a block streams the whole layer's weights
+    // whatever its rows (>= 48 us at the ~115 GB/s a CU takes in), so a small job (a few clips: what TCDiff.py renders,
+    // TCDiff.py:292-303) is fastest on MANY small blocks, one per CU; results do not depend on the choice beyond fp32
+    // summation order (a->mt forces it: tests).
+    const int units = front ? a->dn : 1;
+    int mt = a->mt;
+    if (mt == 0) mt = ((a->M + 15) / 16) * units <= n_cu ? 1 : ((a->M + 31) / 32) * units <= n_cu ? 2 : 4;
+    if (mt != 1 && mt != 2 && mt != 4) return TC_ERR_ARG;
+    dim3 grid(((a->M + 16 * mt - 1) / (16 * mt)) * units);
+#define CH_LAUNCH(MODE_)                                                                                              \
+    do {                                                                                                              \
+        if (mt == 4) hipLaunchKernelGGL((chain_kernel<MODE_, 4>), grid, dim3(512), CH_SMEM, stream, *a);              \
+        else if (mt == 2) hipLaunchKernelGGL((chain_kernel<MODE_, 2>), grid, dim3(512), CH_SMEM, stream, *a);         \
+        else hipLaunchKernelGGL((chain_kernel<MODE_, 1>), grid, dim3(512), CH_SMEM, stream, *a);                      \
+    } while (0)
     switch (a->mode) {
-        case TC_CHAIN_FRONT: hipLaunchKernelGGL(chain_kernel<TC_CHAIN_FRONT>, grid, dim3(512), CH_SMEM, stream, *a); break;
-        case TC_CHAIN_A: hipLaunchKernelGGL(chain_kernel<TC_CHAIN_A>, grid, dim3(512), CH_SMEM, stream, *a); break;
-        case TC_CHAIN_B: hipLaunchKernelGGL(chain_kernel<TC_CHAIN_B>, grid, dim3(512), CH_SMEM, stream, *a); break;
-        case TC_CHAIN_B_LAST: hipLaunchKernelGGL(chain_kernel<TC_CHAIN_B_LAST>, grid, dim3(512), CH_SMEM, stream, *a); break;
-        case TC_CHAIN_FULL: hipLaunchKernelGGL(chain_kernel<TC_CHAIN_FULL>, grid, dim3(512), CH_SMEM, stream, *a); break;
-        default: hipLaunchKernelGGL(chain_kernel<TC_CHAIN_FULL_LAST>, grid, dim3(512), CH_SMEM, stream, *a); break;
+        case TC_CHAIN_FRONT: CH_LAUNCH(TC_CHAIN_FRONT); break;
+        case TC_CHAIN_A: CH_LAUNCH(TC_CHAIN_A); break;
+        case TC_CHAIN_B: CH_LAUNCH(TC_CHAIN_B); break;
+        case TC_CHAIN_B_LAST: CH_LAUNCH(TC_CHAIN_B_LAST); break;
+        case TC_CHAIN_FULL: CH_LAUNCH(TC_CHAIN_FULL); break;
+        default: CH_LAUNCH(TC_CHAIN_FULL_LAST); break;
     }
+#undef CH_LAUNCH
     TC_CHECK_LAUNCH();
     return TC_OK;
 }

@@ -11,7 +11,8 @@ Data layout in HBM (T = bf16 or f32 operand type, always fp32 for the residual s
   Q, K, V    T    [n_seq][8][Lp][64]   head-major attention images, Lp = L rounded up to 128 (zero padded)
   Kc, Vc     T    [8 layers][2B][8][Lpc][64] cross-attention K/V caches: slot 0 = null conditioning,
                                        slot 1+i = clip i; rows 0..S-1 step-invariant, rows S,S+1 = time tokens
-  film       fp32 [2B][24*1024]        (scale|shift) of the 24 DenseFiLM blocks for this step
+  film       fp32 [2B][24*1024]        (scale|shift) of the 24 DenseFiLM blocks for this step; on the chain path the rows are
+                                       pre-folded with the LayerNorm weights / linear2 bias around them (load_weights)
   tables     t_base fp32 [n_t,512], kv_tab T [8][n_t][2][1024]  time path evaluated once per timestep set
 Step-invariant work (music encoder, cross K/V of the 150 music rows, time tables, rotary table) is hoisted
 out of the DDPM loop; results are identical to recomputing it every step.
@@ -233,8 +234,22 @@ class DenoiserEngine:
             for n in ("norm1", "norm2", "norm3", "norm4"):
                 w[f"l{l}.{n}.g"], w[f"l{l}.{n}.b"] = f(g(q + n + ".weight")), f(g(q + n + ".bias"))
             for i in (1, 2, 3):
-                film_w.append(g(q + f"film{i}.block.1.weight"))
-                film_b.append(g(q + f"film{i}.block.1.bias"))
+                Wf = g(q + f"film{i}.block.1.weight").to(self.dev, torch.float32)       # [1024, 512]: scale rows, shift rows
+                bf_ = g(q + f"film{i}.block.1.bias").to(self.dev, torch.float32)
+                if self.use_chain:
+                    # The chain kernels take the FiLM rows PRE-FOLDED with what surrounds them (csrc/chain.hip fc epilogue):
+                    # (scale + 1) * (LN(z) * g + b) + shift = LN(z) * G + Bv with G = g (scale + 1), Bv = b (scale + 1) + shift,
+                    # and for the feed-forward block (scale + 1) * (z + b2) + shift = z * G + Bv with g = 1, b = b2
+                    # (model/model.py:103-106,171-173,327,334,339).  scale and shift are LINEAR in the generator's input
+                    # (DenseFiLM = Linear(Mish(t)), model/model.py:154-168), so G and Bv are too: the fold goes into the
+                    # generator's weights and bias once per checkpoint, in fp32, and costs nothing per step.
+                    gvec = {1: w[f"l{l}.sln.g"], 2: w[f"l{l}.cln.g"], 3: torch.ones(512, device=self.dev)}[i]
+                    bvec = {1: w[f"l{l}.sln.b"], 2: w[f"l{l}.cln.b"], 3: w[f"l{l}.ff2.b"]}[i]
+                    Ws, Wh, bs, bh = Wf[:512], Wf[512:], bf_[:512], bf_[512:]
+                    Wf = torch.cat([gvec[:, None] * Ws, bvec[:, None] * Ws + Wh], 0)
+                    bf_ = torch.cat([gvec * (bs + 1.0), bvec * (bs + 1.0) + bh], 0)
+                film_w.append(Wf)
+                film_b.append(bf_)
         w["film.w"] = p(torch.cat(film_w, 0))          # [NL*3*1024, 512]
         w["film.b"] = f(torch.cat(film_b, 0))
         w["fin.w"], w["fin.b"] = p(g("final_layer.weight")), f(g("final_layer.bias"))
@@ -555,25 +570,25 @@ class DenoiserEngine:
         K.attention(dt, b["Q"], b["K"], b["V"], b["O"], B if l == 0 else nseq, H, Lq, Lq, self.Lp, self.Lp, 512)
         last = l + 1 == NL
         nn = f"l{l + 1}.norm1." if not last else None
-        tail = dict(b1=w[p + "ff1.b"], b2=w[p + "ff2.b"], film3=film0[:, (l * 3 + 2) * 1024:], n4_g=w[p + "norm4.g"],
+        tail = dict(b1=w[p + "ff1.b"], film3=film0[:, (l * 3 + 2) * 1024:], n4_g=w[p + "norm4.g"],
                     n4_b=w[p + "norm4.b"], n4_eps=1e-5, b3=w[p + "l3out.b"] if last and self.fold_out else w[p + "l3.b"],
                     nn_g=None if last else w[nn + "g"], nn_b=None if last else w[nn + "b"], nn_eps=1e-5,
                     q_out=None if last else b["Q"], k_out=None if last else b["K"], v_out=None if last else b["V"],
                     h_out=(b["out"] if self.fold_out else b["h"]) if last else None,
                     out_ld=152 if last and self.fold_out else 0, scale_q=0.125, Lp=self.Lp, H=H)
-        head = dict(a_mod=Rs if l == 0 else 0, ln_g=w[p + "sln.g"], ln_b=w[p + "sln.b"], ln_eps=1e-6,
+        head = dict(a_mod=Rs if l == 0 else 0, ln_eps=1e-6,     # (film rows: pre-folded with sln / cln / ff2.b, load_weights)
                     film=film0[:, (l * 3 + 0) * 1024:], film_ld=fld, xres=b["xs"] if l == 0 else b["xa"],
                     xres_mod=Rs if l == 0 else 0, xres_rowmajor=l == 0 and not self.front, xout=b["xa"], n2_g=w[p + "norm2.g"],
                     n2_b=w[p + "norm2.b"], n2_eps=1e-5, rope=rope)     # b["xa"] is COLUMN-BLOCKED on this path
         if self.use_full:
             # self-attention tail, cross-attention (K / V from the fragment-ordered caches) and feed-forward in ONE launch
             K.chain(L.CHAIN_FULL_LAST if last else L.CHAIN_FULL, R, Lq, b["O"], w[p + "chainF"],
-                    lnb_g=w[p + "cln.g"], lnb_b=w[p + "cln.b"], filmb=film0[:, (l * 3 + 1) * 1024:], n3_g=w[p + "norm3.g"],
+                    filmb=film0[:, (l * 3 + 1) * 1024:], n3_g=w[p + "norm3.g"],
                     n3_b=w[p + "norm3.b"], kf=b["Kf"][l, kv_slot0:], vf=b["Vf"][l, kv_slot0:], n_shared=n_shared,
                     nkt=self.nkt, Lk=S + 2, **head, **tail)
             return
         K.chain(L.CHAIN_A, R, Lq, b["O"], w[p + "chainA"], **head, q_out=b["Q"], scale_q=0.125, Lp=self.Lp, H=H)
         K.attention(dt, b["Q"], Kc0[l], Vc0[l], b["O"], nseq, H, Lq, S + 2, self.Lp, self.Lpc, 512, n_shared=n_shared)
         K.chain(L.CHAIN_B_LAST if last else L.CHAIN_B, R, Lq, b["O"], w[p + "chainB"],
-                ln_g=w[p + "cln.g"], ln_b=w[p + "cln.b"], ln_eps=1e-6, film=film0[:, (l * 3 + 1) * 1024:], film_ld=fld,
+                ln_eps=1e-6, film=film0[:, (l * 3 + 1) * 1024:], film_ld=fld,
                 xres=b["xa"], xout=b["xa"], n2_g=w[p + "norm3.g"], n2_b=w[p + "norm3.b"], n2_eps=1e-5, rope=rope, **tail)

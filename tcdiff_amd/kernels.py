@@ -64,24 +64,32 @@ def attention(dt, Q, K, V, O, n_seq, H, Lq, Lk, Lp_q, Lp_k, ldo, n_shared=0, ng=
     L.check(rc, "tcdiff_attention")
 
 
-def chain(mode, M, Lseq, A, wstream, *, ln_g=None, ln_b=None, ln_eps=1e-6, film=None, film_ld=0, xres=None,
+def chain(mode, M, Lseq, A, wstream, *, ln_eps=1e-6, film=None, film_ld=0, xres=None,
           xout=None, n2_g=None, n2_b=None, n2_eps=1e-5,
-          rope=None, q_out=None, scale_q=0.125, Lp=0, H=8, a_mod=0, xres_mod=0, b1=None, b2=None, film3=None, n4_g=None,
+          rope=None, q_out=None, scale_q=0.125, Lp=0, H=8, a_mod=0, xres_mod=0, b1=None, film3=None, n4_g=None,
           n4_b=None, n4_eps=1e-5, b3=None, nn_g=None, nn_b=None, nn_eps=1e-5, k_out=None, v_out=None, h_out=None,
-          lnb_g=None, lnb_b=None, filmb=None, n3_g=None, n3_b=None, kf=None, vf=None, n_shared=0, nkt=0, Lk=0,
-          xres_rowmajor=False, out_ld=0, dn=1):
+          filmb=None, n3_g=None, n3_b=None, kf=None, vf=None, n_shared=0, nkt=0, Lk=0,
+          xres_rowmajor=False, out_ld=0, dn=1, mt=0):
     """rope: the COLUMN-BLOCKED rotary table (to_cb(rope_table)); xres / xout: column-blocked fp32 residual stream
     (xres_rowmajor: xres is a plain [*, 512] matrix); wstream: [(dn,) 8 waves, n_stages, 2048] bf16, the stage count is
-    read from it.  See include/tcdiff_hip.h tcdiff_chain_args."""
+    read from it.  film / filmb / film3 rows are PRE-FOLDED with the LayerNorm weights / linear2 bias around them
+    (fold_film below; engine.load_weights folds them into the FiLM generator).  See include/tcdiff_hip.h tcdiff_chain_args."""
     if wstream.shape[-1] != 2048 or wstream.shape[-3] != 8 or not wstream.is_contiguous():
         raise L.TcdiffError(f"weight stream must be contiguous [.., 8 waves, n_stages, 2048] bf16, got {tuple(wstream.shape)}")
     n_stages = wstream.shape[-2]
-    a = L.ChainArgs(mode, n_stages, M, Lseq, a_mod, xres_mod, H, Lp, _p(A), _p(wstream), _p(ln_g), _p(ln_b), _p(film),
-                    _p(xres), _p(xout), _p(n2_g), _p(n2_b), _p(rope), _p(q_out), _p(b1), _p(b2), _p(film3), _p(n4_g),
+    a = L.ChainArgs(mode, n_stages, M, Lseq, a_mod, xres_mod, H, Lp, _p(A), _p(wstream), _p(film),
+                    _p(xres), _p(xout), _p(n2_g), _p(n2_b), _p(rope), _p(q_out), _p(b1), _p(film3), _p(n4_g),
                     _p(n4_b), _p(b3), _p(nn_g), _p(nn_b), _p(k_out), _p(v_out), _p(h_out), film_ld, ln_eps, n2_eps,
-                    n4_eps, nn_eps, scale_q, _p(lnb_g), _p(lnb_b), _p(filmb), _p(n3_g), _p(n3_b), _p(kf), _p(vf), n_shared,
-                    nkt, Lk, int(bool(xres_rowmajor)), 0 if rope is None else rope.shape[1], dn, out_ld)
+                    n4_eps, nn_eps, scale_q, _p(filmb), _p(n3_g), _p(n3_b), _p(kf), _p(vf), n_shared,
+                    nkt, Lk, int(bool(xres_rowmajor)), 0 if rope is None else rope.shape[1], dn, mt, out_ld)
     L.check(L.load().tcdiff_chain(C.byref(a), stream()), "tcdiff_chain")
+
+
+def fold_film(film: torch.Tensor, g, b) -> torch.Tensor:
+    """[rows, 1024] raw DenseFiLM rows (scale | shift) -> the pre-folded rows the chain kernels take:
+    [g (scale + 1) | b (scale + 1) + shift]; g = None stands for 1 (the feed-forward block, b = linear2's bias)."""
+    sc1 = film[:, :512] + 1.0
+    return torch.cat([sc1 if g is None else g * sc1, b * sc1 + film[:, 512:1024]], 1).contiguous()
 
 
 def to_cb(x: torch.Tensor) -> torch.Tensor:

@@ -38,6 +38,15 @@ def model_with(chain: int, dn, S):
         os.environ.pop("TCDIFF_CHAIN", None)
 
 
+def folded(film, specs):
+    """the FiLM rows as the chain kernels take them: every 1024-float block at offset `off` folded with the LayerNorm weights
+    (g, b) in front of it -- or (None, linear2 bias) for the feed-forward block (kernels.fold_film)"""
+    out = film.clone()
+    for off, (g, b) in specs.items():
+        out[:, off:off + 1024] = K.fold_film(film[:, off:off + 1024], g, b)
+    return out
+
+
 @pytest.mark.parametrize("dn,S,B", [(2, 60, 1), (2, 60, 3), (3, 150, 2), (3, 150, 5)])
 def test_chained_network_matches_op_by_op_network(dn, S, B):
     """whole denoiser, both CFG branches (layer-0 rows shared between the branches, ragged last row block)"""
@@ -64,7 +73,11 @@ def test_chained_network_matches_op_by_op_network(dn, S, B):
         assert d < 3e-2 and mean < 4e-3
 
 
-def test_chain_a_kernel_against_rowln_plus_tile():
+MTS = pytest.mark.parametrize("mt", [4, 2, 1])      # 16-row tiles per row block (tcdiff_chain_args.mt: 64 / 32 / 16-row blocks)
+
+
+@MTS
+def test_chain_a_kernel_against_rowln_plus_tile(mt):
     """chain A alone on random data: x (fp32) and the Q image, incl. a_mod / xres_mod and a ragged tail block"""
     dt = L.DT_BF16
     Lq, nseq, H = 120, 3, 8
@@ -94,7 +107,7 @@ def test_chain_a_kernel_against_rowln_plus_tile():
     Q2 = torch.zeros_like(Q1)
     # the chain kernels take the rotary table and keep the residual stream COLUMN-BLOCKED ([64][rows][8]); layer 0's
     # residual input (gemm_rowln's output) is row-major
-    K.chain(L.CHAIN_A, M, Lq, Oa, ws, a_mod=Rs, ln_g=g1, ln_b=b1, ln_eps=1e-6, film=film, film_ld=2048, xres=xres,
+    K.chain(L.CHAIN_A, M, Lq, Oa, ws, mt=mt, a_mod=Rs, ln_eps=1e-6, film=folded(film, {0: (g1, b1)}), film_ld=2048, xres=xres,
             xres_mod=Rs, xres_rowmajor=True, xout=x2, n2_g=g2, n2_b=b2, n2_eps=1e-5, rope=K.to_cb(rope), q_out=Q2,
             scale_q=0.125, Lp=Lp, H=H)
     torch.cuda.synchronize()
@@ -107,8 +120,9 @@ def test_chain_a_kernel_against_rowln_plus_tile():
     assert float(Q2[:, :, Lq:].abs().max()) == 0.0                                   # padding rows untouched
 
 
+@MTS
 @pytest.mark.parametrize("last", [False, True])
-def test_chain_b_kernel_against_op_by_op_sequence(last):
+def test_chain_b_kernel_against_op_by_op_sequence(last, mt):
     """chain B alone on random data against gemm_rowln / gemm_tile launched in the engine's op-by-op order"""
     dt = L.DT_BF16
     Lq, nseq, H = 120, 3, 8
@@ -157,9 +171,10 @@ def test_chain_b_kernel_against_op_by_op_sequence(last):
     ws = torch.cat(parts, 1).contiguous()
     xb = K.to_cb(xres)                     # column-blocked residual stream, updated in place
     Q2, K2, V2, hl2 = z(nseq, H, Lp, 64), z(nseq, H, Lp, 64), z(nseq, H, Lp, 64), z(M, 512)
-    K.chain(L.CHAIN_B_LAST if last else L.CHAIN_B, M, Lq, Oa, ws, ln_g=g1, ln_b=b1, ln_eps=1e-6, film=film,
-            film_ld=4096, xres=xb, xout=xb, n2_g=g3, n2_b=b3n, n2_eps=1e-5, rope=K.to_cb(rope), b1=bias1, b2=bias2,
-            film3=film[:, 2048:], n4_g=g4, n4_b=b4, n4_eps=1e-5, b3=bias3, nn_g=None if last else gn,
+    ff = folded(film, {0: (g1, b1), 2048: (None, bias2)})
+    K.chain(L.CHAIN_B_LAST if last else L.CHAIN_B, M, Lq, Oa, ws, mt=mt, ln_eps=1e-6, film=ff,
+            film_ld=4096, xres=xb, xout=xb, n2_g=g3, n2_b=b3n, n2_eps=1e-5, rope=K.to_cb(rope), b1=bias1,
+            film3=ff[:, 2048:], n4_g=g4, n4_b=b4, n4_eps=1e-5, b3=bias3, nn_g=None if last else gn,
             nn_b=None if last else bn, nn_eps=1e-5, q_out=None if last else Q2, k_out=None if last else K2,
             v_out=None if last else V2, h_out=hl2 if last else None, scale_q=0.125, Lp=Lp, H=H)
     torch.cuda.synchronize()
@@ -179,8 +194,9 @@ def test_chain_b_kernel_against_op_by_op_sequence(last):
 
 
 @pytest.mark.parametrize("S", [60, 150])      # 62 keys: the rolled cross-attention loop; 152 keys = 5 tiles: the pipelined one
+@MTS
 @pytest.mark.parametrize("last", [False, True])
-def test_fused_layer_chain_against_chain_a_attention_chain_b(last, S):
+def test_fused_layer_chain_against_chain_a_attention_chain_b(last, S, mt):
     """TC_CHAIN_FULL (cross-attention inside the launch, K / V from the fragment-ordered images) against the three
     launches it replaces on the same random data: blocks that straddle two sequences (L = 120: the second 32-row tile of
     block 1 crosses a sequence boundary), a shared null-conditioning slot for the first sequences, a ragged tail."""
@@ -217,17 +233,18 @@ def test_fused_layer_chain_against_chain_a_attention_chain_b(last, S):
     wsA = torch.cat([E._stages_n512(W["sfc"]), E._stages_n512(W["cq"])], 1).contiguous()
     wsB = torch.cat(partsB, 1).contiguous()
     wsF = torch.cat([wsA, wsB], 1).contiguous()
-    tail = dict(b1=bias1, b2=bias2, film3=film[:, 4096:], n4_g=gs[6], n4_b=gs[7], b3=bias3, nn_g=None if last else gs[8],
+    ff = folded(film, {0: (gs[0], gs[1]), 2048: (gs[4], gs[5]), 4096: (None, bias2)})
+    tail = dict(b1=bias1, film3=ff[:, 4096:], n4_g=gs[6], n4_b=gs[7], b3=bias3, nn_g=None if last else gs[8],
                 nn_b=None if last else gs[9], scale_q=0.125, Lp=Lp, H=H)
     # ---- three launches
     x1 = K.to_cb(xres)
     Qc, O2 = z(nseq, H, Lp, 64), z(M, 512)
-    K.chain(L.CHAIN_A, M, Lq, Oa, wsA, ln_g=gs[0], ln_b=gs[1], ln_eps=1e-6, film=film, film_ld=6144, xres=x1, xout=x1,
+    K.chain(L.CHAIN_A, M, Lq, Oa, wsA, mt=mt, ln_eps=1e-6, film=ff, film_ld=6144, xres=x1, xout=x1,
             n2_g=gs[2], n2_b=gs[3], rope=rope, q_out=Qc, scale_q=0.125, Lp=Lp, H=H)
     K.attention(dt, Qc, Kc, Vc, O2, nseq, H, Lq, Lk, Lp, Lpc, 512, n_shared=n_shared)
     Q1, K1, V1, h1 = z(nseq, H, Lp, 64), z(nseq, H, Lp, 64), z(nseq, H, Lp, 64), z(M, 512)
-    K.chain(L.CHAIN_B_LAST if last else L.CHAIN_B, M, Lq, O2, wsB, ln_g=gs[4], ln_b=gs[5], ln_eps=1e-6,
-            film=film[:, 2048:], film_ld=6144, xres=x1, xout=x1, n2_g=gs[10], n2_b=gs[11], rope=rope,
+    K.chain(L.CHAIN_B_LAST if last else L.CHAIN_B, M, Lq, O2, wsB, mt=mt, ln_eps=1e-6,
+            film=ff[:, 2048:], film_ld=6144, xres=x1, xout=x1, n2_g=gs[10], n2_b=gs[11], rope=rope,
             q_out=None if last else Q1, k_out=None if last else K1, v_out=None if last else V1,
             h_out=h1 if last else None, **tail)
     # ---- one launch
@@ -235,9 +252,9 @@ def test_fused_layer_chain_against_chain_a_attention_chain_b(last, S):
     K.pack_kv_frags(Kc, Vc, Kf, Vf, n_kv, H, Lpc, nkt, 0, Lk)
     x2 = K.to_cb(xres)
     Q2, K2, V2, h2 = z(nseq, H, Lp, 64), z(nseq, H, Lp, 64), z(nseq, H, Lp, 64), z(M, 512)
-    K.chain(L.CHAIN_FULL_LAST if last else L.CHAIN_FULL, M, Lq, Oa, wsF, ln_g=gs[0], ln_b=gs[1], ln_eps=1e-6,
-            film=film, film_ld=6144, xres=x2, xout=x2, n2_g=gs[2], n2_b=gs[3], rope=rope, lnb_g=gs[4], lnb_b=gs[5],
-            filmb=film[:, 2048:], n3_g=gs[10], n3_b=gs[11], kf=Kf, vf=Vf, n_shared=n_shared, nkt=nkt, Lk=Lk,
+    K.chain(L.CHAIN_FULL_LAST if last else L.CHAIN_FULL, M, Lq, Oa, wsF, mt=mt, ln_eps=1e-6,
+            film=ff, film_ld=6144, xres=x2, xout=x2, n2_g=gs[2], n2_b=gs[3], rope=rope,
+            filmb=ff[:, 2048:], n3_g=gs[10], n3_b=gs[11], kf=Kf, vf=Vf, n_shared=n_shared, nkt=nkt, Lk=Lk,
             q_out=None if last else Q2, k_out=None if last else K2, v_out=None if last else V2,
             h_out=h2 if last else None, **tail)
     torch.cuda.synchronize()
@@ -250,7 +267,8 @@ def test_fused_layer_chain_against_chain_a_attention_chain_b(last, S):
         assert d[0] < 1.5e-1 and d[1] < 4e-3
 
 
-def test_front_chain_against_rowln_plus_qkv_tile():
+@MTS
+def test_front_chain_against_rowln_plus_qkv_tile(mt):
     """TC_CHAIN_FRONT (last fusion linear of each dancer over 64-frame blocks + layer 0's norm1 / rotary / Q, K, V) against
     the two launches it replaces, gemm_rowln with dancer groups and the QKV gemm_tile, on random data: 3 dancers, frames
     per sequence not a multiple of anything (S = 70: blocks straddle sequences), a ragged last block."""
@@ -282,7 +300,7 @@ def test_front_chain_against_rowln_plus_qkv_tile():
     assert ws.shape == (dn, 8, 80, 2048)
     xs2 = z(Rs, 512, dtype=torch.float32)
     Q2, K2, V2 = z(nseq, H, Lp, 64), z(nseq, H, Lp, 64), z(nseq, H, Lp, 64)
-    K.chain(L.CHAIN_FRONT, Mf, Lq, f2, ws, b3=b3, nn_g=g1, nn_b=b1, nn_eps=1e-5, rope=K.to_cb(rope), xout=xs2, q_out=Q2,
+    K.chain(L.CHAIN_FRONT, Mf, Lq, f2, ws, mt=mt, b3=b3, nn_g=g1, nn_b=b1, nn_eps=1e-5, rope=K.to_cb(rope), xout=xs2, q_out=Q2,
             k_out=K2, v_out=V2, scale_q=0.125, Lp=Lp, H=H, dn=dn)
     torch.cuda.synchronize()
     md = lambda a_, b_: (float((a_.float() - b_.float()).abs().max()), float((a_.float() - b_.float()).abs().mean()))
@@ -296,7 +314,8 @@ def test_front_chain_against_rowln_plus_qkv_tile():
         assert float(b_[:, :, Lq:].abs().max()) == 0.0              # padding rows untouched
 
 
-def test_fused_layer_chain_against_a_torch_evaluation_of_the_layer_tail():
+@MTS
+def test_fused_layer_chain_against_a_torch_evaluation_of_the_layer_tail(mt):
     """ONE TC_CHAIN_FULL launch against a plain torch (float64) evaluation of model/model.py:103-106,327,331-344 and the next
     layer's :326,374-383 on the same bf16 operands -- not against another kernel of this library.  The reference rounds to
     bf16 exactly where the kernel hands an activation to an MFMA (GEMM / attention operands), nowhere else."""
@@ -333,10 +352,11 @@ def test_fused_layer_chain_against_a_torch_evaluation_of_the_layer_tail():
     K.pack_kv_frags(Kc, Vc, Kf, Vf, n_kv, H, Lpc, nkt, 0, Lk)
     x2 = K.to_cb(xres)
     Q2, K2, V2 = z(nseq, H, Lp, 64), z(nseq, H, Lp, 64), z(nseq, H, Lp, 64)
-    K.chain(L.CHAIN_FULL, M, Lq, Oa, wsF, ln_g=gs[0], ln_b=gs[1], ln_eps=1e-6, film=film, film_ld=6144, xres=x2,
-            xout=x2, n2_g=gs[2], n2_b=gs[3], rope=K.to_cb(rope_rm), lnb_g=gs[4], lnb_b=gs[5], filmb=film[:, 2048:], n3_g=gs[10],
-            n3_b=gs[11], kf=Kf, vf=Vf, n_shared=n_shared, nkt=nkt, Lk=Lk, q_out=Q2, k_out=K2, v_out=V2, b1=bias1, b2=bias2,
-            film3=film[:, 4096:], n4_g=gs[6], n4_b=gs[7], b3=bias3, nn_g=gs[8], nn_b=gs[9], scale_q=0.125, Lp=Lp, H=H)
+    ff = folded(film, {0: (gs[0], gs[1]), 2048: (gs[4], gs[5]), 4096: (None, bias2)})
+    K.chain(L.CHAIN_FULL, M, Lq, Oa, wsF, mt=mt, ln_eps=1e-6, film=ff, film_ld=6144, xres=x2,
+            xout=x2, n2_g=gs[2], n2_b=gs[3], rope=K.to_cb(rope_rm), filmb=ff[:, 2048:], n3_g=gs[10],
+            n3_b=gs[11], kf=Kf, vf=Vf, n_shared=n_shared, nkt=nkt, Lk=Lk, q_out=Q2, k_out=K2, v_out=V2, b1=bias1,
+            film3=ff[:, 4096:], n4_g=gs[6], n4_b=gs[7], b3=bias3, nn_g=gs[8], nn_b=gs[9], scale_q=0.125, Lp=Lp, H=H)
     torch.cuda.synchronize()
     # ---- torch, float64, on the CPU ---------------------------------------------------------------------------------------
     c = lambda t: t.detach().cpu().to(D)

@@ -23,9 +23,9 @@ for nblk in (1, 225):
     kf = rnd(nseq + 1, H, nkt * 2048, scale=0.5).to(bf); vf = rnd(nseq + 1, H, nkt * 2048, scale=0.5).to(bf)
     st = torch.zeros(8 * 64, device=dev, dtype=torch.int64)
     for _ in range(5):
-        K.chain(L.CHAIN_FULL, M, Lq, Oa, wsF, ln_g=g[0], ln_b=g[1], ln_eps=1e-6, film=film, film_ld=6144, xres=x, xout=x,
-                n2_g=g[2], n2_b=g[3], rope=rope, b1=b1, b2=b2, film3=film[:, 4096:], n4_g=g[4], n4_b=g[5], b3=b3, nn_g=g[6],
-                nn_b=g[7], q_out=Q, k_out=Kk, v_out=V, h_out=st, Lp=Lp, H=H, lnb_g=g[0], lnb_b=g[1], filmb=film[:, 2048:],
+        K.chain(L.CHAIN_FULL, M, Lq, Oa, wsF, ln_eps=1e-6, film=film, film_ld=6144, xres=x, xout=x,
+                n2_g=g[2], n2_b=g[3], rope=rope, b1=b1, film3=film[:, 4096:], n4_g=g[4], n4_b=g[5], b3=b3, nn_g=g[6],
+                nn_b=g[7], q_out=Q, k_out=Kk, v_out=V, h_out=st, Lp=Lp, H=H, filmb=film[:, 2048:],
                 n3_g=g[2], n3_b=g[3], kf=kf, vf=vf, n_shared=nseq // 2, nkt=nkt, Lk=S_ + 2)
     torch.cuda.synchronize()
     tw = st.cpu().reshape(8, 64).tolist()
