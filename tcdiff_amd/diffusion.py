@@ -168,9 +168,6 @@ class GaussianDiffusion(nn.Module):
         self.p2_loss_weight_k = 1
         self.p2_loss_weight_gamma = 0.5 if use_p2 else 0
         reg("p2_loss_weight", (self.p2_loss_weight_k + ac / (1 - ac)) ** -self.p2_loss_weight_gamma)
-        if predict_epsilon or not clip_denoised:
-            raise L.TcdiffError("the MI355X samplers implement predict_epsilon=False, clip_denoised=True "
-                                "(the production configuration, TCDiff.py:90-102)")
 
     # ------------------------------------------------------------------------------------------
     # fused sampler core
@@ -307,7 +304,11 @@ class GaussianDiffusion(nn.Module):
     # reference sampling API
     # ------------------------------------------------------------------------------------------
     def predict_start_from_noise(self, x_t, t, noise):
-        return noise  # predict_epsilon=False: the network predicts x_0 (reference model/diffusion.py:176-187)
+        """reference model/diffusion.py:176-187 (inside the samplers the update kernel does this itself, _ddpm_params)"""
+        if self.predict_epsilon:
+            return extract(self.sqrt_recip_alphas_cumprod, t, x_t.shape) * x_t - \
+                extract(self.sqrt_recipm1_alphas_cumprod, t, x_t.shape) * noise
+        return noise
 
     def predict_noise_from_start(self, x_t, t, x0):
         return (extract(self.sqrt_recip_alphas_cumprod, t, x_t.shape) * x_t - x0) / \
@@ -342,6 +343,10 @@ class GaussianDiffusion(nn.Module):
         p = torch.zeros(len(tseq), 8)
         p[:, 0] = torch.tensor([float(self._guidance_weight_at(int(i), weight)) for i in tseq])
         p[:, 1], p[:, 2], p[:, 3] = c1, c2, sig
+        # constructor options outside the production configuration (model/diffusion.py:80-95,176-187,230-233): the update
+        # kernel forms x_0 = sqrt(1/ac) x_t - sqrt(1/ac - 1) eps_hat itself (flag bit 2) and skips the clamp (bit 3)
+        p[:, 4], p[:, 5] = self.sqrt_recip_alphas_cumprod.cpu()[t], self.sqrt_recipm1_alphas_cumprod.cpu()[t]
+        p[:, 7] = (4 if self.predict_epsilon else 0) + (0 if self.clip_denoised else 8)
         return p
 
     @torch.no_grad()
@@ -358,7 +363,8 @@ class GaussianDiffusion(nn.Module):
         w = self._guidance_weight_at(i)
         y = torch.empty(B, Lq, shape[2], device=out.device, dtype=torch.float32)
         K.cfg_combine(b["out"], b["out"][B * Lq:] if w != 1.0 else b["out"], 152, float(w), y, B * Lq, shape[2])
-        return out, y.clamp_(-1.0, 1.0)
+        y = self.predict_start_from_noise(x.to(y).reshape(y.shape), t.to(y.device).long(), y)     # identity unless predict_epsilon
+        return out, (y.clamp_(-1.0, 1.0) if self.clip_denoised else y)
 
     @torch.no_grad()
     def p_sample_loop(self, shape, cond, noise=None, constraint=None, return_diffusion=False, start_point=None, *,
@@ -509,11 +515,15 @@ class GaussianDiffusion(nn.Module):
         chain = [x] if return_diffusion else None
 
         q_noise = kw.get("q_noise")      # optional callable(t, shape): the randn_like q_sample draws in step t
+        if self.predict_epsilon:
+            raise L.TcdiffError("inpaint_loop with predict_epsilon=True is not implemented (its q_sample coefficients share the "
+                                "step parameters' columns; the production configuration predicts x_0, TCDiff.py:96)")
         params = self._ddpm_params(tseq)
         sa, s1 = self.sqrt_alphas_cumprod.cpu(), self.sqrt_one_minus_alphas_cumprod.cpu()
         for i, tt in enumerate(tseq):    # x = q_sample(value, t - 1) * mask + (1 - mask) * x after every step with t > 0
             if tt > 0:
-                params[i, 4], params[i, 5], params[i, 7] = sa[tt - 1], s1[tt - 1], 2.0
+                params[i, 4], params[i, 5] = sa[tt - 1], s1[tt - 1]
+                params[i, 7] += 2.0
         constrain = dict(kind=2, mask=mask.float().expand(shape).reshape(-1, shape[-1]), value=value.float().expand(shape),
                          q_noise=(lambda tt, sh: q_noise(tt, sh).to(device)) if q_noise is not None else None)
         out = self._run(L.SAMPLER_DDPM, tuple(shape), cond, x.float(), tseq, params, step_noise=kw.get("step_noise"),
@@ -537,7 +547,7 @@ class GaussianDiffusion(nn.Module):
 
         params = self._ddpm_params(tseq)
         for i, tt in enumerate(tseq):
-            params[i, 7] = 1.0 if tt > 0 else 0.0
+            params[i, 7] += 1.0 if tt > 0 else 0.0
         out = self._run(L.SAMPLER_DDPM, (B, Lq, nf), cond, x.float(), tseq, params, step_noise=kw.get("step_noise"),
                         seed=kw.get("seed"), collect=chain, couple=(Lq, nf))
         return (out, chain) if return_diffusion else out
@@ -579,8 +589,6 @@ class GaussianDiffusion(nn.Module):
         reference draws it in, ``keep_mask`` (b,) bool; the dropout seed through ``self.model.train_seed``."""
         if trj_dist is not None:
             raise L.TcdiffError("trj_dist is not supported (never passed by the reference's callers, TCDiff.py:227-229)")
-        if self.predict_epsilon:
-            raise L.TcdiffError("p_losses implements predict_epsilon=False (TCDiff.py:96)")
         dev = self._device()
         if dev.type != "cuda":
             raise L.TcdiffError("p_losses runs on MI355X only (no CPU fallback)")
@@ -595,7 +603,10 @@ class GaussianDiffusion(nn.Module):
                         sq, c)
         out = self.model(x_noisy, cond, t, cond_drop_prob=self.cond_drop_prob, keep_mask=keep_mask)
         parents, offsets = self._skeleton(dev)
-        total, terms = _LossFn.apply(out, x_start, t, self.p2_loss_weight, parents, offsets, self.loss_type == "l1")
+        # the regression target (model/diffusion.py:657-660): x_start, or -- predict_epsilon -- the noise, which the reference
+        # then also feeds to the velocity / FK / foot terms as if it were motion (:664-733); same here (dataset layout)
+        target = noise.permute(0, 2, 1, 3).contiguous() if self.predict_epsilon else x_start
+        total, terms = _LossFn.apply(out, target, t, self.p2_loss_weight, parents, offsets, self.loss_type == "l1")
         m = terms
         return total, (m[0], m[1], m[2], m[3])
 

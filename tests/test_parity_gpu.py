@@ -93,6 +93,32 @@ def test_c1_p_sample_loop_vs_reference_golden(golden_dir, c1):
     assert max(errs.values()) < 1e-3
 
 
+@pytest.mark.parametrize("name,eps,clip,start", [("loop_eps_clip", True, True, 30), ("loop_eps_noclip", True, False, 12),
+                                                 ("loop_x0_noclip", False, False, 30)])
+def test_constructor_options_outside_the_production_config_vs_reference_golden(golden_dir, name, eps, clip, start):
+    """predict_epsilon=True (the reference constructor's DEFAULT) and clip_denoised=False (model/diffusion.py:80-95,176-187,
+    230-233), which rounds 1-3 refused: the last `start` DDPM steps of config 1 against the REAL reference with the same
+    injected noise (tests/golden/make_golden_eps.py), f32 mode, 1e-3 of the largest sample value."""
+    ref = gold(golden_dir, "c1_eps")[name]
+    sd = O.synth_state_dict(dn=2, seq_len=60)
+    model = DanceDecoder(nfeats=151, seq_len=60, latent_dim=512, ff_size=1024, num_layers=8, num_heads=8, dropout=0.1,
+                         cond_feature_dim=438, activation=F.gelu, required_dancer_num=2, compute_dtype="f32")
+    model.load_state_dict(sd, strict=True)
+    diff = GaussianDiffusion(model.eval(), 60, 151, None, schedule="cosine", n_timestep=100, predict_epsilon=eps,
+                             clip_denoised=clip, loss_type="l2", use_p2=False, cond_drop_prob=0.25, guidance_weight=2,
+                             seq_len=60).to(DEV).eval()
+    cond = torch.stack([O.synth_cond(0, 60)])
+    xT = torch.stack([O.synth_xT(0, 120)])
+    x = diff.p_sample_loop((1, 120, 151), cond, noise=xT, step_noise=dev_noise([0], 120), start_point=start)
+    e, scale = maxabs(x, ref), float(np.abs(ref).max())
+    print(f"{name}: max-abs vs reference {e:.2e} (|x| max {scale:.2f})")
+    assert e < 1e-3 * max(1.0, scale)
+    # p_sample's second return value is x_start of that step (:241-252)
+    tt = torch.full((1,), 5, dtype=torch.long, device=DEV)
+    xn, x0 = diff.p_sample(xT.to(DEV), cond.to(DEV), tt, noise=torch.zeros_like(xT).to(DEV))
+    assert bool(torch.isfinite(x0).all()) and (not clip or float(x0.abs().max()) <= 1.0)
+
+
 def test_c1_graph_and_eager_agree(c1):
     _, _, diff, cond, xT = c1
     a = diff.p_sample_loop((1, 120, 151), cond, noise=xT, step_noise=dev_noise([0], 120), start_point=12, use_graph=True)

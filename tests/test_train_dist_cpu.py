@@ -75,11 +75,11 @@ def _engine_worker(rank, world, port, q):
     calls = []
     orig_ready = D.FlatGradientAllReducer.ready
 
-    def ready(self, flat, lo, hi):
+    def ready(self, flat, lo, hi, more=True):
         # the kernels are stubs: stand in for them with a rank-specific gradient in the range being published
         flat[lo:hi] = float(rank + 1)
         calls.append((lo, hi))
-        return orig_ready(self, flat, lo, hi)
+        return orig_ready(self, flat, lo, hi, more)
     D.FlatGradientAllReducer.ready = ready
     b = 2
     x, cond = torch.randn(b, 16, 151), torch.randn(b, 17, 438)

@@ -61,6 +61,27 @@ def test_p_losses_forward_vs_reference_golden_and_oracle(golden_dir, compute, re
     assert len(losses2) == 4 and bool(torch.isfinite(total2))
 
 
+def test_p_losses_with_predict_epsilon_vs_reference_golden(golden_dir):
+    """predict_epsilon=True (the reference constructor's DEFAULT, model/diffusion.py:80-95): the regression target is the
+    injected noise (:657-660), which the reference then feeds to the velocity term too (:664-682).  Recon / velocity against the
+    REAL reference (tests/golden/make_golden_eps.py); backward runs."""
+    ref = np.load(os.path.join(golden_dir, "c1_eps.npz"))
+    ref0 = np.load(os.path.join(golden_dir, "c1_p_losses.npz"))
+    dn, S, T, b = 2, 60, 100, 3
+    sd, diff = build(dn, S, T, "f32")
+    diff.predict_epsilon = True
+    x_start, cond, noise = inputs(dn, S, b)
+    t, keep = torch.from_numpy(ref0["t"]), torch.from_numpy(ref0["keep"])
+    total, losses = diff.p_losses(x_start.to(DEV), cond.to(DEV), t.to(DEV), noise=noise.to(DEV), keep_mask=keep.to(DEV))
+    got = [float(v) for v in losses]
+    print(f"p_losses[predict_epsilon]: recon {got[0]:.6f} (reference {float(ref['recon']):.6f}), velocity {got[1]:.6f} "
+          f"(reference {float(ref['velocity']):.6f})")
+    assert abs(got[0] - float(ref["recon"])) < 2e-5 * float(ref["recon"])
+    assert abs(got[1] - float(ref["velocity"])) < 2e-5 * float(ref["velocity"])
+    total.backward()
+    assert all(bool(torch.isfinite(p.grad).all()) for p in diff.model.parameters() if p.grad is not None)
+
+
 def test_l1_loss_type_and_q_sample_kernel_exact(golden_dir):
     ref = np.load(os.path.join(golden_dir, "c1_p_losses.npz"))
     dn, S, T, b = 2, 60, 100, 3

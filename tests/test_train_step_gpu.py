@@ -182,7 +182,10 @@ def test_training_step_at_the_benchmarked_config_vs_oracle_autograd(compute, b):
     # 32 x 450 token rows: every weight gradient is an fp32 sum over 14 400 rows on BOTH sides (split-K partial sums here, torch's
     # blocked CPU summation in the oracle), so the f32 bound is 3x the small-config one; observed worst 1.2e-4 (layer 7's
     # cross-attention w_ks / w_qs, the smallest gradients of the model), median 2e-5
-    bound = 3e-4 if compute == "f32" else 3e-1      # bf16: observed worst 1.9e-1 (layer 7 self-attention w_qs / w_ks), median 5e-2
+    # bf16: observed worst 1.9e-1 (layer 7 self-attention w_qs / w_ks), median 5e-2.  That distance is the FORWARD's bf16 operand
+    # rounding, not the backward kernels': the CPU oracle with rounding emulated in the forward only (exact fp32 backward) lands
+    # the same parameters at 1.45e-1 .. 1.94e-1 (tools/grad_error_study.py, profiles/r04_grad_error_study.txt)
+    bound = 3e-4 if compute == "f32" else 3e-1
     assert len(allr) == 435 - 125 and allr[0][0] < bound, allr[0]
 
 

@@ -17,3 +17,4 @@ for k, v in a.items():
     v = sorted(v)
     print(k, "n=%d mean %.3f median %.3f min %.3f max %.3f" % (len(v), sum(v) / len(v), v[len(v) // 2], v[0], v[-1]))
 PY
+timeout 120 python tools/power_watch.py 10 > gpurun_out/r04_power_watch.txt 2>&1; head -3 gpurun_out/r04_power_watch.txt; grep "^run" gpurun_out/r04_power_watch.txt | sed -n '5,12p'
