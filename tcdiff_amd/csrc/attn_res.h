@@ -76,6 +76,7 @@ __global__ __launch_bounds__(512) void attention_res_kernel(const char* __restri
     for (int c0 = 0; c0 < Lk; c0 += 64 * ATT_RES_MAXT) {
     const int nt = (Lk - c0 + 63) / 64 < ATT_RES_MAXT ? (Lk - c0 + 63) / 64 : ATT_RES_MAXT;
     if (c0 > 0) __syncthreads();           // every wave is done with the previous chunk
+#ifndef ATT_ABLATE_LOAD   // (timing experiment: the launch without its K / V loads -- results wrong)
     for (int blk = wave; blk < nt * 8; blk += 8) {      // blk = 8 consecutive keys of the chunk
         const int row = blk * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ tile_swz(row);
@@ -84,6 +85,7 @@ __global__ __launch_bounds__(512) void attention_res_kernel(const char* __restri
         __builtin_amdgcn_global_load_lds((gbl_void_t*)(Kg + (long)(c0 + row) * 128 + chunk * 16), (lds_void_t*)(Ks + blk * 1024), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((gbl_void_t*)(Vg + (long)(c0 + row) * 128 + chunk * 16), (lds_void_t*)(Vs + blk * 1024), 16, 0, 0);
     }
+#endif
     // (Tried and dropped: replacing this full drain by counted waits, `s_waitcnt vmcnt(2 (nt - 1 - b))` + barrier in front of
     // tile b, so that tile 0 starts one tile's worth of DMA after the launch.  The backend's wait-count pass treats an LDS-DMA
     // in flight as aliasing EVERY later ds_read and puts its own `s_waitcnt vmcnt(0)` in front of the first K fragment read
@@ -142,7 +144,11 @@ __global__ __launch_bounds__(512) void attention_res_kernel(const char* __restri
 #pragma unroll
                     for (int q = 0; q < 16; q += 2) {
                         const f32x2_t x = __builtin_elementwise_fma(f32x2_t{s[g][kt][q], s[g][kt][q + 1]}, l2, nm);
+#ifdef ATT_ABLATE_EXP   // (timing experiment: no transcendental)
+                        const f32x2_t p = x;
+#else
                         const f32x2_t p = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+#endif
                         s[g][kt][q] = p[0];
                         s[g][kt][q + 1] = p[1];
                         rs2 += p;                               // the softmax denominator is taken BEFORE the dropout

@@ -379,9 +379,11 @@ class TrainEngine:
         """W / W^T operand packs of every linear from the fp32 masters, when a parameter changed (once per optimizer step):
         ONE tcdiff_cast_transpose_multi launch over a device table of all ~125 matrices (as separate launches 0.7 ms)."""
         ver = tuple(p._version for p in self.params.values())
-        if ver == self.packed_version:
-            return
+        # (`p.data = other` moves a parameter to new storage WITHOUT changing its version counter -- load_state_dict(assign=True),
+        # model.to(...) on the same device: the addresses are part of the key)
         ptrs = tuple(p.data_ptr() for p in self.params.values())
+        if ver == self.packed_version and ptrs == self._ct_ptrs:
+            return
         if self._ct is None or self._ct_ptrs != ptrs:              # parameters (re)allocated: the table holds raw pointers
             if self._ct is not None:
                 # ... and so do the captured graphs (LayerNorm / null-embedding / bias pointers) and the cached .grad views

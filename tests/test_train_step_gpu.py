@@ -338,3 +338,77 @@ def test_inference_after_training_sees_the_updated_weights():
         sd_now = {n: p.detach().cpu() for n, p in diff.model.state_dict().items()}
         want = O.decoder_forward(sd_now, x, cond, t)
     assert float((got.cpu() - want).abs().max()) < 5e-4
+
+
+def _fixed_step_inputs():
+    x_start, cond, noise = step_inputs(0, 10)
+    t = torch.tensor([73, 5, 40])
+    keep = torch.tensor([True, False, True])
+    return [v.to(DEV) for v in (x_start, cond, t, noise, keep)]
+
+
+def test_backward_of_a_stale_forward_raises_instead_of_using_the_newer_activations():
+    """the engine keeps the activations (and dropout seed) of ONE forward.  fwd(A), fwd(B), loss_A.backward() used
+    to differentiate A through B's activations silently; the autograd node now carries the generation of its forward."""
+    from tcdiff_amd._lib import TcdiffError
+    _, diff = build("f32")
+    diff.eval()
+    x, cond, t, noise, keep = _fixed_step_inputs()
+    la, _ = diff.p_losses(x, cond, t, noise=noise, keep_mask=keep)
+    lb, _ = diff.p_losses(x * 0.5, cond, t, noise=noise, keep_mask=keep)
+    with pytest.raises(TcdiffError, match="no longer the most recent"):
+        la.backward()
+    lb.backward()                                   # the most recent forward is still differentiable
+    assert diff.model.final_layer.weight.grad is not None
+
+
+def test_reallocated_parameters_drop_the_captured_graphs_and_frozen_ones_get_no_gradient():
+    """captured forward / backward graphs bake in raw parameter addresses (LayerNorm weights, biases, the weight-pack
+    table).  After a parameter's storage is replaced (`p.data = ...`) the next steps must recapture and still equal the eager
+    schedule; a parameter with requires_grad=False receives no .grad; `grads_through_autograd` hands gradients to autograd (a
+    tensor hook on a parameter fires)."""
+    _, diff = build("f32")
+    _, ref = build("f32")
+    for d in (diff, ref):
+        d.eval()
+    ref.model.train_engine().use_graphs = 0
+    x, cond, t, noise, keep = _fixed_step_inputs()
+
+    def grads(d, steps):
+        out = None
+        for _ in range(steps):
+            for p in d.model.parameters():
+                p.grad = None
+            total, _ = d.p_losses(x, cond, t, noise=noise, keep_mask=keep)
+            total.backward()
+            out = {n: p.grad.detach().clone() for n, p in d.model.named_parameters() if p.grad is not None}
+        return out
+    g_ref = grads(ref, 1)
+    g0 = grads(diff, 4)                             # eager, eager, captured, replayed
+    eng = diff.model.train_engine()
+    assert any(st["fwd"] is not None for st in eng._graphs.values())
+    assert max(rel(g0[n].cpu().numpy(), g_ref[n].cpu().numpy()) for n in g_ref) < 1e-5
+    # move two parameters to new storage (what load_state_dict(assign=True) / model.to() on the same device do) and change them
+    with torch.no_grad():
+        for name in ("seqTransDecoder.stack.3.norm2.weight", "final_layer.bias"):
+            p = dict(diff.model.named_parameters())[name]
+            p.data = (p.data * 1.5).clone()
+            q = dict(ref.model.named_parameters())[name]
+            q.mul_(1.5)
+    g1, g1_ref = grads(diff, 4), grads(ref, 1)
+    assert eng._graph_broken is None
+    assert max(rel(g1[n].cpu().numpy(), g1_ref[n].cpu().numpy()) for n in g1_ref) < 1e-5
+    assert rel(g1["final_layer.weight"].cpu().numpy(), g0["final_layer.weight"].cpu().numpy()) > 1e-6    # it did change
+    # frozen parameter: no gradient; hook on a live one with grads_through_autograd
+    frozen = diff.model.seqTransDecoder.stack[0].linear1.weight
+    frozen.requires_grad_(False)
+    seen = []
+    live = diff.model.final_layer.weight
+    h = live.register_hook(lambda g: seen.append(float(g.abs().sum())))
+    g2 = grads(diff, 1)
+    h.remove()
+    assert "seqTransDecoder.stack.0.linear1.weight" not in g2 and len(seen) == 1 and seen[0] > 0
+    eng.grads_through_autograd = True
+    g3 = grads(diff, 1)
+    assert "seqTransDecoder.stack.0.linear1.weight" not in g3
+    assert rel(g3["final_layer.weight"].cpu().numpy(), g2["final_layer.weight"].cpu().numpy()) < 1e-6

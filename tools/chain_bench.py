@@ -36,11 +36,11 @@ def run(nblk, mode):
     Q, Kk, V = (torch.zeros(nseq, H, Lp, 64, device=dev, dtype=bf) for _ in range(3))
     def fn():
         if mode == "B":
-            K.chain(L.CHAIN_B, M, Lq, Oa, wsB, ln_eps=1e-6, film=film, film_ld=4096, xres=x, xout=x,
+            K.chain(L.CHAIN_B, M, Lq, Oa, wsB, mt=4, ln_eps=1e-6, film=film, film_ld=4096, xres=x, xout=x,
                     n2_g=g[2], n2_b=g[3], rope=rope, b1=b1, film3=film[:, 2048:], n4_g=g[4], n4_b=g[5], b3=b3, nn_g=g[6],
                     nn_b=g[7], q_out=Q, k_out=Kk, v_out=V, Lp=Lp, H=H)
         else:
-            K.chain(L.CHAIN_A, M, Lq, Oa, wsA, ln_eps=1e-6, film=film, film_ld=4096, xres=x, xout=x,
+            K.chain(L.CHAIN_A, M, Lq, Oa, wsA, mt=4, ln_eps=1e-6, film=film, film_ld=4096, xres=x, xout=x,
                     n2_g=g[2], n2_b=g[3], rope=rope, q_out=Q, Lp=Lp, H=H)
     for _ in range(3): fn()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

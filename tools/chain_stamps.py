@@ -5,10 +5,10 @@ os.environ.setdefault("TCDIFF_LIB_PATH", "tools/probe/libtc_STAMP.so")
 import torch
 exec(open(os.path.join(os.path.dirname(__file__), "chain_bench.py")).read().split("def run(")[0])
 S_, nkt = 150, 5
-order = [(0, "start"), (1, "A block + first stages landed"), (2, "self fc GEMM"), (40, "  barrier after GEMM"), (41, "  LN statistics"),
+order = [(0, "start"), (1, "A block + first stages landed"), (2, "self fc GEMM"), (40, "  (row loads issued)"), (41, "  LN statistics exchange (waits for the SIMD's second wave)"),
          (3, "  LN, FiLM, residual, store"),
          (4, "norm2 stats"), (34, "norm2 + rotary -> LDS + barrier"), (35, "w_qs GEMM"), (36, "cross-attention (incl. barrier)"),
-         (37, "cross fc GEMM (incl. barrier)"), (42, "  barrier after GEMM"), (43, "  LN statistics"), (38, "  LN, FiLM, residual, store"), (39, "norm3 stats"), (5, "norm3 -> LDS, consts, 2 barriers")]
+         (37, "cross fc GEMM (incl. barrier)"), (42, "  (row loads issued)"), (43, "  LN statistics exchange"), (38, "  LN, FiLM, residual, store"), (39, "norm3 stats"), (5, "norm3 -> LDS, consts, 2 barriers")]
 for c in range(4):
     order += [(6 + 4 * c, f"linear1 chunk {c} GEMM"), (8 + 4 * c, "  GELU -> LDS + barrier"), (9 + 4 * c, f"linear2 chunk {c} GEMM")]
 order += [(22, "linear2 epilogue"), (23, "norm4 stats (incl. barrier)"), (24, "norm4 -> LDS + barrier"), (25, "linear3 GEMM"),
@@ -23,7 +23,7 @@ for nblk in (1, 225):
     kf = rnd(nseq + 1, H, nkt * 2048, scale=0.5).to(bf); vf = rnd(nseq + 1, H, nkt * 2048, scale=0.5).to(bf)
     st = torch.zeros(8 * 64, device=dev, dtype=torch.int64)
     for _ in range(5):
-        K.chain(L.CHAIN_FULL, M, Lq, Oa, wsF, ln_eps=1e-6, film=film, film_ld=6144, xres=x, xout=x,
+        K.chain(L.CHAIN_FULL, M, Lq, Oa, wsF, mt=4, ln_eps=1e-6, film=film, film_ld=6144, xres=x, xout=x,
                 n2_g=g[2], n2_b=g[3], rope=rope, b1=b1, film3=film[:, 4096:], n4_g=g[4], n4_b=g[5], b3=b3, nn_g=g[6],
                 nn_b=g[7], q_out=Q, k_out=Kk, v_out=V, h_out=st, Lp=Lp, H=H, filmb=film[:, 2048:],
                 n3_g=g[2], n3_b=g[3], kf=kf, vf=vf, n_shared=nseq // 2, nkt=nkt, Lk=S_ + 2)

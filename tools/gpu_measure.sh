@@ -36,3 +36,9 @@ python tools/train_shapes.py --batch 32 --top 60 2>/dev/null | grep -v amdgpu.id
 python tools/gemm_shapes.py 2>/dev/null | grep -v amdgpu.ids > gpurun_out/${R}_gemm_shapes.log
 python tools/attn_bench.py 2>/dev/null | grep -v amdgpu.ids > gpurun_out/${R}_attn_bench.log
 python tools/tn_probe.py 2>/dev/null | grep -v amdgpu.ids > gpurun_out/${R}_tn_probe.log
+# round 4 additions: in-kernel stamps + shader clock of the fused layer, small-batch modes, pure-load ceiling of the weight stream
+bash tools/ab_build.sh STAMP "-DCH_STAMP" > /dev/null 2>&1
+TCDIFF_LIB_PATH=tools/probe/libtc_STAMP.so timeout 300 python tools/chain_stamps.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_chain_stamps.txt; grep -E "fused layer|last wave|shader clock" gpurun_out/${R}_chain_stamps.txt
+timeout 1200 python tools/small_batch.py 2>&1 | tail -3 > gpurun_out/${R}_small_batch.txt; cat gpurun_out/${R}_small_batch.txt
+python -m pytest tests/test_parity_gpu.py -m gpu -s -q -k "attribution" 2>&1 | grep -E "guided evaluation|  bf16|  f32 parity|passed|failed" >> gpurun_out/${R}_parity_at_benchmarked_config.log
+timeout 120 python tools/power_watch.py 10 > gpurun_out/${R}_power_watch.txt 2>&1; head -2 gpurun_out/${R}_power_watch.txt
