@@ -169,7 +169,7 @@ def kernel_source_sha() -> str:
     """content hash of the sampler's kernel sources: a PMC file belongs to the build it was measured on"""
     import hashlib
     h = hashlib.sha256()
-    for f in ("chain.hip", "attention.hip", "attn_res.h", "gemm.hip", "ops.hip", "common.h"):
+    for f in ("chain.hip", "chain_core.h", "attention.hip", "attn_res.h", "gemm.hip", "ops.hip", "common.h"):
         h.update(open(os.path.join(ROOT, "tcdiff_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:12]
 

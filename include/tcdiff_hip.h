@@ -439,6 +439,32 @@ typedef struct tcdiff_ct_desc {
 int tcdiff_ct_desc_init(int dtype, tcdiff_ct_desc* d);
 int tcdiff_cast_transpose_multi(int dtype, const tcdiff_ct_desc* descs_dev, int n_desc, int n_tiles, hipStream_t stream);
 
+/* ---- row-block GEMM of the training step (bf16; csrc/gemm_rows.hip) -------------------------------------------------
+ * C[M, N] = A[M, K] * Wn[N, K]^T with tcdiff_gemm_tile's epilogues, for the tall products inside the decoder layers
+ * (K = 512 or 1024, N a multiple of 512): a workgroup keeps 64 / 32 / 16 rows of A in LDS (mt = 4 / 2 / 1; 0 = by M and the
+ * CU count) and streams the weights, which arrive as per-wave fragment streams -- the 4-KB stage format of tcdiff_chain:
+ * wstream = [8 waves][N / 512 phases x K / 32 stages][4096 B], wave w's stage (p, ks) holding [n-tile 4][lane group 4][16 rows]
+ * [8 k] = Wn[512 p + 64 w + 16 nt + c][32 ks + 8 PI(g) + j], PI = (0, 3, 1, 2).  tcdiff_pack_row_streams builds such streams on
+ * the device from fp32 matrices: Wn[n][k] = src[n sn + k sk], i.e. (sn, sk) = (ld, 1) for the forward product of an nn.Linear
+ * weight [N, K] and (1, ld) for its input gradient (Wn = W^T); an entry may be a piece of the packed matrix (stacked
+ * parameters).  descs_dev: DEVICE array; max_elems = the largest N * K in it.
+ * A2 / split_n as in tcdiff_gemm_tile (K = 512 only; split_n a multiple of 512).  Epilogue restrictions: act == TC_ACT_NONE,
+ * hgroup == 0; TC_EPI_QKV_HEADS: H = 8, n_q and n_k are 0 or 512 and at most 512 columns of V (one phase per image), no
+ * tok_off / seq_off, L >= 64; ldc / ldc2 / ld_src multiples of 8 (fp32 output: of 4).  Returns TC_ERR_UNSUPPORTED for shapes it
+ * does not take (the caller then uses tcdiff_gemm_tile).
+ * Replaces in the training step: nn.Linear forward and input-gradient products of model/model.py:78-80,103,399-401,344. */
+typedef struct tcdiff_ws_desc {
+    const float* src;
+    void* dst;
+    long sn, sk;                      /* element strides of Wn's n and k in src */
+    int N, K;                         /* this piece: N % 512 == 0, K % 32 == 0 */
+    int np_dst, p0, kst_dst, ks0;     /* dst is a stream of np_dst phases x kst_dst stages per wave; the piece's phase p, k-step ks
+                                         land at (p0 + p, ks0 + ks).  A whole matrix: np_dst = N / 512, kst_dst = K / 32, p0 = ks0 = 0 */
+} tcdiff_ws_desc;
+int tcdiff_pack_row_streams(const tcdiff_ws_desc* descs_dev, int n_desc, int max_elems, hipStream_t stream);
+int tcdiff_gemm_rows(const void* A, const void* A2, int split_n, const void* wstream, int M, int N, int K, int lda,
+                     const tcdiff_tile_epi* epi, int mt, hipStream_t stream);
+
 /* Split-K GEMM with fp32 accumulation into `out`: out[m][n] += sum_k A[m][k] W[n][k] (atomic adds; `splits` workgroups
  * share each 128x128 tile).  The weight gradient dW[N,K] += dY^T X of every nn.Linear, with M = out features, N = in
  * features and the contraction over the token rows. */

@@ -72,6 +72,12 @@ class CtDesc(C.Structure):
                 ("cols_pad", _i), ("ld_dstT", _i), ("rows_pad", _i), ("tile0", _i), ("tiles_x", _i), ("vec", _i)]
 
 
+class WsDesc(C.Structure):
+    """tcdiff_ws_desc (include/tcdiff_hip.h): one matrix of tcdiff_pack_row_streams' table."""
+    _fields_ = [("src", _vp), ("dst", _vp), ("sn", C.c_long), ("sk", C.c_long), ("N", _i), ("K", _i),
+                ("np_dst", _i), ("p0", _i), ("kst_dst", _i), ("ks0", _i)]
+
+
 class TnProblem(C.Structure):
     """tcdiff_tn_problem (include/tcdiff_hip.h): one weight gradient of tcdiff_gemm_tn_grouped."""
     _fields_ = [("A", _vp), ("B", _vp), ("out", _vp), ("M", _i), ("N", _i), ("K", _i), ("lda", _i), ("ldb", _i), ("ldc", _i),
@@ -123,6 +129,8 @@ _SIGS = {
     "tcdiff_gemm_tn_grouped": [_i, C.POINTER(TnProblem), _i, _vp],
     "tcdiff_ct_desc_init": [_i, C.POINTER(CtDesc)],
     "tcdiff_cast_transpose_multi": [_i, _vp, _i, _i, _vp],
+    "tcdiff_pack_row_streams": [_vp, _i, _i, _vp],
+    "tcdiff_gemm_rows": [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp],
     "tcdiff_act_drop": [_i, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, C.c_uint32, _f, _vp],
     "tcdiff_act_drop_bwd": [_i, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i, C.c_uint32, _f, _vp],
     "tcdiff_row_fwd": [_i, C.POINTER(RowArgs), _vp],

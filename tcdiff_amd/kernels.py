@@ -47,6 +47,64 @@ def gemm_tile(dt, A, W, M, N, K, *, lda=None, ldw=None, A2=None, split_n=0, a_mo
     L.check(rc, "tcdiff_gemm_tile")
 
 
+def gemm_rows_ok(dt, N, K) -> bool:
+    """shapes tcdiff_gemm_rows takes (bf16, K = 512 or 1024, N a multiple of 512)"""
+    return dt == L.DT_BF16 and K in (512, 1024) and N > 0 and N % 512 == 0
+
+
+def gemm_rows(A, wstream, M, N, K, *, lda=None, A2=None, split_n=0, mode=L.EPI_STORE_T, bias=None, out=None, ldc=0,
+              out_k=None, out_v=None, scale_q=1.0, Lseq=0, Lp=0, H=0, n_q=0, n_k=0, out2=None, ldc2=0, act_src=None, ld_src=0,
+              act2=L.ACT_NONE, seed=None, site=0, thr=0, drop_scale=1.0, mt=0):
+    """C[M, N] = A[M, K] Wn^T with gemm_tile's epilogues; wstream = row_streams() of Wn: [8 waves][N/512 * K/32][2048] bf16"""
+    if tuple(wstream.shape) != (8, (N // 512) * (K // 32), 2048) or not wstream.is_contiguous():
+        raise L.TcdiffError(f"weight stream of a [{N}, {K}] matrix must be contiguous [8, {(N // 512) * (K // 32)}, 2048], got "
+                            f"{tuple(wstream.shape)}")
+    e = L.TileEpi(mode, L.ACT_NONE, scale_q, _p(bias), _p(out), _p(out_k), _p(out_v), ldc, Lseq, Lp, H, n_q, n_k, 0, 0, 0,
+                  _p(out2), ldc2, _p(act_src), ld_src, act2, _p(seed), site, thr, drop_scale, 0, 0)
+    rc = L.load().tcdiff_gemm_rows(_p(A), _p(A2), split_n, _p(wstream), M, N, K, lda if lda else K, C.byref(e), mt, stream())
+    L.check(rc, "tcdiff_gemm_rows")
+
+
+def ws_table(entries, device):
+    """Device table for pack_row_streams.  entries: dicts with src (fp32 tensor, element (n, k) at src.view(-1)[n sn + k sk]),
+    sn, sk, N, K, dst ([8, np_dst * kst_dst, 2048] bf16) and, for a piece of a stacked matrix, np_dst, p0, kst_dst, ks0 (default:
+    the whole matrix).  Returns (table tensor, n_desc, max N * K); the table holds raw pointers (the caller keeps the tensors
+    alive and rebuilds it when one is reallocated)."""
+    n = len(entries)
+    arr = (L.WsDesc * n)()
+    mx = 0
+    for d, e in zip(arr, entries):
+        N, K_ = e["N"], e["K"]
+        if e["src"].dtype != torch.float32 or N % 512 or K_ % 32:
+            raise L.TcdiffError("pack_row_streams takes fp32 sources with N % 512 == 0 and K % 32 == 0")
+        npd, p0, kd, ks0 = e.get("np_dst", N // 512), e.get("p0", 0), e.get("kst_dst", K_ // 32), e.get("ks0", 0)
+        if p0 + N // 512 > npd or ks0 + K_ // 32 > kd:
+            raise L.TcdiffError("pack_row_streams: the piece does not fit the stream")
+        if e["dst"].numel() != 8 * npd * kd * 2048 or e["dst"].element_size() != 2 or not e["dst"].is_contiguous():
+            raise L.TcdiffError("pack_row_streams: dst must be a contiguous 2-byte tensor of [8, np_dst * kst_dst, 2048]")
+        d.src, d.dst, d.sn, d.sk, d.N, d.K = _p(e["src"]), _p(e["dst"]), e["sn"], e["sk"], N, K_
+        d.np_dst, d.p0, d.kst_dst, d.ks0 = npd, p0, kd, ks0
+        mx = max(mx, N * K_)
+    raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone()
+    return raw.to(device), n, mx
+
+
+def pack_row_streams(table):
+    tab, n, mx = table
+    L.check(L.load().tcdiff_pack_row_streams(_p(tab), n, mx, stream()), "tcdiff_pack_row_streams")
+
+
+def row_streams(W, transposed=False):
+    """the stream pack of one fp32 matrix W [R, C] (a convenience over ws_table + pack_row_streams): Wn = W (N = R, K = C) or,
+    transposed, Wn = W^T (N = C, K = R)"""
+    R, Cc = W.shape
+    N, K_ = (Cc, R) if transposed else (R, Cc)
+    dst = torch.empty(8, (N // 512) * (K_ // 32), 2048, device=W.device, dtype=torch.bfloat16)
+    ld = W.stride(0)
+    pack_row_streams(ws_table([dict(src=W, sn=1 if transposed else ld, sk=ld if transposed else 1, N=N, K=K_, dst=dst)], W.device))
+    return dst
+
+
 def gemm_rowln(dt, A, W, M, K, *, flags, lda=None, ldw=None, a_mod=0, bias=None, ln_g=None, ln_b=None, ln_eps=1e-6,
                film=None, film_ld=0, xres=None, xres_mod=0, xout=None, Lseq=1, nln_g=None, nln_b=None, nln_eps=1e-5,
                hout=None, rout=None, rope=None, out_mul=1, out_add=0, groups=1):

@@ -28,6 +28,7 @@ TCDiff.train_loop does (TCDiff.py:227-234).
 from __future__ import annotations
 
 import math
+import re
 import warnings
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -43,6 +44,7 @@ import os as _os
 # adders to the gradient atomics (batch 32, ms per step in row_bwd: 4 blocks 2.06, 8: 1.46, 16: 1.80, 32: 2.25).
 _ROWB_CHUNKS = int(_os.environ.get("TCDIFF_ROWB_CHUNKS", "8"))
 _ALLOW_CPU = False          # tools/dryrun_train.py only: host-side dry run of the schedule against a stub library
+_ROWS_KEY = re.compile(r"^l\d+\.")      # linears evaluated by tcdiff_gemm_rows: the decoder layers' (see _Lin)
 
 
 def _is_dead(name: str) -> bool:
@@ -61,8 +63,18 @@ class _Lin:
         self.N = sum(self.rows)
         self.Kp = K.round_up(self.K, eng.kt)
         self.groups = [(0, split), (split, self.N)] if split else [(0, self.N)]
-        self.Wf = torch.zeros(self.N, self.Kp, device=eng.dev, dtype=eng.T)
-        self.WbT = [torch.zeros(self.K, K.round_up(hi - lo, eng.kt), device=eng.dev, dtype=eng.T) for lo, hi in self.groups]
+        # The decoder layers' linears (tall products: every token row against K = 512 / 1024) go through the row-block GEMM
+        # (tcdiff_gemm_rows): their operand packs are per-wave fragment streams, forward order and input-gradient order.
+        self.use_rows = bool(eng.use_rows and _ROWS_KEY.match(key) and K.gemm_rows_ok(eng.dt, self.N, self.K) and
+                             all(r % 512 == 0 for r in self.rows) and all(hi - lo in (512, 1024) for lo, hi in self.groups))
+        if self.use_rows:
+            self.Wf, self.WbT = None, None
+            self.Ws = torch.zeros(8, (self.N // 512) * (self.K // 32), 2048, device=eng.dev, dtype=eng.T)
+            self.WsT = [torch.zeros(8, (self.K // 512) * ((hi - lo) // 32), 2048, device=eng.dev, dtype=eng.T)
+                        for lo, hi in self.groups]
+        else:
+            self.Wf = torch.zeros(self.N, self.Kp, device=eng.dev, dtype=eng.T)
+            self.WbT = [torch.zeros(self.K, K.round_up(hi - lo, eng.kt), device=eng.dev, dtype=eng.T) for lo, hi in self.groups]
         # stacked biases need one contiguous copy; a lone bias is the parameter itself
         self.bias = torch.zeros(self.N, device=eng.dev, dtype=torch.float32) if len(self.bnames) > 1 else None
 
@@ -70,6 +82,8 @@ class _Lin:
         """Descriptors of tcdiff_cast_transpose_multi that (re)build this linear's operand packs from the fp32 master
         parameters: W as [N, Kp] and, per operand group, W^T."""
         eng, r0, out = self.eng, 0, []
+        if self.use_rows:
+            return out
         for name, rows in zip(self.wnames, self.rows):
             w = eng.params[name].detach()
             # a parameter that spans the operand split (nn.MultiheadAttention's packed in_proj_weight) is packed in two pieces
@@ -80,6 +94,25 @@ class _Lin:
                 wt = self.WbT[gi]
                 out.append(dict(src=w[a:b], rows=b - a, cols=self.K, ld_src=self.K, dst=self.Wf[r0 + a:], ld_dst=self.Kp,
                                 cols_pad=self.Kp, dstT=wt.view(-1)[r0 + a - lo:], ld_dstT=wt.shape[1], rows_pad=b - a))
+            r0 += rows
+        return out
+
+    def stream_entries(self):
+        """Descriptors of tcdiff_pack_row_streams for this linear's two stream packs: Wn = W going forward (a stacked
+        parameter is a range of 512-column phases), Wn = W[lo:hi]^T per operand group for the input gradient (a stacked
+        parameter is a range of k-steps)."""
+        eng, r0, out = self.eng, 0, []
+        if not self.use_rows:
+            return out
+        Kd = self.K
+        for name, rows in zip(self.wnames, self.rows):
+            w = eng.params[name].detach()
+            out.append(dict(src=w, sn=Kd, sk=1, N=rows, K=Kd, dst=self.Ws, np_dst=self.N // 512, p0=r0 // 512))
+            for gi, (lo, hi) in enumerate(self.groups):
+                a, b = max(lo, r0) - r0, min(hi, r0 + rows) - r0          # this parameter's rows inside the group
+                if a < b:
+                    out.append(dict(src=w[a:b], sn=1, sk=Kd, N=Kd, K=b - a, dst=self.WsT[gi], kst_dst=(hi - lo) // 32,
+                                    ks0=(r0 + a - lo) // 32))
             r0 += rows
         return out
 
@@ -102,13 +135,26 @@ class _Lin:
             thr, sc = (eng.thr, eng.dscale) if site is not None else (0, 1.0)
             y = eng.e(M, out.shape[1])
             ld = ldc if ldc else self.N
-            if self.N % (16 // out.element_size()) == 0 and ld == out.shape[1] and not eng.no_fuse:
+            if self.use_rows:
+                K.gemm_rows(A, self.Ws, M, self.N, self.K, lda=A.shape[1], bias=self.bias, out=out, ldc=ld, out2=y, ldc2=ld, act2=kind,
+                            seed=eng.seed, site=site or 0, thr=thr, drop_scale=sc)
+            elif self.N % (16 // out.element_size()) == 0 and ld == out.shape[1] and not eng.no_fuse:
                 K.gemm_tile(eng.dt, A, self.Wf, M, self.N, self.Kp, bias=self.bias, mode=L.EPI_STORE_T, out=out, ldc=ld, out2=y,
                             ldc2=ld, act2=kind, seed=eng.seed, site=site or 0, thr=thr, drop_scale=sc)
             else:
                 K.gemm_tile(eng.dt, A, self.Wf, M, self.N, self.Kp, bias=self.bias, mode=L.EPI_STORE_T, out=out, ldc=ld)
                 K.act_drop(eng.dt, out, out.shape[1], y, y.shape[1], M, self.N, kind, eng.seed, site or 0, thr, sc)
             return out, y
+        if self.use_rows:
+            if rows:
+                raise L.TcdiffError("a row-streamed linear is evaluated whole")
+            if heads:
+                K.gemm_rows(A, self.Ws, M, self.N, self.K, lda=A.shape[1], A2=A2, split_n=self.split if A2 is not None else 0,
+                            bias=self.bias, mode=L.EPI_QKV_HEADS, H=eng.H, **heads)
+                return None
+            K.gemm_rows(A, self.Ws, M, self.N, self.K, lda=A.shape[1], A2=A2, split_n=self.split if A2 is not None else 0,
+                        bias=self.bias, mode=L.EPI_STORE_F32 if f32 else L.EPI_STORE_T, out=out, ldc=ldc if ldc else self.N)
+            return out
         lo, hi = rows if rows else (0, self.N)
         W = self.Wf[lo:hi]
         bias = self.bias[lo:hi] if self.bias is not None else None
@@ -151,9 +197,23 @@ class _Lin:
         outs = []
         for gi, (lo, hi) in enumerate(self.groups):
             ng = hi - lo
-            ngp = self.WbT[gi].shape[1]
+            ngp = self.WbT[gi].shape[1] if not self.use_rows else ng
             w = want[gi]
-            if w is not None:                                   # dX_g = dY[:, lo:hi] W[lo:hi]
+            if w is not None and self.use_rows:                 # dX_g = dY[:, lo:hi] W[lo:hi], W read as its transposed stream
+                A = dYT.view(-1)[lo:]
+                if w[0] == "HEADS":
+                    K.gemm_rows(A, self.WsT[gi], M, self.K, ng, lda=Np, mode=L.EPI_QKV_HEADS, H=eng.H, **w[1])
+                elif w[0] == "ACT":
+                    _, da, ld, a_src, kind, site = w
+                    thr, sc = (eng.thr, eng.dscale) if site is not None else (0, 1.0)
+                    if a_src.dtype != eng.T or da.dtype != eng.T:
+                        raise L.TcdiffError("the fused activation backward takes T-typed operands")
+                    K.gemm_rows(A, self.WsT[gi], M, self.K, ng, lda=Np, out=da, ldc=ld, act_src=a_src, ld_src=a_src.shape[1],
+                                act2=kind, seed=eng.seed, site=site or 0, thr=thr, drop_scale=sc)
+                else:
+                    K.gemm_rows(A, self.WsT[gi], M, self.K, ng, lda=Np, mode=L.EPI_STORE_F32 if w[0] == "F32" else L.EPI_STORE_T,
+                                out=w[1], ldc=w[2])
+            elif w is not None:                                 # dX_g = dY[:, lo:hi] W[lo:hi]
                 A = dYT.view(-1)[lo:]
                 if w[0] == "HEADS":
                     K.gemm_tile(dt, A, self.WbT[gi], M, self.K, ngp, lda=Np, mode=L.EPI_QKV_HEADS, H=eng.H, **w[1])
@@ -225,6 +285,7 @@ class TrainEngine:
         self.seed = torch.zeros(2, device=self.dev, dtype=torch.int32)
         self.packed_version = None
         self._ct = self._ct_ptrs = self._ct_keep = None
+        self._ws = self._ws_keep = None
         self._wq = []
         self._graphs, self._pool, self._graph_broken = {}, None, None
         self._gv = self._gv_flat = None
@@ -396,7 +457,11 @@ class TrainEngine:
                 self._gv = self._gv_flat = None
             ents = [d for lk in self.lins.values() for d in lk.pack_entries()]
             self._ct, self._ct_ptrs, self._ct_keep = K.ct_table(self.dt, ents, self.dev), ptrs, ents
+            sents = [e for lk in self.lins.values() for e in lk.stream_entries()]
+            self._ws, self._ws_keep = (K.ws_table(sents, self.dev), sents) if sents else (None, None)
         K.cast_transpose_multi(self.dt, self._ct)
+        if self._ws is not None:
+            K.pack_row_streams(self._ws)
         for lk in self.lins.values():
             lk.pack_bias()
         self.packed_version = ver
@@ -411,6 +476,7 @@ class TrainEngine:
         return torch.zeros(*shape, device=self.dev, dtype=self.T if dtype is None else dtype)
 
     no_fuse = bool(int(_os.environ.get("TCDIFF_TRAIN_NOFUSE", "0")))     # A/B: activations as separate launches
+    use_rows = bool(int(_os.environ.get("TCDIFF_TRAIN_ROWS", "1")))      # A/B: 0 = every linear through gemm_tile
     poison = False      # tests: fill every "empty" workspace with NaN, so that a kernel reading what nothing wrote shows up
 
     def pz(self, key, *shape, dtype=None):

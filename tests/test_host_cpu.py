@@ -42,6 +42,12 @@ def test_argument_validation_without_gpu(lib):
     assert lib.tcdiff_attention(L.DT_F32, None, None, None, None, 1, 8, 1, 1, 128, 128, 512, 0, 0, None) == -1
     assert lib.tcdiff_ln_rot(L.DT_F32, None, 1, None, None, 1e-5, None, None, None, None, 0, 0, None) == -1
     assert lib.tcdiff_step_end(None, None) == -1
+    assert lib.tcdiff_gemm_rows(None, None, 0, None, 64, 512, 512, 512, ctypes.byref(e), 0, None) == -1
+    buf = ctypes.create_string_buffer(64)                 # (a non-NULL 16-byte aligned address; nothing is launched)
+    al = ctypes.c_void_p((ctypes.addressof(buf) + 15) & ~15)
+    assert lib.tcdiff_gemm_rows(al, None, 0, al, 64, 512, 768, 768, ctypes.byref(e), 0, None) == -4     # K = 768: unsupported
+    assert lib.tcdiff_gemm_rows(al, None, 0, al, 64, 500, 512, 512, ctypes.byref(e), 0, None) == -4     # N % 512
+    assert lib.tcdiff_pack_row_streams(None, 1, 2048, None) == -1
     with pytest.raises(L.TcdiffError):
         L.check(-2, "x")
 

@@ -54,7 +54,10 @@ def rel(a, b):
 
 # gradient tolerance (relative L2 per parameter): f32 mode is the parity mode (the north-star's fp32 claim); the bf16 mode
 # rounds every GEMM / attention operand and every T-typed activation gradient to 8 bits of mantissa
-TOL = {"f32": (1e-4, 2e-5), "bf16": (2e-1, 2e-2)}      # (per-parameter gradient, loss terms)
+# bf16 observed (worst parameter): 1.1e-1 .. 1.5e-1 with the decoder linears through gemm_tile, 1.5e-1 .. 2.1e-1 through
+# gemm_rows (the default) -- two draws of the same forward rounding noise, see
+# test_row_block_gemm_path_and_tile_path_are_two_roundings_of_the_same_step
+TOL = {"f32": (1e-4, 2e-5), "bf16": (3e-1, 2e-2)}      # (per-parameter gradient, loss terms)
 
 
 @pytest.mark.parametrize("compute", ["f32", "bf16"])
@@ -185,8 +188,57 @@ def test_training_step_at_the_benchmarked_config_vs_oracle_autograd(compute, b):
     # bf16: observed worst 1.9e-1 (layer 7 self-attention w_qs / w_ks), median 5e-2.  That distance is the FORWARD's bf16 operand
     # rounding, not the backward kernels': the CPU oracle with rounding emulated in the forward only (exact fp32 backward) lands
     # the same parameters at 1.45e-1 .. 1.94e-1 (tools/grad_error_study.py, profiles/r04_grad_error_study.txt)
-    bound = 3e-4 if compute == "f32" else 3e-1
+    # (through gemm_rows, the default since round 4: worst 3.0e-1, median 8e-2 -- another draw of the same noise)
+    bound = 3e-4 if compute == "f32" else 4e-1
     assert len(allr) == 435 - 125 and allr[0][0] < bound, allr[0]
+
+
+def test_row_block_gemm_path_and_tile_path_are_two_roundings_of_the_same_step():
+    """The decoder layers' linears run through tcdiff_gemm_rows (default) or tcdiff_gemm_tile (TCDIFF_TRAIN_ROWS=0): the same
+    bf16 operands and fp32 accumulation, another summation order.  One train-mode step (3 clips of 3 x 150) both ways against
+    the oracle's autograd: each path's distance to the oracle, and the two paths' distance to each other."""
+    from tcdiff_amd import train_engine as TE
+    dn, S_, b = 3, 150, 3
+    x_start = torch.stack([O.synth_motion(300 + c, dn * S_).reshape(S_, dn, 151).permute(1, 0, 2) for c in range(b)])
+    cond = torch.stack([O.synth_cond(300 + c, S_) for c in range(b)])
+    noise = torch.stack([O.synth_xT(300 + c, dn * S_).reshape(S_, dn, 151) for c in range(b)])
+    g = torch.Generator().manual_seed(77)
+    t = torch.randint(0, 1000, (b,), generator=g)
+    keep = torch.rand(b, generator=g) > 0.25
+    seed = (2024, 1003)
+    grads, sd = {}, None
+    was = TE.TrainEngine.use_rows
+    try:
+        for rows in (False, True):
+            TE.TrainEngine.use_rows = rows
+            sd, diff = build("bf16", dn=dn, S_=S_, T_=1000)
+            diff.train()
+            diff.model.train_seed = seed
+            total, _ = diff.p_losses(x_start.to(DEV), cond.to(DEV), t.to(DEV), noise=noise.to(DEV), keep_mask=keep.to(DEV))
+            total.backward()
+            assert sum(lk.use_rows for lk in diff.model.train_engine().lins.values()) == (56 if rows else 0)
+            grads[rows] = {n: p.grad.cpu().numpy().copy() for n, p in diff.model.named_parameters() if p.grad is not None}
+    finally:
+        TE.TrainEngine.use_rows = was
+    if ("c5", b) not in _ORACLE_CACHE:
+        sd_now = {n: p.detach().cpu().clone().requires_grad_(True) for n, p in sd.items() if p.is_floating_point()}
+        o_total, o_losses = O.p_losses(sd_now, O.make_tables(1000), x_start, cond, t, noise, keep, drop=O.DropPlan(seed, 0.1))
+        o_total.backward()
+        _ORACLE_CACHE[("c5", b)] = (float(o_total), np.array([float(v) for v in o_losses]),
+                                    {n: (None if v.grad is None else v.grad.numpy().copy()) for n, v in sd_now.items()})
+    ograd = _ORACLE_CACHE[("c5", b)][2]
+    tab = sorted(((rel(grads[True][n], ograd[n]), rel(grads[False][n], ograd[n]), rel(grads[True][n], grads[False][n]), n)
+                  for n in grads[True]), reverse=True)
+    med = [float(np.median([r[i] for r in tab])) for i in range(3)]
+    print("[bf16] rows path vs oracle | tile path vs oracle | rows vs tile, rel-L2 per parameter: median "
+          f"{med[0]:.2e} | {med[1]:.2e} | {med[2]:.2e}; worst by the rows path: " +
+          ", ".join(f"{n} {a:.2e} | {c:.2e} | {d:.2e}" for a, c, d, n in tab[:5]))
+    # The two paths differ from each other by about as much as either differs from the exact gradient: the bf16 step's error is
+    # one draw of forward rounding noise (shared by all parameters through the perturbed output, so a draw moves every
+    # parameter's error together), and a different summation order is another draw -- observed here 6.3e-2 (rows) / 1.6e-1
+    # (tile) median, 1.3e-1 between them; at 32 clips the order is reversed (8.1e-2 / 5e-2).  Neither path is the accurate one.
+    assert med[2] <= 1.5 * max(med[0], med[1])
+    assert tab[0][0] < 4e-1 and max(r[1] for r in tab) < 4e-1
 
 
 _ORACLE_CACHE = {}
