@@ -90,7 +90,14 @@ __global__ __launch_bounds__(512) void attention_res_kernel(const char* __restri
     // tile b, so that tile 0 starts one tile's worth of DMA after the launch.  The backend's wait-count pass treats an LDS-DMA
     // in flight as aliasing EVERY later ds_read and puts its own `s_waitcnt vmcnt(0)` in front of the first K fragment read
     // of each tile -- visible in the ISA -- so the drain happens anyway, one tile later.  Avoiding it needs every LDS read of
-    // the tile in inline asm with hand-counted lgkmcnt; not worth it for ~4 us of a 28-us launch.)
+    // the tile in inline asm with hand-counted lgkmcnt; not worth it for ~4 us of a 28-us launch.
+    // Round 4 built the other way round it: EVERY vector-memory operation of the launch (16 LDS-DMA + the 8 Q loads) issued
+    // from one asm statement the compiler cannot see into, `s_waitcnt vmcnt(12)` + barrier in front of tiles 0-1, a second
+    // wait + barrier in front of the other six; ISA as intended (no compiler-inserted drain), results identical -- and the same
+    // time: 32.0 against 32.4 us in the microbenchmark, 14.0 / 14.1 against 14.1 / 14.6 clips/s in the sampler (same box,
+    // interleaved).  The prologue is ISSUE-bound, not latency-bound: a wave needs ~200 cycles per DMA instruction, 24 of them
+    // are ~2.4 us during which it computes nothing whatever the wait that follows; hiding that means issuing tile b + 2 inside
+    // tile b's work, i.e. a wait + barrier per tile, which is the streaming kernel this one replaced.)
     sync_dma();
 
     if (act0) {

@@ -286,7 +286,7 @@ class TrainEngine:
         self.packed_version = None
         self._ct = self._ct_ptrs = self._ct_keep = None
         self._ws = self._ws_keep = None
-        self._wq, self._wq_live, self._side = [], [], None
+        self._wq = []
         self._graphs, self._pool, self._graph_broken = {}, None, None
         self._gv = self._gv_flat = None
         self.sv = None
@@ -540,33 +540,10 @@ class TrainEngine:
         if len(self._wq) == L.TN_MAX_PROB:
             self.flush_wgrad()
 
-    # The weight gradients of a decoder layer depend on nothing that follows them and nothing before the optimizer depends on
-    # them: their launch (tensor-pipe bound, ~150 us at batch 32) goes to a SIDE stream and runs beside the next layer's
-    # input-gradient chain, most of which is row-local glue bound by memory traffic (row_bwd, attention backward).  Fork: the side
-    # stream waits for everything queued so far; join (one layer later, and at the end of the backward): the main stream waits
-    # for the side stream, and only then are the operand tensors released to the allocator (which hands memory back in the
-    # allocating stream's order).  Under stream capture the same calls become a fork / join inside the graph.
-    overlap_wgrad = bool(int(_os.environ.get("TCDIFF_TRAIN_WGRAD_STREAM", "1")))
-
-    def flush_wgrad(self, fork=False):
-        if not self._wq:
-            return
-        if fork and self.overlap_wgrad and not self.poison:
-            if self._side is None:
-                self._side = torch.cuda.Stream(device=self.dev)
-            self._side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self._side):
-                K.gemm_tn_grouped(self.dt, self._wq)
-            self._wq_live, self._wq = self._wq, []
-        else:
+    def flush_wgrad(self):
+        if self._wq:
             K.gemm_tn_grouped(self.dt, self._wq)
             self._wq = []
-
-    def join_wgrad(self):
-        """the main stream waits for the weight gradients launched on the side stream"""
-        if self._wq_live:
-            torch.cuda.current_stream().wait_stream(self._side)
-            self._wq_live = []
 
     def row_bwd(self, *, M, L_, ln=None, nln=None, lin=None, **kw):
         """tcdiff_row_bwd with its parameter gradients added straight into the flat gradient buffer.
@@ -892,7 +869,7 @@ class TrainEngine:
                     warnings.warn(f"tcdiff_amd: capturing the data-parallel backward failed ({self._graph_broken}); continuing "
                                   f"with the eager schedule")
                     st["bwd_segs"] = None
-                    self._wq, self._wq_live = [], []
+                    self._wq = []
                     self._bwd(sv, d_out, sync, zero=True)
                     return self.deliver_grads()
             else:
@@ -922,7 +899,7 @@ class TrainEngine:
                 self._graph_broken = f"{type(ex).__name__}: {ex}"
                 warnings.warn(f"tcdiff_amd: capturing the training step failed ({self._graph_broken}); continuing with the eager schedule")
                 st["bwd"] = None
-                self._wq, self._wq_live = [], []
+                self._wq = []
                 self._bwd(sv, d_out, None, zero=True)
                 return self.deliver_grads()
         else:
@@ -1059,12 +1036,9 @@ class TrainEngine:
             g_r, g_h = e(M, 512), e(M, 512)
             lins[f"l{l}.qkv"].bwd(dQKV, 1536, M, [s["r1"], s["h1"]], [("T", g_r, 512), ("T", g_h, 512)])
             g_x = gx1
-            # the layer's seven weight gradients: one evenly split launch, on the side stream (flush_wgrad).  The layer behind
-            # this one is complete once ITS launch has been joined: average it across the ranks now
-            self.join_wgrad()
-            if sync is not None and l + 1 < NL:
-                sync.ready(self.flat, *self.layer_range[l + 1])
-            self.flush_wgrad(fork=True)
+            self.flush_wgrad()                            # the layer's seven weight gradients: one evenly split launch
+            if sync is not None:                          # this layer's linears are complete: average them across the ranks now
+                sync.ready(self.flat, *self.layer_range[l])
         # ---- front: layer 0's norm1 / rotary on the fusion projection's output, then the fusion MLP -----------------------------
         dxs = e(M, 512)
         self.row_bwd(M=M, L_=Lq, nln=st + "0.norm1", flags=L.ROWF_NEXT_LN | L.ROWF_STORE_H | L.ROWF_STORE_ROT, z=sv["xs"],
@@ -1157,11 +1131,9 @@ class TrainEngine:
         lins["c2"].bwd(dtok0, 512, Ms, [sv["c1"]], [("T", dc1, dc1.shape[1])], bias_done=True)
         dc0a = self.act_bwd(sv["c0a"], dc1, Ms, self.Cd, L.ACT_RELU)
         lins["c0"].bwd(dc0a, dc0a.shape[1], Ms, [sv["cin"]], [None])
-        self.join_wgrad()
         self.flush_wgrad()
         self.sv = None
-        if sync is not None:                              # layer 0, everything outside the decoder layers, then wait for all of it
-            sync.ready(self.flat, *self.layer_range[0], more=False)
+        if sync is not None:                              # everything outside the decoder layers, then wait for all of it
             sync.ready(self.flat, 0, self.layer_range[0][0], more=False)
             sync.ready(self.flat, self.layer_range[-1][1], self.n_grad, more=False)
             sync.finish()

@@ -117,7 +117,7 @@ def test_two_ranks_average_gradients_and_stay_identical():
     assert a["graph_broken"] is None and b["graph_broken"] is None
     # forward replayed from step 3 on; the data-parallel backward is replayed too, as one graph per decoder layer + the front,
     # with the layer's all-reduce launched between two replays (steps 3 and 4 of this run: capture + replay, then replay)
-    assert a["fwd_replayed"] and not a["bwd_captured"] and a["bwd_segments"] == b["bwd_segments"] == 8
+    assert a["fwd_replayed"] and not a["bwd_captured"] and a["bwd_segments"] == b["bwd_segments"] == 9
     assert one["bwd_captured"] and one["bwd_segments"] == 0   # without a process group: ONE backward graph
     # identical parameters on both ranks after 5 steps (same averaged gradients, deterministic fused Adan)
     worst = max(abs(a["psum"][n] - b["psum"][n]) for n in a["psum"])

@@ -36,6 +36,11 @@ python tools/train_shapes.py --batch 32 --top 60 2>/dev/null | grep -v amdgpu.id
 python tools/gemm_shapes.py 2>/dev/null | grep -v amdgpu.ids > gpurun_out/${R}_gemm_shapes.log
 python tools/attn_bench.py 2>/dev/null | grep -v amdgpu.ids > gpurun_out/${R}_attn_bench.log
 python tools/tn_probe.py 2>/dev/null | grep -v amdgpu.ids > gpurun_out/${R}_tn_probe.log
+python tools/gemm_rows_bench.py 2>/dev/null | grep -v amdgpu.ids > gpurun_out/${R}_gemm_rows_bench.txt
+# the training step with the row-block GEMM on / off, same box, interleaved
+for rep in 1 2 3; do for rows in 1 0; do
+  echo "TCDIFF_TRAIN_ROWS=$rows: $(TCDIFF_TRAIN_ROWS=$rows python tools/train_bench.py --batch 32 --iters 10 2>/dev/null | tail -1 | cut -c88-150)"
+done; done > gpurun_out/${R}_train_rows_ab.txt; cat gpurun_out/${R}_train_rows_ab.txt
 # round 4 additions: in-kernel stamps + shader clock of the fused layer, small-batch modes, pure-load ceiling of the weight stream
 bash tools/ab_build.sh STAMP "-DCH_STAMP" > /dev/null 2>&1
 TCDIFF_LIB_PATH=tools/probe/libtc_STAMP.so timeout 300 python tools/chain_stamps.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_chain_stamps.txt; grep -E "fused layer|last wave|shader clock" gpurun_out/${R}_chain_stamps.txt

@@ -50,12 +50,12 @@ def main():
         out["ddpm_steps_profiled"] = steps
         out["bytes_per_ddpm_step"] = int((2 * total_kb(sys.argv[1], "FETCH_SIZE") + total_kb(sys.argv[2], "WRITE_SIZE"))
                                          * 1024 / steps)
-    import hashlib, os
+    import importlib.util, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    h = hashlib.sha256()
-    for f in ("chain.hip", "attention.hip", "attn_res.h", "gemm.hip", "ops.hip", "common.h"):      # = bench.kernel_source_sha()
-        h.update(open(os.path.join(root, "tcdiff_amd", "csrc", f), "rb").read())
-    out["source_sha"] = h.hexdigest()[:12]
+    spec = importlib.util.spec_from_file_location("tcdiff_bench", os.path.join(root, "bench.py"))     # ONE list of kernel sources
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    out["source_sha"] = bench.kernel_source_sha()
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     print(json.dumps(out, indent=1))
 
