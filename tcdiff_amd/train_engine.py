@@ -65,7 +65,8 @@ class _Lin:
         self.groups = [(0, split), (split, self.N)] if split else [(0, self.N)]
         # The decoder layers' linears (tall products: every token row against K = 512 / 1024) go through the row-block GEMM
         # (tcdiff_gemm_rows): their operand packs are per-wave fragment streams, forward order and input-gradient order.
-        self.use_rows = bool(eng.use_rows and _ROWS_KEY.match(key) and K.gemm_rows_ok(eng.dt, self.N, self.K) and
+        # (head-major scatters cross at most one sequence boundary per 64-row block: sequences of >= 64 tokens)
+        self.use_rows = bool(eng.use_rows and _ROWS_KEY.match(key) and eng.Lq >= 64 and K.gemm_rows_ok(eng.dt, self.N, self.K) and
                              all(r % 512 == 0 for r in self.rows) and all(hi - lo in (512, 1024) for lo, hi in self.groups))
         if self.use_rows:
             self.Wf, self.WbT = None, None

@@ -88,6 +88,15 @@ def test_qkv_heads_with_two_operands_equal_gemm_tile(mt):
     # exact value check of one image against fp32 torch
     want_v = (h.float() @ Wb[1024:].float().t()).view(B, Lq, H, 64).permute(0, 2, 1, 3)
     assert float((V2[:, :, :Lq].float() - want_v).abs().max()) < 1e-2 * float(want_v.abs().max())
+    # with a bias (nn.MultiheadAttention's in_proj_bias, model/model.py:190-192): added before the scatter
+    bias = rnd(1536, seed=21)
+    Q3, K3, V3 = (torch.zeros(B, H, Lp, 64, device=DEV, dtype=BF) for _ in range(3))
+    K.gemm_rows(rot, K.row_streams(W), M, 1536, 512, A2=h, split_n=1024, mode=L.EPI_QKV_HEADS, bias=bias, out=Q3, out_k=K3, out_v=V3,
+                scale_q=0.125, Lseq=Lq, Lp=Lp, H=H, n_q=512, n_k=512, mt=mt)
+    want_k = (rot.float() @ Wb[512:1024].float().t() + bias[512:1024]).view(B, Lq, H, 64).permute(0, 2, 1, 3)
+    want_q = ((rot.float() @ Wb[:512].float().t() + bias[:512]) * 0.125).view(B, Lq, H, 64).permute(0, 2, 1, 3)
+    assert float((K3[:, :, :Lq].float() - want_k).abs().max()) < 1e-2 * float(want_k.abs().max())
+    assert float((Q3[:, :, :Lq].float() - want_q).abs().max()) < 1e-2 * float(want_q.abs().max())
     # a single image (dO of the attention backward, cross-attention's Q): n_q = 512, nothing else
     dO = torch.zeros(B, H, Lp, 64, device=DEV, dtype=BF)
     K.gemm_rows(h, K.row_streams(W[1024:]), M, 512, 512, mode=L.EPI_QKV_HEADS, out=dO, scale_q=1.0, Lseq=Lq, Lp=Lp, H=H, n_q=512,
