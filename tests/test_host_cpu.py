@@ -52,6 +52,23 @@ def test_argument_validation_without_gpu(lib):
         L.check(-2, "x")
 
 
+def test_stream_table_validation_without_gpu(lib):
+    """tcdiff_pack_row_streams' descriptor table is checked on the host before anything is launched"""
+    from tcdiff_amd import kernels as K
+    w = torch.zeros(512, 1024)
+    dst = torch.zeros(8, 32, 2048, dtype=torch.bfloat16)
+    tab, n, mx = K.ws_table([dict(src=w, sn=1024, sk=1, N=512, K=1024, dst=dst)], "cpu")
+    assert n == 1 and mx == 512 * 1024 and tab.numel() == ctypes.sizeof(L.WsDesc)
+    with pytest.raises(L.TcdiffError):                     # N not a multiple of 512
+        K.ws_table([dict(src=w[:500], sn=1024, sk=1, N=500, K=1024, dst=dst)], "cpu")
+    with pytest.raises(L.TcdiffError):                     # a piece beyond the stream's k-steps
+        K.ws_table([dict(src=w, sn=1024, sk=1, N=512, K=1024, dst=dst, kst_dst=32, ks0=16)], "cpu")
+    with pytest.raises(L.TcdiffError):                     # destination of the wrong size
+        K.ws_table([dict(src=w, sn=1024, sk=1, N=512, K=1024, dst=dst[:, :16])], "cpu")
+    with pytest.raises(L.TcdiffError):                     # fp32 sources only
+        K.ws_table([dict(src=w.double(), sn=1024, sk=1, N=512, K=1024, dst=dst)], "cpu")
+
+
 @pytest.fixture(scope="module")
 def small():
     model = DanceDecoder(nfeats=151, seq_len=150, latent_dim=512, ff_size=1024, num_layers=8, num_heads=8, dropout=0.1,
