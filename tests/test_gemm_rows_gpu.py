@@ -157,3 +157,26 @@ def test_refused_shapes_and_arguments():
         K.gemm_rows(A, ws, 64, 512, 512, lda=768, mode=L.EPI_STORE_F32, out=out, ldc=256)
     with pytest.raises(L.TcdiffError):                             # two images in one 512-column phase
         K.gemm_rows(A, ws, 64, 512, 512, lda=768, mode=L.EPI_QKV_HEADS, out=out, out_k=out, Lseq=64, Lp=128, H=8, n_q=256, n_k=256)
+
+
+def test_full_size_products_agree_with_gemm_tile_and_are_linear_in_the_rows():
+    """The training step's shape (28 800 token rows = 32 clips of 3 x 150): the row-block GEMM against the tile GEMM on the same
+    operands (same bf16 products, fp32 accumulation in another order), and a size-independent property -- output rows depend on
+    their own input row only: permuting the rows of A permutes the rows of C bit for bit, and a block of rows computed alone
+    (other block size, other workgroup) equals the same rows of the full product."""
+    M, N, Kd = 28800, 1024, 512
+    A = rnd(M, Kd, seed=31).to(BF)
+    W = rnd(N, Kd, seed=32, scale=0.05)
+    bias = rnd(N, seed=33)
+    ws = K.row_streams(W)
+    c_rows, c_tile = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+    K.gemm_rows(A, ws, M, N, Kd, mode=L.EPI_STORE_F32, bias=bias, out=c_rows, ldc=N)
+    K.gemm_tile(DT, A, W.to(BF), M, N, Kd, mode=L.EPI_STORE_F32, bias=bias, out=c_tile, ldc=N)
+    assert float((c_rows - c_tile).abs().max()) <= 1e-5 * float(c_tile.abs().max())       # fp32 sums of identical products
+    perm = torch.randperm(M, generator=torch.Generator().manual_seed(5)).to(DEV)
+    c_perm = torch.empty(M, N, device=DEV)
+    K.gemm_rows(A[perm].contiguous(), ws, M, N, Kd, mode=L.EPI_STORE_F32, bias=bias, out=c_perm, ldc=N)
+    assert torch.equal(c_perm, c_rows[perm])
+    sub = torch.empty(48, N, device=DEV)
+    K.gemm_rows(A[1000:1048].contiguous(), ws, 48, N, Kd, mode=L.EPI_STORE_F32, bias=bias, out=sub, ldc=N, mt=1)
+    assert torch.equal(sub, c_rows[1000:1048])
