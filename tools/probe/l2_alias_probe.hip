@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 template <int D>
@@ -47,13 +48,31 @@ float run(const u32x4* buf, int per_wave, int pad, int rot, unsigned* out, int n
     return ms / iters * 1e3f;
 }
 
-int main() {
+int main(int argc, char** argv) {
     const int per_wave = 704;                       // KB per wave: one fused-layer stream (352 stages x 2 KB)
     const size_t bytes = (size_t)8 * (per_wave + 64) * 1024;
     u32x4* buf; unsigned* out;
     hipMalloc(&buf, bytes); hipMalloc(&out, 64);
     hipMemset(buf, 1, bytes); hipMemset(out, 0, 64);
     const double mb = 8.0 * per_wave / 1024.0;
+    if (argc >= 4 && !strcmp(argv[1], "loop")) {     // l2_alias_probe loop SECONDS BLOCKS: stream for a while (tools/power_parts.py)
+        const double secs = atof(argv[2]);
+        const int nb = atoi(argv[3]);
+        hipEvent_t s, e;
+        hipEventCreate(&s); hipEventCreate(&e);
+        double spent = 0.0;
+        long launches = 0;
+        while (spent < secs) {
+            hipEventRecord(s);
+            for (int i = 0; i < 2000; ++i) probe<8><<<nb, 512>>>(buf, per_wave, 0, 0, out);
+            hipEventRecord(e); hipEventSynchronize(e);
+            float ms; hipEventElapsedTime(&ms, s, e);
+            spent += ms * 1e-3; launches += 2000;
+        }
+        printf("loop: %ld launches of %d blocks in %.2f s = %.1f us each, %.1f GB/s per CU\n", launches, nb, spent, spent / launches * 1e6,
+               mb * 1e3 / (spent / launches * 1e6));
+        return 0;
+    }
     for (int nb : {1, 64, 128, 225, 256})
         for (int pad : {0, 1, 2, 3, 4, 5, 8, 9, 17, 33}) {
             float a = run<8>(buf, per_wave, pad, 0, out, nb, 20), b = run<16>(buf, per_wave, pad, 0, out, nb, 20);
