@@ -132,8 +132,102 @@ __global__ __launch_bounds__(512) void attention_res_kernel(const char* __restri
                         for (int q = 0; q < 16; ++q)
                             if (kv0 + kt * 32 + acc_row(q, h) >= Lk) s[g][kt][q] = -INFINITY;
             }
-            // ---- online softmax (base 2), the two groups are independent instruction streams
             constexpr float LOG2E = 1.4426950408889634f;
+            if constexpr (!TRAIN) {
+            // ---- online softmax with the exponentials INSIDE the PV MFMA stream.  On a SIMD the VALU work of one wave does not run
+            // under the MFMAs of the other (tools/probe/coissue_probe.hip); what hides is single-issue VALU
+            // work in a wave's OWN stream, ~24 issue cycles per 32x32x16 MFMA, and v_exp_f32 (8 cycles, no packed form) is the ideal
+            // filler.  So: row maximum, rescale, x = s log2e - m in packed math as before -- then the PV phase walks its units (key
+            // tile, 16-key step, row group: eight per 64-key tile with two row groups), each feeding two MFMAs, and the eight exponentials + four packs of unit u + 1 are
+            // issued behind the MFMAs of unit u (three exponentials per MFMA; the last two and the packs in the open).  The same
+            // instructions as before, moved (bit-identical results); the row sums follow the PV phase.  Measured, 256 workgroups,
+            // same box, three interleaved repetitions: 32.2 -> 30.9 us per launch (1 / 2 / 3 / 4 exponentials per MFMA: 31.4 / 31.1 /
+            // 30.9 / 31.0).  Also built: one exponential + four plain v_add_f32 of the row sums per MFMA (31.7: the unpacked sums are
+            // twice the instructions of the packed ones they replace); group 0's eight S MFMAs first and its row maximum + scaling,
+            // unpacked, behind group 1's (K fragments read twice: 2 % slower).
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                float mx = s[g][0][0];
+#pragma unroll
+                for (int kt = 0; kt < NS; ++kt)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) mx = fmaxf(mx, s[g][kt][q]);
+                mx = fmaxf(mx, other_half(mx)) * LOG2E;
+                const float m_new = fmaxf(m_run[g], mx);
+                const f32x2_t l2 = {LOG2E, LOG2E}, nm = {-m_new, -m_new};
+#pragma unroll
+                for (int kt = 0; kt < NS; ++kt)
+#pragma unroll
+                    for (int q = 0; q < 16; q += 2) {
+                        const f32x2_t x = __builtin_elementwise_fma(f32x2_t{s[g][kt][q], s[g][kt][q + 1]}, l2, nm);
+                        s[g][kt][q] = x[0];
+                        s[g][kt][q + 1] = x[1];
+                    }
+                if (__builtin_amdgcn_ballot_w64(m_new > m_run[g]) != 0) {
+                    const float alpha = __builtin_amdgcn_exp2f(m_run[g] - m_new);
+                    l_run[g] *= alpha;
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) o[g][dt][q] *= alpha;
+                    m_run[g] = m_new;
+                }
+            }
+            constexpr int NU = 2 * NS * NG;             // units u = (key tile, 16-key step, row group): g fastest
+            u32x4 pf[2];
+            auto ex = [&](int u, int j) {               // exponential j of unit u, in place
+                const int g = u % NG, kt = u / (2 * NG), q = 8 * ((u / NG) & 1) + j;
+                s[g][kt][q] = __builtin_amdgcn_exp2f(s[g][kt][q]);
+            };
+            auto packs = [&](int u) {
+                const int g = u % NG, kt = u / (2 * NG), q0 = 8 * ((u / NG) & 1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pf[u & 1][i] = pack_bf2(s[g][kt][q0 + 2 * i], s[g][kt][q0 + 2 * i + 1]);
+            };
+            constexpr int EPG = 3;                      // exponentials of unit u + 1 behind each MFMA of unit u
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ex(0, j);
+            packs(0);
+            u32x4 vf[2];
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int g = u % NG, kt = u / (2 * NG), st = (u / NG) & 1;
+                if (g == 0) {
+                    vf[0] = v_frag<P>(vt_base, 0, kt, st, lane);
+                    vf[1] = v_frag<P>(vt_base, 1, kt, st, lane);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                P::mma(o[g][0], vf[0], pf[u & 1]);
+                if (u + 1 < NU) {
+#pragma unroll
+                    for (int j = 0; j < EPG; ++j) ex(u + 1, j);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                P::mma(o[g][1], vf[1], pf[u & 1]);
+                if (u + 1 < NU) {
+#pragma unroll
+                    for (int j = EPG; j < 2 * EPG; ++j) ex(u + 1, j);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (u + 1 < NU) {
+#pragma unroll
+                    for (int j = 2 * EPG; j < 8; ++j) ex(u + 1, j);
+                    packs(u + 1);
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                f32x2_t rs2 = {0.0f, 0.0f};
+#pragma unroll
+                for (int kt = 0; kt < NS; ++kt)
+#pragma unroll
+                    for (int q = 0; q < 16; q += 2) rs2 += f32x2_t{s[g][kt][q], s[g][kt][q + 1]};
+                float rs = rs2[0] + rs2[1];
+                rs += other_half(rs);
+                l_run[g] += rs;
+            }
+            } else {
+            // ---- online softmax (base 2), the two groups are independent instruction streams
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 float mx = s[g][0][0];
@@ -206,6 +300,7 @@ __global__ __launch_bounds__(512) void attention_res_kernel(const char* __restri
                         for (int g = 0; g < NG; ++g) P::mma(o[g][dt], vf, pf[g]);
                     }
                 }
+            }
         };
         // (Measured and dropped, round 3: the same tile as a software pipeline over the wave's two row groups -- S(g1) under
         // the exp stream of g0, PV(g0) under the exp stream of g1, placed with sched_group_barrier; the ISA interleaves as
