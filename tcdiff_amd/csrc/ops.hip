@@ -438,9 +438,10 @@ __global__ void sampler_update_kernel(int mode, const float* __restrict__ out_un
         const float xt = x[xi];
         // params[7] bit 2: the network predicts the noise, x_0 = sqrt(1/ac) x_t - sqrt(1/ac - 1) eps_hat (predict_epsilon,
         // model/diffusion.py:176-187; DDPM steps only: model_predictions :195-204 takes the output as x_0 either way);
-        // bit 3: no clamp (clip_denoised=False, :230-233 -- the DDIM samplers always clamp, :408-409)
+        // bit 3: no clamp (clip_denoised=False: :230-233 for DDPM, and the three DDIM samplers pass
+        // clip_x_start=self.clip_denoised, :316,409,476)
         if (mode == TC_SAMPLER_DDPM && (flags & 4)) g = pr[4] * xt - pr[5] * g;
-        const float x0 = (mode == TC_SAMPLER_DDPM && (flags & 8)) ? g : fminf(fmaxf(g, -1.0f), 1.0f);  // :230-231 / :199-201
+        const float x0 = (flags & 8) ? g : fminf(fmaxf(g, -1.0f), 1.0f);  // :230-231 / :199-201
         const float e = eps ? eps[xi] : z[j];
         float xn;
         if (mode == TC_SAMPLER_DDPM) {

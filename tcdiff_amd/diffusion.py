@@ -330,8 +330,11 @@ class GaussianDiffusion(nn.Module):
 
     @torch.no_grad()
     def p_mean_variance(self, x, cond, t):
+        """reference model/diffusion.py:215-239 (predict_start_from_noise is the identity unless predict_epsilon)"""
         weight = self._guidance_weight_at(int(t[0]))
-        x_recon = self.model.guided_forward(x, cond, t, weight).clamp_(-1.0, 1.0)
+        x_recon = self.predict_start_from_noise(x, t, self.model.guided_forward(x, cond, t, weight))
+        if self.clip_denoised:
+            x_recon = x_recon.clamp_(-1.0, 1.0)
         mean, var, logvar = self.q_posterior(x_start=x_recon, x_t=x, t=t)
         return mean, var, logvar, x_recon
 
@@ -395,6 +398,7 @@ class GaussianDiffusion(nn.Module):
         p = torch.zeros(len(pairs), 8)
         for i, ((time, time_next), w) in enumerate(zip(pairs, weights)):
             p[i, 0], p[i, 1], p[i, 2] = float(w), sr[time], srm1[time]
+            p[i, 7] = 0 if self.clip_denoised else 8      # clip_x_start=self.clip_denoised (model/diffusion.py:316,409,476)
             if time_next < 0:
                 p[i, 6] = 1.0
                 continue

@@ -199,19 +199,20 @@ class DanceDecoder(nn.Module):
         self.compute_dtype = compute_dtype
         self._engine = None
         self._engines = {}
-        self._train_engine = None
+        # the training engine is rebuilt by train_engine() (it compares the arithmetic mode) and hands its gradient averager on
 
     def train_engine(self):
         """The (lazily built) training-step engine: operand packs, flat gradient buffer, forward / backward schedule."""
         from .train_engine import TrainEngine
         eng = self._train_engine
         dev = next(self.parameters()).device
+        # an opt-in gradient averager survives EVERY rebuild (new Parameter objects, another device, another arithmetic mode):
+        # dropping it silently would leave the ranks training unsynchronised replicas
+        sync = eng.grad_sync if eng is not None else None
         if eng is not None and eng.param_ids != tuple(id(p) for p in self.parameters()):
             # Parameter OBJECTS were replaced (load_state_dict(assign=True), a re-wrapped module): everything the engine
             # captured or cached refers to the old ones
-            sync, eng = eng.grad_sync, None
-        else:
-            sync = None
+            eng = None
         if eng is None or eng.dev != dev or eng.dt != K.dtype_id(self.compute_dtype):
             eng = TrainEngine(self, self.compute_dtype)
             if sync is not None:

@@ -853,6 +853,15 @@ class TrainEngine:
                 st["bwd"] = None
                 st["bwd_segs"] = None
         sync = self.grad_sync if (self.grad_sync is not None and self.grad_sync.active()) else None
+        if self.grad_sync is None and not getattr(self, "_warned_no_sync", False):
+            # the reference trains under DDP (TCDiff.py:51-52,232); here averaging is opt-in -- say so ONCE when a multi-rank job
+            # runs a backward without it, instead of training unsynchronised replicas silently
+            self._warned_no_sync = True
+            import torch.distributed as _td
+            if _td.is_available() and _td.is_initialized() and _td.get_world_size() > 1:
+                warnings.warn("tcdiff_amd: torch.distributed has %d ranks but gradient averaging is off: call "
+                              "model.train_engine().enable_grad_sync(group) or set TCDIFF_GRAD_SYNC=1 (a DDP / accelerate wrapper "
+                              "that averages .grad itself needs neither)" % _td.get_world_size(), stacklevel=2)
         B = sv["B"]
         d_out = d_out.reshape(B * self.Lq, self.nf).to(dtype=torch.float32).contiguous()
         st = sv.get("graph")
@@ -952,6 +961,18 @@ class TrainEngine:
                 cut.begin()
                 self._bwd(sv, dout, cut, zero=True)
                 cut.finish()
+        except BaseException:
+            # a failure in the middle of a segment (kernel error, allocation, unsupported op) must not leave `side` in
+            # capture: the caller falls back to the eager schedule on this thread, and a live thread_local capture would
+            # refuse its first allocation or sync
+            if cut.g is not None:
+                try:
+                    cut.g.capture_end()
+                except Exception:
+                    pass
+                cut.g = None
+            segs.clear()
+            raise
         finally:
             L._rec = None
         torch.cuda.current_stream().wait_stream(side)

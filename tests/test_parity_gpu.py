@@ -119,6 +119,32 @@ def test_constructor_options_outside_the_production_config_vs_reference_golden(g
     assert bool(torch.isfinite(x0).all()) and (not clip or float(x0.abs().max()) <= 1.0)
 
 
+@pytest.mark.parametrize("name,clip", [("noclip", False), ("clip", True)])
+def test_ddim_sample_honours_clip_denoised_vs_reference_golden(golden_dir, name, clip):
+    """The DDIM samplers pass clip_x_start=self.clip_denoised (model/diffusion.py:316,409,476): 50 DDIM steps of config 1
+    against the REAL reference with and without the clamp, same injected draws (tests/golden/make_golden_ddim_noclip.py; the
+    two goldens differ by 0.65, so a sampler that always clamps fails the first), f32 mode."""
+    ref = gold(golden_dir, "c1_ddim_noclip")[name]
+    sd = O.synth_state_dict(dn=2, seq_len=60)
+    model = DanceDecoder(nfeats=151, seq_len=60, latent_dim=512, ff_size=1024, num_layers=8, num_heads=8, dropout=0.1,
+                         cond_feature_dim=438, activation=F.gelu, required_dancer_num=2, compute_dtype="f32")
+    model.load_state_dict(sd, strict=True)
+    diff = GaussianDiffusion(model.eval(), 60, 151, None, schedule="cosine", n_timestep=100, predict_epsilon=False,
+                             clip_denoised=clip, loss_type="l2", use_p2=False, cond_drop_prob=0.25, guidance_weight=2,
+                             seq_len=60).to(DEV).eval()
+    cond = torch.stack([O.synth_cond(0, 60)])
+    xT = torch.stack([O.synth_xT(0, 120)])
+    x = diff.ddim_sample((1, 120, 151), cond, init_noise=xT, step_noise=dev_noise([0], 120))
+    e, scale = maxabs(x, ref), float(np.abs(ref).max())
+    print(f"ddim_sample clip_denoised={clip}: max-abs vs reference {e:.2e} (|x| max {scale:.2f})")
+    assert e < 1e-3 * max(1.0, scale)
+    # p_mean_variance is the same arithmetic as p_sample's mean (model/diffusion.py:215-239)
+    tt = torch.full((1,), 5, dtype=torch.long, device=DEV)
+    mean, _, _, x0 = diff.p_mean_variance(xT.to(DEV), cond.to(DEV), tt)
+    xn, x0b = diff.p_sample(xT.to(DEV), cond.to(DEV), tt, noise=torch.zeros_like(xT).to(DEV))
+    assert maxabs(mean, xn.cpu().numpy()) < 1e-5 and maxabs(x0, x0b.cpu().numpy()) < 1e-5
+
+
 def test_c1_graph_and_eager_agree(c1):
     _, _, diff, cond, xT = c1
     a = diff.p_sample_loop((1, 120, 151), cond, noise=xT, step_noise=dev_noise([0], 120), start_point=12, use_graph=True)
@@ -414,8 +440,7 @@ def test_c2_bf16_ddpm_steps_and_ddim_vs_reference_golden(golden_dir, c2_bf16):
 
 @pytest.mark.parametrize("compute,bound", [("f32", 5e-4), ("bf16", BF16_STEPS_BOUND)])
 def test_c2_full_batch_16_clip0_vs_reference_golden(golden_dir, compute, bound):
-    """B = 16 (the benchmarked batch; two half-batch streams forced here, the single-stream default is what
-    test_full_batch_properties... compares it with bit for bit) tied to the reference: clip 0 of the
+    """B = 16 (the benchmarked batch, the single-stream captured step the bench runs) tied to the reference: clip 0 of the
     16-clip batch against the goldens the reference produced for clip 0 alone -- three DDPM steps with injected noise
     and one guided evaluation; clip 1 against the reference's two-clip forward."""
     _, model, diff = build(3, 150, 1000, compute)
@@ -426,7 +451,6 @@ def test_c2_full_batch_16_clip0_vs_reference_golden(golden_dir, compute, bound):
     ref = gold(golden_dir, "c2_ddpm_steps")
     tseq = [999, 998, 997]
     chain = []
-    diff.dual_stream, diff.dual_parts = True, 2      # two half-batch launch chains (7200-row launches)
     diff._run(L.SAMPLER_DDPM, (16, 450, 151), cond, xT.to(DEV), tseq, diff._ddpm_params(tseq),
               step_noise=dev_noise(ids, 450), collect=chain)
     for j, i in enumerate(tseq):
