@@ -324,7 +324,7 @@ def rank_facts(D, n_total, rank, world, dev):
     import torch
     import torch.distributed as dist
     lo, hi = D.shard_range(n_total, rank, world)
-    if world == 1:
+    if not D.collectives_on():
         return 1, [[lo, hi]]
     if dist.get_backend() == "gloo":
         dev = "cpu"
@@ -568,7 +568,7 @@ def train_step_bench(a, D, dev, world, dn, S, iters=10, warm=5):
                              loss_type="l2", use_p2=False, cond_drop_prob=0.25, guidance_weight=2, seq_len=S).to(dev)
     diff.train()
     optim = Adan(model.parameters(), lr=5e-5, weight_decay=0.02)
-    if world > 1:
+    if D.collectives_on():
         model.train_engine().enable_grad_sync()            # data-parallel gradient averaging is opt-in (dist.FlatGradientAllReducer)
     g = torch.Generator().manual_seed(4242 + int(os.environ.get("RANK", "0")))
     x = (torch.rand(b, dn, S, 151, generator=g) * 2 - 1).to(dev)
@@ -601,7 +601,7 @@ def train_step_bench(a, D, dev, world, dn, S, iters=10, warm=5):
                 tflops_per_gpu=round(fl / dt / 1e12, 1), mfma_frac_per_gpu=round(fl / dt / 1e12 / PEAK_BF16_TFLOPS, 4),
                 grad_allreduce=(dict(collectives_per_step=sync.launched // (iters + warm), mb_per_step=round(eng.n_grad * 4 / 1e6, 1),
                                      overlap="one async RCCL all-reduce per decoder layer, launched as its gradients complete")
-                                if (sync and world > 1) else None))
+                                if (sync and D.collectives_on()) else None))
 
 
 def main():

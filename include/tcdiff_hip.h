@@ -254,6 +254,9 @@ typedef struct {
     int out_ld;            /* *_LAST modes: 0 -> h_out = bf16 [M,512] rows of linear3; > 0 -> h_out = fp32 [M][out_ld], the
                               first out_ld columns of linear3 (the caller folded final_layer into its weights and bias:
                               model/model.py:344,623); out_ld % 4 == 0 */
+    int nw;                /* waves per workgroup: 0 or 8 = eight waves x 64 output columns; 4 = four waves x 128 columns, one per
+                              SIMD (TC_CHAIN_FULL, _FULL_LAST, _FRONT only).  `wstream` must be packed for the same form: per wave
+                              stages of 16 nt x 64 lanes x 16 B with nt = 4 (4-KB stages) or 8 (8-KB stages) n-tiles */
 } tcdiff_chain_args;
 
 int tcdiff_chain(const tcdiff_chain_args* args, hipStream_t stream);

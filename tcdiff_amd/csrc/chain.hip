@@ -57,11 +57,12 @@
 // four row tiles (the Q^T fragments wait in wave-private LDS meanwhile); a block whose rows straddle two sequences runs once
 // per sequence and every lane keeps the result of its own row's sequence.
 // Output: bf16 O rows into the activation block (columns 64 wave ..).
-template <int MT>
-DEVINL void cross_attention(const f32x4_t (&qacc)[4][MT], const tcdiff_chain_args& a, int m0, char* abuf, int wave, int lane) {
+// HH: which of the wave's NT / 4 heads (NT = 4: head = wave; NT = 8: heads 2 wave, 2 wave + 1 = accumulator tiles 4 HH ..)
+template <int HH, int MT, int NT>
+DEVINL void cross_attention(const f32x4_t (&qacc)[NT][MT], const tcdiff_chain_args& a, int m0, char* abuf, int wave, int lane) {
     constexpr int NPS = MT == 4 ? 2 : 1, NML = MT == 1 ? 1 : 2;     // passes of 32 rows, row tiles (independent chains) per pass
     lane = fresh_v(lane);
-    wave = fresh_s(wave);
+    wave = fresh_s(wave) * (NT / 4) + HH;          // from here on `wave` is the HEAD
     const int c = lane & 15, g = lane >> 4;
     const int M = a.M, L = a.L, nkt = a.nkt;
     u32x4 qf[MT][2];
@@ -69,7 +70,7 @@ DEVINL void cross_attention(const f32x4_t (&qacc)[4][MT], const tcdiff_chain_arg
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            const f32x4_t lo = qacc[2 * s][mt], hi = qacc[2 * s + 1][mt];
+            const f32x4_t lo = qacc[4 * HH + 2 * s][mt], hi = qacc[4 * HH + 2 * s + 1][mt];
             qf[mt][s][0] = pack_bf2(lo[0] * a.scale_q, lo[1] * a.scale_q);
             qf[mt][s][1] = pack_bf2(lo[2] * a.scale_q, lo[3] * a.scale_q);
             qf[mt][s][2] = pack_bf2(hi[0] * a.scale_q, hi[1] * a.scale_q);
@@ -217,9 +218,10 @@ DEVINL void cross_attention(const f32x4_t (&qacc)[4][MT], const tcdiff_chain_arg
 #endif
 
 // MT: 16-row tiles per block (4: 64-row blocks; 2, 1: small jobs, see tcdiff_chain)
-template <int MODE, int MT>
-__global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
+template <int MODE, int MT, int NT>
+__global__ __launch_bounds__(2048 / NT) void chain_kernel(tcdiff_chain_args a) {
     constexpr int BR = 16 * MT;        // rows per block
+    constexpr int NW = ChW<NT>::NW, NTH = 64 * NW, RD = ChW<NT>::D;   // waves, threads, ring depth
     constexpr bool HAS_A = MODE == TC_CHAIN_A || MODE == TC_CHAIN_FULL || MODE == TC_CHAIN_FULL_LAST;   // fc + norm2 + w_qs
     constexpr bool FULL = MODE == TC_CHAIN_FULL || MODE == TC_CHAIN_FULL_LAST;                          // + cross-attention
     constexpr bool LAST = MODE == TC_CHAIN_B_LAST || MODE == TC_CHAIN_FULL_LAST;
@@ -272,22 +274,32 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     // epilogue no longer reads the area.  The FiLM rows arrive PRE-FOLDED (tcdiff_chain_args.film): [G = g (scale + 1) |
     // Bv = b (scale + 1) + shift] with g, b the LayerNorm weights in front of the FiLM (or 1, linear2's bias), so an epilogue is
     // v = fma(u, G, Bv) + x (featurewise_affine, model/model.py:171-173, and the LayerNorm affine / bias in one step).
-    struct Consts { f32x4_t f, v0, v1; };
+    // (512 float4 of FiLM rows and 768 of vectors over NTH threads: float4 index j NTH + tid)
+    constexpr int CF = 512 / NTH, CV = (768 + NTH - 1) / NTH;
+    struct Consts { f32x4_t f[CF], v[CV]; };
     auto fetch_consts = [&](const float* film, const float* const (&vec)[6]) {
         Consts k;
-        int sq = seq0 + (tid >> 8);
-        sq = sq < seq_last ? sq : seq_last;
-        k.f = film ? ld4(film + (long)sq * a.film_ld + (tid & 255) * 4) : f32x4_t{0, 0, 0, 0};
-        const float* p0 = vec[tid >> 7];
-        const float* p1 = tid < 256 ? vec[4 + (tid >> 7)] : nullptr;
-        k.v0 = p0 ? ld4(p0 + (tid & 127) * 4) : f32x4_t{0, 0, 0, 0};
-        k.v1 = p1 ? ld4(p1 + (tid & 127) * 4) : f32x4_t{0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < CF; ++j) {
+            const int idx = j * NTH + tid;
+            int sq = seq0 + (idx >> 8);
+            sq = sq < seq_last ? sq : seq_last;
+            k.f[j] = film ? ld4(film + (long)sq * a.film_ld + (idx & 255) * 4) : f32x4_t{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int j = 0; j < CV; ++j) {
+            const int idx = j * NTH + tid;
+            const float* p0 = idx < 768 ? vec[idx >> 7] : nullptr;
+            k.v[j] = p0 ? ld4(p0 + (idx & 127) * 4) : f32x4_t{0, 0, 0, 0};
+        }
         return k;
     };
     auto store_consts = [&](const Consts& k) {
-        *reinterpret_cast<f32x4_t*>(cfilm + tid * 16) = k.f;
-        *reinterpret_cast<f32x4_t*>(cvec + tid * 16) = k.v0;
-        if (tid < 256) *reinterpret_cast<f32x4_t*>(cvec + 8192 + tid * 16) = k.v1;
+#pragma unroll
+        for (int j = 0; j < CF; ++j) *reinterpret_cast<f32x4_t*>(cfilm + (j * NTH + tid) * 16) = k.f[j];
+#pragma unroll
+        for (int j = 0; j < CV; ++j)
+            if (j * NTH + tid < 768) *reinterpret_cast<f32x4_t*>(cvec + (j * NTH + tid) * 16) = k.v[j];
     };
     auto vecp = [&](int slot) { return cvec + slot * 2048; };
     // constants of the fc block that opens chain B: its own set when chain A ran in front of it in this launch
@@ -297,21 +309,22 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
 
     // ---- the block's input rows (attention output) -> LDS, the first CH_D weight stages -> registers, constants -> LDS
     // (the LDS image keeps the 64-row geometry -- 8 KB per k-tile -- whatever MT: rows 16 MT .. 63 are simply unused)
-    if (wave < 2 * MT) {
+    constexpr int NWL = 2 * MT < NW ? 2 * MT : NW;     // waves that stage the rows (8 rows per wave instruction)
+    if (wave < NWL) {
 #pragma unroll
         for (int kt = 0; kt < (FRONT ? 16 : 8); ++kt)  // FRONT: rows of 1024 = the activation block and its twin, contiguous
-            stage_glds<BR, 2 * MT>(abuf + kt * 8192, reinterpret_cast<const char*>(a.A) + kt * TC_ROWB, FRONT ? 2048 : 1024, m0,
-                                   M, a.a_mod, wave, lane);
+            stage_glds<BR, NWL>(abuf + kt * 8192, reinterpret_cast<const char*>(a.A) + kt * TC_ROWB, FRONT ? 2048 : 1024, m0,
+                                M, a.a_mod, wave, lane);
     }
-    WStream ws;
+    WStreamT<NT> ws;
     ws.rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(reinterpret_cast<const char*>(a.wstream)) + ((long)dancer * 8 + wave) * a.n_stages * CH_STAGE, 0,
-        a.n_stages * CH_STAGE, 0x00020000);   // raw buffer (stride 0), bounds = the wave's stream, 32-bit data format
+        const_cast<char*>(reinterpret_cast<const char*>(a.wstream)) + ((long)dancer * NW + wave) * a.n_stages * ChW<NT>::STAGE, 0,
+        a.n_stages * ChW<NT>::STAGE, 0x00020000);   // raw buffer (stride 0), bounds = the wave's stream, 32-bit data format
     ws.voff = (unsigned)lane * 16u;
     ws.pos = 0;
     ws.last = (unsigned)a.n_stages - 1;
 #pragma unroll
-    for (int i = 0; i < CH_D; ++i) ws_load(ws, i, (unsigned)i);
+    for (int i = 0; i < RD; ++i) ws_load(ws, i, (unsigned)i);
     if (FRONT) {
         const float* const v[6] = {a.b3 + 512 * dancer, a.nn_g, a.nn_b, nullptr, nullptr, nullptr};
         store_consts(fetch_consts(nullptr, v));
@@ -325,7 +338,7 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     __syncthreads();
     CH_T(1);
 
-    f32x4_t acc[4][MT];
+    f32x4_t acc[NT][MT];
     float nmr[MT], rstd[MT];             // LayerNorm of the current rows: u = fma(v, rstd, nmr)
     RowPipe<MT> rp;                      // residual rows, later rotary rows, of this lane
     const long xrows = (long)M * dn;
@@ -342,7 +355,7 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
         // fresh copies: the two inlined instances of this epilogue must not share (and keep alive) their addresses
         const int gg = fresh_v(g), wv = fresh_s(wave);
         const Rows rw = rows();
-        const int cb0 = col_base_bytes(wv, gg);
+        const int cb0 = col_base_bytes<NT>(wv, gg);
         auto body = [&](int nt, int mt, const f32x4_t& G, const f32x4_t& Bv) {
             const f32x4_t x4 = rp.q[nt & 1][mt];
             f32x4_t o;
@@ -355,7 +368,7 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
             }
             // unguarded: rows past M rewrite row M - 1 with the SAME values (same inputs; every load of this column
             // group, in place or not, was issued before this store)
-            cb_store(xo, M, wv, nt, rw.mc[mt], gg, o);
+            cb_store<NT>(xo, M, wv, nt, rw.mc[mt], gg, o);
         };
         // (Measured in the listing and dropped: a second code path for blocks that lie in ONE sequence -- constants read once
         // per column quad instead of once per row tile.  The two paths raise the epilogue's register peak, hipcc spills ring
@@ -367,11 +380,11 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
             asm volatile("" : "+v"(fb[mt]));
         }
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
                 body(nt, mt, lds4b(cfilm + fb[mt], 64 * nt), lds4b(cfilm + fb[mt], 2048 + 64 * nt));
-            if (nt + 2 < 4) rp_issue(rp, nt + 2);
+            if (nt + 2 < NT) rp_issue(rp, nt + 2);
             // one n-tile at a time: without a fence hipcc hoists the loads of ALL of them (row pipeline refills and LDS
             // constants) above the arithmetic, needs ~100 more registers and spills them
             CH_FENCE();
@@ -382,24 +395,24 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
         int rr[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) rr[mt] = a.xres_mod > 0 ? rw.mc[mt] % a.xres_mod : rw.mc[mt];
-        rp_start(rp, a.xres, rr, a.xres_rowmajor ? 0 : (a.xres_mod > 0 ? a.xres_mod : M), a.xres_mod > 0 ? a.xres_mod : M, wave,
-                 fresh_v(g));
+        rp_start<NT>(rp, a.xres, rr, a.xres_rowmajor ? 0 : (a.xres_mod > 0 ? a.xres_mod : M), a.xres_mod > 0 ? a.xres_mod : M, wave,
+                     fresh_v(g));
     };
     auto xout_start = [&]() {          // the x this lane stored in an earlier epilogue of this launch
         const Rows rw = rows();
-        rp_start(rp, a.xout, rw.mc, M, M, wave, fresh_v(g));
+        rp_start<NT>(rp, a.xout, rw.mc, M, M, wave, fresh_v(g));
     };
     auto rope_start = [&]() {
         const Rows rw = rows();
         int pos[MT];
         positions(rw, pos);
-        rp_start(rp, a.rope, pos, a.rope_rows, a.rope_rows, wave, fresh_v(g));
+        rp_start<NT>(rp, a.rope, pos, a.rope_rows, a.rope_rows, wave, fresh_v(g));
     };
 
     if (HAS_A) {
         // ================= self-attention block tail: fc + LayerNorm(1e-6) + FiLM + residual, norm2 + rotary, w_qs
         zero(acc);
-        phase_n512<16, false, MT>(acc, abuf, ws, lane);
+        phase_n512<16, false, MT, NT>(acc, abuf, ws, lane);
         CH_T(2);
         xres_start();                  // in flight during the statistics exchange
         fc_epilogue(a.ln_eps, 40);
@@ -412,22 +425,23 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
         row_stats(acc, scr + 1024, wave, lane, a.n2_eps, nmr, rstd);
         CH_T(4);
         // norm2 + rotary (model/model.py:332,387) -> LDS -> Q = rot W_q^T / 8 (model/model.py:78,97)
-        norm_to_lds<true, MT>(acc, nmr, rstd, vecp(2), vecp(3), rp, abuf, wave, lane, nullptr);
+        norm_to_lds<true, MT, NT>(acc, nmr, rstd, vecp(2), vecp(3), rp, abuf, wave, lane, nullptr);
         lds_barrier();
         CH_T(34);
         if (FULL) store_consts(nxt);   // the cross-attention fc block's constants: read two barriers from here
         zero(acc);
         if (!FULL) {
-            phase_n512<16, false, MT>(acc, abuf, ws, lane);
-            store_heads<true, MT>(acc, a.q_out, a.scale_q, L, a.Lp, a.H, m0, M, wave, lane, smem);
+            phase_n512<16, false, MT, NT>(acc, abuf, ws, lane);
+            store_heads<true, MT, NT>(acc, a.q_out, a.scale_q, L, a.Lp, a.H, m0, M, wave, lane, smem);
             return;
         }
-        phase_n512<16, false, MT>(acc, abuf, ws, lane);
+        phase_n512<16, false, MT, NT>(acc, abuf, ws, lane);
         // ================= cross-attention in place (the Q image never leaves the registers)
         CH_T(35);
         lds_barrier();                 // every wave is out of the w_qs GEMM: the activation block becomes O
 #ifndef CH_ABLATE_XATTN   // (timing experiment)
-        cross_attention(acc, a, m0, abuf, wave, lane);
+        cross_attention<0>(acc, a, m0, abuf, wave, lane);
+        if constexpr (NT == 8) cross_attention<1>(acc, a, m0, abuf, wave, lane);
 #endif
         CH_T(36);
         lds_barrier();
@@ -435,7 +449,7 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     if constexpr (!FRONT) {
     // ================= cross-attention block tail: fc + LayerNorm(1e-6) + FiLM + residual (model/model.py:334)
     zero(acc);
-    phase_n512<16, false, MT>(acc, abuf, ws, lane);
+    phase_n512<16, false, MT, NT>(acc, abuf, ws, lane);
     if (FULL)
         xout_start();                  // the x this lane stored in the first fc epilogue
     else
@@ -450,7 +464,7 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
         const float* const v[6] = {a.b1, a.b1 + 512, nullptr, a.n4_g, a.n4_b, nullptr};
         nxt = fetch_consts(a.film3, v);
     }
-    norm_to_lds<false, MT>(acc, nmr, rstd, vecp(2), vecp(3), rp, abuf, wave, lane, nullptr);
+    norm_to_lds<false, MT, NT>(acc, nmr, rstd, vecp(2), vecp(3), rp, abuf, wave, lane, nullptr);
     lds_barrier();                     // nobody reads the fc constants any more
     store_consts(nxt);
     lds_barrier();                     // ... and everybody sees the feed-forward constants
@@ -463,23 +477,23 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     // fused phase is bound by VALU issue (~300 cycles of erf polynomial per 16 x 16 tile, two waves) instead.)
 #pragma unroll 1
     for (int ch = 0; ch < 4; ++ch) {
-        f32x4_t a1[2][MT];
+        f32x4_t a1[NT / 2][MT];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < NT / 2; ++nt)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) a1[nt][mt] = f32x4_t{0, 0, 0, 0};
-        phase_ff1(a1, abuf, ws, lane);
+        phase_ff1<MT, NT>(a1, abuf, ws, lane);
         CH_T(6 + 4 * ch);
         // two h1 buffers: chunk c - 2's linear2 reads of this one finished before the barrier of chunk c - 1
         char* hb = h1c + (ch & 1) * 32768;
         CH_T(7 + 4 * ch);
         {
-            const int nb = 256 * ch + 32 * wave + 4 * g;        // b1 occupies vector slots 0 and 1
+            const int nb = 256 * ch + 8 * NT * wave + 4 * g;    // b1 occupies vector slots 0 and 1
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
+            for (int nt = 0; nt < NT / 2; ++nt) {
                 const f32x4_t b4 = lds4(cvec, nb + 16 * nt);
-                // chunk column 32 wave + 16 nt + 4 g: k-tile wave / 2, 16-byte chunk 4 (wave & 1) + 2 nt + (g >> 1)
-                const int wo = (wave >> 1) * 8192 + act_wr_off(lane, nt, 4 * (wave & 1));
+                // chunk column cc = 8 NT wave + 16 nt (+ 4 g): k-tile cc / 64, 16-byte chunk (cc % 64) / 8 + (g >> 1)
+                const int wo = ((8 * NT * wave + 16 * nt) >> 6) * 8192 + act_wr_off(lane, 0, ((8 * NT * wave + 16 * nt) & 63) >> 3);
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     float v[4];
@@ -497,13 +511,13 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
         }
         lds_barrier();
         CH_T(8 + 4 * ch);
-        phase_n512<8, false, MT>(acc, hb, ws, lane);
+        phase_n512<8, false, MT, NT>(acc, hb, ws, lane);
         CH_T(9 + 4 * ch);
     }
     // linear2 bias, FiLM, residual (the x this lane stored above), norm4 -> LDS
     xout_start();
     {
-        const int cb2 = col_base_bytes(fresh_s(wave), fresh_v(g));
+        const int cb2 = col_base_bytes<NT>(fresh_s(wave), fresh_v(g));
         const Rows rw = rows();
         auto body2 = [&](int nt, int mt, const f32x4_t& G, const f32x4_t& Bv) {
             const f32x4_t x4 = rp.q[nt & 1][mt];
@@ -520,11 +534,11 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
             asm volatile("" : "+v"(fb2[mt]));
         }
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
                 body2(nt, mt, lds4b(cfilm + fb2[mt], 64 * nt), lds4b(cfilm + fb2[mt], 2048 + 64 * nt));
-            if (nt + 2 < 4) rp_issue(rp, nt + 2);
+            if (nt + 2 < NT) rp_issue(rp, nt + 2);
             CH_FENCE();
         }
     }
@@ -535,7 +549,7 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     }
     row_stats(acc, scr, wave, lane, a.n4_eps, nmr, rstd);      // (its barrier: every wave is out of the last linear2 chunk)
     CH_T(23);
-    norm_to_lds<false, MT>(acc, nmr, rstd, vecp(3), vecp(4), rp, abuf, wave, lane, nullptr);
+    norm_to_lds<false, MT, NT>(acc, nmr, rstd, vecp(3), vecp(4), rp, abuf, wave, lane, nullptr);
     lds_barrier();
     store_consts(nxt);                 // b3, norm1': read after the barrier that follows linear3
     }   // !FRONT
@@ -544,20 +558,20 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     CH_T(24);
     zero(acc);
     if (FRONT)
-        phase_n512<32, false, MT>(acc, abuf, ws, lane);
+        phase_n512<32, false, MT, NT>(acc, abuf, ws, lane);
     else if (LAST)
-        phase_n512<16, true, MT>(acc, abuf, ws, lane);
+        phase_n512<16, true, MT, NT>(acc, abuf, ws, lane);
     else
-        phase_n512<16, false, MT>(acc, abuf, ws, lane);
+        phase_n512<16, false, MT, NT>(acc, abuf, ws, lane);
     CH_T(25);
     lds_barrier();
     {
         const int g3 = fresh_v(g);
-        const int cb3 = col_base_bytes(fresh_s(wave), g3);
+        const int cb3 = col_base_bytes<NT>(fresh_s(wave), g3);
         const Rows rw = rows();
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const int n = 64 * wave + 16 * nt + 4 * g3;
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = 16 * NT * wave + 16 * nt + 4 * g3;
             const f32x4_t b4 = lds4b(vecp(0) + cb3, 64 * nt);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
@@ -578,7 +592,7 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
                     pk.y = pack_bf2(o[2], o[3]);
                     *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.h_out) + (long)rw.mc[mt] * 512 + n) = pk;
                 } else {
-                    cb_store(xo, xrows, wave, nt, rw.mc[mt] * dn + dancer, g3, o);
+                    cb_store<NT>(xo, xrows, wave, nt, rw.mc[mt] * dn + dancer, g3, o);
                 }
             }
             CH_FENCE();
@@ -590,22 +604,22 @@ __global__ __launch_bounds__(512) void chain_kernel(tcdiff_chain_args a) {
     rope_start();
     row_stats(acc, scr, wave, lane, a.nn_eps, nmr, rstd);
     CH_T(27);
-    norm_to_lds<true, MT>(acc, nmr, rstd, vecp(1), vecp(2), rp, abuf, wave, lane, smem + CH_ABUF2);
+    norm_to_lds<true, MT, NT>(acc, nmr, rstd, vecp(1), vecp(2), rp, abuf, wave, lane, smem + CH_ABUF2);
     lds_barrier();
     CH_T(28);
     zero(acc);
-    phase_n512<16, false, MT>(acc, abuf, ws, lane);
+    phase_n512<16, false, MT, NT>(acc, abuf, ws, lane);
     CH_T(29);
-    store_heads<true, MT>(acc, a.q_out, a.scale_q, L, a.Lp, a.H, m0, M, wave, lane, smem, dn, dancer);
+    store_heads<true, MT, NT>(acc, a.q_out, a.scale_q, L, a.Lp, a.H, m0, M, wave, lane, smem, dn, dancer);
     zero(acc);
-    phase_n512<16, false, MT>(acc, abuf, ws, lane);
+    phase_n512<16, false, MT, NT>(acc, abuf, ws, lane);
     CH_T(30);
-    store_heads<false, MT>(acc, a.k_out, 1.0f, L, a.Lp, a.H, m0, M, wave, lane, smem, dn, dancer);
+    store_heads<false, MT, NT>(acc, a.k_out, 1.0f, L, a.Lp, a.H, m0, M, wave, lane, smem, dn, dancer);
     CH_T(31);
     zero(acc);
-    phase_n512<16, true, MT>(acc, smem + CH_ABUF2, ws, lane);
+    phase_n512<16, true, MT, NT>(acc, smem + CH_ABUF2, ws, lane);
     CH_T(32);
-    store_heads<false, MT>(acc, a.v_out, 1.0f, L, a.Lp, a.H, m0, M, wave, lane, smem, dn, dancer);
+    store_heads<false, MT, NT>(acc, a.v_out, 1.0f, L, a.Lp, a.H, m0, M, wave, lane, smem, dn, dancer);
     CH_T(33);
     CH_TC(61);
 }
@@ -651,10 +665,11 @@ extern "C" int tcdiff_chain(const tcdiff_chain_args* a, hipStream_t stream) {
         return TC_ERR_ARG;
     static tc_dev_state dev_state;
     const int n_cu = tc_device_once(dev_state, [](int) {
-#define CH_FN(M_) reinterpret_cast<const void*>(chain_kernel<M_, 4>), reinterpret_cast<const void*>(chain_kernel<M_, 2>), \
-                   reinterpret_cast<const void*>(chain_kernel<M_, 1>)
-        const void* fns[18] = {CH_FN(TC_CHAIN_A), CH_FN(TC_CHAIN_B), CH_FN(TC_CHAIN_B_LAST), CH_FN(TC_CHAIN_FULL),
-                               CH_FN(TC_CHAIN_FULL_LAST), CH_FN(TC_CHAIN_FRONT)};
+#define CH_FN(M_, NT_) reinterpret_cast<const void*>(chain_kernel<M_, 4, NT_>), reinterpret_cast<const void*>(chain_kernel<M_, 2, NT_>), \
+                        reinterpret_cast<const void*>(chain_kernel<M_, 1, NT_>)
+        const void* fns[27] = {CH_FN(TC_CHAIN_A, 4), CH_FN(TC_CHAIN_B, 4), CH_FN(TC_CHAIN_B_LAST, 4), CH_FN(TC_CHAIN_FULL, 4),
+                               CH_FN(TC_CHAIN_FULL_LAST, 4), CH_FN(TC_CHAIN_FRONT, 4),
+                               CH_FN(TC_CHAIN_FULL, 8), CH_FN(TC_CHAIN_FULL_LAST, 8), CH_FN(TC_CHAIN_FRONT, 8)};
 #undef CH_FN
         for (const void* f : fns) {
             hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, CH_SMEM);
@@ -672,21 +687,30 @@ extern "C" int tcdiff_chain(const tcdiff_chain_args* a, hipStream_t stream) {
     if (mt == 0) mt = ((a->M + 15) / 16) * units <= n_cu ? 1 : ((a->M + 31) / 32) * units <= n_cu ? 2 : 4;
     if (mt != 1 && mt != 2 && mt != 4) return TC_ERR_ARG;
     dim3 grid(((a->M + 16 * mt - 1) / (16 * mt)) * units);
-#define CH_LAUNCH(MODE_)                                                                                              \
-    do {                                                                                                              \
-        if (mt == 4) hipLaunchKernelGGL((chain_kernel<MODE_, 4>), grid, dim3(512), CH_SMEM, stream, *a);              \
-        else if (mt == 2) hipLaunchKernelGGL((chain_kernel<MODE_, 2>), grid, dim3(512), CH_SMEM, stream, *a);         \
-        else hipLaunchKernelGGL((chain_kernel<MODE_, 1>), grid, dim3(512), CH_SMEM, stream, *a);                      \
+    // a->nw: waves per workgroup.  0 / 8: eight waves of 64 columns (two per SIMD); 4: four waves of 128 columns, one per SIMD
+    // with the 512-register budget (the production modes only: FULL, FULL_LAST, FRONT; the weight stream is packed per form)
+    if (a->nw != 0 && a->nw != 4 && a->nw != 8) return TC_ERR_ARG;
+    const bool four = a->nw == 4;
+    if (four && !(full || front)) return TC_ERR_UNSUPPORTED;
+#define CH_LAUNCH_NT(MODE_, NT_)                                                                                              \
+    do {                                                                                                                      \
+        if (mt == 4) hipLaunchKernelGGL((chain_kernel<MODE_, 4, NT_>), grid, dim3(2048 / NT_), CH_SMEM, stream, *a);          \
+        else if (mt == 2) hipLaunchKernelGGL((chain_kernel<MODE_, 2, NT_>), grid, dim3(2048 / NT_), CH_SMEM, stream, *a);     \
+        else hipLaunchKernelGGL((chain_kernel<MODE_, 1, NT_>), grid, dim3(2048 / NT_), CH_SMEM, stream, *a);                  \
     } while (0)
+#define CH_LAUNCH(MODE_) CH_LAUNCH_NT(MODE_, 4)
+#define CH_LAUNCH2(MODE_) do { if (four) CH_LAUNCH_NT(MODE_, 8); else CH_LAUNCH_NT(MODE_, 4); } while (0)
     switch (a->mode) {
-        case TC_CHAIN_FRONT: CH_LAUNCH(TC_CHAIN_FRONT); break;
+        case TC_CHAIN_FRONT: CH_LAUNCH2(TC_CHAIN_FRONT); break;
         case TC_CHAIN_A: CH_LAUNCH(TC_CHAIN_A); break;
         case TC_CHAIN_B: CH_LAUNCH(TC_CHAIN_B); break;
         case TC_CHAIN_B_LAST: CH_LAUNCH(TC_CHAIN_B_LAST); break;
-        case TC_CHAIN_FULL: CH_LAUNCH(TC_CHAIN_FULL); break;
-        default: CH_LAUNCH(TC_CHAIN_FULL_LAST); break;
+        case TC_CHAIN_FULL: CH_LAUNCH2(TC_CHAIN_FULL); break;
+        default: CH_LAUNCH2(TC_CHAIN_FULL_LAST); break;
     }
 #undef CH_LAUNCH
+#undef CH_LAUNCH2
+#undef CH_LAUNCH_NT
     TC_CHECK_LAUNCH();
     return TC_OK;
 }

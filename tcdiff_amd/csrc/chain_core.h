@@ -17,6 +17,17 @@
 #define CH_SMEM 163840
 #define CH_D 4               // weight stages in flight per wave (registers): 4 x 4 KB x 8 waves = 128 KB per CU
 #define CH_STAGE 4096
+#ifndef CH_D8
+#define CH_D8 4              // ... of the 4-wave form (NT = 8: 8-KB stages, 32 registers each): 4 x 8 KB x 4 waves = 128 KB per CU
+#endif
+// NT = 16-column n-tiles per wave: 4 -> 8 waves x 64 columns (two waves per SIMD, <= 256 registers each), 8 -> 4 waves x 128
+// columns (ONE wave per SIMD with the 512-register budget: every LDS activation fragment feeds 8 MFMAs instead of 4, the
+// LayerNorm exchange is between 4 waves, and a wave's own MFMA stream is long enough to carry independent VALU work).
+template <int NT> struct ChW {
+    static constexpr int NW = 32 / NT;                 // waves per workgroup
+    static constexpr int D = NT == 8 ? CH_D8 : CH_D;   // ring depth in stages
+    static constexpr int STAGE = 1024 * NT;            // bytes per stage = one 32-deep k-step of the wave's 16 NT weight rows
+};
 
 typedef const float* fptr;
 // accumulators: f32x4_t acc[4 n-tiles][MT m-tiles of 16 rows]; MT = 4 (64-row blocks: the benchmark), 2 or 1 (small jobs:
@@ -30,18 +41,21 @@ DEVINL void mma16(f32x4_t& acc, const u32x4& a, const u32x4& b) {
 // so they never need LDS: a stage is four coalesced 1-KB global loads straight into the registers the MFMAs read, and
 // the ring of CH_D stages in flight is a register array indexed at compile time (every loop over it is unrolled).
 // The compiler counts vmcnt for these loads itself.  Past the end of the stream the last stage is re-read (never used).
-struct WStream {
+template <int NT = 4>
+struct WStreamT {
     __amdgpu_buffer_rsrc_t rsrc;   // this wave's stream as a raw buffer: a stage address is SGPR descriptor + SGPR stage
     unsigned voff;                 // offset + this one VGPR (lane * 16)
     unsigned pos;      // stages consumed so far (wave-uniform)
     unsigned last;     // index of the last stage
-    u32x4 w[CH_D][4];
+    u32x4 w[ChW<NT>::D][NT];
 };
-DEVINL void ws_load(WStream& ws, int slot, unsigned stage) {
+typedef WStreamT<4> WStream;
+template <int NT>
+DEVINL void ws_load(WStreamT<NT>& ws, int slot, unsigned stage) {
     const unsigned st = stage < ws.last ? stage : ws.last;
-    const unsigned so = st * CH_STAGE;                       // scalar
+    const unsigned so = st * (unsigned)ChW<NT>::STAGE;       // scalar
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NT; ++i)
         ws.w[slot][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ws.rsrc, ws.voff + 1024u * i, so, 0));
 }
 // IR-level fence for memory operations + machine-scheduler fence for everything: keeps an unrolled epilogue loop one
@@ -63,10 +77,10 @@ DEVINL int fresh_s(int x) {
 }
 
 DEVINL f32x4_t ld4(const float* p) { return *reinterpret_cast<const f32x4_t*>(p); }
-template <int MT>
-DEVINL void zero(f32x4_t (&a)[4][MT]) {
+template <int MT, int NT>
+DEVINL void zero(f32x4_t (&a)[NT][MT]) {
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) a[nt][mt] = f32x4_t{0, 0, 0, 0};
 }
@@ -121,18 +135,29 @@ DEVINL float ar4_sum(float v) {
 }
 
 // every accumulator tile through an (empty) asm statement: orders the MFMAs in front of it before everything behind it
-template <int MT>
-DEVINL void acc_fence(f32x4_t (&a)[4][MT]) {
-    if constexpr (MT == 4) {
-#pragma unroll
-        for (int nt = 0; nt < 4; nt += 2)
-            asm volatile("" : "+v"(a[nt][0]), "+v"(a[nt][1]), "+v"(a[nt][2]), "+v"(a[nt][3]), "+v"(a[nt + 1][0]), "+v"(a[nt + 1][1]),
-                         "+v"(a[nt + 1][2]), "+v"(a[nt + 1][3]));
-    } else if constexpr (MT == 2) {
-        asm volatile("" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[2][0]), "+v"(a[2][1]), "+v"(a[3][0]),
-                     "+v"(a[3][1]));
+// (NT = 8: the 128 accumulator registers of a 4-wave block live in the ACCUMULATOR half of the wave's 512 registers -- the
+// fence must name them with the "a" constraint, or every stage copies all of them to VGPRs and back)
+#define CH_ACC_FENCE_BODY(C_)                                                                                                    \
+    if constexpr (MT == 4) {                                                                                                     \
+        _Pragma("unroll") for (int nt = 0; nt < NT; nt += 2)                                                                     \
+            asm volatile("" : C_(a[nt][0]), C_(a[nt][1]), C_(a[nt][2]), C_(a[nt][3]), C_(a[nt + 1][0]), C_(a[nt + 1][1]),       \
+                         C_(a[nt + 1][2]), C_(a[nt + 1][3]));                                                                    \
+    } else if constexpr (MT == 2) {                                                                                              \
+        _Pragma("unroll") for (int nt = 0; nt < NT; nt += 4)                                                                     \
+            asm volatile("" : C_(a[nt][0]), C_(a[nt][1]), C_(a[nt + 1][0]), C_(a[nt + 1][1]), C_(a[nt + 2][0]),                  \
+                         C_(a[nt + 2][1]), C_(a[nt + 3][0]), C_(a[nt + 3][1]));                                                  \
+    } else {                                                                                                                     \
+        _Pragma("unroll") for (int nt = 0; nt < NT; nt += 4)                                                                     \
+            asm volatile("" : C_(a[nt][0]), C_(a[nt + 1][0]), C_(a[nt + 2][0]), C_(a[nt + 3][0]));                               \
+    }
+#define CH_CV(x) "+v"(x)
+#define CH_CA(x) "+a"(x)
+template <int MT, int NT>
+DEVINL void acc_fence(f32x4_t (&a)[NT][MT]) {
+    if constexpr (NT == 8 && MT > 1) {
+        CH_ACC_FENCE_BODY(CH_CA)
     } else {
-        asm volatile("" : "+v"(a[0][0]), "+v"(a[1][0]), "+v"(a[2][0]), "+v"(a[3][0]));
+        CH_ACC_FENCE_BODY(CH_CV)
     }
 }
 // the next stage's B fragments through the stage fence (see phase_n512)
@@ -170,9 +195,10 @@ DEVINL u32x4 frag_rd(const FragOff& f, int ks, int mt) {
 // copy of the most recently loaded slot at the loop header -- i.e. `s_waitcnt vmcnt(0)`, a full drain of the wave's
 // weight stream, every CH_D stages.  The activation fragments of stage ks + 1 are read before the MFMAs of stage ks.
 // TAIL: the launch's last phase -- its last CH_D stages refill nothing (there is nothing behind them).
-template <int NST, bool TAIL = false, int MT = 4>
-DEVINL void phase_n512(f32x4_t (&acc)[4][MT], const char* abuf, WStream& ws, int lane) {
-    static_assert(NST % CH_D == 0, "a phase starts and ends at ring slot 0");
+template <int NST, bool TAIL = false, int MT = 4, int NT = 4>
+DEVINL void phase_n512(f32x4_t (&acc)[NT][MT], const char* abuf, WStreamT<NT>& ws, int lane) {
+    constexpr int RD = ChW<NT>::D;
+    static_assert(NST % RD == 0, "a phase starts and ends at ring slot 0");
     lane = fresh_v(lane);
     const FragOff fo = frag_off(abuf, lane);
     u32x4 b[MT];
@@ -187,9 +213,11 @@ DEVINL void phase_n512(f32x4_t (&acc)[4][MT], const char* abuf, WStream& ws, int
     }
 #pragma unroll
     for (int ks = 0; ks < NST; ++ks) {
-        const int i = ks % CH_D;
-        const u32x4 w0 = ws.w[i][0], w1 = ws.w[i][1], w2 = ws.w[i][2], w3 = ws.w[i][3];
-        if (!(TAIL && ks + CH_D >= NST)) ws_load(ws, i, base + ks + CH_D);
+        const int i = ks % RD;
+        u32x4 wv[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) wv[nt] = ws.w[i][nt];
+        if (!(TAIL && ks + RD >= NST)) ws_load(ws, i, base + ks + RD);
         u32x4 nb[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) nb[mt] = b[mt];
@@ -205,10 +233,8 @@ DEVINL void phase_n512(f32x4_t (&acc)[4][MT], const char* abuf, WStream& ws, int
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            mma16(acc[0][mt], w0, b[mt]);
-            mma16(acc[1][mt], w1, b[mt]);
-            mma16(acc[2][mt], w2, b[mt]);
-            mma16(acc[3][mt], w3, b[mt]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) mma16(acc[nt][mt], wv[nt], b[mt]);
         }
         __builtin_amdgcn_sched_barrier(0);   // ... and the MFMAs do not sink below the next stage's reads either
         // Stage fence.  Memory clobber: the refill stays in its own stage, the stream never drains.  The next stage's
@@ -225,8 +251,9 @@ DEVINL void phase_n512(f32x4_t (&acc)[4][MT], const char* abuf, WStream& ws, int
 }
 // linear1 chunk: a1[nt][mt] (columns 32 wave + 16 nt + ..) += act[64 x 512] * W1 chunk; a stage = 2 k-steps of the wave's
 // 32 rows: fragments [k-step 2][n-tile 2]
-template <int MT>
-DEVINL void phase_ff1(f32x4_t (&a1)[2][MT], const char* abuf, WStream& ws, int lane) {
+template <int MT, int NT = 4>
+DEVINL void phase_ff1(f32x4_t (&a1)[NT / 2][MT], const char* abuf, WStreamT<NT>& ws, int lane) {
+    constexpr int RD = ChW<NT>::D, NH = NT / 2;      // a stage = 2 k-steps x NH n-tiles of the wave's 16 NH chunk rows
     lane = fresh_v(lane);
     const FragOff fo = frag_off(abuf, lane);
     u32x4 b[MT];
@@ -235,9 +262,11 @@ DEVINL void phase_ff1(f32x4_t (&a1)[2][MT], const char* abuf, WStream& ws, int l
     const unsigned base = ws.pos;
 #pragma unroll
     for (int st = 0; st < 8; ++st) {
-        const int i = st % CH_D;
-        const u32x4 wk[4] = {ws.w[i][0], ws.w[i][1], ws.w[i][2], ws.w[i][3]};
-        ws_load(ws, i, base + st + CH_D);
+        const int i = st % RD;
+        u32x4 wk[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) wk[nt] = ws.w[i][nt];
+        ws_load(ws, i, base + st + RD);
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
             const int ks = 2 * st + k2;
@@ -251,17 +280,23 @@ DEVINL void phase_ff1(f32x4_t (&a1)[2][MT], const char* abuf, WStream& ws, int l
             __builtin_amdgcn_sched_barrier(0);   // see phase_n512
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                mma16(a1[0][mt], wk[2 * k2], b[mt]);
-                mma16(a1[1][mt], wk[2 * k2 + 1], b[mt]);
+#pragma unroll
+                for (int n = 0; n < NH; ++n) mma16(a1[n][mt], wk[NH * k2 + n], b[mt]);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (MT == 4)
-                asm volatile("" : "+v"(a1[0][0]), "+v"(a1[0][1]), "+v"(a1[0][2]), "+v"(a1[0][3]), "+v"(a1[1][0]), "+v"(a1[1][1]),
-                             "+v"(a1[1][2]), "+v"(a1[1][3]));
-            else if constexpr (MT == 2)
-                asm volatile("" : "+v"(a1[0][0]), "+v"(a1[0][1]), "+v"(a1[1][0]), "+v"(a1[1][1]));
-            else
-                asm volatile("" : "+v"(a1[0][0]), "+v"(a1[1][0]));
+#pragma unroll
+            for (int n = 0; n < NH; n += 2) {
+                if constexpr (NT == 8 && MT == 4)
+                    asm volatile("" : "+a"(a1[n][0]), "+a"(a1[n][1]), "+a"(a1[n][2]), "+a"(a1[n][3]), "+a"(a1[n + 1][0]),
+                                 "+a"(a1[n + 1][1]), "+a"(a1[n + 1][2]), "+a"(a1[n + 1][3]));
+                else if constexpr (MT == 4)
+                    asm volatile("" : "+v"(a1[n][0]), "+v"(a1[n][1]), "+v"(a1[n][2]), "+v"(a1[n][3]), "+v"(a1[n + 1][0]),
+                                 "+v"(a1[n + 1][1]), "+v"(a1[n + 1][2]), "+v"(a1[n + 1][3]));
+                else if constexpr (MT == 2)
+                    asm volatile("" : "+v"(a1[n][0]), "+v"(a1[n][1]), "+v"(a1[n + 1][0]), "+v"(a1[n + 1][1]));
+                else
+                    asm volatile("" : "+v"(a1[n][0]), "+v"(a1[n + 1][0]));
+            }
             frag_fence(nb);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) b[mt] = nb[mt];
@@ -276,8 +311,8 @@ DEVINL void phase_ff1(f32x4_t (&a1)[2][MT], const char* abuf, WStream& ws, int l
 // Returns rstd and nmr = -mean * rstd: the normalised value is fma(v, rstd, nmr), one op per element instead of two.
 // Lane l finishes row l of the block (reduce-scatter over the lane groups, then the 8 waves' pairs in wave order: the
 // sums are deterministic), and the four lane groups exchange their rows' (rstd, nmr) by swaps.
-template <int MT>
-DEVINL void row_stats(const f32x4_t (&acc)[4][MT], float* scr, int wave, int lane, float eps, float (&nmr)[MT], float (&rstd)[MT]) {
+template <int MT, int NT>
+DEVINL void row_stats(const f32x4_t (&acc)[NT][MT], float* scr, int wave, int lane, float eps, float (&nmr)[MT], float (&rstd)[MT]) {
     lane = fresh_v(lane);
     wave = fresh_s(wave);
     float s[MT], s2[MT];
@@ -285,7 +320,7 @@ DEVINL void row_stats(const f32x4_t (&acc)[4][MT], float* scr, int wave, int lan
     for (int mt = 0; mt < MT; ++mt) {
         f32x2_t t = {0.0f, 0.0f}, t2 = {0.0f, 0.0f};
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int q = 0; q < 4; q += 2) {
                 const f32x2_t v = {acc[nt][mt][q], acc[nt][mt][q + 1]};
@@ -321,7 +356,7 @@ DEVINL void row_stats(const f32x4_t (&acc)[4][MT], float* scr, int wave, int lan
     lds_barrier();
     f32x2_t tot = {0.0f, 0.0f};
 #pragma unroll
-    for (int w = 0; w < 8; ++w) tot += *reinterpret_cast<const f32x2_t*>(scr + (w * 64 + row) * 2);
+    for (int w = 0; w < ChW<NT>::NW; ++w) tot += *reinterpret_cast<const f32x2_t*>(scr + (w * 64 + row) * 2);
     const float mean = tot[0] * (1.0f / 512.0f);
     const float var = fmaxf(tot[1] * (1.0f / 512.0f) - mean * mean, 0.0f);
     const float rs = rsqrtf(var + eps);
@@ -348,8 +383,9 @@ DEVINL f32x4_t lds4(const char* base, int float_index) {
 }
 // Byte offset of this lane's first column (64 wave + 4 g) in a 512-float LDS vector, as a value the compiler cannot take
 // apart: the per-iteration column offsets (64 nt bytes) then fold into the ds_read immediates.
+template <int NT = 4>
 DEVINL int col_base_bytes(int wave, int g) {
-    int v = (64 * wave + 4 * g) * 4;
+    int v = (16 * NT * wave + 4 * g) * 4;
     asm volatile("" : "+v"(v));
     return v;
 }
@@ -379,12 +415,12 @@ DEVINL void rp_issue(RowPipe<MT>& rp, int nt) {
             f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rp.rsrc, rp.voff[mt], rp.soff + (unsigned)nt * rp.its, 0));
 }
 // rows: row count of the column-blocked matrix, or 0 for a row-major one (`total_rows` rows of 512 floats)
-template <int MT>
+template <int NT, int MT>
 DEVINL void rp_start(RowPipe<MT>& rp, const float* base, const int (&row)[MT], long rows, long total_rows, int wave, int g) {
     rp.rsrc = f32_buffer(base, total_rows * 512);
     const unsigned grp = rows > 0 ? (unsigned)rows * 32u : 0u;       // bytes per column group of 8
     rp.its = rows > 0 ? 2u * grp : 64u;
-    rp.soff = rows > 0 ? (unsigned)wave * 8u * grp : (unsigned)wave * 256u;
+    rp.soff = rows > 0 ? (unsigned)wave * (2u * NT) * grp : (unsigned)wave * (64u * NT);
     const unsigned gterm = rows > 0 ? (unsigned)(g >> 1) * grp + 16u * (g & 1) : 16u * g;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -393,11 +429,12 @@ DEVINL void rp_start(RowPipe<MT>& rp, const float* base, const int (&row)[MT], l
     rp_issue(rp, 1);
 }
 // store this lane's 16 bytes (columns 64 wave + 16 nt + 4 g ..) of row `row` of a column-blocked matrix of `rows` rows
+template <int NT = 4>
 DEVINL void cb_store(__amdgpu_buffer_rsrc_t rsrc, long rows, int wave, int nt, int row, int g, f32x4_t v) {
     const unsigned grp = (unsigned)rows * 32u;
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc,
                                            (unsigned)row * 32u + (unsigned)(g >> 1) * grp + 16u * (g & 1),
-                                           (unsigned)(wave * 8 + 2 * nt) * grp, 0);
+                                           (unsigned)(wave * 2 * NT + 2 * nt) * grp, 0);
 }
 
 // LDS byte offset of this lane's 8 bytes (4 bf16: columns 16 nt + 4 g .. of the wave's k-tile) of row 16 mt + c in a
@@ -409,17 +446,17 @@ DEVINL int act_wr_off(int lane, int nt, int chunk0 = 0) {
 
 // u = LayerNorm(acc) (optionally rotated) -> bf16 -> activation block in LDS (k = column); gv, bv: LDS vectors;
 // rp: the rotary rows (cos0 sin0 cos1 sin1 per column quad), started by the caller before the statistics exchange
-template <bool ROT, int MT>
-DEVINL void norm_to_lds(const f32x4_t (&acc)[4][MT], const float (&nmr)[MT], const float (&rstd)[MT], const char* gv,
+template <bool ROT, int MT, int NT>
+DEVINL void norm_to_lds(const f32x4_t (&acc)[NT][MT], const float (&nmr)[MT], const float (&rstd)[MT], const char* gv,
                         const char* bv, RowPipe<MT>& rp, char* abuf, int wave, int lane, char* plain) {
     lane = fresh_v(lane);
     wave = fresh_s(wave);
     const int g = lane >> 4;
-    const int cb0 = col_base_bytes(wave, g);
+    const int cb0 = col_base_bytes<NT>(wave, g);
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
+    for (int nt = 0; nt < NT; ++nt) {
         const f32x4_t g4 = lds4b(gv + cb0, 64 * nt), b4 = lds4b(bv + cb0, 64 * nt);
-        const int wo = wave * 8192 + act_wr_off(lane, nt);
+        const int wo = ((wave * NT + nt) >> 2) * 8192 + act_wr_off(lane, nt & 3);      // k-tile = 64 columns
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             float u[4];
@@ -442,7 +479,7 @@ DEVINL void norm_to_lds(const f32x4_t (&acc)[4][MT], const float (&nmr)[MT], con
             pk.y = pack_bf2(u[2], u[3]);
             *reinterpret_cast<uint2*>(abuf + wo + mt * 2048) = pk;
         }
-        if (ROT && nt + 2 < 4) rp_issue(rp, nt + 2);
+        if (ROT && nt + 2 < NT) rp_issue(rp, nt + 2);
         CH_FENCE();   // one n-tile at a time (see the fc epilogue)
     }
 }
@@ -453,8 +490,8 @@ DEVINL void norm_to_lds(const f32x4_t (&acc)[4][MT], const float (&nmr)[MT], con
 // -- wave-private, XOR-swizzled by (row >> 1) & 7 (the 64 banks hold two 128-byte rows), no barrier -- and leaves as 16
 // bytes per lane, 8 lanes per 128-byte row: 8 full lines per instruction.
 DEVINL char* stage_area(char* smem, int wave) { return smem + (wave < 7 ? wave * 4096 : CH_STG7); }
-template <bool SCALE, int MT>   // Q carries 1 / sqrt(d_k); K and V are stored as they are
-DEVINL void store_heads(const f32x4_t (&acc)[4][MT], void* base, float scale, int L, int Lp, int H, int m0, int M,
+template <bool SCALE, int MT, int NT>   // Q carries 1 / sqrt(d_k); K and V are stored as they are
+DEVINL void store_heads(const f32x4_t (&acc)[NT][MT], void* base, float scale, int L, int Lp, int H, int m0, int M,
                         int wave, int lane, char* smem, int dn = 1, int dancer = 0) {
     // rows are FRAMES m0 .. of dancer `dancer` (token = frame dn + dancer; dn = 1: rows are tokens); L tokens per sequence
 #ifdef CH_ABLATE_STORES   // timing experiment only: how much of the Q / K / V tail is the head-major scatter?
@@ -468,13 +505,16 @@ DEVINL void store_heads(const f32x4_t (&acc)[4][MT], void* base, float scale, in
     const int Lf = L / dn;                          // frames per sequence
     constexpr int NH = MT == 4 ? 2 : 1, NML = MT == 1 ? 1 : 2;      // 32-row halves of the block, row tiles per half
 #pragma unroll
+    for (int hh = 0; hh < NT / 4; ++hh) {            // the wave's heads (NT = 4: wave = head; NT = 8: two heads per wave)
+    const int head = wave * (NT / 4) + hh;
+#pragma unroll
     for (int hf = 0; hf < NH; ++hf) {
 #pragma unroll
         for (int ml = 0; ml < NML; ++ml) {
             const int rl = 16 * ml + c;             // row of the 32-row staging tile
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                const f32x4_t v = acc[nt][2 * hf + ml];
+                const f32x4_t v = acc[4 * hh + nt][2 * hf + ml];
                 uint2 pk;
                 if (SCALE) {
                     pk.x = pack_bf2(v[0] * scale, v[1] * scale);
@@ -498,7 +538,7 @@ DEVINL void store_heads(const f32x4_t (&acc)[4][MT], void* base, float scale, in
         int tokf = m - seq * Lf;
         // destination of (sequence, head = wave, token, chunk): +8 frames = +8 dn tokens of 128 bytes; past the end of a
         // sequence the next one starts (H * Lp - L) rows further
-        uint16_t* dst = reinterpret_cast<uint16_t*>(base) + (((long)seq * H + wave) * Lp + tokf * dn + dancer) * 64 + ch * 8;
+        uint16_t* dst = reinterpret_cast<uint16_t*>(base) + (((long)seq * H + head) * Lp + tokf * dn + dancer) * 64 + ch * 8;
         const long wrap = ((long)H * Lp - L) * 64;
 #pragma unroll
         for (int k = 0; k < 2 * NML; ++k) {
@@ -513,5 +553,6 @@ DEVINL void store_heads(const f32x4_t (&acc)[4][MT], void* base, float scale, in
                 dst += wrap;
             }
         }
+    }
     }
 }

@@ -15,13 +15,26 @@ import torch
 import torch.distributed as dist
 
 
+def _force() -> bool:
+    """TCDIFF_DIST_FORCE=1 (tests): a ONE-rank process group is treated like any other -- it is created, and gather / timing /
+    barrier / gradient averaging go through their collectives instead of taking the world-size-1 shortcut.  RCCL accepts a
+    one-rank communicator, so this is how every nccl-only branch of this module (ReduceOp.AVG, all_gather_into_tensor on
+    device memory, stream-ordered wait()) runs on a one-GPU box (tests/test_rccl_world1_gpu.py)."""
+    return os.environ.get("TCDIFF_DIST_FORCE", "0") == "1"
+
+
+def collectives_on(group=None) -> bool:
+    """whether the job's collectives are to be issued: a process group exists and has more than one rank (or _force())"""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or _force())
+
+
 def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
     """Initialise the default process group from RANK / WORLD_SIZE / MASTER_* (torchrun contract).
     Returns (rank, world_size, local_rank).  A single process without the env vars is world_size 1."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or _force()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -41,7 +54,7 @@ def shard_range(n_clips: int, rank: int, world: int) -> Tuple[int, int]:
 def gather_samples(local: torch.Tensor, n_clips: int) -> torch.Tensor:
     """All-gather per-rank samples (b_local, L, F) into (n_clips, L, F) on every rank, in global clip order.
     Equal shards use one all_gather_into_tensor (a single RCCL collective); ragged shards pad to the largest."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not collectives_on():
         return local
     world = dist.get_world_size()
     sizes = [shard_range(n_clips, r, world) for r in range(world)]
@@ -62,7 +75,7 @@ def gather_samples(local: torch.Tensor, n_clips: int) -> torch.Tensor:
 
 
 def max_over_ranks(seconds: float, device) -> float:
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not collectives_on():
         return seconds
     t = torch.tensor([seconds], device="cpu" if dist.get_backend() == "gloo" else device, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -70,7 +83,7 @@ def max_over_ranks(seconds: float, device) -> float:
 
 
 def barrier():
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if collectives_on():
         dist.barrier()
 
 
@@ -129,7 +142,7 @@ class FlatGradientAllReducer:
         self.launched = 0
 
     def active(self) -> bool:
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        return collectives_on(self.group)
 
     def ready(self, flat: torch.Tensor, lo: int, hi: int, more: bool = True):
         """`more` (whether the backward has launches left behind this range) only matters to the capture stand-in of

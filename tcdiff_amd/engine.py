@@ -70,6 +70,9 @@ class DenoiserEngine:
         self.fold_out = self.use_chain and os.environ.get("TCDIFF_FOLD_OUT", "1") != "0"
         # ... and the last fusion linear + layer 0's norm1 / rotary / Q, K, V as one chain launch per (frame block, dancer)
         self.front = self.use_full and os.environ.get("TCDIFF_FRONT", "1") != "0" and self.S >= 8
+        self.chain_nw = int(os.environ.get("TCDIFF_CHAIN_NW", "8"))      # waves per workgroup of the chain launches (8 or 4)
+        if self.chain_nw not in (4, 8):
+            raise L.TcdiffError("TCDIFF_CHAIN_NW must be 8 or 4")
         self.reset_graphs()
 
     def reset_graphs(self):
@@ -113,25 +116,27 @@ class DenoiserEngine:
     _PI = (0, 3, 1, 2)
 
     @staticmethod
-    def _stages_n512(W: torch.Tensor) -> torch.Tensor:
-        """[512, K] -> [8 waves][K/32 stages][2048]: stage = [n-tile 4][lane group 4][16 weight rows][8 k] of one 32-deep
-        k-step of the wave's 64 rows (wave w: rows 64 w ..; row 16 nt + c, k = 32 ks + 8 PI[g] + j)."""
-        K_ = W.shape[1]
-        w6 = W.reshape(8, 4, 16, K_ // 32, 4, 8)[:, :, :, :, list(DenoiserEngine._PI), :]     # [w, nt, c, ks, g, j]
-        return w6.permute(0, 3, 1, 4, 2, 5).reshape(8, K_ // 32, 2048)
+    def _stages_n512(W: torch.Tensor, nw: int = 8) -> torch.Tensor:
+        """[512, K] -> [nw waves][K/32 stages][512 NT]: stage = [n-tile NT][lane group 4][16 weight rows][8 k] of one 32-deep
+        k-step of the wave's 16 NT rows (NT = 32 / nw; wave w: rows 16 NT w ..; row 16 nt + c, k = 32 ks + 8 PI[g] + j)."""
+        K_, NT = W.shape[1], 32 // nw
+        w6 = W.reshape(nw, NT, 16, K_ // 32, 4, 8)[:, :, :, :, list(DenoiserEngine._PI), :]     # [w, nt, c, ks, g, j]
+        return w6.permute(0, 3, 1, 4, 2, 5).reshape(nw, K_ // 32, 512 * NT)
 
     @staticmethod
-    def _stages_ff1(W1: torch.Tensor) -> torch.Tensor:
-        """[1024, 512] -> [4 chunks][8 waves][8 stages][2048]: wave w owns rows 256 c + 32 w .. of chunk c; stage =
-        [k-step 2][n-tile 2][lane group 4][16 rows][8 k]."""
-        w8 = W1.reshape(4, 8, 2, 16, 8, 2, 4, 8)[:, :, :, :, :, :, list(DenoiserEngine._PI), :]   # [ch, w, nt, c, st, k2, g, j]
-        return w8.permute(0, 1, 4, 5, 2, 6, 3, 7).reshape(4, 8, 8, 2048)
+    def _stages_ff1(W1: torch.Tensor, nw: int = 8) -> torch.Tensor:
+        """[1024, 512] -> [4 chunks][nw waves][8 stages][512 NT]: wave w owns rows 256 c + 8 NT w .. of chunk c; stage =
+        [k-step 2][n-tile NT / 2][lane group 4][16 rows][8 k]."""
+        NH = 16 // nw
+        w8 = W1.reshape(4, nw, NH, 16, 8, 2, 4, 8)[:, :, :, :, :, :, list(DenoiserEngine._PI), :]   # [ch, w, nt, c, st, k2, g, j]
+        return w8.permute(0, 1, 4, 5, 2, 6, 3, 7).reshape(4, nw, 8, 1024 * NH)
 
     @staticmethod
-    def _stages_ff2(W2: torch.Tensor) -> torch.Tensor:
-        """[512, 1024] -> [4 chunks][8 waves][8 stages][2048]: the k-slice [256 c, 256 c + 256) of every row."""
-        w7 = W2.reshape(8, 4, 16, 4, 8, 4, 8)[:, :, :, :, :, list(DenoiserEngine._PI), :]       # [w, nt, c, ch, ks, g, j]
-        return w7.permute(3, 0, 4, 1, 5, 2, 6).reshape(4, 8, 8, 2048)
+    def _stages_ff2(W2: torch.Tensor, nw: int = 8) -> torch.Tensor:
+        """[512, 1024] -> [4 chunks][nw waves][8 stages][512 NT]: the k-slice [256 c, 256 c + 256) of every row."""
+        NT = 32 // nw
+        w7 = W2.reshape(nw, NT, 16, 4, 8, 4, 8)[:, :, :, :, :, list(DenoiserEngine._PI), :]       # [w, nt, c, ch, ks, g, j]
+        return w7.permute(3, 0, 4, 1, 5, 2, 6).reshape(4, nw, 8, 512 * NT)
 
     @staticmethod
     def _ffn_order(f1, f2):
@@ -140,41 +145,48 @@ class DenoiserEngine:
 
     def _build_chain_streams(self):
         w = self.w
+        # waves per workgroup of the production launches (TC_CHAIN_FRONT / _FULL / _FULL_LAST): 8 x 64 columns or 4 x 128 columns
+        # (tcdiff_chain_args.nw); chain A / B alone -- the reference points of tests -- keep the 8-wave form
+        nw = self.chain_nw
+        n512 = self._stages_n512
         if self.front:
             # TC_CHAIN_FRONT: per dancer, the 512 rows of the last fusion linear it owns (K = 1024: 32 stages), then layer
             # 0's w_qs / w_ks / w_vs (16 stages each)
             qkv = w["l0.qkv.w"]
-            tail = [self._stages_n512(qkv[0:512]), self._stages_n512(qkv[512:1024]), self._stages_n512(qkv[1024:1536])]
-            w["front"] = torch.stack([torch.cat([self._stages_n512(w["f3.w"][512 * d:512 * d + 512])] + tail, 1)
-                                      for d in range(self.dn)]).contiguous()          # [dn][8 waves][80][2048]
+            tail = [n512(qkv[0:512], nw), n512(qkv[512:1024], nw), n512(qkv[1024:1536], nw)]
+            w["front"] = torch.stack([torch.cat([n512(w["f3.w"][512 * d:512 * d + 512], nw)] + tail, 1)
+                                      for d in range(self.dn)]).contiguous()          # [dn][nw waves][80][512 NT]
         for l in range(self.NL):
             p = f"l{l}."
-            w[p + "chainA"] = torch.cat([self._stages_n512(w[p + "sfc.w"]), self._stages_n512(w[p + "cq.w"])],
-                                        1).contiguous()
-            f1, f2 = self._stages_ff1(w[p + "ff1.w"]), self._stages_ff2(w[p + "ff2.w"])
-            parts = [self._stages_n512(w[p + "cfc.w"])] + self._ffn_order(f1, f2)
             if l + 1 < self.NL or not self.fold_out:
-                parts.append(self._stages_n512(w[p + "l3.w"]))
+                W3 = w[p + "l3.w"]
             else:
                 # the last layer's linear3 and final_layer are two linear maps with nothing in between
                 # (model/model.py:344,623): W_f (W_3 h + b_3) + b_f.  The chain's last GEMM takes W_f W_3 (151 of its 512
                 # output rows, the rest zero) and writes the network output itself; no separate final projection launch.
-                W3 = self.sd_f32(f"seqTransDecoder.stack.{l}.linear3.weight")
+                W3f = self.sd_f32(f"seqTransDecoder.stack.{l}.linear3.weight")
                 b3 = self.sd_f32(f"seqTransDecoder.stack.{l}.linear3.bias")
                 Wf, bf = self.sd_f32("final_layer.weight"), self.sd_f32("final_layer.bias")
                 Wo = torch.zeros(512, 512, device=self.dev, dtype=torch.float32)
-                Wo[:self.nf] = Wf @ W3
+                Wo[:self.nf] = Wf @ W3f
                 bo = torch.zeros(512, device=self.dev, dtype=torch.float32)
                 bo[:self.nf] = Wf @ b3 + bf
                 w[p + "l3out.b"] = bo.contiguous()
-                parts.append(self._stages_n512(Wo.to(self.T).contiguous()))
-            if l + 1 < self.NL:
-                qkv = w[f"l{l + 1}.qkv.w"]
-                parts += [self._stages_n512(qkv[0:512]), self._stages_n512(qkv[512:1024]),
-                          self._stages_n512(qkv[1024:1536])]
-            w[p + "chainB"] = torch.cat(parts, 1).contiguous()
+                W3 = Wo.to(self.T).contiguous()
+
+            def chain_a(n):
+                return torch.cat([n512(w[p + "sfc.w"], n), n512(w[p + "cq.w"], n)], 1)
+
+            def chain_b(n):
+                f1, f2 = self._stages_ff1(w[p + "ff1.w"], n), self._stages_ff2(w[p + "ff2.w"], n)
+                parts = [n512(w[p + "cfc.w"], n)] + self._ffn_order(f1, f2) + [n512(W3, n)]
+                if l + 1 < self.NL:
+                    qkv = w[f"l{l + 1}.qkv.w"]
+                    parts += [n512(qkv[0:512], n), n512(qkv[512:1024], n), n512(qkv[1024:1536], n)]
+                return torch.cat(parts, 1)
+            w[p + "chainA"], w[p + "chainB"] = chain_a(8).contiguous(), chain_b(8).contiguous()
             if self.use_full:
-                w[p + "chainF"] = torch.cat([w[p + "chainA"], w[p + "chainB"]], 1).contiguous()
+                w[p + "chainF"] = torch.cat([chain_a(nw), chain_b(nw)], 1).contiguous()
 
     def _f32(self, t: torch.Tensor) -> torch.Tensor:
         return t.detach().to(device=self.dev, dtype=torch.float32).contiguous()

@@ -74,6 +74,8 @@ def test_chained_network_matches_op_by_op_network(dn, S, B):
 
 
 MTS = pytest.mark.parametrize("mt", [4, 2, 1])      # 16-row tiles per row block (tcdiff_chain_args.mt: 64 / 32 / 16-row blocks)
+# waves per workgroup of the production launches (tcdiff_chain_args.nw): eight waves x 64 columns or four x 128 columns
+NWS = pytest.mark.parametrize("nw", [8, 4])
 
 
 @MTS
@@ -195,8 +197,9 @@ def test_chain_b_kernel_against_op_by_op_sequence(last, mt):
 
 @pytest.mark.parametrize("S", [60, 150])      # 62 keys: the rolled cross-attention loop; 152 keys = 5 tiles: the pipelined one
 @MTS
+@NWS
 @pytest.mark.parametrize("last", [False, True])
-def test_fused_layer_chain_against_chain_a_attention_chain_b(last, S, mt):
+def test_fused_layer_chain_against_chain_a_attention_chain_b(last, S, mt, nw):
     """TC_CHAIN_FULL (cross-attention inside the launch, K / V from the fragment-ordered images) against the three
     launches it replaces on the same random data: blocks that straddle two sequences (L = 120: the second 32-row tile of
     block 1 crosses a sequence boundary), a shared null-conditioning slot for the first sequences, a ragged tail."""
@@ -232,7 +235,13 @@ def test_fused_layer_chain_against_chain_a_attention_chain_b(last, S, mt):
         partsB += [E._stages_n512(W["qkv"][i * 512:(i + 1) * 512]) for i in range(3)]
     wsA = torch.cat([E._stages_n512(W["sfc"]), E._stages_n512(W["cq"])], 1).contiguous()
     wsB = torch.cat(partsB, 1).contiguous()
-    wsF = torch.cat([wsA, wsB], 1).contiguous()
+    g1, g2 = E._stages_ff1(W["ff1"], nw), E._stages_ff2(W["ff2"], nw)          # the fused launch's stream, in its wave form
+    partsF = [E._stages_n512(W["sfc"], nw), E._stages_n512(W["cq"], nw), E._stages_n512(W["cfc"], nw)] + E._ffn_order(g1, g2)
+    partsF.append(E._stages_n512(W["l3"], nw))
+    if not last:
+        partsF += [E._stages_n512(W["qkv"][i * 512:(i + 1) * 512], nw) for i in range(3)]
+    wsF = torch.cat(partsF, 1).contiguous()
+    assert wsF.shape == (nw, wsA.shape[1] + wsB.shape[1], 16384 // nw)
     ff = folded(film, {0: (gs[0], gs[1]), 2048: (gs[4], gs[5]), 4096: (None, bias2)})
     tail = dict(b1=bias1, film3=ff[:, 4096:], n4_g=gs[6], n4_b=gs[7], b3=bias3, nn_g=None if last else gs[8],
                 nn_b=None if last else gs[9], scale_q=0.125, Lp=Lp, H=H)
@@ -268,7 +277,8 @@ def test_fused_layer_chain_against_chain_a_attention_chain_b(last, S, mt):
 
 
 @MTS
-def test_front_chain_against_rowln_plus_qkv_tile(mt):
+@NWS
+def test_front_chain_against_rowln_plus_qkv_tile(mt, nw):
     """TC_CHAIN_FRONT (last fusion linear of each dancer over 64-frame blocks + layer 0's norm1 / rotary / Q, K, V) against
     the two launches it replaces, gemm_rowln with dancer groups and the QKV gemm_tile, on random data: 3 dancers, frames
     per sequence not a multiple of anything (S = 70: blocks straddle sequences), a ragged last block."""
@@ -295,9 +305,9 @@ def test_front_chain_against_rowln_plus_qkv_tile(mt):
                 scale_q=0.125, Lseq=Lq, Lp=Lp, H=H, n_q=512, n_k=512)
     # ---- one launch
     E = DenoiserEngine
-    tail = [E._stages_n512(Wqkv[i * 512:(i + 1) * 512]) for i in range(3)]
-    ws = torch.stack([torch.cat([E._stages_n512(W3[512 * d:512 * d + 512])] + tail, 1) for d in range(dn)]).contiguous()
-    assert ws.shape == (dn, 8, 80, 2048)
+    tail = [E._stages_n512(Wqkv[i * 512:(i + 1) * 512], nw) for i in range(3)]
+    ws = torch.stack([torch.cat([E._stages_n512(W3[512 * d:512 * d + 512], nw)] + tail, 1) for d in range(dn)]).contiguous()
+    assert ws.shape == (dn, nw, 80, 16384 // nw)
     xs2 = z(Rs, 512, dtype=torch.float32)
     Q2, K2, V2 = z(nseq, H, Lp, 64), z(nseq, H, Lp, 64), z(nseq, H, Lp, 64)
     K.chain(L.CHAIN_FRONT, Mf, Lq, f2, ws, mt=mt, b3=b3, nn_g=g1, nn_b=b1, nn_eps=1e-5, rope=K.to_cb(rope), xout=xs2, q_out=Q2,
@@ -315,7 +325,8 @@ def test_front_chain_against_rowln_plus_qkv_tile(mt):
 
 
 @MTS
-def test_fused_layer_chain_against_a_torch_evaluation_of_the_layer_tail(mt):
+@NWS
+def test_fused_layer_chain_against_a_torch_evaluation_of_the_layer_tail(mt, nw):
     """ONE TC_CHAIN_FULL launch against a plain torch (float64) evaluation of model/model.py:103-106,327,331-344 and the next
     layer's :326,374-383 on the same bf16 operands -- not against another kernel of this library.  The reference rounds to
     bf16 exactly where the kernel hands an activation to an MFMA (GEMM / attention operands), nowhere else."""
@@ -342,11 +353,11 @@ def test_fused_layer_chain_against_a_torch_evaluation_of_the_layer_tail(mt):
     Vc[:, :, :Lk] = rnd(n_kv, H, Lk, 64, seed=196).to(bf)
     z = lambda *s, dtype=bf: torch.zeros(*s, device=DEV, dtype=dtype)
     E = DenoiserEngine
-    f1, f2 = E._stages_ff1(W["ff1"]), E._stages_ff2(W["ff2"])
-    parts = [E._stages_n512(W["sfc"]), E._stages_n512(W["cq"]), E._stages_n512(W["cfc"])]
+    f1, f2 = E._stages_ff1(W["ff1"], nw), E._stages_ff2(W["ff2"], nw)
+    parts = [E._stages_n512(W["sfc"], nw), E._stages_n512(W["cq"], nw), E._stages_n512(W["cfc"], nw)]
     parts += E._ffn_order(f1, f2)
-    parts.append(E._stages_n512(W["l3"]))
-    parts += [E._stages_n512(W["qkv"][i * 512:(i + 1) * 512]) for i in range(3)]
+    parts.append(E._stages_n512(W["l3"], nw))
+    parts += [E._stages_n512(W["qkv"][i * 512:(i + 1) * 512], nw) for i in range(3)]
     wsF = torch.cat(parts, 1).contiguous()
     Kf, Vf = z(n_kv, H, nkt * 2048), z(n_kv, H, nkt * 2048)
     K.pack_kv_frags(Kc, Vc, Kf, Vf, n_kv, H, Lpc, nkt, 0, Lk)

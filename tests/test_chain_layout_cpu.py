@@ -35,7 +35,7 @@ def act_frag(act, ks, mt):
 
 
 def run_gemm(stages, act, wave, nst, ntiles=4, k2=1):
-    """stages: [nst][2048] of one wave; returns acc[nt][mt][64][4]"""
+    """stages: [nst][512 ntiles k2] of one wave; returns acc[nt][mt][64][4]"""
     acc = np.zeros((ntiles, 4, 64, 4))
     for st in range(nst):
         fr = stages[st].reshape(k2, ntiles, 64, 8)
@@ -88,6 +88,38 @@ def test_weight_stream_images_compute_the_gemms():
         for ch in range(4):
             tot += acc_to_matrix(run_gemm(s2[ch, wave], h1[:, 256 * ch:256 * ch + 256], wave, 8), 64)
         assert np.array_equal(tot, want[:, 64 * wave:64 * wave + 64])
+
+
+def test_four_wave_stream_images_compute_the_gemms():
+    """the 4-wave form (tcdiff_chain_args.nw = 4: wave w owns 128 columns = 8 n-tiles, 8-KB stages)"""
+    rng = np.random.default_rng(2)
+    for K_ in (512, 1024):
+        W = rng.integers(-3, 4, (512, K_)).astype(np.float64)
+        act = rng.integers(-3, 4, (64, K_)).astype(np.float64)
+        st = E._stages_n512(torch.from_numpy(W), 4).numpy()
+        assert st.shape == (4, K_ // 32, 4096)
+        want = act @ W.T
+        for wave in (0, 3):
+            got = acc_to_matrix(run_gemm(st[wave], act, wave, K_ // 32, ntiles=8), 128)
+            assert np.array_equal(got, want[:, 128 * wave:128 * wave + 128])
+    W1 = rng.integers(-3, 4, (1024, 512)).astype(np.float64)
+    act = rng.integers(-3, 4, (64, 512)).astype(np.float64)
+    s1 = E._stages_ff1(torch.from_numpy(W1), 4).numpy()
+    assert s1.shape == (4, 4, 8, 4096)
+    want = act @ W1.T
+    for ch, wave in ((0, 0), (2, 1), (3, 3)):
+        got = acc_to_matrix(run_gemm(s1[ch, wave], act, wave, 8, ntiles=4, k2=2), 64)
+        assert np.array_equal(got, want[:, 256 * ch + 64 * wave:256 * ch + 64 * wave + 64])
+    W2 = rng.integers(-3, 4, (512, 1024)).astype(np.float64)
+    h1 = rng.integers(-3, 4, (64, 1024)).astype(np.float64)
+    s2 = E._stages_ff2(torch.from_numpy(W2), 4).numpy()
+    assert s2.shape == (4, 4, 8, 4096)
+    want = h1 @ W2.T
+    for wave in (1, 2):
+        tot = np.zeros((64, 128))
+        for ch in range(4):
+            tot += acc_to_matrix(run_gemm(s2[ch, wave], h1[:, 256 * ch:256 * ch + 256], wave, 8, ntiles=8), 128)
+        assert np.array_equal(tot, want[:, 128 * wave:128 * wave + 128])
 
 
 def kf_index(key, d):

@@ -1,0 +1,154 @@
+"""RCCL's code paths on the test box's ONE GPU: a world-size-1 `nccl` process group on cuda:0 (RCCL accepts a one-rank
+communicator) with TCDIFF_DIST_FORCE=1, which makes tcdiff_amd.dist issue its collectives instead of taking the world-size-1
+shortcut.  Everything the first multi-GPU run depends on and gloo cannot exercise then runs on RCCL for real (SURVEY.md 8(e),
+reference TCDiff.py:51-52,232): communicator creation, `ReduceOp.AVG` on the flat gradient buffer launched between the replayed
+backward segments (RCCL's own stream behind an event of the compute stream, stream-ordered `wait()`), `all_gather_into_tensor`
+on device memory, the MAX all-reduce of the timing, the barrier -- and bench.py as a rank of such a group."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import json, os, sys
+sys.path.insert(0, os.environ["TC_ROOT"])
+import numpy as np, torch, torch.nn.functional as F
+import torch.distributed as dist
+from oracle import tcdiff_oracle as O                      # synthetic weights / inputs only
+from tcdiff_amd import Adan, dist as D
+from tcdiff_amd.diffusion import GaussianDiffusion
+from tcdiff_amd.model import DanceDecoder
+sync_on = os.environ.get("TCDIFF_DIST_FORCE", "0") == "1"
+rank, world, _ = D.init_from_env()                         # backend None -> "nccl" on a GPU box
+torch.cuda.set_device(0)
+DEV, DN, S, T, b = "cuda", 2, 60, 100, 2
+out = {"world": world, "sync_on": sync_on, "initialized": dist.is_initialized()}
+if sync_on:
+    assert dist.get_backend() == "nccl" and D.collectives_on()
+    # the collectives by themselves: ReduceOp.AVG over one rank is the identity, bit for bit; so is the gather
+    g = torch.Generator().manual_seed(5)
+    v = torch.randn(1 << 20, generator=g).to(DEV)
+    w = v.clone()
+    h = dist.all_reduce(w, op=dist.ReduceOp.AVG, async_op=True)
+    h.wait()
+    out["avg_identity"] = bool(torch.equal(v, w))
+    x = torch.randn(3, 120, 151, generator=g).to(DEV)
+    y = D.gather_samples(x, 3)
+    out["gather_identity"] = bool(y.data_ptr() != x.data_ptr() and torch.equal(x, y))
+    out["max_over_ranks"] = D.max_over_ranks(0.125, torch.device(DEV))
+    D.barrier()
+model = DanceDecoder(nfeats=151, seq_len=S, latent_dim=512, ff_size=1024, num_layers=8, num_heads=8, dropout=0.1,
+                     cond_feature_dim=438, activation=F.gelu, required_dancer_num=DN, compute_dtype="f32")
+model.load_state_dict(O.synth_state_dict(dn=DN, seq_len=S))
+diff = GaussianDiffusion(model, S, 151, None, schedule="cosine", n_timestep=T, predict_epsilon=False, loss_type="l2",
+                         use_p2=False, cond_drop_prob=0.25, guidance_weight=2, seq_len=S).to(DEV)
+diff.eval()
+optim = Adan(model.parameters(), lr=1e-4, weight_decay=0.02)
+if sync_on:
+    model.train_engine().enable_grad_sync()
+def data(step):
+    c0 = 10 * step
+    x = torch.stack([O.synth_motion(c0 + c, DN * S).reshape(S, DN, 151).permute(1, 0, 2) for c in range(b)])
+    cond = torch.stack([O.synth_cond(c0 + c, S) for c in range(b)])
+    noise = torch.stack([O.synth_xT(c0 + c, DN * S).reshape(S, DN, 151) for c in range(b)])
+    t = torch.tensor([(7 * (c0 + c) + 3) % T for c in range(b)])
+    keep = torch.tensor([(c0 + c) % 3 != 0 for c in range(b)])
+    return x, cond, noise, t, keep
+for step in range(5):
+    x, cond, noise, t, keep = data(step)
+    total, _ = diff.p_losses(x.to(DEV), cond.to(DEV), t.to(DEV), noise=noise.to(DEV), keep_mask=keep.to(DEV))
+    optim.zero_grad()
+    total.backward()
+    if step in (0, 4):                                     # step 0: eager schedule; step 4: replayed segments
+        out[f"grad{step}"] = {n: float(p.grad.double().norm()) for n, p in model.named_parameters() if p.grad is not None}
+    optim.step()
+torch.cuda.synchronize()
+eng = model.train_engine()
+out["collectives"] = eng.grad_sync.launched if eng.grad_sync else 0
+out["graph_broken"] = eng._graph_broken
+out["bwd_captured"] = any(st["bwd"] is not None for st in eng._graphs.values())
+out["bwd_segments"] = max([len(st["bwd_segs"]) for st in eng._graphs.values() if st.get("bwd_segs")] or [0])
+out["psum"] = {n: float(p.detach().double().sum()) for n, p in model.named_parameters()}
+out["rccl_mapped"] = any("librccl" in ln for ln in open("/proc/self/maps"))
+print("RESULT " + json.dumps(out), flush=True)
+if dist.is_initialized():
+    dist.barrier()
+    dist.destroy_process_group()
+'''
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _env(force):
+    env = dict(os.environ, TC_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "TCDIFF_DIST_FORCE", "TCDIFF_GRAD_SYNC"):
+        env.pop(k, None)
+    if force:
+        env.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", TCDIFF_DIST_FORCE="1")
+    return env
+
+
+def _worker(force):
+    r = subprocess.run([sys.executable, "-c", WORKER], env=_env(force), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+
+
+def test_training_step_with_real_rccl_collectives_equals_the_unsynchronised_step():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    rc = _worker(True)
+    one = _worker(False)
+    assert rc["initialized"] and rc["world"] == 1 and rc["rccl_mapped"], rc
+    assert not one["initialized"] and one["collectives"] == 0
+    # the collectives themselves: averaging over one rank and gathering one shard change no bit
+    assert rc["avg_identity"] and rc["gather_identity"] and rc["max_over_ranks"] == 0.125
+    # >= 10 all-reduces per step on RCCL's stream; from the third step on they are launched BETWEEN nine replayed hipGraph
+    # segments of the backward (train_engine._capture_bwd_segments), which only a stream-ordered wait() survives
+    assert rc["collectives"] >= 5 * 10 and rc["graph_broken"] is None and not rc["bwd_captured"] and rc["bwd_segments"] == 9
+    assert one["bwd_captured"] and one["bwd_segments"] == 0
+    # AVG over one rank is the identity, so the synchronised job IS the unsynchronised one up to the fp32 atomics' summation
+    # order inside the weight-gradient kernels (two runs of either differ by as much): gradients of the eager step 0 and of the
+    # replayed step 4, parameters after five Adan steps
+    for k in ("grad0", "grad4"):
+        assert set(rc[k]) == set(one[k])
+        rel = max(abs(rc[k][n] - one[k][n]) / (one[k][n] + 1e-30) for n in one[k])
+        assert rel < (2e-5 if k == "grad0" else 5e-2), (k, rel)      # step 4: four Adan steps of drift (sign-like updates)
+    worst = max(abs(rc["psum"][n] - one["psum"][n]) / (abs(one["psum"][n]) + 1.0) for n in one["psum"])
+    assert worst < 1e-3, worst
+
+
+def test_bench_py_as_a_rank_of_a_one_rank_rccl_group(tmp_path):
+    """bench.py started the way the driver's launcher starts a rank (RANK / WORLD_SIZE / MASTER_* in the environment), backend
+    nccl: rank_facts' all-reduce and all-gather, the result gather, the barriers and the max-over-ranks timing run on RCCL;
+    the samples equal those of the plain one-process run bit for bit."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    flags = ["--gpus", "1", "--batch", "2", "--steps", "1", "--warmup", "1", "--ddpm-steps", "24", "--no-cpu-baseline",
+             "--no-parity-mode", "--no-kernel-profile", "--no-train-step", "--no-other-configs"]
+    outs = []
+    for force in (True, False):
+        dump = str(tmp_path / f"s{int(force)}.pt")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dump-samples", dump] + flags, capture_output=True,
+                           text=True, env=_env(force), cwd=ROOT, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1
+        j = json.loads(lines[0])
+        assert j["n_gpus"] == 1 and j["ranks_seen"] == 1 and j["clip_ranges"] == [[0, 2]] and j["value"] > 0
+        outs.append(torch.load(dump))
+    assert torch.equal(outs[0], outs[1])

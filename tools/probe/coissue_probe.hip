@@ -138,6 +138,76 @@ float run_same(int mi, float* out, int nb, int with_mfma) {
     return ms / 10 * 1e3f;
 }
 
+// Round 5 (VERDICT r4 "what's weak" #5): in `probe` the MFMA waves issue back to back, so one MFMA is always WAITING at issue for
+// the matrix pipe.  If a waiting MFMA holds the SIMD's vector issue port, "sum, not max" would mean "a wave that camps on the
+// port blocks its neighbour", not "waves never overlap".  Here the MFMA waves pad every MFMA with PAD x `s_nop 7` (scalar: no
+// vector issue slot), so that with enough padding no MFMA ever waits at issue; PRIO raises the VALU waves' priority.
+template <int SHAPE, int PAD, int PRIO>
+__global__ __launch_bounds__(512) void probe_pad(int mode, int mi, int vi, float* out) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wave < 4) {
+        if (!(mode & 1)) return;
+        bf16x8_t a, b;
+        for (int j = 0; j < 8; ++j) { a[j] = (__bf16)(0.001f * (lane + j)); b[j] = (__bf16)(0.002f * (lane - j)); }
+        if (SHAPE == 32) {
+            f32x16_t c[4] = {};
+            for (int i = 0; i < mi; ++i) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    c[k & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c[k & 3], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < PAD; ++q) asm volatile("s_nop 7");
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            out[blockIdx.x * 512 + threadIdx.x] = c[0][0] + c[1][1] + c[2][2] + c[3][3];
+        } else {
+            f32x4_t c[8] = {};
+            for (int i = 0; i < mi; ++i) {
+#pragma unroll
+                for (int k = 0; k < 32; ++k) {
+                    c[k & 7] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c[k & 7], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < PAD; ++q) asm volatile("s_nop 7");
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            out[blockIdx.x * 512 + threadIdx.x] = c[0][0] + c[1][1] + c[2][2] + c[3][3] + c[4][0] + c[5][1] + c[6][2] + c[7][3];
+        }
+    } else {
+        if (!(mode & 2)) return;
+        if (PRIO) __builtin_amdgcn_s_setprio(PRIO);
+        float x[16], sum = 0.f;
+        for (int j = 0; j < 16; ++j) x[j] = 0.01f * (lane + j);
+        const float l2 = 1.0001f, nm = -1e-6f;
+        for (int i = 0; i < vi; ++i) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {         // six unpacked single-issue instructions per element (asm: -O3 would re-pack)
+                float y = x[j];
+                asm volatile("v_fma_f32 %0, %0, %1, %2\n\tv_fma_f32 %0, %0, %2, %1\n\tv_fma_f32 %0, %0, %1, %2\n\t"
+                             "v_fma_f32 %0, %0, %2, %1\n\tv_fma_f32 %0, %0, %1, %2\n\tv_add_f32 %0, %0, %1"
+                             : "+v"(y) : "v"(l2), "v"(nm));
+                sum += y;
+                x[j] = y;
+            }
+        }
+        out[blockIdx.x * 512 + threadIdx.x] = sum;
+    }
+}
+template <int SHAPE, int PAD, int PRIO>
+float run_pad(int mode, int mi, int vi, float* out, int nb) {
+    hipEvent_t s, e;
+    (void)hipEventCreate(&s); (void)hipEventCreate(&e);
+    for (int i = 0; i < 2; ++i) probe_pad<SHAPE, PAD, PRIO><<<nb, 512>>>(mode, mi, vi, out);
+    (void)hipEventRecord(s);
+    for (int i = 0; i < 10; ++i) probe_pad<SHAPE, PAD, PRIO><<<nb, 512>>>(mode, mi, vi, out);
+    (void)hipEventRecord(e); (void)hipEventSynchronize(e);
+    float ms; (void)hipEventElapsedTime(&ms, s, e);
+    return ms / 10 * 1e3f;
+}
+
 int main() {
     float* out; (void)hipMalloc(&out, 256 * 512 * 4);
     const int mi = 2000, vi = 1400;
@@ -165,6 +235,19 @@ int main() {
                run_same<32, NV_, true>(1000, out, nb, 1), run_same<32, NV_, true>(1000, out, nb, 0));
         UROW(2) UROW(4) UROW(6) UROW(8)
 #undef UROW
+    }
+    // padded MFMA waves (no MFMA waits at issue once the pad covers the pipe time) against unpacked-VALU waves, one block
+    {
+        const int nb = 1, mi2 = 1000, vi2 = 1400;
+#define PROW(SH_, PAD_, PRIO_)                                                                                                 \
+        printf("padded probe, %dx%d MFMA + %d x s_nop 7, VALU waves at priority %d: MFMA %7.1f  VALU %7.1f  both %7.1f us\n", SH_, SH_, PAD_, \
+               PRIO_, run_pad<SH_, PAD_, PRIO_>(1, mi2, vi2, out, nb), run_pad<SH_, PAD_, PRIO_>(2, mi2, vi2, out, nb),        \
+               run_pad<SH_, PAD_, PRIO_>(3, mi2, vi2, out, nb));
+        PROW(32, 0, 0) PROW(32, 1, 0) PROW(32, 2, 0) PROW(32, 3, 0) PROW(32, 4, 0) PROW(32, 6, 0)
+        PROW(32, 0, 3) PROW(32, 2, 3) PROW(32, 3, 3)
+        PROW(16, 0, 0) PROW(16, 1, 0) PROW(16, 2, 0) PROW(16, 3, 0)
+        PROW(16, 0, 3) PROW(16, 1, 3)
+#undef PROW
     }
     return 0;
 }
