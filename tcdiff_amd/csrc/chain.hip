@@ -435,7 +435,18 @@ __global__ __launch_bounds__(2048 / NT) void chain_kernel(tcdiff_chain_args a) {
             store_heads<true, MT, NT>(acc, a.q_out, a.scale_q, L, a.Lp, a.H, m0, M, wave, lane, smem);
             return;
         }
+#ifdef CH_STAMP   // per-stage shader-clock stamps of the w_qs GEMM: h_out[512 + wave * 32 + stage], [.. + 16] = the phase's start
+        {
+            unsigned long long* sp = nullptr;
+            if (m0 == 64 * CH_STAMP_BLOCK) {
+                sp = reinterpret_cast<unsigned long long*>(a.h_out) + 512 + wave * 32;
+                if (lane == 0) sp[16] = __builtin_amdgcn_s_memtime();
+            }
+            phase_n512<16, false, MT, NT>(acc, abuf, ws, lane, sp);
+        }
+#else
         phase_n512<16, false, MT, NT>(acc, abuf, ws, lane);
+#endif
         // ================= cross-attention in place (the Q image never leaves the registers)
         CH_T(35);
         lds_barrier();                 // every wave is out of the w_qs GEMM: the activation block becomes O

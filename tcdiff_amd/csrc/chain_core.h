@@ -196,7 +196,8 @@ DEVINL u32x4 frag_rd(const FragOff& f, int ks, int mt) {
 // weight stream, every CH_D stages.  The activation fragments of stage ks + 1 are read before the MFMAs of stage ks.
 // TAIL: the launch's last phase -- its last CH_D stages refill nothing (there is nothing behind them).
 template <int NST, bool TAIL = false, int MT = 4, int NT = 4>
-DEVINL void phase_n512(f32x4_t (&acc)[NT][MT], const char* abuf, WStreamT<NT>& ws, int lane) {
+DEVINL void phase_n512(f32x4_t (&acc)[NT][MT], const char* abuf, WStreamT<NT>& ws, int lane,
+                       unsigned long long* stage_stamps = nullptr) {     // (diagnostic builds: s_memtime after every stage)
     constexpr int RD = ChW<NT>::D;
     static_assert(NST % RD == 0, "a phase starts and ends at ring slot 0");
     lane = fresh_v(lane);
@@ -244,6 +245,9 @@ DEVINL void phase_n512(f32x4_t (&acc)[NT][MT], const char* abuf, WStreamT<NT>& w
         // three stages of fragments and refills live -- 232 VGPRs and four ring slots spilled behind `s_waitcnt vmcnt(0)`).
         acc_fence(acc);
         frag_fence(nb);
+#ifdef CH_STAMP
+        if (stage_stamps && (threadIdx.x & 63) == 0) stage_stamps[ks] = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) b[mt] = nb[mt];
     }
