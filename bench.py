@@ -45,7 +45,7 @@ def parse(argv=None):
     p.add_argument("--dancers", type=int, default=3)
     p.add_argument("--frames", type=int, default=150)
     p.add_argument("--ddpm-steps", type=int, default=1000)
-    p.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    p.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "bf16x3"])
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-parity-mode", action="store_true", help="skip the f32-mode timing")
     p.add_argument("--no-kernel-profile", action="store_true", help="skip the in-sampler per-kernel timing pass")
@@ -452,19 +452,26 @@ def rank_main(a):
         res["roofline"] = roof
         res["kernels"] = rows
         if world == 1 and not a.no_parity_mode and a.dtype == "bf16" and T >= 200:
-            # the f32 mode (v_mfma_f32_32x32x2_f32) is the one held to <= 1e-3 against the reference: time it here too
-            d32 = build("f32")
-            d32.p_sample_loop((nb, Lq, 151), cond, noise=xT, seed=1234, start_point=int(0.1 * T) + 4)   # warm + capture
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            d32.p_sample_loop((nb, Lq, 151), cond, noise=xT, seed=1234)
-            torch.cuda.synchronize()
-            d1 = time.perf_counter() - t1
-            res["parity_mode"] = {"dtype": "f32", "value": round(nb / d1, 4), "unit": "clips/s",
-                                  "ms_per_step": round(d1 * 1e3, 1), "sample": f"one full job of {nb} clips x {T} steps",
-                                  "tolerance": "max-abs <= 1e-3 vs the reference on fp32 (tests/test_parity_gpu.py)",
-                                  "mfma_frac_f32_peak": round(nb / d1 * gf * T / 1e3 / PEAK_F32_TFLOPS, 4) if gf else None}
-            del d32
+            # the two modes held to <= 1e-3 against the reference, timed on the same workload: "f32" (v_mfma_f32_32x32x2_f32, an
+            # exact fp32 fma chain) and "bf16x3" (fp32 storage, every product as three bf16 MFMAs on (hi, lo) splits)
+            pm = {}
+            for mode in ("f32", "bf16x3"):
+                dm = build(mode)
+                dm.p_sample_loop((nb, Lq, 151), cond, noise=xT, seed=1234, start_point=int(0.1 * T) + 4)   # warm + capture
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                dm.p_sample_loop((nb, Lq, 151), cond, noise=xT, seed=1234)
+                torch.cuda.synchronize()
+                d1 = time.perf_counter() - t1
+                pm[mode] = {"dtype": mode, "value": round(nb / d1, 4), "unit": "clips/s", "ms_per_step": round(d1 * 1e3, 1),
+                            "sample": f"one full job of {nb} clips x {T} steps",
+                            "tolerance": "max-abs <= 1e-3 vs the reference on fp32 (tests/test_parity_gpu.py)"}
+                del dm
+            pm["f32"]["mfma_frac_f32_peak"] = round(pm["f32"]["value"] * gf * T / 1e3 / PEAK_F32_TFLOPS, 4) if gf else None
+            # three bf16 MFMAs per product: executed matrix work = 3 x the algorithmic FLOPs, priced against the bf16 peak
+            pm["bf16x3"]["mfma_frac_bf16_peak_executed"] = \
+                round(3 * pm["bf16x3"]["value"] * gf * T / 1e3 / PEAK_BF16_TFLOPS, 4) if gf else None
+            res["parity_mode"] = dict(pm["f32"], fast=pm["bf16x3"])
         if world == 1 and (dn, S, T) == (3, 150, 1000):
             # how far the BENCHMARKED arithmetic is from the reference: one guided evaluation of clip 0 at two timesteps against
             # the committed outputs of the real reference on the same name-keyed synthetic weights and inputs

@@ -10,7 +10,8 @@
  *     synchronises the host; all pointers are caller-owned DEVICE pointers; work is enqueued on `stream`.
  *   - `dtype` selects the arithmetic of GEMM/attention operands: TC_DTYPE_BF16 (bf16 operands,
  *     v_mfma_f32_32x32x16_bf16, fp32 accumulate) or TC_DTYPE_F32 (fp32 operands, v_mfma_f32_32x32x2_f32:
- *     an exact fp32 fma chain -- the parity mode).  "T" below means that element type.
+ *     an exact fp32 fma chain -- the parity mode).  "T" below means that element type.  TC_DTYPE_BF16X3 (three GEMM-like
+ *     launchers only, see its definition) keeps TC_DTYPE_F32's storage and evaluates products as split-bf16 triples.
  *   - the residual stream, LayerNorm statistics, softmax, FiLM and the diffusion update are always fp32.
  *   - matrices are row-major; `ld*` are leading dimensions in ELEMENTS; operand rows must be 16-byte
  *     aligned and K must be a multiple of 64 (bf16) / 32 (f32) elements (pad with zeros).
@@ -36,6 +37,10 @@ typedef struct ihipStream_t* hipStream_t;
 
 #define TC_DTYPE_F32 0
 #define TC_DTYPE_BF16 1
+#define TC_DTYPE_BF16X3 2 /* tcdiff_gemm_tile (forward epilogues), tcdiff_gemm_rowln, tcdiff_attention only: operands stored as fp32
+                             exactly as for TC_DTYPE_F32; every product a b is formed as a_hi b_hi + a_hi b_lo + a_lo b_hi with
+                             a_hi = bf16(a), a_lo = bf16(a - a_hi) -- three bf16 MFMAs, fp32 accumulate: ~2^-16 per product, the
+                             reference's fp32 path (model/model.py:548-624 runs without autocast) to well inside 1e-3 */
 
 /* activations (fused into GEMM epilogues and elementwise helpers) */
 #define TC_ACT_NONE 0

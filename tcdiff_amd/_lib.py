@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TCDIFF_LIB_PATH") or os.path.join(HERE, "libtcdiff_gfx950.so")   # override: diagnostic builds
 
-DT_F32, DT_BF16 = 0, 1
+DT_F32, DT_BF16, DT_BF16X3 = 0, 1, 2      # TC_DTYPE_* of include/tcdiff_hip.h
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_MISH, ACT_SILU = 0, 1, 2, 3, 4
 EPI_STORE_T, EPI_STORE_F32, EPI_QKV_HEADS = 0, 1, 2
 ROW_BIAS, ROW_LN_POST, ROW_FILM, ROW_RES, ROW_STORE_X, ROW_NEXT_LN, ROW_STORE_H, ROW_STORE_ROT = \

@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const char* __restrict__
 extern "C" int tcdiff_attention(int dtype, const void* Q, const void* K, const void* V, void* O, int n_seq, int H,
                                 int Lq, int Lk, int Lp_q, int Lp_k, int ldo, int n_shared, int ng, hipStream_t stream) {
     if (!Q || !K || !V || !O || n_seq <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return TC_ERR_ARG;
-    if (dtype != TC_DTYPE_BF16 && dtype != TC_DTYPE_F32) return TC_ERR_ARG;
+    if (dtype != TC_DTYPE_BF16 && dtype != TC_DTYPE_F32 && dtype != TC_DTYPE_BF16X3) return TC_ERR_ARG;
     if (ng < 0 || ng > 2) return TC_ERR_ARG;
     if (Lp_q % 128 != 0 || Lp_k % 64 != 0 || Lp_q < Lq || Lp_k < Lk || ldo < H * 64 || ldo % 4 != 0) return TC_ERR_ARG;
     if (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O) & 15) return TC_ERR_ALIGN;
@@ -241,6 +241,9 @@ extern "C" int tcdiff_attention(int dtype, const void* Q, const void* K, const v
     dim3 grid((Lp_q / 128) * H * n_seq);
     if (dtype == TC_DTYPE_BF16)
         hipLaunchKernelGGL(attention_kernel<MmaBF16>, grid, dim3(256), 0, stream, (const char*)Q, (const char*)K,
+                           (const char*)V, (char*)O, H, Lq, Lk, Lp_q, Lp_k, ldo, n_shared);
+    else if (dtype == TC_DTYPE_BF16X3)      // fp32 images, products as split-bf16 triples (common.h MmaBF16x3)
+        hipLaunchKernelGGL(attention_kernel<MmaBF16x3>, grid, dim3(256), 0, stream, (const char*)Q, (const char*)K,
                            (const char*)V, (char*)O, H, Lq, Lk, Lp_q, Lp_k, ldo, n_shared);
     else
         hipLaunchKernelGGL(attention_kernel<MmaF32>, grid, dim3(256), 0, stream, (const char*)Q, (const char*)K,

@@ -4,7 +4,6 @@
 #include "common.h"
 #include <type_traits>
 
-typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
 
 template <class P>

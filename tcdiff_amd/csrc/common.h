@@ -1,8 +1,9 @@
 // Common device helpers for the TCDiff gfx950 (MI355X / CDNA4) kernels.
 //
-// Two arithmetic policies share every kernel template:
-//   * MmaBF16 : operands bf16 in HBM/LDS, v_mfma_f32_32x32x16_bf16, fp32 accumulate  (throughput mode)
-//   * MmaF32  : operands fp32,             v_mfma_f32_32x32x2_f32  (exact fp32 fma chain; parity mode)
+// Three arithmetic policies share the kernel templates:
+//   * MmaBF16   : operands bf16 in HBM/LDS, v_mfma_f32_32x32x16_bf16, fp32 accumulate  (throughput mode)
+//   * MmaF32    : operands fp32,             v_mfma_f32_32x32x2_f32  (exact fp32 fma chain; parity mode)
+//   * MmaBF16x3 : operands fp32 (MmaF32's storage), each product as three bf16 MFMAs on (hi, lo) splits (fast parity mode)
 // Both policies stage operand tiles as rows of 128 bytes (64 bf16 / 32 f32 along K) and every lane
 // fetches its MFMA fragment as ONE 16-byte LDS read, so staging, swizzle and addressing are
 // byte-identical for the two; only the MFMA issue differs.
@@ -69,6 +70,41 @@ struct MmaF32 {
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1], bf[1], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[2], bf[2], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[3], bf[3], acc, 0, 0, 0);
+    }
+};
+
+// Split-bf16 ("bf16x3"): operands are stored and staged as fp32 (everything of MmaF32 applies: elem_t, KT, chunk maps), and
+// every product a b is evaluated as a_hi b_hi + a_hi b_lo + a_lo b_hi with a_hi = bf16(a), a_lo = bf16(a - a_hi) (lo lo, ~2^-18
+// of the product, is dropped): three bf16 MFMAs with fp32 accumulation instead of four exact-fp32 ones at 1/16 of the rate.  Each
+// operand keeps ~16 significant bits, so a product is good to ~2^-16 relative -- two orders of magnitude inside the north-star's
+// 1e-3 over the whole sampler (measured: tests/test_parity_gpu.py, compute_dtype = "bf16x3"), at several times the f32 mode's
+// speed.  One 16-byte chunk holds k = 4 h + j of the k-step's 8 (both operands alike), which is exactly the A / B lane map of
+// v_mfma_f32_32x32x8_bf16_1k (lane half h supplies k = 4 h .. 4 h + 3).
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+struct MmaBF16x3 {
+    typedef float elem_t;
+    static constexpr int KT = 32;
+    static constexpr int EPC = 4;
+    static constexpr bool IS_BF16 = false;
+    static DEVINL elem_t from_f32(float f) { return f; }
+    static DEVINL float to_f32(elem_t e) { return e; }
+    static DEVINL void split(const u32x4& c, s16x4_t& hi, s16x4_t& lo) {
+        const f32x4_t f = __builtin_bit_cast(f32x4_t, c);
+        const uint32_t h01 = pack_bf2(f[0], f[1]), h23 = pack_bf2(f[2], f[3]);      // round to nearest even
+        const float g0 = __builtin_bit_cast(float, h01 << 16), g1 = __builtin_bit_cast(float, h01 & 0xFFFF0000u);
+        const float g2 = __builtin_bit_cast(float, h23 << 16), g3 = __builtin_bit_cast(float, h23 & 0xFFFF0000u);
+        const uint32_t l01 = pack_bf2(f[0] - g0, f[1] - g1), l23 = pack_bf2(f[2] - g2, f[3] - g3);   // the differences are exact
+        const uint2 hh = {h01, h23}, ll = {l01, l23};
+        hi = __builtin_bit_cast(s16x4_t, hh);
+        lo = __builtin_bit_cast(s16x4_t, ll);
+    }
+    static DEVINL void mma(f32x16_t& acc, const u32x4& a, const u32x4& b) {
+        s16x4_t ah, al, bh, bl;
+        split(a, ah, al);
+        split(b, bh, bl);
+        acc = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(al, bh, acc, 0, 0, 0);       // the small terms first
+        acc = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(ah, bl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(ah, bh, acc, 0, 0, 0);
     }
 };
 

@@ -747,7 +747,10 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 static int launch_tile(int dtype, const void* A, const void* A2, int split_n, const void* W, int M, int N, int K,
                        int lda, int ldw, int a_mod, const tcdiff_tile_epi* epi, hipStream_t stream) {
     if (!A || !W || !epi || M <= 0 || N <= 0 || K <= 0) return TC_ERR_ARG;
-    if (dtype != TC_DTYPE_BF16 && dtype != TC_DTYPE_F32) return TC_ERR_ARG;
+    if (dtype != TC_DTYPE_BF16 && dtype != TC_DTYPE_F32 && dtype != TC_DTYPE_BF16X3) return TC_ERR_ARG;
+    // TC_DTYPE_BF16X3: fp32 storage (every size and alignment rule of TC_DTYPE_F32), products as split-bf16 triples; the plain
+    // forward epilogues only (the sampler's path: no split-K, no fused training epilogues)
+    if (dtype == TC_DTYPE_BF16X3 && (epi->mode == TC_EPI_ATOMIC_F32 || epi->out2 || epi->act_src)) return TC_ERR_UNSUPPORTED;
     const int es = dtype == TC_DTYPE_BF16 ? 2 : 4;
     const int kt = dtype == TC_DTYPE_BF16 ? 64 : 32;
     if (K % kt != 0) return TC_ERR_ARG;
@@ -794,6 +797,7 @@ static int launch_tile(int dtype, const void* A, const void* A2, int split_n, co
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 128 * TC_ROWB);
         TC_TILE_ATTR(MmaBF16, 0) TC_TILE_ATTR(MmaBF16, 1) TC_TILE_ATTR(MmaBF16, 2) TC_TILE_ATTR(MmaBF16, 3)
         TC_TILE_ATTR(MmaF32, 0) TC_TILE_ATTR(MmaF32, 1) TC_TILE_ATTR(MmaF32, 2) TC_TILE_ATTR(MmaF32, 3)
+        TC_TILE_ATTR(MmaBF16x3, 0) TC_TILE_ATTR(MmaBF16x3, 1) TC_TILE_ATTR(MmaBF16x3, 2) TC_TILE_ATTR(MmaBF16x3, 3)
 #undef TC_TILE_ATTR
         return err;
     });
@@ -818,6 +822,8 @@ static int launch_tile(int dtype, const void* A, const void* A2, int split_n, co
     }
     if (dtype == TC_DTYPE_BF16) {
         TC_DISPATCH_TILE(MmaBF16)
+    } else if (dtype == TC_DTYPE_BF16X3) {
+        TC_DISPATCH_TILE(MmaBF16x3)
     } else {
         TC_DISPATCH_TILE(MmaF32)
     }
@@ -938,7 +944,7 @@ extern "C" int tcdiff_gemm_tn_grouped(int dtype, const tcdiff_tn_problem* probs,
 extern "C" int tcdiff_gemm_rowln(int dtype, const void* A, const void* W, int M, int K, int lda, int ldw, int a_mod,
                                  const tcdiff_row_epi* epi, hipStream_t stream) {
     if (!A || !W || !epi || M <= 0 || K <= 0) return TC_ERR_ARG;
-    if (dtype != TC_DTYPE_BF16 && dtype != TC_DTYPE_F32) return TC_ERR_ARG;
+    if (dtype != TC_DTYPE_BF16 && dtype != TC_DTYPE_F32 && dtype != TC_DTYPE_BF16X3) return TC_ERR_ARG;
     const int es = dtype == TC_DTYPE_BF16 ? 2 : 4;
     const int kt = dtype == TC_DTYPE_BF16 ? 64 : 32;
     if (K % kt != 0) return TC_ERR_ARG;
@@ -968,12 +974,17 @@ extern "C" int tcdiff_gemm_rowln(int dtype, const void* A, const void* W, int M,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, ROWLN_SMEM);
         hipError_t b = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rowln_kernel<MmaF32>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, ROWLN_SMEM);
-        return a != hipSuccess ? a : b;
+        hipError_t c = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rowln_kernel<MmaBF16x3>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, ROWLN_SMEM);
+        return a != hipSuccess ? a : b != hipSuccess ? b : c;
     });
     if (n_cu < 0) return n_cu;
     dim3 grid(((M + 63) / 64) * e.groups);
     if (dtype == TC_DTYPE_BF16)
         hipLaunchKernelGGL(gemm_rowln_kernel<MmaBF16>, grid, dim3(512), ROWLN_SMEM, stream, (const char*)A,
+                           (const char*)W, M, K, (long)lda * es, (long)ldw * es, a_mod, e);
+    else if (dtype == TC_DTYPE_BF16X3)
+        hipLaunchKernelGGL(gemm_rowln_kernel<MmaBF16x3>, grid, dim3(512), ROWLN_SMEM, stream, (const char*)A,
                            (const char*)W, M, K, (long)lda * es, (long)ldw * es, a_mod, e);
     else
         hipLaunchKernelGGL(gemm_rowln_kernel<MmaF32>, grid, dim3(512), ROWLN_SMEM, stream, (const char*)A,

@@ -6,19 +6,29 @@ import torch
 
 from . import _lib as L
 
-TORCH_DT = {L.DT_F32: torch.float32, L.DT_BF16: torch.bfloat16}
+TORCH_DT = {L.DT_F32: torch.float32, L.DT_BF16: torch.bfloat16, L.DT_BF16X3: torch.float32}
 
 
 def dtype_id(name_or_dtype) -> int:
+    if isinstance(name_or_dtype, str) and name_or_dtype == "bf16x3":
+        return L.DT_BF16X3
     if name_or_dtype in ("bf16", torch.bfloat16, L.DT_BF16):
         return L.DT_BF16
     if name_or_dtype in ("f32", "fp32", torch.float32, L.DT_F32):
         return L.DT_F32
-    raise ValueError(f"unsupported compute dtype {name_or_dtype!r} (bf16 or f32)")
+    if name_or_dtype == L.DT_BF16X3 and not isinstance(name_or_dtype, bool):
+        return L.DT_BF16X3
+    raise ValueError(f"unsupported compute dtype {name_or_dtype!r} (bf16, f32 or bf16x3)")
 
 
 def k_tile(dt: int) -> int:
     return 64 if dt == L.DT_BF16 else 32
+
+
+def _sdt(dt: int) -> int:
+    """STORAGE dtype of an arithmetic mode: the split-bf16 mode (TC_DTYPE_BF16X3) keeps every operand in fp32 and differs from
+    the f32 mode only inside tcdiff_gemm_tile / tcdiff_gemm_rowln / tcdiff_attention; every other launcher sees TC_DTYPE_F32"""
+    return L.DT_F32 if dt == L.DT_BF16X3 else dt
 
 
 def round_up(x: int, m: int) -> int:
@@ -169,7 +179,7 @@ def pack_kv_frags(Kc, Vc, Kf, Vf, n_slots, H, Lp, nkt, key_lo, key_hi):
 
 
 def ln_rot(dt, x, rows, g, b, eps, *, h=None, rot=None, y32=None, rope=None, pos_mod=0, pos_base=0):
-    rc = L.load().tcdiff_ln_rot(dt, _p(x), rows, _p(g), _p(b), eps, _p(h), _p(rot), _p(y32), _p(rope), pos_mod,
+    rc = L.load().tcdiff_ln_rot(_sdt(dt), _p(x), rows, _p(g), _p(b), eps, _p(h), _p(rot), _p(y32), _p(rope), pos_mod,
                                 pos_base, stream())
     L.check(rc, "tcdiff_ln_rot")
 
@@ -181,12 +191,12 @@ def rope_table(freqs, rope, n_pos):
 def convert_pad(dt, src, dst, rows, cols, ld_dst, rows_per_batch=None, batch_stride=0, row_stride=None):
     rpb = rows if rows_per_batch is None else rows_per_batch
     rs = cols if row_stride is None else row_stride
-    rc = L.load().tcdiff_convert_pad(dt, _p(src), _p(dst), rows, cols, ld_dst, rpb, batch_stride, rs, stream())
+    rc = L.load().tcdiff_convert_pad(_sdt(dt), _p(src), _p(dst), rows, cols, ld_dst, rpb, batch_stride, rs, stream())
     L.check(rc, "tcdiff_convert_pad")
 
 
 def sinusoidal(dt, times_i32, n, freq, emb):
-    L.check(L.load().tcdiff_sinusoidal(dt, _p(times_i32), n, _p(freq), _p(emb), stream()), "tcdiff_sinusoidal")
+    L.check(L.load().tcdiff_sinusoidal(_sdt(dt), _p(times_i32), n, _p(freq), _p(emb), stream()), "tcdiff_sinusoidal")
 
 
 def mean_pool(x, out, B, S, Cn):
@@ -194,12 +204,12 @@ def mean_pool(x, out, B, S, Cn):
 
 
 def add_act(dt, a, ia, b, n, act, out=None, out32=None):
-    L.check(L.load().tcdiff_add_act(dt, _p(a), _p(ia), _p(b), n, act, _p(out), _p(out32), stream()),
+    L.check(L.load().tcdiff_add_act(_sdt(dt), _p(a), _p(ia), _p(b), n, act, _p(out), _p(out32), stream()),
             "tcdiff_add_act")
 
 
 def scatter_time_kv(dt, tab, n_t, tidx, Kc, Vc, NL, n_kv, H, Lp, tok0):
-    rc = L.load().tcdiff_scatter_time_kv(dt, _p(tab), n_t, _p(tidx), _p(Kc), _p(Vc), NL, n_kv, H, Lp, tok0,
+    rc = L.load().tcdiff_scatter_time_kv(_sdt(dt), _p(tab), n_t, _p(tidx), _p(Kc), _p(Vc), NL, n_kv, H, Lp, tok0,
                                          stream())
     L.check(rc, "tcdiff_scatter_time_kv")
 
@@ -218,7 +228,7 @@ def step_prologue(dt, counter, tseq, tidx, t_base, hidden, film_in, n_seq, tab, 
     a = L.StepPrologueArgs(_p(counter), _p(tseq), _p(tidx), _p(t_base), _p(hidden), _p(film_in), n_seq, _p(tab), n_t,
                            _p(Kc), _p(Vc), _p(Kf), _p(Vf), NL, n_kv, H, Lp, nkt, tok0, _p(x), _p(xin), rows, nfeat,
                            ld_xin, _p(film_tab), _p(film_out), film_rows, nfilm, n_unc)
-    L.check(L.load().tcdiff_step_prologue(dt, C.byref(a), stream()), "tcdiff_step_prologue")
+    L.check(L.load().tcdiff_step_prologue(_sdt(dt), C.byref(a), stream()), "tcdiff_step_prologue")
 
 
 def sampler_update(mode, out_unc, out_cond, ldo, x, eps, traj, x0_out, n_rows, nfeat, Lseq, counter, params, tseq,
@@ -313,13 +323,13 @@ def drop_params(p: float):
 def cast_transpose(dt, src, rows, cols, ld_src, *, dst=None, ld_dst=0, cols_pad=0, dstT=None, ld_dstT=0, rows_pad=0,
                    colsum=None):
     src_f32 = int(src.dtype == torch.float32)           # fp32 source (always, in the f32 mode) or a T-typed one
-    rc = L.load().tcdiff_cast_transpose(dt, src_f32, _p(src), rows, cols, ld_src, _p(dst), ld_dst, cols_pad, _p(dstT),
+    rc = L.load().tcdiff_cast_transpose(_sdt(dt), src_f32, _p(src), rows, cols, ld_src, _p(dst), ld_dst, cols_pad, _p(dstT),
                                         ld_dstT, rows_pad, _p(colsum), stream())
     L.check(rc, "tcdiff_cast_transpose")
 
 
 def gemm_splitk(dt, A, W, M, N, K, lda, ldw, out, ldc, splits):
-    L.check(L.load().tcdiff_gemm_splitk(dt, _p(A), _p(W), M, N, K, lda, ldw, _p(out), ldc, splits, stream()),
+    L.check(L.load().tcdiff_gemm_splitk(_sdt(dt), _p(A), _p(W), M, N, K, lda, ldw, _p(out), ldc, splits, stream()),
             "tcdiff_gemm_splitk")
 
 
@@ -330,7 +340,7 @@ def gemm_tn_ok(dt, M, N, K) -> bool:
 
 def gemm_tn(dt, A, B, M, N, K, lda, ldb, out, ldc, splits):
     """out[m][n] += sum_k A[k][m] B[k][n] (both operands row-major over the contraction index)."""
-    L.check(L.load().tcdiff_gemm_tn(dt, _p(A), _p(B), M, N, K, lda, ldb, _p(out), ldc, splits, stream()), "tcdiff_gemm_tn")
+    L.check(L.load().tcdiff_gemm_tn(_sdt(dt), _p(A), _p(B), M, N, K, lda, ldb, _p(out), ldc, splits, stream()), "tcdiff_gemm_tn")
 
 
 def gemm_tn_grouped(dt, problems):
@@ -341,7 +351,7 @@ def gemm_tn_grouped(dt, problems):
     for d, (A, B, M, N, K, lda, ldb, out, ldc) in zip(arr, problems):
         d.A, d.B, d.out = _p(A), _p(B), _p(out)
         d.M, d.N, d.K, d.lda, d.ldb, d.ldc = M, N, K, lda, ldb, ldc
-    L.check(L.load().tcdiff_gemm_tn_grouped(dt, arr, n, stream()), "tcdiff_gemm_tn_grouped")
+    L.check(L.load().tcdiff_gemm_tn_grouped(_sdt(dt), arr, n, stream()), "tcdiff_gemm_tn_grouped")
 
 
 def ct_table(dt, entries, device):
@@ -359,7 +369,7 @@ def ct_table(dt, entries, device):
         d.ld_dst, d.cols_pad, d.ld_dstT, d.rows_pad = e.get("ld_dst", 0), e.get("cols_pad", 0), e.get("ld_dstT", 0), \
             e.get("rows_pad", 0)
         d.tile0 = tile0
-        cnt = lib.tcdiff_ct_desc_init(dt, C.byref(d))
+        cnt = lib.tcdiff_ct_desc_init(_sdt(dt), C.byref(d))
         L.check(min(cnt, 0), "tcdiff_ct_desc_init")
         tile0 += cnt
     raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone()
@@ -368,18 +378,18 @@ def ct_table(dt, entries, device):
 
 def cast_transpose_multi(dt, table):
     tab, n, tiles = table
-    L.check(L.load().tcdiff_cast_transpose_multi(dt, _p(tab), n, tiles, stream()), "tcdiff_cast_transpose_multi")
+    L.check(L.load().tcdiff_cast_transpose_multi(_sdt(dt), _p(tab), n, tiles, stream()), "tcdiff_cast_transpose_multi")
 
 
 def act_drop(dt, a, ld_a, y, ld_y, rows, cols, act, seed=None, site=0, thr=0, scale=1.0):
     a_f32 = int(a.dtype == torch.float32)
-    L.check(L.load().tcdiff_act_drop(dt, a_f32, _p(a), ld_a, _p(y), ld_y, rows, cols, act, _p(seed), site, thr, scale,
+    L.check(L.load().tcdiff_act_drop(_sdt(dt), a_f32, _p(a), ld_a, _p(y), ld_y, rows, cols, act, _p(seed), site, thr, scale,
                                      stream()), "tcdiff_act_drop")
 
 
 def act_drop_bwd(dt, a, ld_a, dy, ld_y, da, rows, cols, act, seed=None, site=0, thr=0, scale=1.0):
     a_f32 = int(a.dtype == torch.float32)
-    L.check(L.load().tcdiff_act_drop_bwd(dt, a_f32, _p(a), ld_a, _p(dy), ld_y, _p(da), rows, cols, act, _p(seed), site,
+    L.check(L.load().tcdiff_act_drop_bwd(_sdt(dt), a_f32, _p(a), ld_a, _p(dy), ld_y, _p(da), rows, cols, act, _p(seed), site,
                                          thr, scale, stream()), "tcdiff_act_drop_bwd")
 
 
@@ -388,11 +398,11 @@ def row_args(**kw) -> "L.RowArgs":
 
 
 def row_fwd(dt, a):
-    L.check(L.load().tcdiff_row_fwd(dt, C.byref(a), stream()), "tcdiff_row_fwd")
+    L.check(L.load().tcdiff_row_fwd(_sdt(dt), C.byref(a), stream()), "tcdiff_row_fwd")
 
 
 def row_bwd(dt, a):
-    L.check(L.load().tcdiff_row_bwd(dt, C.byref(a), stream()), "tcdiff_row_bwd")
+    L.check(L.load().tcdiff_row_bwd(_sdt(dt), C.byref(a), stream()), "tcdiff_row_bwd")
 
 
 def row_param_reduce(partials, n_blocks, d_bias=None, d_ln_g=None, d_ln_b=None, d_nln_g=None, d_nln_b=None):
@@ -401,13 +411,13 @@ def row_param_reduce(partials, n_blocks, d_bias=None, d_ln_g=None, d_ln_b=None, 
 
 
 def attention_train(dt, Q, K, V, O, lse, n_seq, H, Lq, Lk, Lp_q, Lp_k, ldo, seed, site, thr, scale):
-    L.check(L.load().tcdiff_attention_train(dt, _p(Q), _p(K), _p(V), _p(O), _p(lse), n_seq, H, Lq, Lk, Lp_q, Lp_k, ldo,
+    L.check(L.load().tcdiff_attention_train(_sdt(dt), _p(Q), _p(K), _p(V), _p(O), _p(lse), n_seq, H, Lq, Lk, Lp_q, Lp_k, ldo,
                                             _p(seed), site, thr, scale, stream()), "tcdiff_attention_train")
 
 
 def attention_bwd(dt, Q, K, V, O, dO, lse, delta, dQ, ld_dq, dK, dV, ld_dkv, n_seq, H, Lq, Lk, Lp_q, Lp_k, ldo, scale_q,
                   seed, site, thr, scale):
-    L.check(L.load().tcdiff_attention_bwd(dt, _p(Q), _p(K), _p(V), _p(O), _p(dO), _p(lse), _p(delta), _p(dQ), ld_dq,
+    L.check(L.load().tcdiff_attention_bwd(_sdt(dt), _p(Q), _p(K), _p(V), _p(O), _p(dO), _p(lse), _p(delta), _p(dQ), ld_dq,
                                           _p(dK), _p(dV), ld_dkv, n_seq, H, Lq, Lk, Lp_q, Lp_k, ldo, scale_q, _p(seed),
                                           site, thr, scale, stream()), "tcdiff_attention_bwd")
 

@@ -194,7 +194,9 @@ class DanceDecoder(nn.Module):
         return eng
 
     def set_compute_dtype(self, compute_dtype: str):
-        """'bf16' (throughput) or 'f32' (exact-fp32 MFMA, parity mode)."""
+        """'bf16' (throughput), 'f32' (exact-fp32 MFMA, parity mode) or 'bf16x3' (fp32 storage, split-bf16 products: the
+        reference's fp32 results to well inside 1e-3 at several times the f32 mode's speed; sampler / forward only -- a training
+        step in this mode runs the f32 schedule)."""
         K.dtype_id(compute_dtype)
         self.compute_dtype = compute_dtype
         self._engine = None
@@ -213,7 +215,7 @@ class DanceDecoder(nn.Module):
             # Parameter OBJECTS were replaced (load_state_dict(assign=True), a re-wrapped module): everything the engine
             # captured or cached refers to the old ones
             eng = None
-        if eng is None or eng.dev != dev or eng.dt != K.dtype_id(self.compute_dtype):
+        if eng is None or eng.dev != dev or eng.mode_dt != K.dtype_id(self.compute_dtype):
             eng = TrainEngine(self, self.compute_dtype)
             if sync is not None:
                 eng.grad_sync = sync

@@ -270,6 +270,11 @@ class TrainEngine:
             raise L.TcdiffError("the training step runs on MI355X only (no CPU fallback; the CPU oracle is test-only)")
         self.dev = p0.device
         self.dt = K.dtype_id(compute)
+        if self.dt == L.DT_BF16X3:
+            # the split-bf16 arithmetic exists for the sampler's GEMM / attention launchers only; a training step of a model in that
+            # mode runs the exact-fp32 schedule (same storage, same gradients as compute_dtype="f32")
+            self.dt = L.DT_F32
+        self.mode_dt = K.dtype_id(compute)      # what model.train_engine() compares with the model's mode
         self.T = K.TORCH_DT[self.dt]
         self.kt = K.k_tile(self.dt)
         c = model.engine_config()

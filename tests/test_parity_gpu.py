@@ -355,7 +355,7 @@ def test_c4_long_sequence_forward_and_steps_vs_oracle():
     assert e < 5e-4
 
 
-@pytest.mark.parametrize("compute,bound", [("f32", 5e-4), ("bf16", 2.5e-2)])
+@pytest.mark.parametrize("compute,bound", [("f32", 5e-4), ("bf16x3", 1e-3), ("bf16", 2.5e-2)])
 def test_c4_vs_reference_golden(golden_dir, compute, bound):
     """BASELINE config 4 against the REAL reference (tests/golden/make_golden_c4.py): a guided evaluation at t = 500 and
     the first two DDPM steps, 5 dancers x 300 frames."""
@@ -537,12 +537,13 @@ def test_weights_written_by_fused_ema_and_adan_are_seen_by_the_next_forward():
     assert maxabs(ma(x, cond, t), y_cur) > 1e-4
 
 
-@pytest.mark.parametrize("compute,bound", [("f32", 1e-3), ("bf16", 1.5e-2)])
+@pytest.mark.parametrize("compute,bound", [("f32", 1e-3), ("bf16x3", 1e-3), ("bf16", 1.5e-2)])
 def test_c2_full_1000_step_loop_vs_reference_golden(golden_dir, compute, bound):
     """The north-star claim at the benchmark's own length: one clip of 3 dancers x 150 frames through ALL 1000 DDPM steps
     of the REAL reference's p_sample_loop with injected noise (tests/golden/make_golden_c2_full.py), here as clip 0 of a
-    two-clip batch.  f32 mode: max-abs <= 1e-3 at every checkpoint and at the end; bf16 (the benchmarked mode): its own
-    stated bound, with the observed deviation from the reference printed."""
+    two-clip batch.  f32 mode AND the split-bf16 mode ("bf16x3": fp32 storage, three bf16 MFMAs per product): max-abs <= 1e-3
+    (the north-star's tolerance) at every checkpoint and at the end; bf16 (the benchmarked mode): its own stated bound, with
+    the observed deviation from the reference printed."""
     ref = gold(golden_dir, "c2_p_sample_loop_full")
     _, _, diff = build(3, 150, 1000, compute=compute)
     cond = torch.stack([O.synth_cond(c, 150) for c in (0, 1)])
@@ -607,3 +608,62 @@ def test_bf16_error_attribution_by_switch(golden_dir):
     # operand rounding of eight layers, not one of the folds
     base = worst["bf16 default"]
     assert all(base - e < 0.5 * base for n, e in worst.items() if n.startswith("bf16,")), worst
+
+
+# ---- the split-bf16 mode (compute_dtype = "bf16x3": fp32 storage, every GEMM / attention product as three bf16 MFMAs on (hi, lo)
+# splits, csrc/common.h MmaBF16x3) against the REAL reference's goldens at the north-star's tolerance, 1e-3 -------------------
+@pytest.fixture(scope="module")
+def c2_x3():
+    sd, model, diff = build(3, 150, 1000, "bf16x3")
+    cond = torch.stack([O.synth_cond(c, 150) for c in (0, 1)])
+    xT = torch.stack([O.synth_xT(c, 450) for c in (0, 1)])
+    return sd, model, diff, cond, xT
+
+
+def test_bf16x3_c1_forward_and_loop_vs_reference_golden(golden_dir):
+    _, model, diff = build(2, 60, 100, "bf16x3")
+    cond = torch.stack([O.synth_cond(0, 60)])
+    xT = torch.stack([O.synth_xT(0, 120)])
+    ref = gold(golden_dir, "c1_forward")
+    for t in (99, 3):
+        tt = torch.full((1,), t, dtype=torch.long, device=DEV)
+        e_c = maxabs(model(xT.to(DEV), cond.to(DEV), tt, cond_drop_prob=0.0), ref[f"fwd_cond_t{t}"])
+        e_g = maxabs(model.guided_forward(xT.to(DEV), cond.to(DEV), tt, 2), ref[f"guided_w2_t{t}"])
+        print(f"bf16x3 C1 forward t={t}: cond {e_c:.2e} guided {e_g:.2e}")
+        assert e_c < 1e-3 and e_g < 1e-3
+    ref = gold(golden_dir, "c1_p_sample_loop")
+    x, chain = diff.p_sample_loop((1, 120, 151), cond, noise=xT, step_noise=dev_noise([0], 120), return_diffusion=True)
+    errs = {k: maxabs(chain[i], ref[k]) for k, i in (("after_step_99", 1), ("after_step_50", 50), ("after_step_10", 90),
+                                                    ("after_step_1", 99))}
+    errs["final"] = maxabs(x, ref["final"])
+    print("bf16x3 C1 p_sample_loop max-abs vs reference:", {k: f"{v:.2e}" for k, v in errs.items()})
+    assert max(errs.values()) < 1e-3
+
+
+def test_bf16x3_c2_forward_steps_and_ddim_vs_reference_golden(golden_dir, c2_x3):
+    _, model, diff, cond, xT = c2_x3
+    ref = gold(golden_dir, "c2_forward")
+    for t in (999, 37):
+        tt = torch.full((1,), t, dtype=torch.long, device=DEV)
+        e = maxabs(model.guided_forward(xT[:1].to(DEV), cond[:1].to(DEV), tt, 2), ref[f"guided_w2_t{t}"])
+        print(f"bf16x3 C2 guided t={t}: {e:.2e}")
+        assert e < 1e-3
+    out = model(xT.to(DEV), cond.to(DEV), torch.tensor([500, 20], device=DEV), cond_drop_prob=0.0)
+    e = maxabs(out, ref["fwd_cond_b2_t500_20"])
+    print(f"bf16x3 C2 forward per-clip timesteps: {e:.2e}")
+    assert e < 1e-3
+    ref = gold(golden_dir, "c2_ddpm_steps")
+    from tcdiff_amd import _lib as L
+    tseq = [999, 998, 997]
+    chain = []
+    diff._run(L.SAMPLER_DDPM, (1, 450, 151), cond[:1], xT[:1].to(DEV), tseq, diff._ddpm_params(tseq),
+              step_noise=dev_noise([0], 450), collect=chain)
+    for j, i in enumerate(tseq):
+        e = maxabs(chain[j], ref[f"after_step_{i}"])
+        print(f"bf16x3 C2 DDPM step {i}: {e:.2e}")
+        assert e < 1e-3
+    x0 = torch.stack([O.synth_traj(0, 450)])
+    x = diff.ddim_sample((1, 450, 151), cond[:1], x_0=x0, init_noise=xT[:1], step_noise=dev_noise([0], 450))
+    e = maxabs(x, gold(golden_dir, "c2_ddim")["final"])
+    print(f"bf16x3 C2 ddim_sample (50 steps, trajectory in-painting): {e:.2e}")
+    assert e < 1e-3
