@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const char* __restrict__
                 } else {
                     // f32: MFMA j of the k-step pairs register 4st+j of both halves: keys 8st + j and 8st + 4 + j
                     const f32x4_t pv = {s[kt][4 * st + 0], s[kt][4 * st + 1], s[kt][4 * st + 2], s[kt][4 * st + 3]};
-                    pf = __builtin_bit_cast(u32x4, pv);  // whole-vector cast (element-wise bit_cast is miscompiled)
+                    pf = P::chunk_from4(pv);  // f32: whole-vector cast (element-wise bit_cast is miscompiled); bf16x3: the (hi, lo) split
                 }
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
@@ -192,8 +192,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const char* __restrict__
                     pk.y = pack_bf2(v2, v3);
                     *reinterpret_cast<uint2*>(orow + d0) = pk;
                 } else {
-                    f32x4_t pk = {v0, v1, v2, v3};
-                    *reinterpret_cast<f32x4_t*>(orow + d0) = pk;
+                    const f32x4_t pk = {v0, v1, v2, v3};
+                    *reinterpret_cast<u32x4*>(orow + d0) = P::chunk_from4(pk);
                 }
             }
     }

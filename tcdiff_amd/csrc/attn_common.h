@@ -43,6 +43,21 @@ DEVINL u32x4 v_frag(const char* vt, int dt, int kt, int st, int lane) {
         const u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
         u32x4 out = {l2[0], l2[1], h2[0], h2[1]};
         return out;
+    } else if constexpr (P::IS_X3) {
+        // bf16x3: element (key, d) of the staged V tile = bf16 slots (d & 3) [hi] and 4 + (d & 3) [lo] of the 16-byte chunk d / 4 of
+        // the key's row.  The fragment wants keys k0 .. k0 + 3 of ONE d: hi quad | lo quad, gathered with 2-byte reads.
+        const int r = lane & 31, h = lane >> 5;
+        const int d = dt * 32 + r;
+        const int k0 = kt * 32 + 8 * st + 4 * h;
+        uint32_t hv[4], lv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const char* c = vt + kv_off<P>(k0 + j, d & ~3) + 2 * (d & 3);
+            hv[j] = *reinterpret_cast<const uint16_t*>(c);
+            lv[j] = *reinterpret_cast<const uint16_t*>(c + 8);
+        }
+        const u32x4 out = {hv[0] | (hv[1] << 16), hv[2] | (hv[3] << 16), lv[0] | (lv[1] << 16), lv[2] | (lv[3] << 16)};
+        return out;
     } else {
         // MFMA j of the k-step takes key kt*32 + 8*st + 4*h + j
         const int r = lane & 31, h = lane >> 5;

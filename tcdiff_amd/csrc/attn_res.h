@@ -14,12 +14,6 @@
 // workgroups: one per CU.
 // =================================================================================================
 #define ATT_RES_MAXT 8   // up to 8 tiles of 64 keys
-#ifndef ATT_UNPACK
-#define ATT_UNPACK 0
-#endif
-#ifndef ATT_PRIO
-#define ATT_PRIO 0
-#endif
 
 // TRAIN (attention_train.hip): dropout on the softmax weights (counter hash of train_common.h, flat index of the element in
 // the reference's [n_seq * H, Lq, Lk] weights tensor) and the row statistic lse = m + log2(l) for the backward pass.
@@ -151,10 +145,6 @@ __global__ __launch_bounds__(512) void attention_res_kernel(const char* __restri
             // 30.9 / 31.0).  Also built: one exponential + four plain v_add_f32 of the row sums per MFMA (31.7: the unpacked sums are
             // twice the instructions of the packed ones they replace); group 0's eight S MFMAs first and its row maximum + scaling,
             // unpacked, behind group 1's (K fragments read twice: 2 % slower).
-#if ATT_PRIO   // the softmax arithmetic in the open runs at raised issue priority: beside the SIMD's other wave it then gets the vector
-            // issue slots that wave's WAITING MFMAs would otherwise hold (tools/probe/coissue_probe.hip, round 5: padded probe rows)
-            __builtin_amdgcn_s_setprio(ATT_PRIO);
-#endif
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 float mx = s[g][0][0];
@@ -164,17 +154,6 @@ __global__ __launch_bounds__(512) void attention_res_kernel(const char* __restri
                     for (int q = 0; q < 16; ++q) mx = fmaxf(mx, s[g][kt][q]);
                 mx = fmaxf(mx, other_half(mx)) * LOG2E;
                 const float m_new = fmaxf(m_run[g], mx);
-#if ATT_UNPACK   // single-issue v_fma_f32 (asm: -O3 re-packs adjacent scalar FMAs): packed f32 never runs beside another wave's MFMAs
-                const float nm1 = -m_new;
-#pragma unroll
-                for (int kt = 0; kt < NS; ++kt)
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        float x;
-                        asm("v_fma_f32 %0, %1, %2, %3" : "=v"(x) : "v"(s[g][kt][q]), "s"(LOG2E), "v"(nm1));
-                        s[g][kt][q] = x;
-                    }
-#else
                 const f32x2_t l2 = {LOG2E, LOG2E}, nm = {-m_new, -m_new};
 #pragma unroll
                 for (int kt = 0; kt < NS; ++kt)
@@ -184,7 +163,6 @@ __global__ __launch_bounds__(512) void attention_res_kernel(const char* __restri
                         s[g][kt][q] = x[0];
                         s[g][kt][q + 1] = x[1];
                     }
-#endif
                 if (__builtin_amdgcn_ballot_w64(m_new > m_run[g]) != 0) {
                     const float alpha = __builtin_amdgcn_exp2f(m_run[g] - m_new);
                     l_run[g] *= alpha;
@@ -210,9 +188,6 @@ __global__ __launch_bounds__(512) void attention_res_kernel(const char* __restri
 #pragma unroll
             for (int j = 0; j < 8; ++j) ex(0, j);
             packs(0);
-#if ATT_PRIO
-            __builtin_amdgcn_s_setprio(0);              // the PV stream (its fillers are in this wave's own MFMA gaps)
-#endif
             u32x4 vf[2];
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
@@ -240,35 +215,17 @@ __global__ __launch_bounds__(512) void attention_res_kernel(const char* __restri
                     packs(u + 1);
                 }
             }
-#if ATT_PRIO
-            __builtin_amdgcn_s_setprio(ATT_PRIO);
-#endif
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
-#if ATT_UNPACK   // four independent chains of single-issue adds (same pairing as the packed form: bit-identical sums)
-                float r0 = 0.0f, r1 = 0.0f;
-#pragma unroll
-                for (int kt = 0; kt < NS; ++kt)
-#pragma unroll
-                    for (int q = 0; q < 16; q += 2) {
-                        asm("v_add_f32 %0, %0, %1" : "+v"(r0) : "v"(s[g][kt][q]));
-                        asm("v_add_f32 %0, %0, %1" : "+v"(r1) : "v"(s[g][kt][q + 1]));
-                    }
-                float rs = r0 + r1;
-#else
                 f32x2_t rs2 = {0.0f, 0.0f};
 #pragma unroll
                 for (int kt = 0; kt < NS; ++kt)
 #pragma unroll
                     for (int q = 0; q < 16; q += 2) rs2 += f32x2_t{s[g][kt][q], s[g][kt][q + 1]};
                 float rs = rs2[0] + rs2[1];
-#endif
                 rs += other_half(rs);
                 l_run[g] += rs;
             }
-#if ATT_PRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
             } else {
             // ---- online softmax (base 2), the two groups are independent instruction streams
 #pragma unroll

@@ -18,6 +18,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
@@ -47,6 +48,10 @@ struct MmaBF16 {
     static constexpr int KT = 64;        // elements of K per 128-B staged row
     static constexpr int EPC = 8;        // elements per 16-B chunk
     static constexpr bool IS_BF16 = true;
+    static constexpr bool IS_X3 = false;
+    // (the 4-element chunk helpers of the 4-byte policies: referenced from the untaken side of `if (P::IS_BF16)` branches only)
+    static DEVINL u32x4 chunk_from4(const f32x4_t& f) { return __builtin_bit_cast(u32x4, f); }
+    static DEVINL f32x4_t chunk_to4(const u32x4& c) { return __builtin_bit_cast(f32x4_t, c); }
     static DEVINL elem_t from_f32(float f) { return f2bf(f); }
     static DEVINL float to_f32(elem_t e) { return bf2f(e); }
     static DEVINL void mma(f32x16_t& acc, const u32x4& a, const u32x4& b) {
@@ -60,6 +65,9 @@ struct MmaF32 {
     static constexpr int KT = 32;
     static constexpr int EPC = 4;
     static constexpr bool IS_BF16 = false;
+    static constexpr bool IS_X3 = false;
+    static DEVINL u32x4 chunk_from4(const f32x4_t& f) { return __builtin_bit_cast(u32x4, f); }   // four elements <-> a 16-byte chunk
+    static DEVINL f32x4_t chunk_to4(const u32x4& c) { return __builtin_bit_cast(f32x4_t, c); }
     static DEVINL elem_t from_f32(float f) { return f; }
     static DEVINL float to_f32(elem_t e) { return e; }
     static DEVINL void mma(f32x16_t& acc, const u32x4& a, const u32x4& b) {
@@ -73,40 +81,69 @@ struct MmaF32 {
     }
 };
 
-// Split-bf16 ("bf16x3"): operands are stored and staged as fp32 (everything of MmaF32 applies: elem_t, KT, chunk maps), and
-// every product a b is evaluated as a_hi b_hi + a_hi b_lo + a_lo b_hi with a_hi = bf16(a), a_lo = bf16(a - a_hi) (lo lo, ~2^-18
-// of the product, is dropped): three bf16 MFMAs with fp32 accumulation instead of four exact-fp32 ones at 1/16 of the rate.  Each
-// operand keeps ~16 significant bits, so a product is good to ~2^-16 relative -- two orders of magnitude inside the north-star's
-// 1e-3 over the whole sampler (measured: tests/test_parity_gpu.py, compute_dtype = "bf16x3"), at several times the f32 mode's
-// speed.  One 16-byte chunk holds k = 4 h + j of the k-step's 8 (both operands alike), which is exactly the A / B lane map of
-// v_mfma_f32_32x32x8_bf16_1k (lane half h supplies k = 4 h .. 4 h + 3).
+// Split-bf16 ("bf16x3"): every product a b is evaluated as a_hi b_hi + a_hi b_lo + a_lo b_hi with a_hi = bf16(a), a_lo = bf16(a - a_hi)
+// (lo lo, ~2^-18 of the product, is dropped): three bf16 MFMAs with fp32 accumulation instead of four exact-fp32 ones at 1/16 of
+// the rate.  Each operand keeps ~16 significant bits, so a product is good to ~2^-16 relative -- two orders of magnitude inside
+// the north-star's 1e-3 over the whole sampler (tests/test_parity_gpu.py, compute_dtype = "bf16x3").
+// STORAGE: an element still takes 4 bytes at the position fp32 would give it (so every size, stride, staging and swizzle rule of
+// MmaF32 applies unchanged), but a 16-byte chunk of four consecutive elements e0..e3 is kept ALREADY SPLIT,
+//     [hi(e0) hi(e1) hi(e2) hi(e3) | lo(e0) lo(e1) lo(e2) lo(e3)]   (eight bf16),
+// by whoever produces it (GEMM / attention / elementwise epilogues, the host's weight packer): the 16 bytes a lane fetches as
+// its MFMA fragment ARE the A / B operands of v_mfma_f32_32x32x8_bf16_1k (lane half h supplies k = 4 h .. 4 h + 3) -- the first
+// 8 bytes the hi quad, the second the lo quad -- and the k-loops contain no conversion at all.
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+struct x3_word { uint32_t u; };      // a 4-byte storage slot of the split format: never a value by itself (chunk_to4 / load_T)
 struct MmaBF16x3 {
-    typedef float elem_t;
+    typedef x3_word elem_t;
     static constexpr int KT = 32;
     static constexpr int EPC = 4;
     static constexpr bool IS_BF16 = false;
-    static DEVINL elem_t from_f32(float f) { return f; }
-    static DEVINL float to_f32(elem_t e) { return e; }
-    static DEVINL void split(const u32x4& c, s16x4_t& hi, s16x4_t& lo) {
-        const f32x4_t f = __builtin_bit_cast(f32x4_t, c);
+    static constexpr bool IS_X3 = true;
+    static DEVINL u32x4 chunk_from4(const f32x4_t& f) {
         const uint32_t h01 = pack_bf2(f[0], f[1]), h23 = pack_bf2(f[2], f[3]);      // round to nearest even
         const float g0 = __builtin_bit_cast(float, h01 << 16), g1 = __builtin_bit_cast(float, h01 & 0xFFFF0000u);
         const float g2 = __builtin_bit_cast(float, h23 << 16), g3 = __builtin_bit_cast(float, h23 & 0xFFFF0000u);
-        const uint32_t l01 = pack_bf2(f[0] - g0, f[1] - g1), l23 = pack_bf2(f[2] - g2, f[3] - g3);   // the differences are exact
-        const uint2 hh = {h01, h23}, ll = {l01, l23};
-        hi = __builtin_bit_cast(s16x4_t, hh);
-        lo = __builtin_bit_cast(s16x4_t, ll);
+        const u32x4 c = {h01, h23, pack_bf2(f[0] - g0, f[1] - g1), pack_bf2(f[2] - g2, f[3] - g3)};   // the differences are exact
+        return c;
+    }
+    static DEVINL f32x4_t chunk_to4(const u32x4& c) {
+        const f32x4_t f = {__builtin_bit_cast(float, c[0] << 16) + __builtin_bit_cast(float, c[2] << 16),
+                           __builtin_bit_cast(float, c[0] & 0xFFFF0000u) + __builtin_bit_cast(float, c[2] & 0xFFFF0000u),
+                           __builtin_bit_cast(float, c[1] << 16) + __builtin_bit_cast(float, c[3] << 16),
+                           __builtin_bit_cast(float, c[1] & 0xFFFF0000u) + __builtin_bit_cast(float, c[3] & 0xFFFF0000u)};
+        return f;
     }
     static DEVINL void mma(f32x16_t& acc, const u32x4& a, const u32x4& b) {
-        s16x4_t ah, al, bh, bl;
-        split(a, ah, al);
-        split(b, bh, bl);
+        const uint2 a_h = {a[0], a[1]}, a_l = {a[2], a[3]}, b_h = {b[0], b[1]}, b_l = {b[2], b[3]};
+        const s16x4_t ah = __builtin_bit_cast(s16x4_t, a_h), al = __builtin_bit_cast(s16x4_t, a_l);
+        const s16x4_t bh = __builtin_bit_cast(s16x4_t, b_h), bl = __builtin_bit_cast(s16x4_t, b_l);
         acc = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(al, bh, acc, 0, 0, 0);       // the small terms first
         acc = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(ah, bl, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(ah, bh, acc, 0, 0, 0);
     }
 };
+
+// One T-typed element by index (the elementwise kernels of ops.hip: conversions, embeddings, small tables -- not hot paths)
+template <class P>
+DEVINL void store_T(typename P::elem_t* base, long i, float v) {
+    if constexpr (std::is_same<P, MmaBF16x3>::value) {
+        const uint16_t hi = f2bf(v);
+        uint16_t* c = reinterpret_cast<uint16_t*>(base) + (i >> 2) * 8 + (i & 3);
+        c[0] = hi;
+        c[4] = f2bf(v - bf2f(hi));
+    } else {
+        base[i] = P::from_f32(v);
+    }
+}
+template <class P>
+DEVINL float load_T(const typename P::elem_t* base, long i) {
+    if constexpr (std::is_same<P, MmaBF16x3>::value) {
+        const uint16_t* c = reinterpret_cast<const uint16_t*>(base) + (i >> 2) * 8 + (i & 3);
+        return bf2f(c[0]) + bf2f(c[4]);
+    } else {
+        return P::to_f32(base[i]);
+    }
+}
 
 // Row of the C/D tile held in accumulator register `reg` by a lane of half `h`.
 DEVINL int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }

@@ -70,7 +70,7 @@ DEVINL void unpack_chunk(const u32x4& c, float (&v)[16 / sizeof(typename P::elem
             v[2 * j + 1] = bf2f((uint16_t)(c[j] >> 16));
         }
     } else {
-        const f32x4_t f = __builtin_bit_cast(f32x4_t, c);
+        const f32x4_t f = P::chunk_to4(c);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = f[j];
     }
@@ -83,7 +83,7 @@ DEVINL u32x4 pack_chunk(const float (&v)[16 / sizeof(typename P::elem_t)]) {
         for (int j = 0; j < 4; ++j) c[j] = pack_bf2(v[2 * j], v[2 * j + 1]);
     } else {
         const f32x4_t f = {v[0], v[1], v[2], v[3]};
-        c = __builtin_bit_cast(u32x4, f);
+        c = P::chunk_from4(f);
     }
     return c;
 }
@@ -311,8 +311,8 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(const char* __restrict__
                             pk.y = pack_bf2(v[2], v[3]);
                             *reinterpret_cast<uint2*>(dst) = pk;
                         } else {
-                            f32x4_t pk = {v[0], v[1], v[2], v[3]};
-                            *reinterpret_cast<f32x4_t*>(dst) = pk;
+                            const f32x4_t pk = {v[0], v[1], v[2], v[3]};      // columns nl .. nl + 3: one whole chunk
+                            *reinterpret_cast<u32x4*>(dst) = P::chunk_from4(pk);
                         }
                     }
             }
@@ -668,8 +668,8 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(const char* __restrict_
             *reinterpret_cast<uint2*>(p + c0) = pa;
             *reinterpret_cast<uint2*>(p + c1) = pb;
         } else {
-            *reinterpret_cast<f32x4_t*>(p + c0) = va;
-            *reinterpret_cast<f32x4_t*>(p + c1) = vb;
+            *reinterpret_cast<u32x4*>(p + c0) = P::chunk_from4(va);
+            *reinterpret_cast<u32x4*>(p + c1) = P::chunk_from4(vb);
         }
     };
 

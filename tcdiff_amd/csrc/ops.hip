@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void ln_rot_kernel(const float* __restrict__ x
                 pk.y = pack_bf2(u[2], u[3]);
                 *reinterpret_cast<uint2*>(hp) = pk;
             } else {
-                *reinterpret_cast<f32x4_t*>(hp) = u;
+                *reinterpret_cast<u32x4*>(hp) = P::chunk_from4(u);
             }
         }
         if (rout) {
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void ln_rot_kernel(const float* __restrict__ x
                 pk.y = pack_bf2(y[2], y[3]);
                 *reinterpret_cast<uint2*>(rp) = pk;
             } else {
-                *reinterpret_cast<f32x4_t*>(rp) = y;
+                *reinterpret_cast<u32x4*>(rp) = P::chunk_from4(y);
             }
         }
     }
@@ -95,10 +95,13 @@ extern "C" int tcdiff_ln_rot(int dtype, const float* x, int rows, const float* g
                              void* rot, float* y32, const float* rope, int pos_mod, int pos_base,
                              hipStream_t stream) {
     if (!x || !g || !b || rows <= 0 || (rot && !rope)) return TC_ERR_ARG;
-    if (dtype != TC_DTYPE_BF16 && dtype != TC_DTYPE_F32) return TC_ERR_ARG;
+    if (dtype != TC_DTYPE_BF16 && dtype != TC_DTYPE_F32 && dtype != TC_DTYPE_BF16X3) return TC_ERR_ARG;
     dim3 grid((rows + 3) / 4);
     if (dtype == TC_DTYPE_BF16)
         hipLaunchKernelGGL(ln_rot_kernel<MmaBF16>, grid, dim3(256), 0, stream, x, rows, g, b, eps, h, rot, y32, rope,
+                           pos_mod, pos_base);
+    else if (dtype == TC_DTYPE_BF16X3)
+        hipLaunchKernelGGL(ln_rot_kernel<MmaBF16x3>, grid, dim3(256), 0, stream, x, rows, g, b, eps, h, rot, y32, rope,
                            pos_mod, pos_base);
     else
         hipLaunchKernelGGL(ln_rot_kernel<MmaF32>, grid, dim3(256), 0, stream, x, rows, g, b, eps, h, rot, y32, rope,
@@ -139,7 +142,7 @@ __global__ void convert_pad_kernel(const float* __restrict__ src, typename P::el
     int r = (int)(i / ld_dst), c = (int)(i % ld_dst);
     float v = 0.0f;
     if (c < cols) v = src[(long)(r / rows_per_batch) * batch_stride + (long)(r % rows_per_batch) * row_stride + c];
-    dst[i] = P::from_f32(v);
+    store_T<P>(dst, i, v);
 }
 
 extern "C" int tcdiff_convert_pad(int dtype, const float* src, void* dst, int rows, int cols, int ld_dst,
@@ -152,6 +155,9 @@ extern "C" int tcdiff_convert_pad(int dtype, const float* src, void* dst, int ro
                            ld_dst, rows_per_batch, batch_stride, row_stride);
     else if (dtype == TC_DTYPE_F32)
         hipLaunchKernelGGL(convert_pad_kernel<MmaF32>, grid, dim3(256), 0, stream, src, (float*)dst, rows, cols, ld_dst,
+                           rows_per_batch, batch_stride, row_stride);
+    else if (dtype == TC_DTYPE_BF16X3 && ld_dst % 4 == 0)
+        hipLaunchKernelGGL(convert_pad_kernel<MmaBF16x3>, grid, dim3(256), 0, stream, src, (x3_word*)dst, rows, cols, ld_dst,
                            rows_per_batch, batch_stride, row_stride);
     else
         return TC_ERR_ARG;
@@ -170,8 +176,8 @@ __global__ void sinusoidal_kernel(const int* __restrict__ times, int n, const fl
     float a = (float)times[row] * freq[k];
     float s, c;
     sincosf(a, &s, &c);
-    emb[(long)row * 512 + k] = P::from_f32(s);
-    emb[(long)row * 512 + 256 + k] = P::from_f32(c);
+    store_T<P>(emb, (long)row * 512 + k, s);
+    store_T<P>(emb, (long)row * 512 + 256 + k, c);
 }
 
 extern "C" int tcdiff_sinusoidal(int dtype, const int* times, int n, const float* freq, void* emb,
@@ -182,6 +188,8 @@ extern "C" int tcdiff_sinusoidal(int dtype, const int* times, int n, const float
         hipLaunchKernelGGL(sinusoidal_kernel<MmaBF16>, grid, dim3(256), 0, stream, times, n, freq, (uint16_t*)emb);
     else if (dtype == TC_DTYPE_F32)
         hipLaunchKernelGGL(sinusoidal_kernel<MmaF32>, grid, dim3(256), 0, stream, times, n, freq, (float*)emb);
+    else if (dtype == TC_DTYPE_BF16X3)
+        hipLaunchKernelGGL(sinusoidal_kernel<MmaBF16x3>, grid, dim3(256), 0, stream, times, n, freq, (x3_word*)emb);
     else
         return TC_ERR_ARG;
     TC_CHECK_LAUNCH();
@@ -214,7 +222,7 @@ __global__ void add_act_kernel(const float* __restrict__ a, const int* __restric
     int ra = ia ? ia[row] : row;
     float v = a[(long)ra * 512 + c] + (b ? b[i] : 0.0f);
     v = apply_act(v, act);
-    if (out) out[i] = P::from_f32(v);
+    if (out) store_T<P>(out, i, v);
     if (out32) out32[i] = v;
 }
 
@@ -226,6 +234,8 @@ extern "C" int tcdiff_add_act(int dtype, const float* a, const int* ia, const fl
         hipLaunchKernelGGL(add_act_kernel<MmaBF16>, grid, dim3(256), 0, stream, a, ia, b, n, act, (uint16_t*)out, out32);
     else if (dtype == TC_DTYPE_F32)
         hipLaunchKernelGGL(add_act_kernel<MmaF32>, grid, dim3(256), 0, stream, a, ia, b, n, act, (float*)out, out32);
+    else if (dtype == TC_DTYPE_BF16X3)
+        hipLaunchKernelGGL(add_act_kernel<MmaBF16x3>, grid, dim3(256), 0, stream, a, ia, b, n, act, (x3_word*)out, out32);
     else
         return TC_ERR_ARG;
     TC_CHECK_LAUNCH();
@@ -264,6 +274,9 @@ extern "C" int tcdiff_scatter_time_kv(int dtype, const void* tab, int n_t, const
         hipLaunchKernelGGL(scatter_time_kv_kernel<MmaBF16>, grid, dim3(256), 0, stream, (const uint16_t*)tab, n_t, tidx,
                            (uint16_t*)Kc, (uint16_t*)Vc, NL, n_kv, H, Lp, tok0);
     else if (dtype == TC_DTYPE_F32)
+        hipLaunchKernelGGL(scatter_time_kv_kernel<MmaF32>, grid, dim3(256), 0, stream, (const float*)tab, n_t, tidx,
+                           (float*)Kc, (float*)Vc, NL, n_kv, H, Lp, tok0);
+    else if (dtype == TC_DTYPE_BF16X3)   // 4-byte slots copied one by one: a split chunk's four slots move together (d = c mod 64)
         hipLaunchKernelGGL(scatter_time_kv_kernel<MmaF32>, grid, dim3(256), 0, stream, (const float*)tab, n_t, tidx,
                            (float*)Kc, (float*)Vc, NL, n_kv, H, Lp, tok0);
     else
@@ -326,7 +339,7 @@ __global__ __launch_bounds__(256) void step_prologue_kernel(tcdiff_step_prologue
         } else if (i < n_film) {
             const int c = (int)(i & 511);
             if (c == 0) a.tidx[i >> 9] = t;
-            if (!a.film_tab) ((E*)a.film_in)[i] = P::from_f32(mish_f(a.t_base[(long)t * 512 + c] + a.hidden[i]));
+            if (!a.film_tab) store_T<P>((E*)a.film_in, i, mish_f(a.t_base[(long)t * 512 + c] + a.hidden[i]));
         } else if (i < n_film + n_kv) {
             const long k = i - n_film;
             const int c = (int)(k & 1023), rr = (int)((k >> 10) & 1);
@@ -344,7 +357,7 @@ __global__ __launch_bounds__(256) void step_prologue_kernel(tcdiff_step_prologue
         } else {
             const long k = i - n_film - n_kv;
             const int r = (int)(k / a.ld_xin), c = (int)(k % a.ld_xin);
-            ((E*)a.xin)[k] = P::from_f32(c < a.nfeat ? a.x[(long)r * a.nfeat + c] : 0.0f);
+            store_T<P>((E*)a.xin, k, c < a.nfeat ? a.x[(long)r * a.nfeat + c] : 0.0f);
         }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) counter[0] = step;
@@ -368,6 +381,8 @@ extern "C" int tcdiff_step_prologue(int dtype, const tcdiff_step_prologue_args* 
         hipLaunchKernelGGL(step_prologue_kernel<MmaBF16>, dim3(grid), dim3(256), 0, stream, *a);
     else if (dtype == TC_DTYPE_F32)
         hipLaunchKernelGGL(step_prologue_kernel<MmaF32>, dim3(grid), dim3(256), 0, stream, *a);
+    else if (dtype == TC_DTYPE_BF16X3 && a->ld_xin % 4 == 0)
+        hipLaunchKernelGGL(step_prologue_kernel<MmaBF16x3>, dim3(grid), dim3(256), 0, stream, *a);
     else
         return TC_ERR_ARG;
     TC_CHECK_LAUNCH();

@@ -107,6 +107,8 @@ class DenoiserEngine:
         kp = K.round_up(k, 64) if kpad is None else kpad
         out = torch.zeros(n, kp, device=self.dev, dtype=self.T)
         out[:, :k] = w.to(device=self.dev, dtype=self.T)
+        if self.dt == L.DT_BF16X3:         # split-bf16 storage: [hi x4 | lo x4] per 16-byte chunk (csrc/common.h MmaBF16x3)
+            return K.to_x3(out)
         return out.contiguous()
 
     # ---- weight streams of the chain kernels (include/tcdiff_hip.h, tcdiff_chain_args.wstream) -------------------

@@ -26,9 +26,31 @@ def k_tile(dt: int) -> int:
 
 
 def _sdt(dt: int) -> int:
-    """STORAGE dtype of an arithmetic mode: the split-bf16 mode (TC_DTYPE_BF16X3) keeps every operand in fp32 and differs from
-    the f32 mode only inside tcdiff_gemm_tile / tcdiff_gemm_rowln / tcdiff_attention; every other launcher sees TC_DTYPE_F32"""
+    """the split-bf16 mode (TC_DTYPE_BF16X3) exists on the sampler's path only (GEMM / attention / elementwise launchers of the
+    denoiser); the training-step launchers never see it (TrainEngine maps the mode to f32)"""
     return L.DT_F32 if dt == L.DT_BF16X3 else dt
+
+
+def to_x3(w: torch.Tensor) -> torch.Tensor:
+    """fp32 [..., K] (K % 4 == 0) -> the split-bf16 storage of csrc/common.h MmaBF16x3, returned as a float32-typed tensor of the
+    same shape holding the bit patterns: every 16-byte chunk of four elements becomes [hi x4 | lo x4] bf16 with hi = bf16(e),
+    lo = bf16(e - hi) (round to nearest even, as v_cvt_pk_bf16_f32)."""
+    w = w.to(torch.float32).contiguous()
+    if w.shape[-1] % 4:
+        raise ValueError("to_x3: the last dimension must be a multiple of 4")
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.to(torch.float32)).to(torch.bfloat16)
+    q = w.shape[:-1] + (w.shape[-1] // 4, 4)
+    out = torch.cat([hi.view(torch.int16).reshape(q), lo.view(torch.int16).reshape(q)], -1).contiguous()   # [..., K/4, 8] int16
+    return out.view(torch.float32).reshape(w.shape)
+
+
+def from_x3(t: torch.Tensor) -> torch.Tensor:
+    """inverse of to_x3 (tests, diagnostics): hi + lo as fp32"""
+    q = t.contiguous().view(torch.int16).reshape(t.shape[:-1] + (t.shape[-1] // 4, 8))
+    hi = q[..., :4].contiguous().view(torch.bfloat16).to(torch.float32)
+    lo = q[..., 4:].contiguous().view(torch.bfloat16).to(torch.float32)
+    return (hi + lo).reshape(t.shape)
 
 
 def round_up(x: int, m: int) -> int:
@@ -179,7 +201,7 @@ def pack_kv_frags(Kc, Vc, Kf, Vf, n_slots, H, Lp, nkt, key_lo, key_hi):
 
 
 def ln_rot(dt, x, rows, g, b, eps, *, h=None, rot=None, y32=None, rope=None, pos_mod=0, pos_base=0):
-    rc = L.load().tcdiff_ln_rot(_sdt(dt), _p(x), rows, _p(g), _p(b), eps, _p(h), _p(rot), _p(y32), _p(rope), pos_mod,
+    rc = L.load().tcdiff_ln_rot(dt, _p(x), rows, _p(g), _p(b), eps, _p(h), _p(rot), _p(y32), _p(rope), pos_mod,
                                 pos_base, stream())
     L.check(rc, "tcdiff_ln_rot")
 
@@ -191,12 +213,12 @@ def rope_table(freqs, rope, n_pos):
 def convert_pad(dt, src, dst, rows, cols, ld_dst, rows_per_batch=None, batch_stride=0, row_stride=None):
     rpb = rows if rows_per_batch is None else rows_per_batch
     rs = cols if row_stride is None else row_stride
-    rc = L.load().tcdiff_convert_pad(_sdt(dt), _p(src), _p(dst), rows, cols, ld_dst, rpb, batch_stride, rs, stream())
+    rc = L.load().tcdiff_convert_pad(dt, _p(src), _p(dst), rows, cols, ld_dst, rpb, batch_stride, rs, stream())
     L.check(rc, "tcdiff_convert_pad")
 
 
 def sinusoidal(dt, times_i32, n, freq, emb):
-    L.check(L.load().tcdiff_sinusoidal(_sdt(dt), _p(times_i32), n, _p(freq), _p(emb), stream()), "tcdiff_sinusoidal")
+    L.check(L.load().tcdiff_sinusoidal(dt, _p(times_i32), n, _p(freq), _p(emb), stream()), "tcdiff_sinusoidal")
 
 
 def mean_pool(x, out, B, S, Cn):
@@ -204,12 +226,12 @@ def mean_pool(x, out, B, S, Cn):
 
 
 def add_act(dt, a, ia, b, n, act, out=None, out32=None):
-    L.check(L.load().tcdiff_add_act(_sdt(dt), _p(a), _p(ia), _p(b), n, act, _p(out), _p(out32), stream()),
+    L.check(L.load().tcdiff_add_act(dt, _p(a), _p(ia), _p(b), n, act, _p(out), _p(out32), stream()),
             "tcdiff_add_act")
 
 
 def scatter_time_kv(dt, tab, n_t, tidx, Kc, Vc, NL, n_kv, H, Lp, tok0):
-    rc = L.load().tcdiff_scatter_time_kv(_sdt(dt), _p(tab), n_t, _p(tidx), _p(Kc), _p(Vc), NL, n_kv, H, Lp, tok0,
+    rc = L.load().tcdiff_scatter_time_kv(dt, _p(tab), n_t, _p(tidx), _p(Kc), _p(Vc), NL, n_kv, H, Lp, tok0,
                                          stream())
     L.check(rc, "tcdiff_scatter_time_kv")
 
@@ -228,7 +250,7 @@ def step_prologue(dt, counter, tseq, tidx, t_base, hidden, film_in, n_seq, tab, 
     a = L.StepPrologueArgs(_p(counter), _p(tseq), _p(tidx), _p(t_base), _p(hidden), _p(film_in), n_seq, _p(tab), n_t,
                            _p(Kc), _p(Vc), _p(Kf), _p(Vf), NL, n_kv, H, Lp, nkt, tok0, _p(x), _p(xin), rows, nfeat,
                            ld_xin, _p(film_tab), _p(film_out), film_rows, nfilm, n_unc)
-    L.check(L.load().tcdiff_step_prologue(_sdt(dt), C.byref(a), stream()), "tcdiff_step_prologue")
+    L.check(L.load().tcdiff_step_prologue(dt, C.byref(a), stream()), "tcdiff_step_prologue")
 
 
 def sampler_update(mode, out_unc, out_cond, ldo, x, eps, traj, x0_out, n_rows, nfeat, Lseq, counter, params, tseq,
