@@ -31,6 +31,69 @@ DK = 64  # SBI_MSA hard-codes d_k = 64 (model/model.py:55)
 
 
 # ----------------------------------------------------------------------------------------------
+# optional bf16 OPERAND-ROUNDING emulation (test infrastructure for the bf16 training step, round 5)
+# ----------------------------------------------------------------------------------------------
+# The product's bf16 mode rounds every GEMM / attention OPERAND to bf16 (fp32 accumulation), keeps the gradients of T-typed
+# activations in bf16 and -- in the training engine -- stores the GEMM outputs it keeps for the backward (z1 .. z4, Q / K / V, O) in
+# bf16.  `operand_rounding(...)` re-routes this module's own F.linear / torch.matmul calls through
+# versions that round at exactly those sites (values stay fp32 tensors on the bf16 grid), so that autograd through the oracle
+# yields "the fp32 algorithm with the kernels' rounding points" -- the thing a bf16 step can be held to, as opposed to the exact
+# fp32 gradient it cannot reach.  Not a reference restatement: the reference has no reduced-precision path.
+import contextlib
+import types
+
+
+def _bf(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+class _RoundF(torch.autograd.Function):      # value rounded in the forward, gradient passed through
+    @staticmethod
+    def forward(ctx, x):
+        return _bf(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _RoundB(torch.autograd.Function):      # identity in the forward, gradient rounded
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _bf(g)
+
+
+@contextlib.contextmanager
+def operand_rounding(fwd: bool = True, bwd: bool = True, out: bool = False):
+    """fwd: GEMM / attention operands rounded in the forward; bwd: gradients of linear inputs / outputs and of the attention
+    products' operands rounded (dX, dY, dQ, dK, dV, dP, dO; parameter gradients stay fp32); out: GEMM outputs rounded too."""
+    g = globals()
+    real_F, real_torch = g["F"], g["torch"]
+    rf = (lambda x: _RoundF.apply(x)) if fwd else (lambda x: x)
+    rb = (lambda x: _RoundB.apply(x)) if bwd else (lambda x: x)
+
+    def linear(x, w, b=None):
+        y = rb(real_F.linear(rf(rb(x)), rf(w), b))
+        return _RoundF.apply(y) if out else y
+
+    def matmul(a, b):
+        return rb(real_torch.matmul(rf(rb(a)), rf(rb(b))))
+    Fp = types.SimpleNamespace(**{k: getattr(real_F, k) for k in dir(real_F) if not k.startswith("__")})
+    Fp.linear = linear
+    Tp = types.SimpleNamespace(**{k: getattr(real_torch, k) for k in dir(real_torch) if not k.startswith("__")})
+    Tp.matmul = matmul
+    g["F"], g["torch"] = Fp, Tp
+    try:
+        yield
+    finally:
+        g["F"], g["torch"] = real_F, real_torch
+
+
+# ----------------------------------------------------------------------------------------------
 # schedule tables  (model/utils.py:67-99, model/diffusion.py:109-169)
 # ----------------------------------------------------------------------------------------------
 def cosine_betas(n_timestep: int, s: float = 8e-3) -> np.ndarray:

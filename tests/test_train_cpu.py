@@ -186,3 +186,25 @@ def test_dropout_hash_of_the_oracle_is_a_fair_independent_mask():
     x = torch.ones(64, 512)
     y = O.DropPlan((1234, 5678), 0.1)(x, 17)
     assert torch.equal(y != 0, a) and abs(float(y.max()) - 1 / 0.9) < 1e-6
+
+
+def test_operand_rounding_mode_of_the_oracle_rounds_and_restores():
+    """oracle.operand_rounding (the bf16 rounding-point emulation the GPU training tests hold the bf16 step to): inside the context
+    the denoiser's output moves by bf16-operand noise, gradients flow, and on exit the exact fp32 arithmetic is back"""
+    import torch
+    from oracle import tcdiff_oracle as O
+    dn, S = 2, 60
+    sd = {n: (p.clone().requires_grad_(True) if p.is_floating_point() else p) for n, p in O.synth_state_dict(dn=dn, seq_len=S).items()}
+    x = torch.stack([O.synth_xT(0, dn * S)])
+    cond = torch.stack([O.synth_cond(0, S)])
+    t = torch.tensor([37])
+    keep = torch.ones(1, dtype=torch.bool)
+    a = O.decoder_forward(sd, x, cond, t, keep_mask=keep)
+    with O.operand_rounding(fwd=True, bwd=True, out=True):
+        b = O.decoder_forward(sd, x, cond, t, keep_mask=keep)
+        (b ** 2).mean().backward()
+    c = O.decoder_forward(sd, x, cond, t, keep_mask=keep)
+    d = float((a - b).abs().max())
+    assert torch.equal(a, c) and 1e-5 < d < 1e-1, d
+    g = sd["seqTransDecoder.stack.3.linear1.weight"].grad
+    assert g is not None and bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0

@@ -241,6 +241,72 @@ def test_row_block_gemm_path_and_tile_path_are_two_roundings_of_the_same_step():
     assert tab[0][0] < 4e-1 and max(r[1] for r in tab) < 4e-1
 
 
+@pytest.mark.parametrize("b", [3, 32])
+def test_bf16_step_against_the_oracle_that_rounds_where_the_kernels_round(b):
+    """VERDICT r4 #3.  The bf16 step cannot be held to the EXACT fp32 gradient tightly: rounding the forward's GEMM / attention
+    operands to bf16 alone moves the gradients by 5e-2 .. 1.4e-1 (median over the parameters) and up to 2.6e-1 (self- /
+    cross-attention w_qs / w_ks of the last layers), whatever the backward does -- and two roundings of the same step (another
+    summation order) land that far from each other too.  What it CAN be held to is the oracle with the kernels' rounding points
+    (oracle.operand_rounding: operands in the forward, T-typed activation gradients, stored GEMM outputs): this test computes, on
+    the same weights / draws / dropout masks (train mode, the full four-term loss, 3 dancers x 150 frames),
+        e_k = kernels vs exact,   e_A, e_D = two emulated roundings vs exact   (per parameter, relative L2)
+    and requires the kernels' error distribution to sit inside the emulations' own: median and worst <= 2 x the larger emulated
+    value.  A defect in a backward kernel (a wrong dS, a dropped term, bf16 where fp32 is claimed) adds to e_k and not to e_A / e_D.
+    Measured on the build host (CPU emulation): b = 3: e_A median 1.4e-1 / worst 2.6e-1, e_D 6.6e-2 / 1.4e-1 (without dropout 7.7e-2 /
+    1.7e-1 and 6.3e-2 / 2.2e-1); b = 32: e_A 5.1e-2 / 1.8e-1, e_D 5.6e-2 / 2.2e-1 -- the kernels: 6.3e-2 / 2.1e-1 (b = 3), 8.1e-2 / 3.0e-1
+    (b = 32), i.e. the fixed bounds of this file (3e-1 at the C1 shape, 4e-1 here) are ~1.4 x the emulation's own worst case."""
+    dn, S_ = 3, 150
+    sd, diff = build("bf16", dn=dn, S_=S_, T_=1000)
+    model = diff.model
+    diff.train()
+    x_start = torch.stack([O.synth_motion(300 + c, dn * S_).reshape(S_, dn, 151).permute(1, 0, 2) for c in range(b)])
+    cond = torch.stack([O.synth_cond(300 + c, S_) for c in range(b)])
+    noise = torch.stack([O.synth_xT(300 + c, dn * S_).reshape(S_, dn, 151) for c in range(b)])
+    g = torch.Generator().manual_seed(77)
+    t = torch.randint(0, 1000, (b,), generator=g)
+    keep = torch.rand(b, generator=g) > 0.25
+    seed = (2024, 1003)
+    model.train_seed = seed
+    total, _ = diff.p_losses(x_start.to(DEV), cond.to(DEV), t.to(DEV), noise=noise.to(DEV), keep_mask=keep.to(DEV))
+    for p in model.parameters():
+        p.grad = None
+    total.backward()
+    gk = {n: p.grad.cpu().numpy().copy() for n, p in model.named_parameters() if p.grad is not None}
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+
+    def oracle_grads(mode):
+        sd_now = {n: p.detach().cpu().clone().requires_grad_(True) for n, p in sd.items() if p.is_floating_point()}
+        if mode is None:
+            o_total, o_losses = O.p_losses(sd_now, O.make_tables(1000), x_start, cond, t, noise, keep, drop=O.DropPlan(seed, 0.1))
+            o_total.backward()
+        else:
+            with O.operand_rounding(**mode):
+                o_total, o_losses = O.p_losses(sd_now, O.make_tables(1000), x_start, cond, t, noise, keep, drop=O.DropPlan(seed, 0.1))
+                o_total.backward()
+        return (float(o_total), np.array([float(v) for v in o_losses]),
+                {n: (None if v.grad is None else v.grad.numpy().copy()) for n, v in sd_now.items()})
+    if ("c5", b) not in _ORACLE_CACHE:
+        _ORACLE_CACHE[("c5", b)] = oracle_grads(None)
+    g0 = _ORACLE_CACHE[("c5", b)][2]
+    modes = {"A (forward operands)": dict(fwd=True, bwd=False), "D (operands, gradients, stored outputs)": dict(fwd=True, bwd=True, out=True)}
+    if b == 32:
+        modes.pop("A (forward operands)")       # one emulated evaluation at the large batch (a minute of CPU)
+    stats = {}
+    for name, mode in modes.items():
+        ge = oracle_grads(mode)[2]
+        e = np.array(sorted(rel(ge[n], g0[n]) for n in gk))
+        ek_e = np.array(sorted(rel(gk[n], ge[n]) for n in gk))
+        stats[name] = (float(np.median(e)), float(e[-1]))
+        print(f"[bf16, {b} x 3 x 150] emulation {name} vs exact: median {np.median(e):.2e} worst {e[-1]:.2e}; kernels vs this emulation: "
+              f"median {np.median(ek_e):.2e} worst {ek_e[-1]:.2e}")
+    ek = sorted(((rel(gk[n], g0[n]), n) for n in gk), reverse=True)
+    med_k, worst_k = float(np.median([v for v, _ in ek])), ek[0][0]
+    med_e, worst_e = max(v[0] for v in stats.values()), max(v[1] for v in stats.values())
+    print(f"[bf16, {b} x 3 x 150] kernels vs exact: median {med_k:.2e} worst {worst_k:.2e} ({ek[0][1]}); emulations: median <= {med_e:.2e}, "
+          f"worst <= {worst_e:.2e}")
+    assert med_k <= 2.0 * med_e and worst_k <= 2.0 * worst_e, (med_k, med_e, worst_k, worst_e)
+
+
 _ORACLE_CACHE = {}
 
 
