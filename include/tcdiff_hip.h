@@ -172,7 +172,10 @@ typedef struct {       /* Python-side doubles of adan.py rounded to fp32 where t
     float b1, omb1, b2, omb2, b3, omb3;   /* betas and 1 - beta */
     float cm, cv, cn;                     /* bias corrections 1 / (1 - (1 - beta)^step) */
     float eps, lr, denom;                 /* denom = 1 + weight_decay * lr */
-    int first;                            /* step == 0 before the call: m, v, n are left untouched (adan.py:71) */
+    int first;                            /* bit 0: step == 0 before the call: m, v, n are left untouched (adan.py:71);
+                                             bit 1: RESTART of these tensors (adan.py:109-114): m = g, v = 0, n = g^2, then the
+                                             parameter update; bit 2: prev_grad is not written (the caller evaluates
+                                             restart_cond(state) on the old prev_grad between the two launches) */
 } tcdiff_adan_scalars;
 
 int tcdiff_adan_step(const tcdiff_adan_chunk* chunks, int n_chunks, const tcdiff_adan_scalars* scalars,

@@ -54,7 +54,7 @@ class Adan(Optimizer):
                 continue
             states = [self._init_state(p) for p in ps]
             step0 = states[0]["step"]
-            fused = not exists(restart_cond) and all(
+            fused = all(
                 p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous()
                 and not p.grad.is_sparse and s["step"] == step0 for p, s in zip(ps, states))
             if fused:
@@ -67,14 +67,27 @@ class Adan(Optimizer):
                     self._tables[gi] = (key, tab)
                 step = step0 + 1
                 cm, cv, cn = (1 / (1 - (1 - b) ** step) for b in (beta1, beta2, beta3))
+                flags = int(step0 == 0) | (4 if exists(restart_cond) else 0)
                 sc = L.AdanScalars(beta1, 1 - beta1, beta2, 1 - beta2, beta3, 1 - beta3, cm, cv, cn, eps, lr,
-                                   1 + weight_decay * lr, int(step0 == 0))
+                                   1 + weight_decay * lr, flags)
                 K.adan_step(self._tables[gi][1], sc)
+                if exists(restart_cond):
+                    # adan.py:107-114: the condition sees the state as the reference leaves it at that point -- moments updated,
+                    # prev_grad and step still the previous step's -- and the tensors it selects are restarted by a second launch
+                    # (m = g, v = 0, n = g^2, parameter update once more); prev_grad <- grad afterwards for everybody
+                    again = [(p, s) for p, s in zip(ps, states) if restart_cond(s)]
+                    if again:
+                        tab = K.adan_chunk_table([p.data for p, _ in again], [p.grad for p, _ in again], [s["m"] for _, s in again],
+                                                 [s["v"] for _, s in again], [s["n"] for _, s in again],
+                                                 [s["prev_grad"] for _, s in again], ps[0].device)
+                        sc.first = 2 | 4
+                        K.adan_step(tab, sc)
+                    torch._foreach_copy_([s["prev_grad"] for s in states], [p.grad for p in ps])
                 torch.autograd.graph.increment_version(ps)     # written through raw pointers: keep ._version honest
                 for s in states:
                     s["step"] = step
                 continue
             raise L.TcdiffError(
-                "Adan.step runs as one fused HIP launch over contiguous fp32 CUDA parameters with equal step counts and no "
-                "restart_cond (the configuration of TCDiff.py:110); there is no CPU / per-tensor fallback")
+                "Adan.step runs as one fused HIP launch over contiguous fp32 CUDA parameters with equal step counts (the "
+                "configuration of TCDiff.py:110); there is no CPU / per-tensor fallback")
         return loss

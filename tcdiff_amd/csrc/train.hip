@@ -198,7 +198,11 @@ extern "C" int tcdiff_loss_terms(const float* model_out, const float* x_start, c
 // one element of the update; every rounding point is the reference's (see tcdiff_hip.h)
 DEVINL void adan_element(const tcdiff_adan_scalars& k, float g, float pg, float& p, float& m, float& v, float& n) {
 #pragma clang fp contract(off)
-    if (!k.first) {
+    if (k.first & 2) {            // restart (adan.py:109-114): m = g, v = 0, n = g^2, then the parameter update once more
+        m = g;
+        v = 0.0f;
+        n = g * g;
+    } else if (!(k.first & 1)) {
         m = __builtin_fmaf(g, k.b1, m * k.omb1);
         const float gd = g - pg;
         v = __builtin_fmaf(gd, k.b2, v * k.omb2);
@@ -226,35 +230,35 @@ __global__ __launch_bounds__(256) void adan_step_kernel(const tcdiff_adan_chunk*
             f32x4_t p = reinterpret_cast<f32x4_t*>(c.p)[i], m = reinterpret_cast<f32x4_t*>(c.m)[i];
             f32x4_t v = reinterpret_cast<f32x4_t*>(c.v)[i], n = reinterpret_cast<f32x4_t*>(c.n_)[i];
             f32x4_t pg = {0.f, 0.f, 0.f, 0.f};
-            if (!k.first) pg = reinterpret_cast<f32x4_t*>(c.pg)[i];
+            if (!(k.first & 3)) pg = reinterpret_cast<f32x4_t*>(c.pg)[i];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 float pe = p[t], me = m[t], ve = v[t], ne = n[t];
                 adan_element(k, g[t], pg[t], pe, me, ve, ne);
                 p[t] = pe; m[t] = me; v[t] = ve; n[t] = ne;
             }
-            if (!k.first) {
+            if (!(k.first & 1)) {
                 reinterpret_cast<f32x4_t*>(c.m)[i] = m;
                 reinterpret_cast<f32x4_t*>(c.v)[i] = v;
                 reinterpret_cast<f32x4_t*>(c.n_)[i] = n;
             }
             reinterpret_cast<f32x4_t*>(c.p)[i] = p;
-            reinterpret_cast<f32x4_t*>(c.pg)[i] = g;
+            if (!(k.first & 4)) reinterpret_cast<f32x4_t*>(c.pg)[i] = g;
         }
         i0 = n4 << 2;
     }
     for (long i = i0 + threadIdx.x; i < c.n; i += 256) {
         const float g = c.g[i];
         float p = c.p[i], m = c.m[i], v = c.v[i], n = c.n_[i];
-        const float pg = k.first ? 0.0f : c.pg[i];
+        const float pg = (k.first & 3) ? 0.0f : c.pg[i];
         adan_element(k, g, pg, p, m, v, n);
-        if (!k.first) {
+        if (!(k.first & 1)) {
             c.m[i] = m;
             c.v[i] = v;
             c.n_[i] = n;
         }
         c.p[i] = p;
-        c.pg[i] = g;
+        if (!(k.first & 4)) c.pg[i] = g;
     }
 }
 

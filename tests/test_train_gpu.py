@@ -149,6 +149,33 @@ def test_fused_adan_step_bit_exact_vs_reference_golden(golden_dir):
         Adan(cpu, lr=5e-5, weight_decay=0.02).step()
 
 
+def test_fused_adan_with_a_restart_condition_bit_exact_vs_reference_golden(golden_dir):
+    """Adan(restart_cond=...) (model/adan.py:107-114; rounds 1-4 refused it): the condition is evaluated on the state the
+    reference shows it (moments updated, prev_grad and step still the previous step's) and the tensors it selects take a second
+    fused launch (m = g, v = 0, n = g^2, parameter update once more).  Five steps of the REAL reference, two of them restarting two
+    of the three tensors (tests/golden/make_golden_adan_restart.py): parameters after every step and the final state, bit for bit."""
+    ref = np.load(os.path.join(golden_dir, "adan_restart.npz"))
+    params = [torch.nn.Parameter(torch.from_numpy(ref[f"p{i}_init"].copy()).to(DEV)) for i in range(3)]
+    seen = []
+
+    def cond(state):
+        seen.append((state["step"], state["m"].numel()))
+        return state["step"] in (1, 3) and state["m"].numel() != 37
+    opt = Adan(params, lr=5e-5, weight_decay=0.02, restart_cond=cond)
+    for step in range(int(ref["n_steps"])):
+        for i, p in enumerate(params):
+            p.grad = torch.from_numpy(ref[f"g{i}_step{step}"].copy()).to(DEV)
+        opt.step()
+        for i, p in enumerate(params):
+            assert np.array_equal(p.detach().cpu().numpy(), ref[f"p{i}_step{step}"]), (i, step)
+    assert len(seen) == 15 and seen[3][0] == 1        # the condition sees the previous step count, as in the reference
+    for i, p in enumerate(params):
+        st = opt.state[p]
+        assert st["step"] == 5
+        for k in ("m", "v", "n", "prev_grad"):
+            assert np.array_equal(st[k].cpu().numpy(), ref[f"{k}{i}_final"]), (i, k)
+
+
 def test_adan_drives_the_full_parameter_list_in_one_launch():
     """435 tensors / 61.4 M parameters of the production model: one fused launch per step, state_dict round trip"""
     model = DanceDecoder(nfeats=151, seq_len=150, latent_dim=512, ff_size=1024, num_layers=8, num_heads=8, dropout=0.1,
