@@ -49,6 +49,8 @@ def parse(argv=None):
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-parity-mode", action="store_true", help="skip the f32-mode timing")
     p.add_argument("--no-kernel-profile", action="store_true", help="skip the in-sampler per-kernel timing pass")
+    p.add_argument("--no-pmc", action="store_true",
+                   help="skip the two rocprofv3 PMC child passes (FETCH_SIZE, WRITE_SIZE) that measure roofline.traffic live")
     p.add_argument("--cpu-seconds", type=float, default=30.0, help="total CPU-baseline budget (three samples of a third each)")
     p.add_argument("--no-train-step", action="store_true", help="skip the secondary config-5 training-step timing")
     p.add_argument("--no-other-configs", action="store_true", help="skip the config-1 / config-4 sampling lines")
@@ -245,6 +247,69 @@ def kernel_roofline(times, n_steps, B_launch, streams, dn, S, dtype):
         except Exception:
             continue
     return roof, rows
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# HBM-side traffic, measured by THIS run: two rocprofv3 PMC passes over a short child run of this script
+# ----------------------------------------------------------------------------------------------------------------
+PMC_FAMILIES = {"chain": "chain_kernel", "gemm_rowln": "gemm_rowln_kernel", "gemm_tile": "gemm_tile_kernel", "attention": "attention"}
+
+
+def live_pmc_traffic(a, dom, steps=20, timeout=240.0):
+    """rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, as MI355X_MICROARCH.md prescribes: the two do
+    not fit one pass) around `python3 bench.py --ddpm-steps <steps>` with everything but the sampler switched off, started as a
+    CHILD of this process (never an exec: this process has the GPU open).  Returns {family: bytes per launch, ..., "per_step":
+    bytes per DDPM step} with the guide's gfx950 correction (FETCH_SIZE counts 128-byte requests as 64: doubled; both in KB), or
+    raises.  The child works on the same build, shapes and batch as the timed run, 20 DDPM steps (18 two-branch)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        raise RuntimeError("rocprofv3 not found")
+    child = [sys.executable if os.path.basename(sys.executable).startswith("python") else "python3", os.path.abspath(__file__),
+             "--steps", "1", "--warmup", "1", "--ddpm-steps", str(steps), "--batch", str(a.batch), "--dancers", str(a.dancers),
+             "--frames", str(a.frames), "--dtype", a.dtype, "--no-cpu-baseline", "--no-kernel-profile", "--no-parity-mode",
+             "--no-train-step", "--no-other-configs", "--no-pmc"]
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    tot, fam, n_update = {}, {}, 0
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="tcdiff_pmc_", dir="/tmp")
+        try:
+            r = subprocess.run([exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + child,
+                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                raise RuntimeError(f"rocprofv3 --pmc {counter}: rc {r.returncode}, {len(files)} counter files: {r.stderr[-300:]}")
+            kb_all, kb_fam, n_fam, n_upd = 0.0, {k: 0.0 for k in PMC_FAMILIES}, {k: 0 for k in PMC_FAMILIES}, 0
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    if row.get("Counter_Name") != counter:
+                        continue
+                    v, name = float(row["Counter_Value"]), row.get("Kernel_Name", "")
+                    kb_all += v
+                    n_upd += "sampler_update_kernel" in name
+                    for k, sym in PMC_FAMILIES.items():
+                        if sym in name.split("(")[0]:
+                            kb_fam[k] += v
+                            n_fam[k] += 1
+            tot[counter], fam[counter], n_update = kb_all, (kb_fam, n_fam), n_upd
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    if n_update <= 0:
+        raise RuntimeError("no sampler_update launches in the PMC trace")
+    out = {"per_step": int((2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024 / n_update), "ddpm_steps_profiled": n_update}
+    (fk, fn), (wk, wn) = fam["FETCH_SIZE"], fam["WRITE_SIZE"]
+    for k in PMC_FAMILIES:
+        if fn[k] and wn[k]:
+            out[k] = int((2 * fk[k] / fn[k] + wk[k] / wn[k]) * 1024)
+    if dom not in out:
+        raise RuntimeError(f"no launches of the dominant family {dom!r} in the PMC trace")
+    return out
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -449,6 +514,17 @@ def rank_main(a):
                 roof, rows = kernel_roofline(times, n_prof, nb // streams, streams, dn, S, a.dtype)
             except Exception as e:   # the throughput line must not depend on the profiler
                 res["kernel_profile_error"] = repr(e)[:300]
+        if roof and world == 1 and not a.no_pmc and a.dtype == "bf16":
+            # roofline.traffic measured by THIS run: two PMC child passes over 20 DDPM steps of the same job
+            try:
+                pm = live_pmc_traffic(a, roof["kernel"] if roof["kernel"] in PMC_FAMILIES else "chain")
+                dom = roof["kernel"] if roof["kernel"] in PMC_FAMILIES else "chain"
+                roof["traffic"] = pm[dom]
+                roof["traffic_from"] = (f"this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE child passes over "
+                                        f"{pm['ddpm_steps_profiled']} DDPM steps of the same job (FETCH_SIZE doubled, KB -> bytes)")
+                roof["traffic_per_ddpm_step"] = {"bytes": pm["per_step"], "algorithmic_min_bytes": 110e6, "from": "this run"}
+            except Exception as e:   # the committed file's figure (if it belongs to this build) stays
+                roof["traffic_live_error"] = repr(e)[:300]
         res["roofline"] = roof
         res["kernels"] = rows
         if world == 1 and not a.no_parity_mode and a.dtype == "bf16" and T >= 200:

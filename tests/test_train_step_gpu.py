@@ -250,7 +250,7 @@ def test_bf16_step_against_the_oracle_that_rounds_where_the_kernels_round(b):
     (oracle.operand_rounding: operands in the forward, T-typed activation gradients, stored GEMM outputs): this test computes, on
     the same weights / draws / dropout masks (train mode, the full four-term loss, 3 dancers x 150 frames),
         e_k = kernels vs exact,   e_A, e_D = two emulated roundings vs exact   (per parameter, relative L2)
-    and requires the kernels' error distribution to sit inside the emulations' own: median and worst <= 2 x the larger emulated
+    and requires the kernels' error distribution to sit inside the emulations' own: median and worst <= 2.5 x the larger emulated
     value.  A defect in a backward kernel (a wrong dS, a dropped term, bf16 where fp32 is claimed) adds to e_k and not to e_A / e_D.
     Measured on the build host (CPU emulation): b = 3: e_A median 1.4e-1 / worst 2.6e-1, e_D 6.6e-2 / 1.4e-1 (without dropout 7.7e-2 /
     1.7e-1 and 6.3e-2 / 2.2e-1); b = 32: e_A 5.1e-2 / 1.8e-1, e_D 5.6e-2 / 2.2e-1 -- the kernels: 6.3e-2 / 2.1e-1 (b = 3), 8.1e-2 / 3.0e-1
@@ -304,7 +304,10 @@ def test_bf16_step_against_the_oracle_that_rounds_where_the_kernels_round(b):
     med_e, worst_e = max(v[0] for v in stats.values()), max(v[1] for v in stats.values())
     print(f"[bf16, {b} x 3 x 150] kernels vs exact: median {med_k:.2e} worst {worst_k:.2e} ({ek[0][1]}); emulations: median <= {med_e:.2e}, "
           f"worst <= {worst_e:.2e}")
-    assert med_k <= 2.0 * med_e and worst_k <= 2.0 * worst_e, (med_k, med_e, worst_k, worst_e)
+    # 2.5 x: two roundings of one step differ from each other by up to that much -- emulations A / D 1.4e-1 / 6.6e-2 (b = 3, build host),
+    # the two HIP paths 6.3e-2 / 1.6e-1 (b = 3) -- and the emulated draw itself moves with the CPU's thread count; observed here on
+    # MI355X boxes: kernels / emulation = 0.66 (b = 3), 1.76 (b = 32, median and worst alike)
+    assert med_k <= 2.5 * med_e and worst_k <= 2.5 * worst_e, (med_k, med_e, worst_k, worst_e)
 
 
 _ORACLE_CACHE = {}
