@@ -1,14 +1,14 @@
 #!/bin/bash
-# round-4 measurement pass (one box visit): full GPU suite, parity log at the benchmarked config, default bench, rocprofv3 kernel
+# measurement pass of a round (one box visit; R=rNN names the outputs): full GPU suite, parity log at the benchmarked config, default bench, rocprofv3 kernel
 # stats (200 steps), FETCH/WRITE PMC passes (30 steps), SQ counters (20 steps), chain block-count scaling, training-step bench
-R=r04
+R=${R:-r05}
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 python -m pytest tests -q -m gpu 2>&1 | tail -3
 python -m pytest tests/test_parity_gpu.py -m gpu -s -q -k "c2 or bf16 or drift" > gpurun_out/${R}_parity_at_benchmarked_config.log 2>&1; tail -2 gpurun_out/${R}_parity_at_benchmarked_config.log
-python -m pytest tests/test_train_step_gpu.py -m gpu -s -q 2>&1 | grep -E "\[f32\]|\[bf16\]|passed|failed" > gpurun_out/${R}_train_step_parity.log; tail -3 gpurun_out/${R}_train_step_parity.log
+python -m pytest tests/test_train_step_gpu.py -m gpu -s -q 2>&1 | grep -E "\[f32\]|\[bf16|passed|failed" > gpurun_out/${R}_train_step_parity.log; tail -3 gpurun_out/${R}_train_step_parity.log
 python bench.py 2>gpurun_out/bench_default_err.log > gpurun_out/${R}_bench_full_1000steps.json; tail -c 2500 gpurun_out/${R}_bench_full_1000steps.json
-python tools/chain_bench.py 2>/dev/null | grep "chain B" > gpurun_out/${R}_chain_block_scaling.txt; cat gpurun_out/${R}_chain_block_scaling.txt
+python tools/chain_full_bench.py --forms 8 --reps 3 2>/dev/null | grep "waves:" > gpurun_out/${R}_chain_block_scaling.txt; cat gpurun_out/${R}_chain_block_scaling.txt
 for b in 4 32; do python tools/train_bench.py --batch $b --iters 8 --kernels 2>/dev/null | tail -1; done > gpurun_out/${R}_train_step.jsonl; cut -c1-400 gpurun_out/${R}_train_step.jsonl
 ARGS="bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-profile --no-parity-mode --no-train-step --no-other-configs"
 rm -rf gpurun_out/prof_trace
@@ -16,14 +16,7 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p
 echo "trace rc=$?"
 f=$(find gpurun_out/prof_trace -name "*kernel_stats.csv" | head -1); cp "$f" gpurun_out/${R}_kernel_stats_bench_200steps.csv; head -16 "$f" | cut -c1-160
 rm -rf gpurun_out/prof_trace
-for c in FETCH_SIZE WRITE_SIZE; do
-  rm -rf gpurun_out/prof_$c
-  timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/prof_$c -- python3 $ARGS --ddpm-steps 30 > gpurun_out/prof_$c.log 2>&1
-  echo "$c rc=$?"
-  python3 tools/pmc_summary.py gpurun_out/prof_$c > gpurun_out/${R}_pmc_${c}_30steps.txt
-  rm -rf gpurun_out/prof_$c
-done
-python3 tools/make_pmc_json.py gpurun_out/${R}_pmc_FETCH_SIZE_30steps.txt gpurun_out/${R}_pmc_WRITE_SIZE_30steps.txt gpurun_out/${R}_pmc.json 0
+# (roofline.traffic: bench.py runs the FETCH_SIZE / WRITE_SIZE passes itself since round 5; the default run above carries them)
 SETS="SQ_LDS_BANK_CONFLICT,SQ_LDS_IDX_ACTIVE,SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES,SQ_INSTS_VALU,SQ_INSTS_MFMA,SQ_BUSY_CYCLES" bash tools/gpu_pmc2.sh > /dev/null 2>&1
 cp gpurun_out/pmc2_summary.txt gpurun_out/${R}_pmc_SQ_counters_20steps.txt; head -8 gpurun_out/${R}_pmc_SQ_counters_20steps.txt | cut -c1-250
 # the training step under rocprofv3 (kernel stats of 6 steps at batch 32)
