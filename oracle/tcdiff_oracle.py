@@ -254,8 +254,12 @@ def affine(x, scale_shift):
     return (scale + 1) * x + shift
 
 
+FF_ACTIVATION = None     # tests of the constructor's `activation` option set this (a callable); None = F.gelu, the production value
+
+
 def gelu(x):
-    return F.gelu(x)  # exact erf form: TCDiff.py:85 passes F.gelu
+    # the feed-forward activation of the encoder / decoder layers (model/model.py:244,400); exact-erf GELU: TCDiff.py:85 passes F.gelu
+    return F.gelu(x) if FF_ACTIVATION is None else FF_ACTIVATION(x)
 
 
 def encoder_layer(x, sd: SD, prefix: str, freqs, n_head: int, drop=_nodrop, site0: int = 0) -> torch.Tensor:

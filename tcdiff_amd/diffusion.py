@@ -235,6 +235,12 @@ class GaussianDiffusion(nn.Module):
         st["rows"][:n] = torch.tensor(rows, dtype=torch.int32)
         st["tseq"][:n] = torch.tensor([int(t) for t in tseq], dtype=torch.int32)
         st["params"][:n] = params.to(torch.float32)
+        # the constraint kernel's own step table (q_sample coefficients in columns 4, 5, enable bit in column 7): separate from the
+        # update kernel's, whose columns 4, 5 carry the predict_epsilon coefficients
+        cpar = st["params"]
+        if constrain is not None and constrain.get("params") is not None:
+            st["cparams"][:n] = constrain["params"].to(torch.float32)
+            cpar = st["cparams"]
         if traj is not None:
             st["traj"].copy_(traj.reshape(B * Lq, 3))
         mask_rows = 0
@@ -260,7 +266,7 @@ class GaussianDiffusion(nn.Module):
             if constrain is not None:
                 K.sampler_constrain(constrain["kind"], st["x"], st["cmask"], mask_rows, st["cval"],
                                     st["qeps"] if constrain.get("q_noise") is not None else None, B * Lq, nf, Lq,
-                                    st["counter"], st["params"], st["tseq"], seed=0, clip0=clip_offset)
+                                    st["counter"], cpar, st["tseq"], seed=0, clip0=clip_offset)
             if couple is not None:
                 K.window_couple_step(st["x"], B, couple[0], couple[1], st["counter"], st["params"])
 
@@ -450,7 +456,7 @@ class GaussianDiffusion(nn.Module):
         params = self._ddim_params(pairs, weights)
         row = (Lq // self.seq_len) * nf
         for i, (time, time_next) in enumerate(pairs):       # x[1:, :half] = x[:-1, half:] after every step but the last
-            params[i, 7] = 1.0 if (time_next >= 0 and time > 0) else 0.0
+            params[i, 7] += 1.0 if (time_next >= 0 and time > 0) else 0.0      # (bit 3, no clamp, stays: _ddim_params)
         after = None
         if halo is not None:
             def after(i, t, xv):
@@ -488,7 +494,7 @@ class GaussianDiffusion(nn.Module):
             x = torch.where(mask[None], x_0, x)
             constrain = dict(kind=1, mask=mask.float(), value=x_0)     # re-imposed inside every captured step but the last
             for i, (_, time_next) in enumerate(pairs):
-                params[i, 7] = 2.0 if time_next >= 0 else 0.0
+                params[i, 7] += 2.0 if time_next >= 0 else 0.0
         x = self._run(L.SAMPLER_DDIM, (B, Lq, nf), cond, x, [a for a, _ in pairs], params, traj=traj,
                       step_noise=kwargs.get("step_noise"), seed=kwargs.get("seed"),
                       clip_offset=kwargs.get("clip_offset", 0), constrain=constrain)
@@ -519,17 +525,15 @@ class GaussianDiffusion(nn.Module):
         chain = [x] if return_diffusion else None
 
         q_noise = kw.get("q_noise")      # optional callable(t, shape): the randn_like q_sample draws in step t
-        if self.predict_epsilon:
-            raise L.TcdiffError("inpaint_loop with predict_epsilon=True is not implemented (its q_sample coefficients share the "
-                                "step parameters' columns; the production configuration predicts x_0, TCDiff.py:96)")
         params = self._ddpm_params(tseq)
+        cpar = torch.zeros(len(tseq), 8)
         sa, s1 = self.sqrt_alphas_cumprod.cpu(), self.sqrt_one_minus_alphas_cumprod.cpu()
         for i, tt in enumerate(tseq):    # x = q_sample(value, t - 1) * mask + (1 - mask) * x after every step with t > 0
             if tt > 0:
-                params[i, 4], params[i, 5] = sa[tt - 1], s1[tt - 1]
-                params[i, 7] += 2.0
+                cpar[i, 4], cpar[i, 5] = sa[tt - 1], s1[tt - 1]
+                cpar[i, 7] = 2.0
         constrain = dict(kind=2, mask=mask.float().expand(shape).reshape(-1, shape[-1]), value=value.float().expand(shape),
-                         q_noise=(lambda tt, sh: q_noise(tt, sh).to(device)) if q_noise is not None else None)
+                         q_noise=(lambda tt, sh: q_noise(tt, sh).to(device)) if q_noise is not None else None, params=cpar)
         out = self._run(L.SAMPLER_DDPM, tuple(shape), cond, x.float(), tseq, params, step_noise=kw.get("step_noise"),
                         seed=kw.get("seed"), collect=chain, constrain=constrain)
         return (out, chain) if return_diffusion else out

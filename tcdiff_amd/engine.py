@@ -57,8 +57,9 @@ class DenoiserEngine:
         self.film_tab = None
         self._sampler_state = None
         # row-block chain kernels (csrc/chain.hip): bf16 only; the f32 parity mode keeps the op-by-op kernels
+        self.act = int(cfg.get("act", L.ACT_GELU))    # feed-forward activation (TC_ACT_*); the chain kernels are GELU only
         self.use_chain = self.dt == L.DT_BF16 and os.environ.get("TCDIFF_CHAIN", "1") != "0" and self.ff == 1024 \
-            and self.H == 8
+            and self.H == 8 and self.act == L.ACT_GELU
         # TCDIFF_CHAIN=2 (default): cross-attention inside the chain too: per layer self-attention + ONE chain launch
         self.use_full = self.use_chain and os.environ.get("TCDIFF_CHAIN", "2") == "2"
         self.nkt = (self.S + 2 + 31) // 32          # 32-key tiles of the cross-attention memory
@@ -94,7 +95,7 @@ class DenoiserEngine:
                       traj=torch.zeros(rows, 3, device=dev), counter=torch.zeros(8, device=dev, dtype=torch.int32),
                       rows=torch.zeros(cap, device=dev, dtype=torch.int32),
                       tseq=torch.zeros(cap, device=dev, dtype=torch.int32),
-                      params=torch.zeros(cap, 8, device=dev))
+                      params=torch.zeros(cap, 8, device=dev), cparams=torch.zeros(cap, 8, device=dev))
             self._sampler_state = st
             self.reset_graphs()
         return st
@@ -354,7 +355,7 @@ class DenoiserEngine:
             K.gemm_rowln(dt, b["mO"], w[e + "o.w"], M, 512, bias=w[e + "o.b"], xres=b["tok"], xout=b["tok"], Lseq=S,
                          flags=L.ROW_BIAS | L.ROW_RES | L.ROW_STORE_X | L.ROW_NEXT_LN | L.ROW_STORE_H,
                          nln_g=w[e + "norm2.g"], nln_b=w[e + "norm2.b"], nln_eps=1e-5, hout=b["mh"])
-            K.gemm_tile(dt, b["mh"], w[e + "l1.w"], M, 1024, 512, bias=w[e + "l1.b"], act=L.ACT_GELU, out=b["mh1"],
+            K.gemm_tile(dt, b["mh"], w[e + "l1.w"], M, 1024, 512, bias=w[e + "l1.b"], act=self.act, out=b["mh1"],
                         ldc=1024)
             K.gemm_rowln(dt, b["mh1"], w[e + "l2.w"], M, 1024, bias=w[e + "l2.b"], xres=b["tok"], xout=b["tok"],
                          Lseq=S, flags=L.ROW_BIAS | L.ROW_RES | L.ROW_STORE_X)
@@ -548,7 +549,7 @@ class DenoiserEngine:
                          film_ld=fld, xres=b["xa"], xout=b["xa"], Lseq=Lq, nln_g=w[p + "norm3.g"],
                          nln_b=w[p + "norm3.b"], nln_eps=1e-5, hout=b["h"])
             # ---- feed-forward block (model/model.py:338-339,399-401)
-            K.gemm_tile(dt, b["h"], w[p + "ff1.w"], R, 1024, 512, bias=w[p + "ff1.b"], act=L.ACT_GELU, out=b["h1"],
+            K.gemm_tile(dt, b["h"], w[p + "ff1.w"], R, 1024, 512, bias=w[p + "ff1.b"], act=self.act, out=b["h1"],
                         ldc=1024)
             K.gemm_rowln(dt, b["h1"], w[p + "ff2.w"], R, 1024, flags=L.ROW_BIAS | L.ROW_FILM | L.ROW_NEXT_LN | L.ROW_STORE_H,
                          bias=w[p + "ff2.b"], film=film0[:, (l * 3 + 2) * 1024:], film_ld=fld, xres=b["xa"], Lseq=Lq,

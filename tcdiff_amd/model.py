@@ -122,8 +122,14 @@ class DanceDecoder(nn.Module):
         super().__init__()
         if not use_rotary:
             raise L.TcdiffError("the MI355X path implements the rotary configuration only (TCDiff.py:76-87)")
-        if activation is not F.gelu:
-            raise L.TcdiffError("the MI355X path implements activation=F.gelu (TCDiff.py:85)")
+        # feed-forward activation of the encoder / decoder layers (model/model.py:244,400): the production configuration passes
+        # F.gelu (TCDiff.py:85) and only that runs on the fused chain kernels; relu / silu / mish run on the op-by-op kernels
+        acts = {F.gelu: L.ACT_GELU, F.relu: L.ACT_RELU, F.silu: L.ACT_SILU, F.mish: L.ACT_MISH}
+        if isinstance(activation, str):
+            activation = {"gelu": F.gelu, "relu": F.relu, "silu": F.silu, "mish": F.mish}.get(activation, activation)
+        if activation not in acts:
+            raise L.TcdiffError("the MI355X path implements activation in {F.gelu, F.relu, F.silu, F.mish} (model/model.py:244,400)")
+        self.act_id = acts[activation]
         self.nfeats = nfeats
         self.latent_dim = latent_dim
         self.required_dancer_num = required_dancer_num
@@ -169,7 +175,8 @@ class DanceDecoder(nn.Module):
     # ------------------------------------------------------------------------------------------
     def engine_config(self) -> dict:
         return dict(latent=self.latent_dim, nfeats=self.nfeats, dn=self.required_dancer_num, seq_len=self.seq_len,
-                    n_layers=self.num_layers, n_head=self.num_heads, ff=self.ff_size, cond_dim=self.cond_feature_dim)
+                    n_layers=self.num_layers, n_head=self.num_heads, ff=self.ff_size, cond_dim=self.cond_feature_dim,
+                    act=self.act_id)
 
     def _weights_version(self):
         return tuple(p._version for p in self.parameters()) + (str(next(self.parameters()).device),)

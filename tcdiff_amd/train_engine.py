@@ -275,6 +275,7 @@ class TrainEngine:
             # mode runs the exact-fp32 schedule (same storage, same gradients as compute_dtype="f32")
             self.dt = L.DT_F32
         self.mode_dt = K.dtype_id(compute)      # what model.train_engine() compares with the model's mode
+        self.act = int(getattr(model, "act_id", L.ACT_GELU))      # feed-forward activation (model/model.py:244,400)
         self.T = K.TORCH_DT[self.dt]
         self.kt = K.k_tile(self.dt)
         c = model.engine_config()
@@ -695,7 +696,7 @@ class TrainEngine:
             self.row_fwd(flags=L.ROWF_DROP_PRE | L.ROWF_RES | L.ROWF_STORE_X | L.ROWF_NEXT_LN | L.ROWF_STORE_H, M=Ms, L=S,
                          z=zo, xres=tok, xout=x2, nln_g=P(q + "norm2.weight"), nln_b=P(q + "norm2.bias"), nln_eps=1e-5,
                          hout=h2, site_pre=4 * i + 1)
-            a, f = lins[f"e{i}.l1"].fwd(h2, Ms, out=e(Ms, 1024), act=(L.ACT_GELU, 4 * i + 2))
+            a, f = lins[f"e{i}.l1"].fwd(h2, Ms, out=e(Ms, 1024), act=(self.act, 4 * i + 2))
             zf = e(Ms, 512, dtype=f32)
             lins[f"e{i}.l2"].fwd(f, Ms, out=zf, f32=True)
             x3 = e(Ms, 512, dtype=f32)
@@ -806,7 +807,7 @@ class TrainEngine:
                          ln_b=P(q + "multihead_attn.layer_norm.bias"), ln_eps=1e-6, film=film[:, (3 * l + 1) * 1024:],
                          film_ld=nfilm, xres=x2, xout=x3, nln_g=P(q + "norm3.weight"), nln_b=P(q + "norm3.bias"), nln_eps=1e-5,
                          hout=h3, site_pre=sd + 4, site_post=sd + 5)
-            a, f = lins[f"l{l}.ff1"].fwd(h3, M, out=e(M, 1024), act=(L.ACT_GELU, sd + 6))
+            a, f = lins[f"l{l}.ff1"].fwd(h3, M, out=e(M, 1024), act=(self.act, sd + 6))
             z3 = e(M, 512, dtype=f32)
             lins[f"l{l}.ff2"].fwd(f, M, out=z3, f32=True)
             h4 = e(M, 512)
@@ -1026,7 +1027,7 @@ class TrainEngine:
                          nln_g=P(q + "norm4.weight"), nln_b=P(q + "norm4.bias"), nln_eps=1e-5, site_pre=sd + 7, d_h=dh4, d_z=dz3,
                          d_xres=gx3, d_film=dfilm[:, (3 * l + 2) * 1024:], dfilm_ld=nfilm)
             da = e(M, 1024)
-            lins[f"l{l}.ff2"].bwd(dz3, 512, M, [s["f"]], [("ACT", da, 1024, s["a"], L.ACT_GELU, sd + 6)], bias_done=True)
+            lins[f"l{l}.ff2"].bwd(dz3, 512, M, [s["f"]], [("ACT", da, 1024, s["a"], self.act, sd + 6)], bias_done=True)
             dh3 = e(M, 512)
             lins[f"l{l}.ff1"].bwd(da, 1024, M, [s["h3"]], [("T", dh3, 512)])
             # cross-attention block
@@ -1131,7 +1132,7 @@ class TrainEngine:
                 self.row_bwd(M=Ms, L_=S, lin=f"e{i}.l2", flags=fl, z=s["zf"], xres=s["x2"], site_pre=4 * i + 3, d_xn=g_tok,
                              d_z=dzf, d_xres=gx2)
             da = e(Ms, 1024)
-            lins[f"e{i}.l2"].bwd(dzf, 512, Ms, [s["f"]], [("ACT", da, 1024, s["a"], L.ACT_GELU, 4 * i + 2)], bias_done=True)
+            lins[f"e{i}.l2"].bwd(dzf, 512, Ms, [s["f"]], [("ACT", da, 1024, s["a"], self.act, 4 * i + 2)], bias_done=True)
             dh2 = e(Ms, 512)
             lins[f"e{i}.l1"].bwd(da, 1024, Ms, [s["h2"]], [("T", dh2, 512)])
             dzo, gx1 = e(Ms, 512), e(Ms, 512, dtype=f32)

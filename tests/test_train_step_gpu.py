@@ -193,6 +193,37 @@ def test_training_step_at_the_benchmarked_config_vs_oracle_autograd(compute, b):
     assert len(allr) == 435 - 125 and allr[0][0] < bound, allr[0]
 
 
+@pytest.mark.parametrize("name", ["relu", "silu"])
+def test_training_step_with_another_feed_forward_activation_vs_oracle_autograd(name):
+    """DanceDecoder(activation=F.relu | F.silu): one train-mode step (dropout live) at the C1 shape in the f32 mode, every live
+    parameter's gradient against the oracle's autograd with the same activation (oracle.FF_ACTIVATION): <= 1e-4 relative L2."""
+    fn = {"relu": F.relu, "silu": F.silu}[name]
+    sd = O.synth_state_dict(dn=DN, seq_len=S)
+    model = DanceDecoder(nfeats=151, seq_len=S, latent_dim=512, ff_size=1024, num_layers=8, num_heads=8, dropout=0.1,
+                         cond_feature_dim=438, activation=fn, required_dancer_num=DN, compute_dtype="f32")
+    model.load_state_dict(sd)
+    diff = GaussianDiffusion(model, S, 151, None, schedule="cosine", n_timestep=T, predict_epsilon=False, loss_type="l2",
+                             use_p2=False, cond_drop_prob=0.25, guidance_weight=2, seq_len=S).to(DEV)
+    diff.train()
+    x_start, cond, noise = step_inputs(0, 10)
+    t, keep, seed = torch.tensor([17, 80, 3]), torch.tensor([True, False, True]), (11, 5)
+    model.train_seed = seed
+    total, _ = diff.p_losses(x_start.to(DEV), cond.to(DEV), t.to(DEV), noise=noise.to(DEV), keep_mask=keep.to(DEV))
+    total.backward()
+    sd_now = {n: p.detach().clone().requires_grad_(True) for n, p in sd.items() if p.is_floating_point()}
+    O.FF_ACTIVATION = fn
+    try:
+        o_total, _ = O.p_losses(sd_now, O.make_tables(T), x_start, cond, t, noise, keep, drop=O.DropPlan(seed, 0.1))
+        o_total.backward()
+    finally:
+        O.FF_ACTIVATION = None
+    allr = sorted(((rel(p.grad.cpu().numpy(), sd_now[n].grad.numpy()), n) for n, p in model.named_parameters() if p.grad is not None),
+                  reverse=True)
+    print(f"[f32, activation={name}] total {float(total):.6f} (oracle {float(o_total):.6f}); {len(allr)} gradients vs the oracle's autograd: "
+          f"worst {allr[0][1]} {allr[0][0]:.2e}, median {np.median([v for v, _ in allr]):.2e}")
+    assert abs(float(total) - float(o_total)) <= 2e-5 * abs(float(o_total)) and allr[0][0] < 1e-4
+
+
 def test_row_block_gemm_path_and_tile_path_are_two_roundings_of_the_same_step():
     """The decoder layers' linears run through tcdiff_gemm_rows (default) or tcdiff_gemm_tile (TCDIFF_TRAIN_ROWS=0): the same
     bf16 operands and fp32 accumulation, another summation order.  One train-mode step (3 clips of 3 x 150) both ways against
