@@ -99,11 +99,22 @@ __global__ __launch_bounds__(256) void attention_kernel(const char* __restrict__
         for (int kt = 0; kt < C::NKT; ++kt) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) s[kt][q] = 0.0f;
+            if constexpr (P::IS_X3) {     // split-bf16: the d k-steps in pairs (common.h MmaBF16x3::mma2)
+#pragma unroll
+                for (int ks = 0; ks < C::NKS; ks += 2) {
+                    const int sub = ks >> 2, ch = 2 * (ks & 3) + h;
+                    const char* kp = kt_base + sub * (KB * TC_ROWB);
+                    const u32x4 k0 = *reinterpret_cast<const u32x4*>(kp + tile_off(kt * 32 + r, ch));
+                    const u32x4 k1 = *reinterpret_cast<const u32x4*>(kp + tile_off(kt * 32 + r, ch + 2));
+                    P::mma2(s[kt], k0, k1, qf[ks], qf[ks + 1]);
+                }
+            } else {
 #pragma unroll
             for (int ks = 0; ks < C::NKS; ++ks) {
                 const int sub = ks >> 2, ch = 2 * (ks & 3) + h;
                 u32x4 kf = *reinterpret_cast<const u32x4*>(kt_base + sub * (KB * TC_ROWB) + tile_off(kt * 32 + r, ch));
                 P::mma(s[kt], kf, qf[ks]);
+            }
             }
         }
         // ---- mask keys beyond Lk (last tile only) -------------------------------------------------
@@ -148,6 +159,20 @@ __global__ __launch_bounds__(256) void attention_kernel(const char* __restrict__
         // ---- O^T += V^T P^T --------------------------------------------------------------------------
 #pragma unroll
         for (int kt = 0; kt < C::NKT; ++kt) {
+            if constexpr (P::IS_X3) {     // split-bf16: the 8-key k-steps of the tile in pairs
+#pragma unroll
+                for (int st = 0; st < C::PV_STEPS; st += 2) {
+                    const f32x4_t p0 = {s[kt][4 * st + 0], s[kt][4 * st + 1], s[kt][4 * st + 2], s[kt][4 * st + 3]};
+                    const f32x4_t p1 = {s[kt][4 * st + 4], s[kt][4 * st + 5], s[kt][4 * st + 6], s[kt][4 * st + 7]};
+                    const u32x4 pf0 = P::chunk_from4(p0), pf1 = P::chunk_from4(p1);
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        const u32x4 v0 = v_frag<P>(vt_base, dt, kt, st, lane), v1 = v_frag<P>(vt_base, dt, kt, st + 1, lane);
+                        P::mma2(o[dt], v0, v1, pf0, pf1);
+                    }
+                }
+                continue;
+            }
 #pragma unroll
             for (int st = 0; st < C::PV_STEPS; ++st) {
                 u32x4 pf;

@@ -113,6 +113,17 @@ struct MmaBF16x3 {
                            __builtin_bit_cast(float, c[1] & 0xFFFF0000u) + __builtin_bit_cast(float, c[3] & 0xFFFF0000u)};
         return f;
     }
+    // TWO consecutive k-steps at once (K = 16): the hi quads of the two chunks side by side are the 8-element operand of
+    // v_mfma_f32_32x32x16_bf16 (lane half h supplies k = 8 h + j: j < 4 from the first k-step's chunk, j >= 4 from the second's;
+    // A and B alike), which costs the same 32 cycles as the K = 8 form below: half the matrix-pipe time per product.  Every k-loop
+    // of the split-bf16 kernels walks its k-steps in pairs; `mma` (one k-step) remains for odd tails.
+    static DEVINL void mma2(f32x16_t& acc, const u32x4& a0, const u32x4& a1, const u32x4& b0, const u32x4& b1) {
+        const u32x4 ah = {a0[0], a0[1], a1[0], a1[1]}, al = {a0[2], a0[3], a1[2], a1[3]};
+        const u32x4 bh = {b0[0], b0[1], b1[0], b1[1]}, bl = {b0[2], b0[3], b1[2], b1[3]};
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, al), __builtin_bit_cast(bf16x8_t, bh), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ah), __builtin_bit_cast(bf16x8_t, bl), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ah), __builtin_bit_cast(bf16x8_t, bh), acc, 0, 0, 0);
+    }
     static DEVINL void mma(f32x16_t& acc, const u32x4& a, const u32x4& b) {
         const uint2 a_h = {a[0], a[1]}, a_l = {a[2], a[3]}, b_h = {b[0], b[1]}, b_l = {b[2], b[3]};
         const s16x4_t ah = __builtin_bit_cast(s16x4_t, a_h), al = __builtin_bit_cast(s16x4_t, a_l);

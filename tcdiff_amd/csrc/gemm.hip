@@ -182,6 +182,24 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(const char* __restrict__
                 }
             continue;
         }
+        if constexpr (P::IS_X3) {     // split-bf16: k-steps in pairs, one K = 16 MFMA triple per pair (common.h MmaBF16x3::mma2)
+#pragma unroll
+            for (int ks = 0; ks < 4; ks += 2) {
+                u32x4 fa[2][2], fw[2][2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) fa[i][q] = lds_frag(ta, i * 32 + r, 2 * (ks + q) + h);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) fw[j][q] = lds_frag(tw, j * 32 + r, 2 * (ks + q) + h);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) P::mma2(acc[i][j], fw[j][0], fw[j][1], fa[i][0], fa[i][1]);
+            }
+            continue;
+        }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             u32x4 fa[2], fw[2];
@@ -598,6 +616,17 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(const char* __restrict_
         }
         const char* ta = smem + cur * STAGE + (wm * 32) * TC_ROWB;
         const char* tw = smem + cur * STAGE + WOFF + (wn * 128) * TC_ROWB;
+        if constexpr (P::IS_X3) {     // split-bf16: k-steps in pairs (see gemm_tile_kernel)
+#pragma unroll
+            for (int ks = 0; ks < 4; ks += 2) {
+                const u32x4 fa0 = lds_frag(ta, r, 2 * ks + h), fa1 = lds_frag(ta, r, 2 * ks + 2 + h);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const u32x4 fw0 = lds_frag(tw, j * 32 + r, 2 * ks + h), fw1 = lds_frag(tw, j * 32 + r, 2 * ks + 2 + h);
+                    P::mma2(acc[j], fa0, fa1, fw0, fw1);
+                }
+            }
+        } else {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             u32x4 fa = lds_frag(ta, r, 2 * ks + h);
@@ -606,6 +635,7 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(const char* __restrict_
                 u32x4 fw = lds_frag(tw, j * 32 + r, 2 * ks + h);
                 P::mma(acc[j], fa, fw);
             }
+        }
         }
         sync_dma();
     }
