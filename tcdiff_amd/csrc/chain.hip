@@ -60,7 +60,11 @@
 // HH: which of the wave's NT / 4 heads (NT = 4: head = wave; NT = 8: heads 2 wave, 2 wave + 1 = accumulator tiles 4 HH ..)
 template <int HH, int MT, int NT>
 DEVINL void cross_attention(const f32x4_t (&qacc)[NT][MT], const tcdiff_chain_args& a, int m0, char* abuf, int wave, int lane) {
+#ifdef CH_XATT_ONEPASS   // diagnostic build (profiles/r05_chain_wave_forms.txt): all four row tiles in ONE pass over the K / V tiles
+    constexpr int NML = MT, NPS = 1;
+#else
     constexpr int NPS = MT == 4 ? 2 : 1, NML = MT == 1 ? 1 : 2;     // passes of 32 rows, row tiles (independent chains) per pass
+#endif
     lane = fresh_v(lane);
     wave = fresh_s(wave) * (NT / 4) + HH;          // from here on `wave` is the HEAD
     const int c = lane & 15, g = lane >> 4;
@@ -76,6 +80,14 @@ DEVINL void cross_attention(const f32x4_t (&qacc)[NT][MT], const tcdiff_chain_ar
             qf[mt][s][2] = pack_bf2(hi[0] * a.scale_q, hi[1] * a.scale_q);
             qf[mt][s][3] = pack_bf2(hi[2] * a.scale_q, hi[3] * a.scale_q);
         }
+#ifdef CH_XATT_ONEPASS
+    // the packed Q^T fragments wait in LDS (the GELU chunk area is idle here; 8 KB per wave, wave-private: no barrier)
+    char* qpark = abuf + (CH_H1C - CH_ABUF) + wave * 8192 + lane * 16;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) *reinterpret_cast<u32x4*>(qpark + (mt * 2 + s) * 1024) = qf[mt][s];
+#endif
     constexpr float LOG2E = 1.4426950408889634f;
     const unsigned voff = (unsigned)lane * 16u;
     const __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.kf), 0, -1, 0x00020000);
@@ -86,14 +98,14 @@ DEVINL void cross_attention(const f32x4_t (&qacc)[NT][MT], const tcdiff_chain_ar
     };
 #pragma unroll
     for (int ps = 0; ps < NPS; ++ps) {             // rows 32 ps .. 32 ps + 31 = row tiles 2 ps, 2 ps + 1
-        int ra = m0 + 32 * ps, rb = ra + 16 * NML - 1;
+        int ra = m0 + 16 * NML * ps, rb = ra + 16 * NML - 1;
         ra = ra < M ? ra : M - 1;
         rb = rb < M ? rb : M - 1;
         const int sa = ra / L, sb = rb / L;                 // wave-uniform
         int my_seq[NML];
 #pragma unroll
         for (int ml = 0; ml < NML; ++ml) {
-            int mrow = m0 + 32 * ps + 16 * ml + c;
+            int mrow = m0 + 16 * NML * ps + 16 * ml + c;
             mrow = mrow < M ? mrow : M - 1;
             my_seq[ml] = mrow / L;
         }
@@ -121,18 +133,33 @@ DEVINL void cross_attention(const f32x4_t (&qacc)[NT][MT], const tcdiff_chain_ar
                 for (int i = 0; i < 4; ++i) kc[i] = kn[i];
                 ld_tile(vr, so0 + (unsigned)kt * 4096u, vc);       // V of this tile: in flight under QK^T and the softmax
                 const int nx = kt + 1 < nkt ? kt + 1 : kt;       // the last iteration re-reads its own tile (unused)
+#ifndef CH_XATT_ONEPASS
                 ld_tile(kr, so0 + (unsigned)nx * 4096u, kn);
+#endif
                 // the two row tiles of the pass are independent chains in ONE basic block (no per-tile branch between them)
                 f32x4_t s0[NML], s1[NML];                              // keys 4 g + j and 16 + 4 g + j of the tile
 #pragma unroll
                 for (int ml = 0; ml < NML; ++ml) {
-                    const int mt = 2 * ps + ml;
+                    const int mt = NML * ps + ml;
                     s0[ml] = s1[ml] = f32x4_t{0, 0, 0, 0};
-                    mma16(s0[ml], kc[0], qf[mt][0]);
-                    mma16(s1[ml], kc[2], qf[mt][0]);
-                    mma16(s0[ml], kc[1], qf[mt][1]);
-                    mma16(s1[ml], kc[3], qf[mt][1]);
+#ifdef CH_XATT_ONEPASS
+                    char* qp = qpark;
+                    asm volatile("" : "+v"(qp));      // opaque per tile: the reads stay in the loop (hoisted, they are 32 registers again)
+                    const u32x4 q0 = *reinterpret_cast<const u32x4*>(qp + (mt * 2) * 1024);
+                    const u32x4 q1 = *reinterpret_cast<const u32x4*>(qp + (mt * 2 + 1) * 1024);
+#else
+                    const u32x4 q0 = qf[mt][0], q1 = qf[mt][1];
+#endif
+                    mma16(s0[ml], kc[0], q0);
+                    mma16(s1[ml], kc[2], q0);
+                    mma16(s0[ml], kc[1], q1);
+                    mma16(s1[ml], kc[3], q1);
                 }
+#ifdef CH_XATT_ONEPASS   // the next tile's K fragments are fetched once this tile's score MFMAs have issued (16 registers fewer in flight)
+#pragma unroll
+                for (int ml = 0; ml < NML; ++ml) asm volatile("" : "+v"(s0[ml]), "+v"(s1[ml]));
+                ld_tile(kr, so0 + (unsigned)nx * 4096u, kn);
+#endif
                 if (kt * 32 + 32 > a.Lk) {
 #pragma unroll
                     for (int ml = 0; ml < NML; ++ml)
@@ -152,7 +179,8 @@ DEVINL void cross_attention(const f32x4_t (&qacc)[NT][MT], const tcdiff_chain_ar
                 }
                 // the running maximum moves in the first tile or two; afterwards the whole wave skips the rescale
                 bool moved = m_new[0] > m_run[0];
-                if constexpr (NML == 2) moved = moved || m_new[1] > m_run[1];
+#pragma unroll
+                for (int ml = 1; ml < NML; ++ml) moved = moved || m_new[ml] > m_run[ml];
                 if (__builtin_amdgcn_ballot_w64(moved) != 0) {
 #pragma unroll
                     for (int ml = 0; ml < NML; ++ml) {
@@ -189,7 +217,7 @@ DEVINL void cross_attention(const f32x4_t (&qacc)[NT][MT], const tcdiff_chain_ar
                 const float lsum = ar4_sum(l_run[ml]);
                 if (my_seq[ml] == seq) {
                     const float inv = __builtin_amdgcn_rcpf(lsum);    // 1 ulp; the quotient is rounded to bf16 next
-                    const int mt = 2 * ps + ml;
+                    const int mt = NML * ps + ml;
 #pragma unroll
                     for (int dt = 0; dt < 4; ++dt) {
                         uint2 pk;

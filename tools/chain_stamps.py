@@ -5,6 +5,9 @@ os.environ.setdefault("TCDIFF_LIB_PATH", "tools/probe/libtc_STAMP.so")
 import torch
 exec(open(os.path.join(os.path.dirname(__file__), "chain_bench.py")).read().split("def run(")[0])
 S_, nkt = 150, 5
+if os.environ.get("XATT_KEYS"):      # diagnostic: the in-kernel attention over a longer key set (e.g. 450 = a self-attention's)
+    S_ = int(os.environ["XATT_KEYS"]) - 2
+    nkt = (S_ + 2 + 31) // 32
 order = [(0, "start"), (1, "A block + first stages landed"), (2, "self fc GEMM"), (40, "  (row loads issued)"), (41, "  LN statistics exchange (waits for the SIMD's second wave)"),
          (3, "  LN, FiLM, residual, store"),
          (4, "norm2 stats"), (34, "norm2 + rotary -> LDS + barrier"), (35, "w_qs GEMM"), (36, "cross-attention (incl. barrier)"),
