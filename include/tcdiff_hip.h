@@ -265,6 +265,27 @@ typedef struct {
     int nw;                /* waves per workgroup: 0 or 8 = eight waves x 64 output columns; 4 = four waves x 128 columns, one per
                               SIMD (TC_CHAIN_FULL, _FULL_LAST, _FRONT only).  `wstream` must be packed for the same form: per wave
                               stages of 16 nt x 64 lanes x 16 B with nt = 4 (4-KB stages) or 8 (8-KB stages) n-tiles */
+    /* ---- round 5: the layer's SELF-attention inside the launch (TC_CHAIN_FULL / _FULL_LAST, nw = 8) ------------------------
+     * seq_blocks = 1: row blocks are cut per sequence -- block (s, b) holds rows s L + 16 mt b .. of sequence s only (grid = (M / L)
+     * x ceil(L / (16 mt)); no block straddles two sequences, its rows are keys 16 mt b .. of its sequence).
+     * sa_q != NULL: instead of reading the attention output `A`, the block computes softmax((Q / 8) K^T) V of its rows itself
+     * (model/model.py:97-102; wave = head, online softmax over 32-key tiles as the in-kernel cross-attention) from
+     *   sa_q  : the block's Q^T fragments, bf16, as the PREVIOUS launch left them in `qf_out`: [block][8 waves][mt][2][64 lanes][8]
+     *           (already scaled by 1 / sqrt(d_k));
+     *   sa_kf, sa_vf : K / V of the layer in the fragment order of tcdiff_pack_kv_frags, bf16 [M / L][8 heads][sa_nkt][4][64][8],
+     *           sa_nkt = ceil(L / 32) tiles; keys >= L of the last tile must be finite.
+     * qf_out / kf_out / vf_out != NULL (all three together; requires seq_blocks): the next layer's Q, K, V leave in those formats
+     * (written straight from the accumulators: 1-KB pieces per wave instruction) instead of the head-major images q_out / k_out /
+     * v_out; out_nkt = the key tiles per (sequence, head) of kf_out / vf_out. */
+    int seq_blocks;
+    const void* sa_q;
+    const void* sa_kf;
+    const void* sa_vf;
+    int sa_nkt;
+    void* qf_out;
+    void* kf_out;
+    void* vf_out;
+    int out_nkt;
 } tcdiff_chain_args;
 
 int tcdiff_chain(const tcdiff_chain_args* args, hipStream_t stream);

@@ -44,7 +44,8 @@ class ChainArgs(C.Structure):
                 ("k_out", _vp), ("v_out", _vp), ("h_out", _vp), ("film_ld", _i), ("ln_eps", _f), ("n2_eps", _f),
                 ("n4_eps", _f), ("nn_eps", _f), ("scale_q", _f), ("filmb", _vp),
                 ("n3_g", _vp), ("n3_b", _vp), ("kf", _vp), ("vf", _vp), ("n_shared", _i), ("nkt", _i), ("Lk", _i),
-                ("xres_rowmajor", _i), ("rope_rows", _i), ("dn", _i), ("mt", _i), ("out_ld", _i), ("nw", _i)]
+                ("xres_rowmajor", _i), ("rope_rows", _i), ("dn", _i), ("mt", _i), ("out_ld", _i), ("nw", _i), ("seq_blocks", _i), ("sa_q", _vp), ("sa_kf", _vp), ("sa_vf", _vp),
+                ("sa_nkt", _i), ("qf_out", _vp), ("kf_out", _vp), ("vf_out", _vp), ("out_nkt", _i)]
 
 
 class StepPrologueArgs(C.Structure):

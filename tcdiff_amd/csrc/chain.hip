@@ -46,6 +46,11 @@
 
 #include "chain_core.h"
 
+#define CH_LOG2E 1.4426950408889634f
+#ifndef CH_ATT_THR
+#define CH_ATT_THR 5.0f      // in-kernel attention: a tile moves the running maximum when a score exceeds it by more than this (log2 units)
+#endif
+
 // Cross-attention of this wave's head inside the chain (model/model.py:386-396,97-102 with cached K / V): the wave owns
 // head `wave` of all 64 rows.  qacc = (rot W_q^T)^T tiles straight from the projection GEMM (lane = row, registers = d):
 // scaled and packed, the pairs (nt = 2 s, 2 s + 1) ARE the B operand of S^T = K Q^T for the 32-deep d-step s, with d in the
@@ -58,40 +63,61 @@
 // per sequence and every lane keeps the result of its own row's sequence.
 // Output: bf16 O rows into the activation block (columns 64 wave ..).
 // HH: which of the wave's NT / 4 heads (NT = 4: head = wave; NT = 8: heads 2 wave, 2 wave + 1 = accumulator tiles 4 HH ..)
-template <int HH, int MT, int NT>
-DEVINL void cross_attention(const f32x4_t (&qacc)[NT][MT], const tcdiff_chain_args& a, int m0, char* abuf, int wave, int lane) {
-#ifdef CH_XATT_ONEPASS   // diagnostic build (profiles/r05_chain_wave_forms.txt): all four row tiles in ONE pass over the K / V tiles
-    constexpr int NML = MT, NPS = 1;
+// SELF (round 5): the layer's SELF-attention with the same loop, in front of the fc GEMM (tcdiff_chain_args.sa_q): the Q^T
+// fragments are the ones this block's previous launch packed (store_qfrag), the keys are the block's own sequence (K / V in
+// fragment order from store_kfrag / store_vfrag of the previous launch, Lk = L, no slot mapping); blocks are cut per sequence.
+// Mv: first row past the block's valid rows (M, or the end of the block's sequence); lblk: the block's logical index.
+template <int HH, int MT, int NT, bool SELF = false>
+DEVINL void cross_attention(const f32x4_t (&qacc)[NT][MT], const tcdiff_chain_args& a, int m0, int Mv, int lblk, char* abuf,
+                            int wave, int lane) {
+    // Cross-attention: passes of 32 rows, two row tiles (independent chains) per pass -- the weight ring is resident beside it.
+    // SELF: all row tiles in ONE pass over the K / V tiles (the ring is loaded after it: the registers are there, and with 450 keys of
+    // the block's own sequence a second pass doubles a K / V stream that already runs near the L2's rate when every CU does it at once).
+    // CH_XATT_ONEPASS: diagnostic build (profiles/r05_chain_wave_forms.txt) -- one pass for the cross-attention too, Q^T parked in LDS.
+#ifdef CH_XATT_ONEPASS
+    constexpr bool PARK = !SELF;
 #else
-    constexpr int NPS = MT == 4 ? 2 : 1, NML = MT == 1 ? 1 : 2;     // passes of 32 rows, row tiles (independent chains) per pass
+    constexpr bool PARK = false;
 #endif
+    constexpr bool ONEPASS = SELF || PARK;
+    constexpr int NPS = ONEPASS ? 1 : (MT == 4 ? 2 : 1), NML = ONEPASS ? MT : (MT == 1 ? 1 : 2);
     lane = fresh_v(lane);
     wave = fresh_s(wave) * (NT / 4) + HH;          // from here on `wave` is the HEAD
     const int c = lane & 15, g = lane >> 4;
-    const int M = a.M, L = a.L, nkt = a.nkt;
+    const int M = Mv, L = a.L, nkt = SELF ? a.sa_nkt : a.nkt, Lk = SELF ? a.L : a.Lk;
+    const float qs = a.scale_q * CH_LOG2E;         // the scores come out of the MFMAs in the exp2 domain
     u32x4 qf[MT][2];
+    if constexpr (SELF) {
+        const u32x4* qsrc = reinterpret_cast<const u32x4*>(a.sa_q) + ((long)(lblk * 8 + wave) * 8) * 64 + lane;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const f32x4_t lo = qacc[4 * HH + 2 * s][mt], hi = qacc[4 * HH + 2 * s + 1][mt];
-            qf[mt][s][0] = pack_bf2(lo[0] * a.scale_q, lo[1] * a.scale_q);
-            qf[mt][s][1] = pack_bf2(lo[2] * a.scale_q, lo[3] * a.scale_q);
-            qf[mt][s][2] = pack_bf2(hi[0] * a.scale_q, hi[1] * a.scale_q);
-            qf[mt][s][3] = pack_bf2(hi[2] * a.scale_q, hi[3] * a.scale_q);
-        }
-#ifdef CH_XATT_ONEPASS
-    // the packed Q^T fragments wait in LDS (the GELU chunk area is idle here; 8 KB per wave, wave-private: no barrier)
+            for (int s = 0; s < 2; ++s) qf[mt][s] = qsrc[(mt * 2 + s) * 64];
+    } else {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const f32x4_t lo = qacc[4 * HH + 2 * s][mt], hi = qacc[4 * HH + 2 * s + 1][mt];
+                qf[mt][s][0] = pack_bf2(lo[0] * qs, lo[1] * qs);
+                qf[mt][s][1] = pack_bf2(lo[2] * qs, lo[3] * qs);
+                qf[mt][s][2] = pack_bf2(hi[0] * qs, hi[1] * qs);
+                qf[mt][s][3] = pack_bf2(hi[2] * qs, hi[3] * qs);
+            }
+    }
+    // (PARK) the packed Q^T fragments wait in LDS (the GELU chunk area is idle here; 8 KB per wave, wave-private: no barrier)
     char* qpark = abuf + (CH_H1C - CH_ABUF) + wave * 8192 + lane * 16;
+    if constexpr (PARK) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) *reinterpret_cast<u32x4*>(qpark + (mt * 2 + s) * 1024) = qf[mt][s];
-#endif
-    constexpr float LOG2E = 1.4426950408889634f;
+            for (int s = 0; s < 2; ++s) *reinterpret_cast<u32x4*>(qpark + (mt * 2 + s) * 1024) = qf[mt][s];
+    }
+    u32x4 ones = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};     // bf16 1.0 x 8: the A operand of the row-sum MFMA
+    asm volatile("" : "+v"(ones));
     const unsigned voff = (unsigned)lane * 16u;
-    const __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.kf), 0, -1, 0x00020000);
-    const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.vf), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(SELF ? a.sa_kf : a.kf), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(SELF ? a.sa_vf : a.vf), 0, -1, 0x00020000);
     auto ld_tile = [&](const __amdgpu_buffer_rsrc_t& r, unsigned so, u32x4 (&f)[4]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) f[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff + 1024u * i, so, 0));
@@ -111,18 +137,28 @@ DEVINL void cross_attention(const f32x4_t (&qacc)[NT][MT], const tcdiff_chain_ar
         }
 #pragma unroll 1
         for (int seq = sa; seq <= sb; ++seq) {
-            const int kv = seq < a.n_shared ? 0 : seq - a.n_shared + (a.n_shared > 0 ? 1 : 0);
+            const int kv = SELF ? seq : seq < a.n_shared ? 0 : seq - a.n_shared + (a.n_shared > 0 ? 1 : 0);
             const unsigned so0 = (unsigned)((kv * a.H + wave) * nkt) * 4096u;      // this (slot, head)'s image (< 4 GB: launcher)
             f32x4_t o[4][NML];                              // [d tile][row tile of the pass]
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
                 for (int ml = 0; ml < NML; ++ml) o[dt][ml] = f32x4_t{0, 0, 0, 0};
-            float m_run[NML], l_run[NML];
+            // Softmax bookkeeping that costs no VALU work in the common tile (the loop is bound by vector issue: 8 cycles per MFMA or
+            // v_exp, 4 per other instruction, and they add):
+            //  * the scores leave the MFMAs as s - m_run: the accumulators START at -m_run (nb), Q carries log2(e) / sqrt(d_k);
+            //  * m_run is only an estimate of the row maximum: it moves when some score of the tile exceeds it by more than CH_ATT_THR
+            //    (exp2 <= 2^THR: harmless in fp32 / bf16) -- a lane-local test, no cross-lane maximum in the common tile; the first
+            //    tile always takes the exact path and sets m_run to its row maxima;
+            //  * the row sums come from the matrix pipe: one more MFMA with an all-ones A operand sums the bf16 P^T columns (every row
+            //    of its result is the sum over the tile's 32 keys: no cross-lane reduction at the end either).
+            f32x4_t lacc[NML];
+            float m_run[NML], nb[NML];
 #pragma unroll
             for (int ml = 0; ml < NML; ++ml) {
                 m_run[ml] = -INFINITY;
-                l_run[ml] = 0.0f;
+                nb[ml] = 0.0f;
+                lacc[ml] = f32x4_t{0, 0, 0, 0};
             }
             u32x4 kn[4];                                           // K fragments run one tile ahead
             ld_tile(kr, so0, kn);
@@ -133,76 +169,79 @@ DEVINL void cross_attention(const f32x4_t (&qacc)[NT][MT], const tcdiff_chain_ar
                 for (int i = 0; i < 4; ++i) kc[i] = kn[i];
                 ld_tile(vr, so0 + (unsigned)kt * 4096u, vc);       // V of this tile: in flight under QK^T and the softmax
                 const int nx = kt + 1 < nkt ? kt + 1 : kt;       // the last iteration re-reads its own tile (unused)
-#ifndef CH_XATT_ONEPASS
-                ld_tile(kr, so0 + (unsigned)nx * 4096u, kn);
-#endif
-                // the two row tiles of the pass are independent chains in ONE basic block (no per-tile branch between them)
+                if constexpr (!PARK) ld_tile(kr, so0 + (unsigned)nx * 4096u, kn);
+                // the row tiles of the pass are independent chains in ONE basic block (no per-tile branch between them)
                 f32x4_t s0[NML], s1[NML];                              // keys 4 g + j and 16 + 4 g + j of the tile
 #pragma unroll
                 for (int ml = 0; ml < NML; ++ml) {
                     const int mt = NML * ps + ml;
-                    s0[ml] = s1[ml] = f32x4_t{0, 0, 0, 0};
-#ifdef CH_XATT_ONEPASS
-                    char* qp = qpark;
-                    asm volatile("" : "+v"(qp));      // opaque per tile: the reads stay in the loop (hoisted, they are 32 registers again)
-                    const u32x4 q0 = *reinterpret_cast<const u32x4*>(qp + (mt * 2) * 1024);
-                    const u32x4 q1 = *reinterpret_cast<const u32x4*>(qp + (mt * 2 + 1) * 1024);
-#else
-                    const u32x4 q0 = qf[mt][0], q1 = qf[mt][1];
-#endif
+                    s0[ml] = s1[ml] = f32x4_t{nb[ml], nb[ml], nb[ml], nb[ml]};
+                    u32x4 q0 = qf[mt][0], q1 = qf[mt][1];
+                    if constexpr (PARK) {
+                        char* qp = qpark;
+                        asm volatile("" : "+v"(qp));      // opaque per tile: the reads stay in the loop (hoisted, they are 32 registers again)
+                        q0 = *reinterpret_cast<const u32x4*>(qp + (mt * 2) * 1024);
+                        q1 = *reinterpret_cast<const u32x4*>(qp + (mt * 2 + 1) * 1024);
+                    }
                     mma16(s0[ml], kc[0], q0);
                     mma16(s1[ml], kc[2], q0);
                     mma16(s0[ml], kc[1], q1);
                     mma16(s1[ml], kc[3], q1);
                 }
-#ifdef CH_XATT_ONEPASS   // the next tile's K fragments are fetched once this tile's score MFMAs have issued (16 registers fewer in flight)
+                if constexpr (PARK) {   // the next tile's K fragments are fetched once this tile's score MFMAs have issued (16 registers fewer in flight)
 #pragma unroll
-                for (int ml = 0; ml < NML; ++ml) asm volatile("" : "+v"(s0[ml]), "+v"(s1[ml]));
-                ld_tile(kr, so0 + (unsigned)nx * 4096u, kn);
-#endif
-                if (kt * 32 + 32 > a.Lk) {
+                    for (int ml = 0; ml < NML; ++ml) asm volatile("" : "+v"(s0[ml]), "+v"(s1[ml]));
+                    ld_tile(kr, so0 + (unsigned)nx * 4096u, kn);
+                }
+                if (kt * 32 + 32 > Lk) {
 #pragma unroll
                     for (int ml = 0; ml < NML; ++ml)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            if (kt * 32 + 4 * g + j >= a.Lk) s0[ml][j] = -INFINITY;
-                            if (kt * 32 + 16 + 4 * g + j >= a.Lk) s1[ml][j] = -INFINITY;
+                            if (kt * 32 + 4 * g + j >= Lk) s0[ml][j] = -INFINITY;
+                            if (kt * 32 + 16 + 4 * g + j >= Lk) s1[ml][j] = -INFINITY;
                         }
                 }
-                float m_new[NML];
+                float lm[NML];
+                bool hot = kt == 0;
 #pragma unroll
                 for (int ml = 0; ml < NML; ++ml) {
-                    float mx = fmaxf(fmaxf(fmaxf(s0[ml][0], s0[ml][1]), fmaxf(s0[ml][2], s0[ml][3])),
-                                     fmaxf(fmaxf(s1[ml][0], s1[ml][1]), fmaxf(s1[ml][2], s1[ml][3])));
-                    mx = ar4_max(mx) * LOG2E;
-                    m_new[ml] = fmaxf(m_run[ml], mx);
+                    lm[ml] = fmaxf(fmaxf(fmaxf(s0[ml][0], s0[ml][1]), fmaxf(s0[ml][2], s0[ml][3])),
+                                   fmaxf(fmaxf(s1[ml][0], s1[ml][1]), fmaxf(s1[ml][2], s1[ml][3])));
+                    hot = hot || lm[ml] > CH_ATT_THR;
                 }
-                // the running maximum moves in the first tile or two; afterwards the whole wave skips the rescale
-                bool moved = m_new[0] > m_run[0];
-#pragma unroll
-                for (int ml = 1; ml < NML; ++ml) moved = moved || m_new[ml] > m_run[ml];
-                if (__builtin_amdgcn_ballot_w64(moved) != 0) {
+                if (__builtin_amdgcn_ballot_w64(hot) != 0) {
+                    // exact path (first tile; afterwards rare): the row maxima across the lane groups, m_run moves up to them, what was
+                    // accumulated so far is rescaled and this tile's scores are shifted by the same amount
 #pragma unroll
                     for (int ml = 0; ml < NML; ++ml) {
-                        const float alpha = __builtin_amdgcn_exp2f(m_run[ml] - m_new[ml]);   // first tile: exp2(-inf) = 0, o is 0
-                        l_run[ml] *= alpha;
+                        const float mx = ar4_max(lm[ml]);                       // relative to -nb
+                        // a row moves its maximum on ITS OWN scores only (first tile, or past the threshold): what a row computes must
+                        // not depend on which rows share its wave (a clip's sample does not depend on its batch)
+                        const float m_new = (kt == 0 || mx > CH_ATT_THR) ? fmaxf(m_run[ml], mx - nb[ml]) : m_run[ml];
+                        const float shift = m_new + nb[ml];
+                        const float alpha = __builtin_amdgcn_exp2f(m_run[ml] - m_new);   // first tile: exp2(-inf) = 0, o and lacc are 0
+                        m_run[ml] = m_new;
+                        nb[ml] = -m_new;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            lacc[ml][j] *= alpha;
+                            s0[ml][j] -= shift;
+                            s1[ml][j] -= shift;
+                        }
 #pragma unroll
                         for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
                             for (int j = 0; j < 4; ++j) o[dt][ml][j] *= alpha;
-                        m_run[ml] = m_new[ml];
                     }
                 }
 #pragma unroll
                 for (int ml = 0; ml < NML; ++ml) {
-                    float rs = 0.0f;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        s0[ml][j] = __builtin_amdgcn_exp2f(fmaf(s0[ml][j], LOG2E, -m_new[ml]));
-                        s1[ml][j] = __builtin_amdgcn_exp2f(fmaf(s1[ml][j], LOG2E, -m_new[ml]));
-                        rs += s0[ml][j] + s1[ml][j];
+                        s0[ml][j] = __builtin_amdgcn_exp2f(s0[ml][j]);
+                        s1[ml][j] = __builtin_amdgcn_exp2f(s1[ml][j]);
                     }
-                    l_run[ml] += rs;
                     u32x4 pf;
                     pf[0] = pack_bf2(s0[ml][0], s0[ml][1]);
                     pf[1] = pack_bf2(s0[ml][2], s0[ml][3]);
@@ -210,11 +249,12 @@ DEVINL void cross_attention(const f32x4_t (&qacc)[NT][MT], const tcdiff_chain_ar
                     pf[3] = pack_bf2(s1[ml][2], s1[ml][3]);
 #pragma unroll
                     for (int dt = 0; dt < 4; ++dt) mma16(o[dt][ml], vc[dt], pf);
+                    mma16(lacc[ml], ones, pf);
                 }
             }
 #pragma unroll
             for (int ml = 0; ml < NML; ++ml) {
-                const float lsum = ar4_sum(l_run[ml]);
+                const float lsum = lacc[ml][0];
                 if (my_seq[ml] == seq) {
                     const float inv = __builtin_amdgcn_rcpf(lsum);    // 1 ulp; the quotient is rounded to bf16 next
                     const int mt = NML * ps + ml;
@@ -226,6 +266,80 @@ DEVINL void cross_attention(const f32x4_t (&qacc)[NT][MT], const tcdiff_chain_ar
                         *reinterpret_cast<uint2*>(abuf + wave * 8192 + act_wr_off(lane, dt) + mt * 2048) = pk;
                     }
                 }
+            }
+        }
+    }
+}
+
+// The next layer's Q^T / K / V^T in the order the in-kernel attention loads them, straight from the accumulators (NT = 4: wave =
+// head): every store is a 1-KB piece of one wave instruction.  The block is block `bis` of sequence `seq` (tcdiff_chain_args.seq_blocks).
+// Q: private to the (block, wave) that reads it back in the next launch -- [lblk][wave][mt < 4][d-step s][lane][8], scaled by
+// log2(e) / sqrt(d_k) (the attention works in the exp2 domain).
+template <int MT>
+DEVINL void store_qfrag(const f32x4_t (&acc)[4][MT], void* base, float scale, int lblk, int wave, int lane) {
+    u32x4* dst = reinterpret_cast<u32x4*>(base) + ((long)(lblk * 8 + wave) * 8) * 64 + lane;     // 8 pieces per (block, wave) whatever MT
+    scale *= CH_LOG2E;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const f32x4_t lo = acc[2 * s][mt], hi = acc[2 * s + 1][mt];
+            u32x4 f;
+            f[0] = pack_bf2(lo[0] * scale, lo[1] * scale);
+            f[1] = pack_bf2(lo[2] * scale, lo[3] * scale);
+            f[2] = pack_bf2(hi[0] * scale, hi[1] * scale);
+            f[3] = pack_bf2(hi[2] * scale, hi[3] * scale);
+            dst[(mt * 2 + s) * 64] = f;
+        }
+}
+// K: the 16 keys of row tile mt and d-step s are piece 2 (first_row / 16 + mt) + s of the (sequence, head) image [nkt][4][64 lanes][8]
+// (tcdiff_pack_kv_frags' K order: tile = 32 keys, piece = 2 (key half) + d-step); pieces of tiles >= nkt (rows past the last tile
+// of the sequence: clamped copies) are dropped.
+template <int MT>
+DEVINL void store_kfrag(const f32x4_t (&acc)[4][MT], void* base, int seq, int first_row, int nkt, int wave, int lane) {
+    u32x4* dst = reinterpret_cast<u32x4*>(base) + ((long)(seq * 8 + wave) * nkt) * 256 + lane;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int pc = 2 * ((first_row >> 4) + mt);
+        if ((pc >> 2) < nkt) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const f32x4_t lo = acc[2 * s][mt], hi = acc[2 * s + 1][mt];
+                u32x4 f = {pack_bf2(lo[0], lo[1]), pack_bf2(lo[2], lo[3]), pack_bf2(hi[0], hi[1]), pack_bf2(hi[2], hi[3])};
+                dst[(pc + s) * 64] = f;
+            }
+        }
+    }
+}
+// V: accT = the TRANSPOSED projection tiles (phase_n512<.., SWAP>): lane (c, g) holds keys 16 mt + 4 g + j of feature 16 nt + c,
+// and the pair of row tiles (2 t, 2 t + 1) IS the A operand of O^T += V^T P^T for the 32-key tile (MT / 2) bis + t and d tile nt.
+// first_row: the block's first row within its sequence (a multiple of 32).  MT = 1 (a sequence's last block when it holds <= 16
+// rows): keys 16 .. 31 of the tile lie past the sequence and are written as zeros.
+template <int MT>
+DEVINL void store_vfrag(const f32x4_t (&accT)[4][MT], void* base, int seq, int first_row, int nkt, int wave, int lane) {
+    u32x4* dst = reinterpret_cast<u32x4*>(base) + ((long)(seq * 8 + wave) * nkt) * 256 + lane;
+    if constexpr (MT == 1) {
+        const int kt = first_row >> 5;
+        if (kt < nkt) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const f32x4_t lo = accT[nt][0];
+                u32x4 f = {pack_bf2(lo[0], lo[1]), pack_bf2(lo[2], lo[3]), 0u, 0u};
+                dst[(kt * 4 + nt) * 64] = f;
+            }
+        }
+        return;
+    }
+    const int bis = first_row / (16 * MT);
+#pragma unroll
+    for (int t = 0; t < MT / 2; ++t) {
+        const int kt = (MT / 2) * bis + t;
+        if (kt < nkt) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const f32x4_t lo = accT[nt][2 * t], hi = accT[nt][2 * t + 1];
+                u32x4 f = {pack_bf2(lo[0], lo[1]), pack_bf2(lo[2], lo[3]), pack_bf2(hi[0], hi[1]), pack_bf2(hi[2], hi[3])};
+                dst[(kt * 4 + nt) * 64] = f;
             }
         }
     }
@@ -245,10 +359,12 @@ DEVINL void cross_attention(const f32x4_t (&qacc)[NT][MT], const tcdiff_chain_ar
 #define CH_T(i) do { } while (0)
 #endif
 
-// MT: 16-row tiles per block (4: 64-row blocks; 2, 1: small jobs, see tcdiff_chain)
-template <int MODE, int MT, int NT>
-__global__ __launch_bounds__(2048 / NT) void chain_kernel(tcdiff_chain_args a) {
-    constexpr int BR = 16 * MT;        // rows per block
+// BRK: rows per block of the LAUNCH (16 x the kernel's MT); MT: row tiles this block computes -- BRK / 16, or 1 for a sequence's
+// last block when it holds <= 16 rows (seq_blocks: 450 = 7 x 64 + 2; the block streams the weights like any other but runs a
+// quarter of the MFMAs).
+template <int MODE, int MT, int NT, int BRK>
+DEVINL void chain_body(const tcdiff_chain_args& a) {
+    constexpr int BR = BRK;            // rows per block (MT row tiles of them computed)
     constexpr int NW = ChW<NT>::NW, NTH = 64 * NW, RD = ChW<NT>::D;   // waves, threads, ring depth
     constexpr bool HAS_A = MODE == TC_CHAIN_A || MODE == TC_CHAIN_FULL || MODE == TC_CHAIN_FULL_LAST;   // fc + norm2 + w_qs
     constexpr bool FULL = MODE == TC_CHAIN_FULL || MODE == TC_CHAIN_FULL_LAST;                          // + cross-attention
@@ -263,10 +379,18 @@ __global__ __launch_bounds__(2048 / NT) void chain_kernel(tcdiff_chain_args a) {
     const int c = lane & 15, g = lane >> 4;
     const int dn = FRONT ? a.dn : 1;
     const int dancer = FRONT ? (int)(blockIdx.x % (unsigned)dn) : 0;
-    const int m0 = FRONT ? (int)(blockIdx.x / (unsigned)dn) * BR : xcd_remap(blockIdx.x, gridDim.x) * BR;
+    // logical block: FRONT (frame block, dancer); else consecutive logical blocks share an XCD (and its L2: FiLM rows, K / V).
+    // seq_blocks: logical block = (sequence, block of the sequence); its rows end with the sequence (Mv), the clamped rows behind
+    // them recompute the sequence's last row and are never stored.
+    const int lblk = FRONT ? (int)(blockIdx.x / (unsigned)dn) : xcd_remap(blockIdx.x, gridDim.x);
+    const bool seqcut = !FRONT && a.seq_blocks;
+    const int nbs = seqcut ? (a.L + BR - 1) / BR : 1;                 // blocks per sequence
+    const int bseq = seqcut ? lblk / nbs : 0, bis = seqcut ? lblk - bseq * nbs : 0;
+    const int m0 = seqcut ? bseq * a.L + bis * BR : lblk * BR;
     CH_T(0);
     CH_TC(60);
-    const int M = a.M, L = a.L;        // FRONT: M = frames, L = TOKENS per sequence
+    const int Mtot = a.M, L = a.L;     // FRONT: M = frames, L = TOKENS per sequence
+    const int M = seqcut ? (bseq + 1) * L : Mtot;                     // first row past the block's valid rows
     char* abuf = smem + CH_ABUF;
     char* h1c = smem + CH_H1C;
     float* scr = reinterpret_cast<float*>(smem + CH_SCR);
@@ -277,7 +401,7 @@ __global__ __launch_bounds__(2048 / NT) void chain_kernel(tcdiff_chain_args a) {
     // Every phase recomputes what it needs of them from a fresh copy of the lane index (a few VALU ops) -- kept as arrays
     // they are 16 registers alive across the whole kernel.
     const int seq0 = (m0 < M ? m0 : M - 1) / L;
-    const int seq_last = (M - 1) / L;
+    const int seq_last = (Mtot - 1) / L;
     const int seqb = (seq0 + 1) * L;   // first row of the block's second sequence (L >= 64 rows per sequence: launcher)
     struct Rows { int mc[MT], sidx[MT]; };
     auto rows = [&]() {
@@ -317,7 +441,9 @@ __global__ __launch_bounds__(2048 / NT) void chain_kernel(tcdiff_chain_args a) {
 #pragma unroll
         for (int j = 0; j < CV; ++j) {
             const int idx = j * NTH + tid;
-            const float* p0 = idx < 768 ? vec[idx >> 7] : nullptr;
+            // (a chain of selects: indexing the array with a lane-dependent index would put it in scratch)
+            const int vi = idx >> 7;
+            const float* p0 = vi == 0 ? vec[0] : vi == 1 ? vec[1] : vi == 2 ? vec[2] : vi == 3 ? vec[3] : vi == 4 ? vec[4] : vi == 5 ? vec[5] : nullptr;
             k.v[j] = p0 ? ld4(p0 + (idx & 127) * 4) : f32x4_t{0, 0, 0, 0};
         }
         return k;
@@ -338,12 +464,8 @@ __global__ __launch_bounds__(2048 / NT) void chain_kernel(tcdiff_chain_args a) {
     // ---- the block's input rows (attention output) -> LDS, the first CH_D weight stages -> registers, constants -> LDS
     // (the LDS image keeps the 64-row geometry -- 8 KB per k-tile -- whatever MT: rows 16 MT .. 63 are simply unused)
     constexpr int NWL = 2 * MT < NW ? 2 * MT : NW;     // waves that stage the rows (8 rows per wave instruction)
-    if (wave < NWL) {
-#pragma unroll
-        for (int kt = 0; kt < (FRONT ? 16 : 8); ++kt)  // FRONT: rows of 1024 = the activation block and its twin, contiguous
-            stage_glds<BR, NWL>(abuf + kt * 8192, reinterpret_cast<const char*>(a.A) + kt * TC_ROWB, FRONT ? 2048 : 1024, m0,
-                                M, a.a_mod, wave, lane);
-    }
+    // sa_q: the rows are not read but computed -- this layer's self-attention runs here, from the fragments the previous launch left
+    const bool self_att = FULL && NT == 4 && a.sa_q != nullptr;
     WStreamT<NT> ws;
     ws.rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(reinterpret_cast<const char*>(a.wstream)) + ((long)dancer * NW + wave) * a.n_stages * ChW<NT>::STAGE, 0,
@@ -351,8 +473,28 @@ __global__ __launch_bounds__(2048 / NT) void chain_kernel(tcdiff_chain_args a) {
     ws.voff = (unsigned)lane * 16u;
     ws.pos = 0;
     ws.last = (unsigned)a.n_stages - 1;
+    auto ring_fill = [&]() {
 #pragma unroll
-    for (int i = 0; i < RD; ++i) ws_load(ws, i, (unsigned)i);
+        for (int i = 0; i < RD; ++i) ws_load(ws, i, (unsigned)i);
+    };
+    f32x4_t acc[NT][MT];
+    if constexpr (FULL && NT == 4) {
+        if (self_att) {
+            // ============= self-attention of the block's rows (model/model.py:97-102,326-327): O -> the activation block (wave-private
+            // columns; the barrier below publishes them).  The weight ring is filled behind it: its 64 registers are the attention's.
+            cross_attention<0, MT, NT, true>(acc, a, m0, M, lblk, abuf, wave, lane);
+            ring_fill();      // (issued from inside the attention's epilogue the ring spills: its 64 registers beside the 64 of O)
+        }
+    }
+    if (!self_att) {
+        if (wave < NWL) {
+#pragma unroll
+            for (int kt = 0; kt < (FRONT ? 16 : 8); ++kt)  // FRONT: rows of 1024 = the activation block and its twin, contiguous
+                stage_glds<16 * MT, NWL>(abuf + kt * 8192, reinterpret_cast<const char*>(a.A) + kt * TC_ROWB, FRONT ? 2048 : 1024, m0,
+                                    M, a.a_mod, wave, lane);
+        }
+        ring_fill();
+    }
     if (FRONT) {
         const float* const v[6] = {a.b3 + 512 * dancer, a.nn_g, a.nn_b, nullptr, nullptr, nullptr};
         store_consts(fetch_consts(nullptr, v));
@@ -366,10 +508,10 @@ __global__ __launch_bounds__(2048 / NT) void chain_kernel(tcdiff_chain_args a) {
     __syncthreads();
     CH_T(1);
 
-    f32x4_t acc[NT][MT];
+
     float nmr[MT], rstd[MT];             // LayerNorm of the current rows: u = fma(v, rstd, nmr)
     RowPipe<MT> rp;                      // residual rows, later rotary rows, of this lane
-    const long xrows = (long)M * dn;
+    const long xrows = (long)Mtot * dn;
     const __amdgpu_buffer_rsrc_t xo = f32_buffer(a.xout, xrows * 512);     // the residual stream out
     Consts nxt;
 
@@ -396,7 +538,7 @@ __global__ __launch_bounds__(2048 / NT) void chain_kernel(tcdiff_chain_args a) {
             }
             // unguarded: rows past M rewrite row M - 1 with the SAME values (same inputs; every load of this column
             // group, in place or not, was issued before this store)
-            cb_store<NT>(xo, M, wv, nt, rw.mc[mt], gg, o);
+            cb_store<NT>(xo, Mtot, wv, nt, rw.mc[mt], gg, o);
         };
         // (Measured in the listing and dropped: a second code path for blocks that lie in ONE sequence -- constants read once
         // per column quad instead of once per row tile.  The two paths raise the epilogue's register peak, hipcc spills ring
@@ -423,12 +565,12 @@ __global__ __launch_bounds__(2048 / NT) void chain_kernel(tcdiff_chain_args a) {
         int rr[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) rr[mt] = a.xres_mod > 0 ? rw.mc[mt] % a.xres_mod : rw.mc[mt];
-        rp_start<NT>(rp, a.xres, rr, a.xres_rowmajor ? 0 : (a.xres_mod > 0 ? a.xres_mod : M), a.xres_mod > 0 ? a.xres_mod : M, wave,
+        rp_start<NT>(rp, a.xres, rr, a.xres_rowmajor ? 0 : (a.xres_mod > 0 ? a.xres_mod : Mtot), a.xres_mod > 0 ? a.xres_mod : Mtot, wave,
                      fresh_v(g));
     };
     auto xout_start = [&]() {          // the x this lane stored in an earlier epilogue of this launch
         const Rows rw = rows();
-        rp_start<NT>(rp, a.xout, rw.mc, M, M, wave, fresh_v(g));
+        rp_start<NT>(rp, a.xout, rw.mc, Mtot, Mtot, wave, fresh_v(g));
     };
     auto rope_start = [&]() {
         const Rows rw = rows();
@@ -479,8 +621,8 @@ __global__ __launch_bounds__(2048 / NT) void chain_kernel(tcdiff_chain_args a) {
         CH_T(35);
         lds_barrier();                 // every wave is out of the w_qs GEMM: the activation block becomes O
 #ifndef CH_ABLATE_XATTN   // (timing experiment)
-        cross_attention<0>(acc, a, m0, abuf, wave, lane);
-        if constexpr (NT == 8) cross_attention<1>(acc, a, m0, abuf, wave, lane);
+        cross_attention<0>(acc, a, m0, M, lblk, abuf, wave, lane);
+        if constexpr (NT == 8) cross_attention<1>(acc, a, m0, M, lblk, abuf, wave, lane);
 #endif
         CH_T(36);
         lds_barrier();
@@ -649,18 +791,55 @@ __global__ __launch_bounds__(2048 / NT) void chain_kernel(tcdiff_chain_args a) {
     zero(acc);
     phase_n512<16, false, MT, NT>(acc, abuf, ws, lane);
     CH_T(29);
-    store_heads<true, MT, NT>(acc, a.q_out, a.scale_q, L, a.Lp, a.H, m0, M, wave, lane, smem, dn, dancer);
+    // qf_out: Q / K / V leave in the fragment order of the next launch's in-kernel self-attention (seq_blocks; 8-wave form, MT >= 2)
+    constexpr bool FRAG = !FRONT && NT == 4 && BRK >= 32;
+    bool frag_out = false;
+    if constexpr (FRAG) frag_out = a.qf_out != nullptr;
+    if constexpr (FRAG) {
+        if (frag_out) store_qfrag<MT>(acc, a.qf_out, a.scale_q, lblk, wave, lane);
+    }
+    if (!frag_out) store_heads<true, MT, NT>(acc, a.q_out, a.scale_q, L, a.Lp, a.H, m0, M, wave, lane, smem, dn, dancer);
     zero(acc);
     phase_n512<16, false, MT, NT>(acc, abuf, ws, lane);
     CH_T(30);
-    store_heads<false, MT, NT>(acc, a.k_out, 1.0f, L, a.Lp, a.H, m0, M, wave, lane, smem, dn, dancer);
+    if constexpr (FRAG) {
+        if (frag_out) store_kfrag<MT>(acc, a.kf_out, bseq, bis * BR, a.out_nkt, wave, lane);
+    }
+    if (!frag_out) store_heads<false, MT, NT>(acc, a.k_out, 1.0f, L, a.Lp, a.H, m0, M, wave, lane, smem, dn, dancer);
     CH_T(31);
     zero(acc);
+    if constexpr (FRAG) {
+        if (frag_out) {
+            phase_n512<16, true, MT, NT, true>(acc, smem + CH_ABUF2, ws, lane);
+            CH_T(32);
+            store_vfrag<MT>(acc, a.vf_out, bseq, bis * BR, a.out_nkt, wave, lane);
+            CH_T(33);
+            CH_TC(61);
+            return;
+        }
+    }
     phase_n512<16, true, MT, NT>(acc, smem + CH_ABUF2, ws, lane);
     CH_T(32);
     store_heads<false, MT, NT>(acc, a.v_out, 1.0f, L, a.Lp, a.H, m0, M, wave, lane, smem, dn, dancer);
     CH_T(33);
     CH_TC(61);
+}
+
+// MT: 16-row tiles per block (4: 64-row blocks; 2, 1: small jobs, see tcdiff_chain)
+template <int MODE, int MT, int NT>
+__global__ __launch_bounds__(2048 / NT) void chain_kernel(tcdiff_chain_args a) {
+    constexpr bool DUAL = (MODE == TC_CHAIN_FULL || MODE == TC_CHAIN_FULL_LAST) && NT == 4 && MT > 1;
+    if constexpr (DUAL) {
+        if (a.seq_blocks) {      // a sequence's last block with <= 16 rows computes one row tile
+            const int lblk = xcd_remap(blockIdx.x, gridDim.x);
+            const int nbs = (a.L + 16 * MT - 1) / (16 * MT);
+            if (a.L - (lblk % nbs) * 16 * MT <= 16) {
+                chain_body<MODE, 1, NT, 16 * MT>(a);
+                return;
+            }
+        }
+    }
+    chain_body<MODE, MT, NT, 16 * MT>(a);
 }
 
 static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -695,13 +874,24 @@ extern "C" int tcdiff_chain(const tcdiff_chain_args* a, hipStream_t stream) {
     if (has_a && (!a->rope || a->H != 8)) return TC_ERR_ARG;
     if (a->mode == TC_CHAIN_A && (!a->q_out || a->Lp <= 0)) return TC_ERR_ARG;
     if (has_b && (!a->b1 || !a->film3 || !a->n4_g || !a->n4_b || !a->b3)) return TC_ERR_ARG;
+    const bool frag_out = a->qf_out || a->kf_out || a->vf_out;      // fragment-order Q / K / V instead of the head-major images
     if (has_b && !last &&
-        (!a->rope || !a->nn_g || !a->nn_b || !a->q_out || !a->k_out || !a->v_out || a->H != 8 || a->Lp <= 0))
+        (!a->rope || !a->nn_g || !a->nn_b || (!frag_out && (!a->q_out || !a->k_out || !a->v_out)) || a->H != 8 || a->Lp <= 0))
         return TC_ERR_ARG;
     if (last && !a->h_out) return TC_ERR_ARG;
     if (full && (!a->filmb || !a->n3_g || !a->n3_b || !a->kf || !a->vf || a->nkt <= 0 ||
                  a->Lk <= 0 || a->Lk > 32 * a->nkt || a->n_shared < 0))
         return TC_ERR_ARG;
+    // sequence-cut blocks, the in-kernel self-attention and the fragment-order outputs (round 5)
+    if (a->seq_blocks && (front || a->M % a->L)) return TC_ERR_ARG;
+    if (a->sa_q && (!full || !a->seq_blocks || !a->sa_kf || !a->sa_vf || a->sa_nkt <= 0 || a->L > 32 * a->sa_nkt)) return TC_ERR_ARG;
+    if (frag_out && (!a->qf_out || !a->kf_out || !a->vf_out || !has_b || last || !a->seq_blocks || a->out_nkt <= 0 ||
+                     a->L > 32 * a->out_nkt))
+        return TC_ERR_ARG;
+    if ((a->sa_q || frag_out) && a->nw == 4) return TC_ERR_UNSUPPORTED;
+    for (const void* p : {a->sa_q, a->sa_kf, a->sa_vf, (const void*)a->qf_out, (const void*)a->kf_out, (const void*)a->vf_out})
+        if (p && !al16(p)) return TC_ERR_ALIGN;
+    if (a->sa_q && (long)(a->M / a->L) * 8 * a->sa_nkt * 4096 >= (1L << 32)) return TC_ERR_ARG;
     static tc_dev_state dev_state;
     const int n_cu = tc_device_once(dev_state, [](int) {
 #define CH_FN(M_, NT_) reinterpret_cast<const void*>(chain_kernel<M_, 4, NT_>), reinterpret_cast<const void*>(chain_kernel<M_, 2, NT_>), \
@@ -725,7 +915,12 @@ extern "C" int tcdiff_chain(const tcdiff_chain_args* a, hipStream_t stream) {
     int mt = a->mt;
     if (mt == 0) mt = ((a->M + 15) / 16) * units <= n_cu ? 1 : ((a->M + 31) / 32) * units <= n_cu ? 2 : 4;
     if (mt != 1 && mt != 2 && mt != 4) return TC_ERR_ARG;
+    if ((a->sa_q || frag_out) && mt == 1) {
+        if (a->mt == 1) return TC_ERR_UNSUPPORTED;      // a V^T fragment needs the 32 keys of two row tiles
+        mt = 2;
+    }
     dim3 grid(((a->M + 16 * mt - 1) / (16 * mt)) * units);
+    if (a->seq_blocks) grid.x = (a->M / a->L) * ((a->L + 16 * mt - 1) / (16 * mt));
     // a->nw: waves per workgroup.  0 / 8: eight waves of 64 columns (two per SIMD); 4: four waves of 128 columns, one per SIMD
     // with the 512-register budget (the production modes only: FULL, FULL_LAST, FRONT; the weight stream is packed per form)
     if (a->nw != 0 && a->nw != 4 && a->nw != 8) return TC_ERR_ARG;

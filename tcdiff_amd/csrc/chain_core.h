@@ -195,7 +195,9 @@ DEVINL u32x4 frag_rd(const FragOff& f, int ks, int mt) {
 // copy of the most recently loaded slot at the loop header -- i.e. `s_waitcnt vmcnt(0)`, a full drain of the wave's
 // weight stream, every CH_D stages.  The activation fragments of stage ks + 1 are read before the MFMAs of stage ks.
 // TAIL: the launch's last phase -- its last CH_D stages refill nothing (there is nothing behind them).
-template <int NST, bool TAIL = false, int MT = 4, int NT = 4>
+// SWAP: the MFMA operands change places -- acc[nt][mt] then holds the TRANSPOSED tiles (lane (c, g): rows 16 mt + 4 g + j, column
+// 64 wave + 16 nt + c), which is the order a V^T fragment of the attention wants its keys in (chain.hip, store_vfrag).
+template <int NST, bool TAIL = false, int MT = 4, int NT = 4, bool SWAP = false>
 DEVINL void phase_n512(f32x4_t (&acc)[NT][MT], const char* abuf, WStreamT<NT>& ws, int lane,
                        unsigned long long* stage_stamps = nullptr) {     // (diagnostic builds: s_memtime after every stage)
     constexpr int RD = ChW<NT>::D;
@@ -235,7 +237,10 @@ DEVINL void phase_n512(f32x4_t (&acc)[NT][MT], const char* abuf, WStreamT<NT>& w
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) mma16(acc[nt][mt], wv[nt], b[mt]);
+            for (int nt = 0; nt < NT; ++nt) {
+                if (SWAP) mma16(acc[nt][mt], b[mt], wv[nt]);
+                else mma16(acc[nt][mt], wv[nt], b[mt]);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);   // ... and the MFMAs do not sink below the next stage's reads either
         // Stage fence.  Memory clobber: the refill stays in its own stage, the stream never drains.  The next stage's

@@ -71,6 +71,12 @@ class DenoiserEngine:
         self.fold_out = self.use_chain and os.environ.get("TCDIFF_FOLD_OUT", "1") != "0"
         # ... and the last fusion linear + layer 0's norm1 / rotary / Q, K, V as one chain launch per (frame block, dancer)
         self.front = self.use_full and os.environ.get("TCDIFF_FRONT", "1") != "0" and self.S >= 8
+        # the self-attention of layers 1.. inside the chain launch (row blocks cut per sequence, Q / K / V handed from launch to
+        # launch in MFMA-fragment order; csrc/chain.hip): large jobs only (64-row blocks), bf16, 8-wave form
+        self.fuse_sa = self.use_full and self.dt == L.DT_BF16 and os.environ.get("TCDIFF_FUSE_SA", "0") == "1"
+        # ... from the size at which the launcher leaves 16-row blocks (a V^T fragment needs the 32 keys of two row tiles)
+        self.sa_min_rows = int(os.environ.get("TCDIFF_FUSE_SA_ROWS", "4097"))
+        self.n_cu = torch.cuda.get_device_properties(self.dev).multi_processor_count if self.fuse_sa else 0
         self.chain_nw = int(os.environ.get("TCDIFF_CHAIN_NW", "8"))      # waves per workgroup of the chain launches (8 or 4)
         if self.chain_nw not in (4, 8):
             raise L.TcdiffError("TCDIFF_CHAIN_NW must be 8 or 4")
@@ -311,6 +317,11 @@ class DenoiserEngine:
         if self.use_full:                            # fragment-ordered images of the same caches (csrc/chain.hip)
             b["Kf"] = z(NL, 2 * B, H, self.nkt * 2048)
             b["Vf"] = z(NL, 2 * B, H, self.nkt * 2048)
+        if self.fuse_sa:                             # fragment-order Q (per 64-row block of a sequence), K, V of the next layer
+            self.skt = (Lq + 31) // 32
+            b["Qf"] = z(2 * B * ((Lq + 31) // 32), 8, 4, 2, 64, 8)       # (block, wave)-private; enough for 32-row blocks
+            # two of each: a launch reads layer l's keys in every block's prologue while its early blocks already write layer l + 1's
+            b["sKf"], b["sVf"] = z(2, 2 * B, H, self.skt * 2048), z(2, 2 * B, H, self.skt * 2048)
         b["hidden_all"] = z(2 * B, 512, dtype=torch.float32)
         b["tidx"] = torch.zeros(2 * B, device=dev, dtype=torch.int32)
         # music encoder (setup only)
@@ -582,7 +593,10 @@ class DenoiserEngine:
             K.gemm_tile(dt, b["rot"], w[p + "qkv.w"], Rs, 1536, 512, A2=b["h"], split_n=1024, mode=L.EPI_QKV_HEADS,
                         out=b["Q"], out_k=b["K"], out_v=b["V"], scale_q=0.125, Lseq=Lq, Lp=self.Lp, H=H, n_q=512,
                         n_k=512)
-        K.attention(dt, b["Q"], b["K"], b["V"], b["O"], B if l == 0 else nseq, H, Lq, Lq, self.Lp, self.Lp, 512)
+        # fused: layers 1.. compute their self-attention inside the chain launch from the fragments the previous launch wrote
+        fused = self.fuse_sa and R >= self.sa_min_rows and self.chain_nw == 8
+        if not (fused and l > 0):
+            K.attention(dt, b["Q"], b["K"], b["V"], b["O"], B if l == 0 else nseq, H, Lq, Lq, self.Lp, self.Lp, 512)
         last = l + 1 == NL
         nn = f"l{l + 1}.norm1." if not last else None
         tail = dict(b1=w[p + "ff1.b"], film3=film0[:, (l * 3 + 2) * 1024:], n4_g=w[p + "norm4.g"],
@@ -591,6 +605,14 @@ class DenoiserEngine:
                     q_out=None if last else b["Q"], k_out=None if last else b["K"], v_out=None if last else b["V"],
                     h_out=(b["out"] if self.fold_out else b["h"]) if last else None,
                     out_ld=152 if last and self.fold_out else 0, scale_q=0.125, Lp=self.Lp, H=H)
+        if fused:
+            # 32-row blocks while every one of them gets a CU (a block streams the layer's weights whatever its rows), else 64
+            tail.update(seq_blocks=True, mt=2 if nseq * ((Lq + 31) // 32) <= self.n_cu else 4)
+            if l > 0:
+                tail.update(sa_q=b["Qf"], sa_kf=b["sKf"][l & 1], sa_vf=b["sVf"][l & 1], sa_nkt=self.skt)
+            if not last:
+                tail.update(q_out=None, k_out=None, v_out=None, qf_out=b["Qf"], kf_out=b["sKf"][(l + 1) & 1],
+                            vf_out=b["sVf"][(l + 1) & 1], out_nkt=self.skt)
         head = dict(a_mod=Rs if l == 0 else 0, ln_eps=1e-6,     # (film rows: pre-folded with sln / cln / ff2.b, load_weights)
                     film=film0[:, (l * 3 + 0) * 1024:], film_ld=fld, xres=b["xs"] if l == 0 else b["xa"],
                     xres_mod=Rs if l == 0 else 0, xres_rowmajor=l == 0 and not self.front, xout=b["xa"], n2_g=w[p + "norm2.g"],

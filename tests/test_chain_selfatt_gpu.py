@@ -1,0 +1,176 @@
+"""The decoder layer's SELF-attention inside the chain launch (csrc/chain.hip, tcdiff_chain_args.seq_blocks / sa_q / qf_out ..):
+row blocks cut per sequence, the next layer's Q / K / V written in MFMA-fragment order straight from the accumulators, and the
+attention over them computed by the next launch in front of its fc GEMM -- against the launches it replaces (chain with
+head-major Q / K / V images + the attention kernel, which tests/test_chain_gpu.py and tests/test_parity_gpu.py hold to the
+reference)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tcdiff_amd import _lib as L  # noqa: E402
+from tcdiff_amd import kernels as K  # noqa: E402
+from tcdiff_amd.engine import DenoiserEngine as E  # noqa: E402
+
+DEV = "cuda"
+bf = torch.bfloat16
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+def folded(film, specs):
+    out = film.clone()
+    for off, (g, b) in specs.items():
+        out[:, off:off + 1024] = K.fold_film(film[:, off:off + 1024], g, b)
+    return out
+
+
+# element maps of the fragment images (csrc/ops.hip kf_index / vf_index; tests/test_chain_layout_cpu.py checks them against
+# plain matrix products)
+def kf_index(key, d):
+    kt, k32, d32 = key >> 5, key & 31, d & 31
+    g, jj = (d32 & 15) >> 2, 4 * (d32 >> 4) + (d32 & 3)
+    return (((kt * 2 + (k32 >> 4)) * 2 + (d >> 5)) * 64 + g * 16 + (k32 & 15)) * 8 + jj
+
+
+def vf_index(key, d):
+    kt, k32 = key >> 5, key & 31
+    g, jj = (k32 & 15) >> 2, 4 * (k32 >> 4) + (k32 & 3)
+    return ((kt * 4 + (d >> 4)) * 64 + g * 16 + (d & 15)) * 8 + jj
+
+
+def unpack_kv(img, fn, nkeys):
+    """[n_seq, H, nkt * 2048] fragment image -> [n_seq, H, nkeys, 64]"""
+    key, d = np.meshgrid(np.arange(nkeys), np.arange(64), indexing="ij")
+    idx = torch.from_numpy(fn(key, d).astype(np.int64)).to(img.device)
+    return img[:, :, idx.reshape(-1)].reshape(img.shape[0], img.shape[1], nkeys, 64)
+
+
+def unpack_q(qf, nseq, Lq, rows):
+    """[blocks, 8 waves, 4 (rows / 16 of them used), 2, 64 lanes, 8] -> [n_seq, H, Lq, 64] (the valid rows of every block)"""
+    nbs = (Lq + rows - 1) // rows
+    q = qf[:, :, :rows // 16].reshape(nseq, nbs, 8, rows // 16, 2, 4, 16, 2, 4)            # seq, block, head, mt, s, g, c, jj >> 2, jj & 3
+    # row = rows b + 16 mt + c ; d = 32 s + 16 (jj >> 2) + 4 g + (jj & 3)
+    q = q.permute(0, 2, 1, 3, 6, 4, 7, 5, 8).reshape(nseq, 8, nbs * rows, 64)
+    return q[:, :, :Lq]
+
+
+class Layer:
+    """random weights / constants of one fused decoder-layer launch"""
+
+    def __init__(self, seed, nseq, last):
+        W = {n: rnd(*s, seed=seed + i, scale=s[1] ** -0.5).to(bf) for i, (n, s) in enumerate(
+            [("sfc", (512, 512)), ("cq", (512, 512)), ("cfc", (512, 512)), ("ff1", (1024, 512)), ("ff2", (512, 1024)),
+             ("l3", (512, 512)), ("qkv", (1536, 512))])}
+        vec = lambda sd, base=0.0, amp=0.1: base + amp * rnd(512, seed=sd)
+        gs = [vec(seed + 10 + i, 1 if i % 2 == 0 else 0) for i in range(12)]
+        bias1, bias2, bias3 = 0.05 * rnd(1024, seed=seed + 30), vec(seed + 31), vec(seed + 32)
+        film = 0.3 * rnd(nseq, 6144, seed=seed + 33)
+        f1, f2 = E._stages_ff1(W["ff1"]), E._stages_ff2(W["ff2"])
+        parts = [E._stages_n512(W["sfc"]), E._stages_n512(W["cq"]), E._stages_n512(W["cfc"])] + E._ffn_order(f1, f2)
+        parts.append(E._stages_n512(W["l3"]))
+        if not last:
+            parts += [E._stages_n512(W["qkv"][i * 512:(i + 1) * 512]) for i in range(3)]
+        self.ws = torch.cat(parts, 1).contiguous()
+        self.mode = L.CHAIN_FULL_LAST if last else L.CHAIN_FULL
+        ff = folded(film, {0: (gs[0], gs[1]), 2048: (gs[4], gs[5]), 4096: (None, bias2)})
+        self.kw = dict(ln_eps=1e-6, film=ff, film_ld=6144, n2_g=gs[2], n2_b=gs[3], filmb=ff[:, 2048:], n3_g=gs[10], n3_b=gs[11],
+                       b1=bias1, film3=ff[:, 4096:], n4_g=gs[6], n4_b=gs[7], b3=bias3, nn_g=None if last else gs[8],
+                       nn_b=None if last else gs[9], scale_q=0.125, H=8)
+
+
+# 450 = 7 x 64 + 2, 130 = 2 x 64 + 2, 100 = 3 x 32 + 4: a last block of <= 16 rows runs the one-row-tile body; 150 = 2 x 64 + 22: it does not
+@pytest.mark.parametrize("Lq,nseq,mt", [(150, 3, 4), (150, 3, 2), (450, 2, 4), (130, 3, 4), (64, 5, 4), (100, 4, 2)])
+def test_self_attention_inside_the_chain_launch(Lq, nseq, mt):
+    """Two consecutive decoder layers.  Path 1: fused launch -> head-major Q / K / V -> attention kernel -> fused launch.
+    Path 2: sequence-cut fused launch -> fragment-order Q / K / V -> fused launch that computes the attention itself.
+    The first launch's outputs must agree exactly (same arithmetic per row, another block cut and output order); the second
+    launch's within the bounds the in-kernel cross-attention is held to (another softmax summation order, O fed on as bf16)."""
+    H, S = 8, 60
+    M = nseq * Lq
+    rows = 16 * mt
+    Lp, Lk = K.round_up(Lq, 128), S + 2
+    Lpc, nkt = K.round_up(Lk, 128), (Lk + 31) // 32
+    n_shared, n_kv = 1, nseq - 1 + 1
+    l0, l1 = Layer(100, nseq, False), Layer(200, nseq, True)
+    Oa = rnd(M, 512, seed=51, scale=0.5).to(bf)
+    xres = rnd(M, 512, seed=94)
+    rope = torch.empty(Lq, 512, device=DEV)
+    K.rope_table((1.0 / (10000 ** (torch.arange(0, 512, 2).float() / 512))).to(DEV), rope, Lq)
+    rope = K.to_cb(rope)
+    z = lambda *s, dtype=bf: torch.zeros(*s, device=DEV, dtype=dtype)
+    Kc, Vc = z(n_kv, H, Lpc, 64), z(n_kv, H, Lpc, 64)
+    Kc[:, :, :Lk] = rnd(n_kv, H, Lk, 64, seed=95).to(bf)
+    Vc[:, :, :Lk] = rnd(n_kv, H, Lk, 64, seed=96).to(bf)
+    Kf, Vf = z(n_kv, H, nkt * 2048), z(n_kv, H, nkt * 2048)
+    K.pack_kv_frags(Kc, Vc, Kf, Vf, n_kv, H, Lpc, nkt, 0, Lk)
+    xatt = dict(kf=Kf, vf=Vf, n_shared=n_shared, nkt=nkt, Lk=Lk, rope=rope, Lp=Lp, mt=mt)
+
+    # ---- path 1
+    x1 = K.to_cb(xres)
+    Q1, K1, V1, O1, h1 = z(nseq, H, Lp, 64), z(nseq, H, Lp, 64), z(nseq, H, Lp, 64), z(M, 512), z(M, 512)
+    K.chain(l0.mode, M, Lq, Oa, l0.ws, xres=x1, xout=x1, q_out=Q1, k_out=K1, v_out=V1, **l0.kw, **xatt)
+    K.attention(L.DT_BF16, Q1, K1, V1, O1, nseq, H, Lq, Lq, Lp, Lp, 512)
+    K.chain(l1.mode, M, Lq, O1, l1.ws, xres=x1, xout=x1, h_out=h1, **l1.kw, **xatt)
+    # ---- path 1 again with sequence-cut blocks only: exactly the same numbers
+    x3 = K.to_cb(xres)
+    Q3, K3, V3 = z(nseq, H, Lp, 64), z(nseq, H, Lp, 64), z(nseq, H, Lp, 64)
+    K.chain(l0.mode, M, Lq, Oa, l0.ws, xres=x3, xout=x3, q_out=Q3, k_out=K3, v_out=V3, seq_blocks=True, **l0.kw, **xatt)
+    # ---- path 2
+    nbs = (Lq + rows - 1) // rows
+    skt = (Lq + 31) // 32
+    x2 = K.to_cb(xres)
+    qf = z(nseq * nbs, 8, 4, 2, 64, 8)
+    skf, svf = z(nseq, H, skt * 2048), z(nseq, H, skt * 2048)
+    h2 = z(M, 512)
+    K.chain(l0.mode, M, Lq, Oa, l0.ws, xres=x2, xout=x2, seq_blocks=True, qf_out=qf, kf_out=skf, vf_out=svf, out_nkt=skt,
+            **l0.kw, **xatt)
+    x2a = x2.clone()
+    K.chain(l1.mode, M, Lq, Oa, l1.ws, xres=x2, xout=x2, h_out=h2, seq_blocks=True, sa_q=qf, sa_kf=skf, sa_vf=svf, sa_nkt=skt,
+            **l1.kw, **xatt)
+    torch.cuda.synchronize()
+    for nm, a, b in (("Q", Q1, Q3), ("K", K1, K3), ("V", V1, V3)):
+        assert torch.equal(a, b), f"sequence-cut blocks changed {nm}"
+    assert torch.equal(x3, x2a), "fragment outputs changed the residual stream"
+    q2 = unpack_q(qf, nseq, Lq, rows)
+    k2, v2 = unpack_kv(skf, kf_index, Lq), unpack_kv(svf, vf_index, Lq)
+    # the Q fragments carry log2(e) / sqrt(d_k) (the in-kernel softmax works in the exp2 domain): one bf16 rounding apart
+    qd = (Q1[:, :, :Lq].float() * 1.4426950408889634 - q2.float()).abs()
+    print(f"L={Lq} mt={mt}: fragment-order Q against log2(e) x the head-major image: max diff {float(qd.max()):.2e}")
+    assert float((qd / (Q1[:, :, :Lq].float().abs() * 1.4426950408889634 + 1e-6)).max()) < 2.0 ** -7
+    for nm, a, b in (("K", K1[:, :, :Lq], k2), ("V", V1[:, :, :Lq], v2)):
+        d = float((a.float() - b.float()).abs().max())
+        print(f"L={Lq} mt={mt}: fragment-order {nm} against the head-major image: max diff {d:.2e}")
+        assert d == 0.0, nm
+    d = (float((h1.float() - h2.float()).abs().max()), float((h1.float() - h2.float()).abs().mean()))
+    print(f"L={Lq} mt={mt}: layer output, in-kernel self-attention against the attention kernel: max/mean diff {d[0]:.2e}/{d[1]:.2e} "
+          f"(max |h| {float(h1.float().abs().max()):.2f})")
+    assert d[0] < 1.5e-1 and d[1] < 4e-3
+
+
+def test_launcher_refuses_inconsistent_self_attention_arguments():
+    nseq, Lq = 2, 150
+    M = nseq * Lq
+    l0 = Layer(100, nseq, False)
+    z = lambda *s, dtype=bf: torch.zeros(*s, device=DEV, dtype=dtype)
+    rope = K.to_cb(torch.zeros(Lq, 512, device=DEV))
+    Kf = z(2, 8, 2 * 2048)
+    x = K.to_cb(torch.zeros(M, 512, device=DEV))
+    base = dict(xres=x, xout=x, rope=rope, Lp=256, kf=Kf, vf=Kf, n_shared=1, nkt=2, Lk=62, **l0.kw)
+    Q = z(nseq, 8, 256, 64)
+    qf, sk = z(nseq * 3, 8, 4, 2, 64, 8), z(nseq, 8, 5 * 2048)
+    A = z(M, 512)
+    with pytest.raises(L.TcdiffError):      # fragment outputs need sequence-cut blocks
+        K.chain(l0.mode, M, Lq, A, l0.ws, qf_out=qf, kf_out=sk, vf_out=sk, out_nkt=5, **base)
+    with pytest.raises(L.TcdiffError):      # all three images or none
+        K.chain(l0.mode, M, Lq, A, l0.ws, seq_blocks=True, qf_out=qf, q_out=Q, k_out=Q, v_out=Q, out_nkt=5, **base)
+    with pytest.raises(L.TcdiffError):      # too few key tiles for the sequence
+        K.chain(l0.mode, M, Lq, A, l0.ws, seq_blocks=True, qf_out=qf, kf_out=sk, vf_out=sk, out_nkt=4, **base)
+    with pytest.raises(L.TcdiffError):      # whole sequences only
+        K.chain(l0.mode, M - 6, Lq, A, l0.ws, seq_blocks=True, q_out=Q, k_out=Q, v_out=Q, **base)
+    with pytest.raises(L.TcdiffError):      # 16-row blocks cannot hold a V^T fragment
+        K.chain(l0.mode, M, Lq, A, l0.ws, seq_blocks=True, qf_out=qf, kf_out=sk, vf_out=sk, out_nkt=5, mt=1, **base)
