@@ -95,13 +95,15 @@ def launch_ranks(argv, world, timeout=3600.0):
 # ----------------------------------------------------------------------------------------------------------------
 # per-kernel accounting
 # ----------------------------------------------------------------------------------------------------------------
-def family_flops_per_step(B, dn, S, NL=8, H=8, nf=151, ff=1024, branches=2):
+def family_flops_per_step(B, dn, S, NL=8, H=8, nf=151, ff=1024, branches=2, sa_in_chain=False):
     """ALGORITHMIC FLOPs of one two-branch DDPM step of B clips, per kernel family (2 FLOP per MAC; the shapes are
     SURVEY.md 2.3 / Appendix B, layer-0 self-attention evaluated once for both branches as the engine does).
     `chain` = the row-block chain launches (csrc/chain.hip): every projection of a layer behind the self-attention
     (fc, w_qs, cross-attention, fc, linear1/2/3, next w_qs/w_ks/w_vs), the final layer (folded into the last linear3) and
     the front launch (last fusion linear + layer-0 QKV); `attention` = self-attention; `gemm_tile` = what is left outside
-    the layers (FiLM stack, input projection + fusion linears 1-2); `gemm_rowln` is not launched per step any more."""
+    the layers (FiLM stack, input projection + fusion linears 1-2); `gemm_rowln` is not launched per step any more.
+    sa_in_chain (round 5, the default bf16 path): the self-attention of layers 1.. runs INSIDE the chain launches (chain.hip,
+    tcdiff_chain_args.sa_q) -- its FLOPs belong to that family; only layer 0's stays an attention launch."""
     Lq = dn * S
     Rs, R = B * Lq, branches * B * Lq
     M = S + 2
@@ -113,7 +115,11 @@ def family_flops_per_step(B, dn, S, NL=8, H=8, nf=151, ff=1024, branches=2):
     chain += 2.0 * B * S * 1024 * 512 * dn + 2.0 * Rs * 1536 * 512   # front launch: last fusion linear + layer-0 QKV
     for l in range(NL):
         nseq_sa = B if l == 0 else branches * B
-        att += 4.0 * nseq_sa * H * Lq * Lq * 64
+        sa = 4.0 * nseq_sa * H * Lq * Lq * 64
+        if sa_in_chain and l > 0:
+            chain += sa
+        else:
+            att += sa
         chain += 3 * 2.0 * R * 512 * 512 + 2.0 * R * 512 * ff          # fc, fc, linear3, linear2
         chain += 2.0 * R * 512 * 512 + 2.0 * R * ff * 512              # cross-attention w_qs, linear1
         chain += 4.0 * branches * B * H * Lq * M * 64                  # cross-attention
@@ -122,10 +128,12 @@ def family_flops_per_step(B, dn, S, NL=8, H=8, nf=151, ff=1024, branches=2):
     return {"chain": chain, "gemm_rowln": rowln, "gemm_tile": tile, "attention": att}
 
 
-def family_bytes_per_step(B, dn, S, es, NL=8, H=8, ff=1024):
+def family_bytes_per_step(B, dn, S, es, NL=8, H=8, ff=1024, sa_in_chain=False):
     """ALGORITHMIC HBM bytes of one two-branch DDPM step per family at launch granularity: every operand of a launch
     read once, every result written once (SURVEY.md 8(d)'s 110 MB is the figure if no intermediate ever left the chip).
-    Chain launch: O in, x in / out (fp32), Q / K / V images out, the layer's weights and K / V caches once."""
+    Chain launch: O in, x in / out (fp32), Q / K / V images out, the layer's weights and K / V caches once.
+    sa_in_chain: layers 1.. read the previous launch's Q / K / V (3 x R x 512) instead of O (R x 512); one attention launch
+    (layer 0: one branch's Q / K / V in, O out) is left."""
     Lq = dn * S
     R = 2 * B * Lq
     act = lambda cols, e=es: R * cols * e
@@ -134,6 +142,9 @@ def family_bytes_per_step(B, dn, S, es, NL=8, H=8, ff=1024):
     wl = (5 * 512 * 512 + 2 * 512 * ff + 1536 * 512) * es                 # weights of one chain launch
     chain = NL * (act(512) + 2 * x32 + 3 * act(512) + wl + 2 * (B + 1) * H * lpc * 64 * es)
     att = NL * (3 * act(512) + act(512))
+    if sa_in_chain:
+        chain += (NL - 1) * 2 * act(512)
+        att = (3 * act(512) + act(512)) // 2
     tile = (act(512) + 1536 * 512 * es + 3 * act(512)) // 2
     return {"chain": chain, "gemm_rowln": 0.0, "gemm_tile": tile, "attention": att}
 
@@ -182,8 +193,11 @@ def kernel_roofline(times, n_steps, B_launch, streams, dn, S, dtype):
     peak = PEAK_BF16_TFLOPS if dtype == "bf16" else PEAK_F32_TFLOPS
     es = 2 if dtype == "bf16" else 4
     B = B_launch * streams
-    flops = family_flops_per_step(B, dn, S)
-    nbytes = family_bytes_per_step(B, dn, S, es)
+    # the self-attention of layers 1.. runs inside the chain launches when the profile shows one attention launch per step
+    n_att = sum(c for n, (c, _) in times.items() if any(p in n for p in FAMILIES["attention"])) / max(n_steps, 1)
+    sa_in_chain = n_att < 4
+    flops = family_flops_per_step(B, dn, S, sa_in_chain=sa_in_chain)
+    nbytes = family_bytes_per_step(B, dn, S, es, sa_in_chain=sa_in_chain)
     fam = {}
     total_us = sum(t for _, t in times.values())
     for name, (cnt, us) in times.items():
@@ -218,7 +232,8 @@ def kernel_roofline(times, n_steps, B_launch, streams, dn, S, dtype):
         # the same 5.5 MB at 113-117 GB/s (26-29 TB/s chip-wide) at 1, 225 and 256 blocks -- the per-CU vector-memory return
         # path, not the L2, is the ceiling of the stream -- and the chain launch's slow-down from 1 to 225 blocks is the shader
         # clock (2.39 -> 1.9-2.0 GHz at the power limit), not contention.  Reported beside the MFMA figure.
-        n_blk = (2 * B * dn * S + 63) // 64
+        # (row blocks are cut per sequence when the self-attention runs inside the launch: 8 blocks per 450-row sequence)
+        n_blk = 2 * B * ((dn * S + 63) // 64) if sa_in_chain else (2 * B * dn * S + 63) // 64
         per_step = (7 * 176 + 128) * 4096 * 8 * n_blk + 80 * 4096 * 8 * ((B * S + 63) // 64) * dn
         gbps = per_step / (d["device_ms_per_ddpm_step"] * 1e-3) / 1e9
         roof["weight_stream"] = dict(

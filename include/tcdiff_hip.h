@@ -273,7 +273,8 @@ typedef struct {
      *   sa_q  : the block's Q^T fragments, bf16, as the PREVIOUS launch left them in `qf_out`: [block][8 waves][mt][2][64 lanes][8]
      *           (already scaled by 1 / sqrt(d_k));
      *   sa_kf, sa_vf : K / V of the layer in the fragment order of tcdiff_pack_kv_frags, bf16 [M / L][8 heads][sa_nkt][4][64][8],
-     *           sa_nkt = ceil(L / 32) tiles; keys >= L of the last tile must be finite.
+     *           sa_nkt = ceil(L / 32) tiles; keys >= L of the last tile must be finite (the images must start zeroed: a launch
+     *           writes the keys it owns, in 16-row blocks one 8-byte half of a V piece per lane).
      * qf_out / kf_out / vf_out != NULL (all three together; requires seq_blocks): the next layer's Q, K, V leave in those formats
      * (written straight from the accumulators: 1-KB pieces per wave instruction) instead of the head-major images q_out / k_out /
      * v_out; out_nkt = the key tiles per (sequence, head) of kf_out / vf_out. */

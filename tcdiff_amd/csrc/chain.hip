@@ -313,19 +313,20 @@ DEVINL void store_kfrag(const f32x4_t (&acc)[4][MT], void* base, int seq, int fi
 }
 // V: accT = the TRANSPOSED projection tiles (phase_n512<.., SWAP>): lane (c, g) holds keys 16 mt + 4 g + j of feature 16 nt + c,
 // and the pair of row tiles (2 t, 2 t + 1) IS the A operand of O^T += V^T P^T for the 32-key tile (MT / 2) bis + t and d tile nt.
-// first_row: the block's first row within its sequence (a multiple of 32).  MT = 1 (a sequence's last block when it holds <= 16
-// rows): keys 16 .. 31 of the tile lie past the sequence and are written as zeros.
+// first_row: the block's first row within its sequence.  MT = 1 (16-row blocks, or a sequence's last block when it holds <= 16
+// rows): the block owns one half of every lane's 16 bytes -- keys 16 (first_row / 16 & 1) .. + 15 of the tile; a half that lies past
+// the sequence is never written (the caller's image starts zeroed and only ever holds finite values; those keys are masked).
 template <int MT>
 DEVINL void store_vfrag(const f32x4_t (&accT)[4][MT], void* base, int seq, int first_row, int nkt, int wave, int lane) {
     u32x4* dst = reinterpret_cast<u32x4*>(base) + ((long)(seq * 8 + wave) * nkt) * 256 + lane;
     if constexpr (MT == 1) {
-        const int kt = first_row >> 5;
+        const int kt = first_row >> 5, half = (first_row >> 4) & 1;
         if (kt < nkt) {
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 const f32x4_t lo = accT[nt][0];
-                u32x4 f = {pack_bf2(lo[0], lo[1]), pack_bf2(lo[2], lo[3]), 0u, 0u};
-                dst[(kt * 4 + nt) * 64] = f;
+                uint2 f = {pack_bf2(lo[0], lo[1]), pack_bf2(lo[2], lo[3])};
+                *reinterpret_cast<uint2*>(reinterpret_cast<char*>(dst + (kt * 4 + nt) * 64) + 8 * half) = f;
             }
         }
         return;
@@ -791,8 +792,8 @@ DEVINL void chain_body(const tcdiff_chain_args& a) {
     zero(acc);
     phase_n512<16, false, MT, NT>(acc, abuf, ws, lane);
     CH_T(29);
-    // qf_out: Q / K / V leave in the fragment order of the next launch's in-kernel self-attention (seq_blocks; 8-wave form, MT >= 2)
-    constexpr bool FRAG = !FRONT && NT == 4 && BRK >= 32;
+    // qf_out: Q / K / V leave in the fragment order of the next launch's in-kernel self-attention (seq_blocks; 8-wave form)
+    constexpr bool FRAG = !FRONT && NT == 4;
     bool frag_out = false;
     if constexpr (FRAG) frag_out = a.qf_out != nullptr;
     if constexpr (FRAG) {
@@ -915,10 +916,6 @@ extern "C" int tcdiff_chain(const tcdiff_chain_args* a, hipStream_t stream) {
     int mt = a->mt;
     if (mt == 0) mt = ((a->M + 15) / 16) * units <= n_cu ? 1 : ((a->M + 31) / 32) * units <= n_cu ? 2 : 4;
     if (mt != 1 && mt != 2 && mt != 4) return TC_ERR_ARG;
-    if ((a->sa_q || frag_out) && mt == 1) {
-        if (a->mt == 1) return TC_ERR_UNSUPPORTED;      // a V^T fragment needs the 32 keys of two row tiles
-        mt = 2;
-    }
     dim3 grid(((a->M + 16 * mt - 1) / (16 * mt)) * units);
     if (a->seq_blocks) grid.x = (a->M / a->L) * ((a->L + 16 * mt - 1) / (16 * mt));
     // a->nw: waves per workgroup.  0 / 8: eight waves of 64 columns (two per SIMD); 4: four waves of 128 columns, one per SIMD

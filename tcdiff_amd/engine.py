@@ -73,10 +73,8 @@ class DenoiserEngine:
         self.front = self.use_full and os.environ.get("TCDIFF_FRONT", "1") != "0" and self.S >= 8
         # the self-attention of layers 1.. inside the chain launch (row blocks cut per sequence, Q / K / V handed from launch to
         # launch in MFMA-fragment order; csrc/chain.hip): large jobs only (64-row blocks), bf16, 8-wave form
-        self.fuse_sa = self.use_full and self.dt == L.DT_BF16 and os.environ.get("TCDIFF_FUSE_SA", "0") == "1"
-        # ... from the size at which the launcher leaves 16-row blocks (a V^T fragment needs the 32 keys of two row tiles)
-        self.sa_min_rows = int(os.environ.get("TCDIFF_FUSE_SA_ROWS", "4097"))
-        self.n_cu = torch.cuda.get_device_properties(self.dev).multi_processor_count if self.fuse_sa else 0
+        self.fuse_sa = self.use_full and self.dt == L.DT_BF16 and os.environ.get("TCDIFF_FUSE_SA", "1") == "1"
+        self.sa_min_rows = int(os.environ.get("TCDIFF_FUSE_SA_ROWS", "0"))        # (experiments: the old path below this many rows)
         self.chain_nw = int(os.environ.get("TCDIFF_CHAIN_NW", "8"))      # waves per workgroup of the chain launches (8 or 4)
         if self.chain_nw not in (4, 8):
             raise L.TcdiffError("TCDIFF_CHAIN_NW must be 8 or 4")
@@ -319,7 +317,8 @@ class DenoiserEngine:
             b["Vf"] = z(NL, 2 * B, H, self.nkt * 2048)
         if self.fuse_sa:                             # fragment-order Q (per 64-row block of a sequence), K, V of the next layer
             self.skt = (Lq + 31) // 32
-            b["Qf"] = z(2 * B * ((Lq + 31) // 32), 8, 4, 2, 64, 8)       # (block, wave)-private; enough for 32-row blocks
+            self.n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+            b["Qf"] = z(2 * B * ((Lq + 15) // 16), 8, 4, 2, 64, 8)       # (block, wave)-private; enough for 16-row blocks
             # two of each: a launch reads layer l's keys in every block's prologue while its early blocks already write layer l + 1's
             b["sKf"], b["sVf"] = z(2, 2 * B, H, self.skt * 2048), z(2, 2 * B, H, self.skt * 2048)
         b["hidden_all"] = z(2 * B, 512, dtype=torch.float32)
@@ -606,8 +605,8 @@ class DenoiserEngine:
                     h_out=(b["out"] if self.fold_out else b["h"]) if last else None,
                     out_ld=152 if last and self.fold_out else 0, scale_q=0.125, Lp=self.Lp, H=H)
         if fused:
-            # 32-row blocks while every one of them gets a CU (a block streams the layer's weights whatever its rows), else 64
-            tail.update(seq_blocks=True, mt=2 if nseq * ((Lq + 31) // 32) <= self.n_cu else 4)
+            # the smallest row blocks that still give every block its own CU (a block streams the layer's weights whatever its rows)
+            tail.update(seq_blocks=True, mt=next((m for m in (1, 2) if nseq * ((Lq + 16 * m - 1) // (16 * m)) <= self.n_cu), 4))
             if l > 0:
                 tail.update(sa_q=b["Qf"], sa_kf=b["sKf"][l & 1], sa_vf=b["sVf"][l & 1], sa_nkt=self.skt)
             if not last:

@@ -84,7 +84,8 @@ class Layer:
 
 
 # 450 = 7 x 64 + 2, 130 = 2 x 64 + 2, 100 = 3 x 32 + 4: a last block of <= 16 rows runs the one-row-tile body; 150 = 2 x 64 + 22: it does not
-@pytest.mark.parametrize("Lq,nseq,mt", [(150, 3, 4), (150, 3, 2), (450, 2, 4), (130, 3, 4), (64, 5, 4), (100, 4, 2)])
+@pytest.mark.parametrize("Lq,nseq,mt", [(150, 3, 4), (150, 3, 2), (150, 3, 1), (450, 2, 4), (450, 2, 1), (130, 3, 4), (64, 5, 4),
+                                        (100, 4, 2)])
 def test_self_attention_inside_the_chain_launch(Lq, nseq, mt):
     """Two consecutive decoder layers.  Path 1: fused launch -> head-major Q / K / V -> attention kernel -> fused launch.
     Path 2: sequence-cut fused launch -> fragment-order Q / K / V -> fused launch that computes the attention itself.
@@ -172,5 +173,3 @@ def test_launcher_refuses_inconsistent_self_attention_arguments():
         K.chain(l0.mode, M, Lq, A, l0.ws, seq_blocks=True, qf_out=qf, kf_out=sk, vf_out=sk, out_nkt=4, **base)
     with pytest.raises(L.TcdiffError):      # whole sequences only
         K.chain(l0.mode, M - 6, Lq, A, l0.ws, seq_blocks=True, q_out=Q, k_out=Q, v_out=Q, **base)
-    with pytest.raises(L.TcdiffError):      # 16-row blocks cannot hold a V^T fragment
-        K.chain(l0.mode, M, Lq, A, l0.ws, seq_blocks=True, qf_out=qf, kf_out=sk, vf_out=sk, out_nkt=5, mt=1, **base)
