@@ -67,6 +67,13 @@
 // fragments are the ones this block's previous launch packed (store_qfrag), the keys are the block's own sequence (K / V in
 // fragment order from store_kfrag / store_vfrag of the previous launch, Lk = L, no slot mapping); blocks are cut per sequence.
 // Mv: first row past the block's valid rows (M, or the end of the block's sequence); lblk: the block's logical index.
+// (fmaxf canonicalises each operand first -- one more instruction per value -- and the loop below is bound by the number of
+// instructions a wave can issue: one per four cycles, whatever their kind)
+DEVINL float max3f(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 template <int HH, int MT, int NT, bool SELF = false>
 DEVINL void cross_attention(const f32x4_t (&qacc)[NT][MT], const tcdiff_chain_args& a, int m0, int Mv, int lblk, char* abuf,
                             int wave, int lane) {
@@ -206,8 +213,8 @@ DEVINL void cross_attention(const f32x4_t (&qacc)[NT][MT], const tcdiff_chain_ar
                 bool hot = kt == 0;
 #pragma unroll
                 for (int ml = 0; ml < NML; ++ml) {
-                    lm[ml] = fmaxf(fmaxf(fmaxf(s0[ml][0], s0[ml][1]), fmaxf(s0[ml][2], s0[ml][3])),
-                                   fmaxf(fmaxf(s1[ml][0], s1[ml][1]), fmaxf(s1[ml][2], s1[ml][3])));
+                    lm[ml] = max3f(max3f(s0[ml][0], s0[ml][1], s0[ml][2]), max3f(s0[ml][3], s1[ml][0], s1[ml][1]),
+                                   max3f(s1[ml][2], s1[ml][3], s1[ml][3]));
                     hot = hot || lm[ml] > CH_ATT_THR;
                 }
                 if (__builtin_amdgcn_ballot_w64(hot) != 0) {

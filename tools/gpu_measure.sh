@@ -6,10 +6,12 @@ mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 python -m pytest tests -q -m gpu 2>&1 | tail -3
 python -m pytest tests/test_parity_gpu.py -m gpu -s -q -k "c2 or bf16 or drift" > gpurun_out/${R}_parity_at_benchmarked_config.log 2>&1; tail -2 gpurun_out/${R}_parity_at_benchmarked_config.log
+if [ -z "$SKIP_TRAIN" ]; then
 python -m pytest tests/test_train_step_gpu.py -m gpu -s -q 2>&1 | grep -E "\[f32\]|\[bf16|passed|failed" > gpurun_out/${R}_train_step_parity.log; tail -3 gpurun_out/${R}_train_step_parity.log
+fi
 python bench.py 2>gpurun_out/bench_default_err.log > gpurun_out/${R}_bench_full_1000steps.json; tail -c 2500 gpurun_out/${R}_bench_full_1000steps.json
 python tools/chain_full_bench.py --forms 8 --reps 3 2>/dev/null | grep "waves:" > gpurun_out/${R}_chain_block_scaling.txt; cat gpurun_out/${R}_chain_block_scaling.txt
-for b in 4 32; do python tools/train_bench.py --batch $b --iters 8 --kernels 2>/dev/null | tail -1; done > gpurun_out/${R}_train_step.jsonl; cut -c1-400 gpurun_out/${R}_train_step.jsonl
+[ -z "$SKIP_TRAIN" ] && for b in 4 32; do python tools/train_bench.py --batch $b --iters 8 --kernels 2>/dev/null | tail -1; done > gpurun_out/${R}_train_step.jsonl; cut -c1-400 gpurun_out/${R}_train_step.jsonl
 ARGS="bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-profile --no-parity-mode --no-train-step --no-other-configs"
 rm -rf gpurun_out/prof_trace
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_trace -- python3 $ARGS --ddpm-steps 200 > gpurun_out/prof_trace.log 2>&1
@@ -19,6 +21,7 @@ rm -rf gpurun_out/prof_trace
 # (roofline.traffic: bench.py runs the FETCH_SIZE / WRITE_SIZE passes itself since round 5; the default run above carries them)
 SETS="SQ_LDS_BANK_CONFLICT,SQ_LDS_IDX_ACTIVE,SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES,SQ_INSTS_VALU,SQ_INSTS_MFMA,SQ_BUSY_CYCLES" bash tools/gpu_pmc2.sh > /dev/null 2>&1
 cp gpurun_out/pmc2_summary.txt gpurun_out/${R}_pmc_SQ_counters_20steps.txt; head -8 gpurun_out/${R}_pmc_SQ_counters_20steps.txt | cut -c1-250
+if [ -z "$SKIP_TRAIN" ]; then
 # the training step under rocprofv3 (kernel stats of 6 steps at batch 32)
 rm -rf gpurun_out/prof_train
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_train -- python3 tools/train_bench.py --batch 32 --iters 4 > gpurun_out/prof_train.log 2>&1
@@ -34,9 +37,16 @@ python tools/gemm_rows_bench.py 2>/dev/null | grep -v amdgpu.ids > gpurun_out/${
 for rep in 1 2 3; do for rows in 1 0; do
   echo "TCDIFF_TRAIN_ROWS=$rows: $(TCDIFF_TRAIN_ROWS=$rows python tools/train_bench.py --batch 32 --iters 10 2>/dev/null | tail -1 | cut -c88-150)"
 done; done > gpurun_out/${R}_train_rows_ab.txt; cat gpurun_out/${R}_train_rows_ab.txt
+fi
 # round 4 additions: in-kernel stamps + shader clock of the fused layer, small-batch modes, pure-load ceiling of the weight stream
 bash tools/ab_build.sh STAMP "-DCH_STAMP" > /dev/null 2>&1
 TCDIFF_LIB_PATH=tools/probe/libtc_STAMP.so timeout 300 python tools/chain_stamps.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_chain_stamps.txt; grep -E "fused layer|last wave|shader clock" gpurun_out/${R}_chain_stamps.txt
+# round 5: the launch with the self-attention inside (blocks cut per sequence: 8 / 256 blocks), its forms against each other, and the sampler with / without it
+SA=1 TCDIFF_LIB_PATH=tools/probe/libtc_STAMP.so timeout 300 python tools/chain_stamps.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_chain_stamps_self_attention.txt; grep -E "fused layer|last wave|shader clock|self-attention" gpurun_out/${R}_chain_stamps_self_attention.txt
+timeout 300 python tools/chain_sa_bench.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_chain_self_attention_forms.txt; cat gpurun_out/${R}_chain_self_attention_forms.txt
+for rep in 1 2; do for f in 0 1; do
+  echo "TCDIFF_FUSE_SA=$f: $(TCDIFF_FUSE_SA=$f timeout 900 python bench.py --steps 120 --warmup 10 --no-pmc --no-kernel-profile --no-parity-mode --no-cpu-baseline --no-train-step --no-other-configs 2>/dev/null | tail -1 | cut -c80-190)"
+done; done > gpurun_out/${R}_sampler_self_attention_ab.txt; cat gpurun_out/${R}_sampler_self_attention_ab.txt
 timeout 1200 python tools/small_batch.py 2>&1 | tail -3 > gpurun_out/${R}_small_batch.txt; cat gpurun_out/${R}_small_batch.txt
 python -m pytest tests/test_parity_gpu.py -m gpu -s -q -k "attribution" 2>&1 | grep -E "guided evaluation|  bf16|  f32 parity|passed|failed" >> gpurun_out/${R}_parity_at_benchmarked_config.log
 timeout 120 python tools/power_watch.py 10 > gpurun_out/${R}_power_watch.txt 2>&1; head -2 gpurun_out/${R}_power_watch.txt
