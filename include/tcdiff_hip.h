@@ -270,8 +270,9 @@ typedef struct {
      * x ceil(L / (16 mt)); no block straddles two sequences, its rows are keys 16 mt b .. of its sequence).
      * sa_q != NULL: instead of reading the attention output `A`, the block computes softmax((Q / 8) K^T) V of its rows itself
      * (model/model.py:97-102; wave = head, online softmax over 32-key tiles as the in-kernel cross-attention) from
-     *   sa_q  : the block's Q^T fragments, bf16, as the PREVIOUS launch left them in `qf_out`: [block][8 waves][mt][2][64 lanes][8]
-     *           (already scaled by 1 / sqrt(d_k));
+     *   sa_q  : the block's Q^T fragments, bf16, as the PREVIOUS launch left them in `qf_out`: [block][8 waves][8 pieces = (row tile
+     *           mt < 4, d-step s < 2)][64 lanes][8] -- 8 KB per (block, wave) whatever the launch's rows per block -- scaled by
+     *           log2(e) / sqrt(d_k): the in-kernel softmax works in the exp2 domain;
      *   sa_kf, sa_vf : K / V of the layer in the fragment order of tcdiff_pack_kv_frags, bf16 [M / L][8 heads][sa_nkt][4][64][8],
      *           sa_nkt = ceil(L / 32) tiles; keys >= L of the last tile must be finite (the images must start zeroed: a launch
      *           writes the keys it owns, in 16-row blocks one 8-byte half of a V piece per lane).

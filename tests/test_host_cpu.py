@@ -52,6 +52,65 @@ def test_argument_validation_without_gpu(lib):
         L.check(-2, "x")
 
 
+def test_ctypes_structures_match_the_header(tmp_path):
+    """The argument structures cross the C ABI by value / by pointer: the ctypes mirrors in _lib.py must have the header's sizes and
+    (for the largest one) field offsets -- checked with the C compiler itself."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None or not os.path.isdir("/opt/rocm/include"):
+        pytest.skip("needs gcc and the HIP headers")
+    pairs = [("tcdiff_tile_epi", L.TileEpi), ("tcdiff_row_epi", L.RowEpi), ("tcdiff_chain_args", L.ChainArgs),
+             ("tcdiff_step_prologue_args", L.StepPrologueArgs), ("tcdiff_row_args", L.RowArgs), ("tcdiff_ct_desc", L.CtDesc),
+             ("tcdiff_ws_desc", L.WsDesc), ("tcdiff_tn_problem", L.TnProblem), ("tcdiff_adan_scalars", L.AdanScalars)]
+    chain_fields = [f[0] for f in L.ChainArgs._fields_]
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "tcdiff_hip.h"', "int main(void) {"]
+    src += [f'  printf("%zu\\n", sizeof({c}));' for c, _ in pairs]
+    src += [f'  printf("%zu\\n", offsetof(tcdiff_chain_args, {f}));' for f in chain_fields]
+    src += ["  return 0;", "}"]
+    cfile, exe = tmp_path / "abi.c", tmp_path / "abi"
+    cfile.write_text("\n".join(src))
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", str(cfile),
+                    "-o", str(exe)], check=True, capture_output=True)
+    out = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    for (cname, cls), size in zip(pairs, out):
+        assert ctypes.sizeof(cls) == size, f"{cname}: header {size} bytes, ctypes mirror {ctypes.sizeof(cls)}"
+    for f, off in zip(chain_fields, out[len(pairs):]):
+        assert getattr(L.ChainArgs, f).offset == off, f"tcdiff_chain_args.{f}: header offset {off}, ctypes {getattr(L.ChainArgs, f).offset}"
+
+
+def test_chain_launcher_validates_the_self_attention_arguments_without_gpu(lib):
+    """tcdiff_chain refuses inconsistent seq_blocks / sa_* / *f_out combinations before it touches the device (-1); a consistent set
+    passes validation and fails only at the device query (-4 here: no GPU)."""
+    P = 0x1000
+
+    def rc(**kw):
+        a = L.ChainArgs()
+        base = dict(mode=L.CHAIN_FULL, n_stages=176, M=450, L=150, H=8, Lp=256, A=P, wstream=P, film=P, xres=P, xout=P, n2_g=P,
+                    n2_b=P, rope=P, b1=P, film3=P, n4_g=P, n4_b=P, b3=P, nn_g=P, nn_b=P, film_ld=6144, filmb=P, n3_g=P, n3_b=P, kf=P,
+                    vf=P, n_shared=1, nkt=2, Lk=62, rope_rows=150, dn=1, mt=4)
+        base.update(kw)
+        for k, v in base.items():
+            setattr(a, k, v)
+        return lib.tcdiff_chain(ctypes.byref(a), None)
+
+    frag = dict(qf_out=P, kf_out=P, vf_out=P, out_nkt=5)
+    sa = dict(sa_q=P, sa_kf=P, sa_vf=P, sa_nkt=5)
+    if torch.cuda.is_available():
+        pytest.skip("valid argument sets would launch on fake pointers")
+    assert rc(q_out=P, k_out=P, v_out=P) == -4                                  # the plain fused launch
+    assert rc(q_out=P, k_out=P, v_out=P, seq_blocks=1) == -4
+    assert rc(seq_blocks=1, **frag) == -4 and rc(seq_blocks=1, **frag, **sa) == -4
+    assert rc(mode=L.CHAIN_FULL_LAST, n_stages=128, h_out=P, seq_blocks=1, **sa) == -4
+    assert rc(**frag) == -1                                                     # fragment outputs need sequence-cut blocks
+    assert rc(seq_blocks=1, qf_out=P, out_nkt=5, q_out=P, k_out=P, v_out=P) == -1      # all three images or none
+    assert rc(seq_blocks=1, qf_out=P, kf_out=P, vf_out=P, out_nkt=4) == -1      # 150 keys need 5 tiles
+    assert rc(q_out=P, k_out=P, v_out=P, seq_blocks=1, M=444) == -1             # whole sequences only
+    assert rc(q_out=P, k_out=P, v_out=P, **sa) == -1                            # the in-kernel attention needs sequence-cut blocks
+    assert rc(seq_blocks=1, **frag, sa_q=P, sa_kf=P, sa_vf=P, sa_nkt=4) == -1
+    assert rc(seq_blocks=1, nw=4, **frag) == -4                                 # (unsupported in the four-wave form -- also -4)
+    assert rc(seq_blocks=1, **frag, sa_q=P + 8, sa_kf=P, sa_vf=P, sa_nkt=5) == -2      # alignment
+
+
 def test_stream_table_validation_without_gpu(lib):
     """tcdiff_pack_row_streams' descriptor table is checked on the host before anything is launched"""
     from tcdiff_amd import kernels as K
