@@ -3,15 +3,20 @@ row blocks cut per sequence, the next layer's Q / K / V written in MFMA-fragment
 attention over them computed by the next launch in front of its fc GEMM -- against the launches it replaces (chain with
 head-major Q / K / V images + the attention kernel, which tests/test_chain_gpu.py and tests/test_parity_gpu.py hold to the
 reference)."""
+import os
+
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
+from oracle import tcdiff_oracle as O  # noqa: E402  (synthetic inputs only)
 from tcdiff_amd import _lib as L  # noqa: E402
 from tcdiff_amd import kernels as K  # noqa: E402
 from tcdiff_amd.engine import DenoiserEngine as E  # noqa: E402
+from tcdiff_amd.model import DanceDecoder  # noqa: E402
 
 DEV = "cuda"
 bf = torch.bfloat16
@@ -173,3 +178,47 @@ def test_launcher_refuses_inconsistent_self_attention_arguments():
         K.chain(l0.mode, M, Lq, A, l0.ws, seq_blocks=True, qf_out=qf, kf_out=sk, vf_out=sk, out_nkt=4, **base)
     with pytest.raises(L.TcdiffError):      # whole sequences only
         K.chain(l0.mode, M - 6, Lq, A, l0.ws, seq_blocks=True, q_out=Q, k_out=Q, v_out=Q, **base)
+
+
+def model_with(fuse_sa: bool, dn, S):
+    os.environ["TCDIFF_FUSE_SA"] = "1" if fuse_sa else "0"
+    try:
+        m = DanceDecoder(nfeats=151, seq_len=S, latent_dim=512, ff_size=1024, num_layers=8, num_heads=8, dropout=0.1,
+                         cond_feature_dim=438, activation=F.gelu, required_dancer_num=dn, compute_dtype="bf16")
+        m.load_state_dict(O.synth_state_dict(dn=dn, seq_len=S))
+        m.to(DEV).eval()
+        m.engine(1)                       # the engine reads the switch when it is built
+        assert m._engines[0].fuse_sa == fuse_sa
+        return m
+    finally:
+        os.environ.pop("TCDIFF_FUSE_SA", None)
+
+
+@pytest.mark.parametrize("dn,S,B", [(2, 60, 1), (3, 150, 2), (3, 150, 5), (3, 150, 16)])
+def test_network_with_in_launch_self_attention_matches_the_attention_kernel_path(dn, S, B):
+    """The whole denoiser (both CFG branches, and a plain forward) with the self-attention of layers 1-7 inside the chain launches
+    (the default) against the same engine with TCDIFF_FUSE_SA=0 (rounds 2-4's launch sequence, held to the reference by three rounds
+    of parity tests): 16-, 32- and 64-row blocks by job size.  The two paths differ by the softmax's summation order and where O is
+    rounded; beyond two layers their bf16 rounding errors are independent (see test_chain_gpu.py's network test for the bound)."""
+    Lq = dn * S
+    cond = torch.stack([O.synth_cond(c, S) for c in range(B)]).to(DEV)
+    x = torch.stack([O.synth_xT(c, Lq) for c in range(B)]).to(DEV)
+    outs = []
+    for fuse in (False, True):
+        m = model_with(fuse, dn, S)
+        os.environ["TCDIFF_FUSE_SA"] = "1" if fuse else "0"      # (engines built later -- the plain forward's -- read it too)
+        try:
+            tt = torch.full((B,), 640, dtype=torch.long, device=DEV)
+            g = m.guided_forward(x, cond, tt, 2.0)
+            with torch.no_grad():         # (with gradients enabled the forward is the training engine's: another path)
+                f = m(x, cond, torch.arange(B, device=DEV) * 37 + 5, cond_drop_prob=0.0)
+            assert all(e.fuse_sa == fuse for e in m._engines.values())
+        finally:
+            os.environ.pop("TCDIFF_FUSE_SA", None)
+        outs.append((g.clone(), f.clone()))
+    for nm, a, b in zip(("guided", "forward"), outs[0], outs[1]):
+        d, mean = float((a - b).abs().max()), float((a - b).abs().mean())
+        print(f"in-launch self-attention vs attention kernel ({dn}x{S}, B={B}, {nm}): max-abs {d:.2e}, mean-abs {mean:.2e}, "
+              f"|out| max {float(a.abs().max()):.2f}")
+        assert torch.isfinite(b).all()
+        assert d < 3e-2 and mean < 4e-3
