@@ -67,10 +67,11 @@ def unpack_q(qf, nseq, Lq, rows):
 class Layer:
     """random weights / constants of one fused decoder-layer launch"""
 
-    def __init__(self, seed, nseq, last):
+    def __init__(self, seed, nseq, last, qk_gain=1.0):
         W = {n: rnd(*s, seed=seed + i, scale=s[1] ** -0.5).to(bf) for i, (n, s) in enumerate(
             [("sfc", (512, 512)), ("cq", (512, 512)), ("cfc", (512, 512)), ("ff1", (1024, 512)), ("ff2", (512, 1024)),
              ("l3", (512, 512)), ("qkv", (1536, 512))])}
+        W["qkv"][:1024] *= qk_gain          # larger Q and K: logits far outside the range the lazy running maximum absorbs
         vec = lambda sd, base=0.0, amp=0.1: base + amp * rnd(512, seed=sd)
         gs = [vec(seed + 10 + i, 1 if i % 2 == 0 else 0) for i in range(12)]
         bias1, bias2, bias3 = 0.05 * rnd(1024, seed=seed + 30), vec(seed + 31), vec(seed + 32)
@@ -89,9 +90,10 @@ class Layer:
 
 
 # 450 = 7 x 64 + 2, 130 = 2 x 64 + 2, 100 = 3 x 32 + 4: a last block of <= 16 rows runs the one-row-tile body; 150 = 2 x 64 + 22: it does not
-@pytest.mark.parametrize("Lq,nseq,mt", [(150, 3, 4), (150, 3, 2), (150, 3, 1), (450, 2, 4), (450, 2, 1), (130, 3, 4), (64, 5, 4),
-                                        (100, 4, 2)])
-def test_self_attention_inside_the_chain_launch(Lq, nseq, mt):
+@pytest.mark.parametrize("Lq,nseq,mt,qk_gain", [(150, 3, 4, 1.0), (150, 3, 2, 1.0), (150, 3, 1, 1.0), (450, 2, 4, 1.0), (450, 2, 1, 1.0),
+                                                (130, 3, 4, 1.0), (64, 5, 4, 1.0), (100, 4, 2, 1.0), (150, 3, 4, 3.0), (450, 2, 4, 4.0),
+                                                (150, 3, 2, 6.0)])
+def test_self_attention_inside_the_chain_launch(Lq, nseq, mt, qk_gain):
     """Two consecutive decoder layers.  Path 1: fused launch -> head-major Q / K / V -> attention kernel -> fused launch.
     Path 2: sequence-cut fused launch -> fragment-order Q / K / V -> fused launch that computes the attention itself.
     The first launch's outputs must agree exactly (same arithmetic per row, another block cut and output order); the second
@@ -102,7 +104,9 @@ def test_self_attention_inside_the_chain_launch(Lq, nseq, mt):
     Lp, Lk = K.round_up(Lq, 128), S + 2
     Lpc, nkt = K.round_up(Lk, 128), (Lk + 31) // 32
     n_shared, n_kv = 1, nseq - 1 + 1
-    l0, l1 = Layer(100, nseq, False), Layer(200, nseq, True)
+    # qk_gain > 1: logits of tens to hundreds -- later tiles exceed the running maximum by more than its threshold again and again
+    # (the exact path of the in-kernel softmax with rescaling), rows turn nearly one-hot
+    l0, l1 = Layer(100, nseq, False, qk_gain), Layer(200, nseq, True)
     Oa = rnd(M, 512, seed=51, scale=0.5).to(bf)
     xres = rnd(M, 512, seed=94)
     rope = torch.empty(Lq, 512, device=DEV)
@@ -153,9 +157,12 @@ def test_self_attention_inside_the_chain_launch(Lq, nseq, mt):
         print(f"L={Lq} mt={mt}: fragment-order {nm} against the head-major image: max diff {d:.2e}")
         assert d == 0.0, nm
     d = (float((h1.float() - h2.float()).abs().max()), float((h1.float() - h2.float()).abs().mean()))
-    print(f"L={Lq} mt={mt}: layer output, in-kernel self-attention against the attention kernel: max/mean diff {d[0]:.2e}/{d[1]:.2e} "
+    print(f"L={Lq} mt={mt} gain={qk_gain}: layer output, in-kernel self-attention against the attention kernel: max/mean diff {d[0]:.2e}/{d[1]:.2e} "
           f"(max |h| {float(h1.float().abs().max()):.2f})")
-    assert d[0] < 1.5e-1 and d[1] < 4e-3
+    # (nearly one-hot rows: a near-tie between two keys resolves differently in the two softmax implementations now and then, and
+    # the row then follows another V row -- rare, bounded by |V| after the fc / LayerNorm chain)
+    assert torch.isfinite(h2.float()).all()
+    assert d[0] < (1.5e-1 if qk_gain == 1.0 else 3e-1) and d[1] < (4e-3 if qk_gain == 1.0 else 8e-3)      # measured: 1.1e-1 / 5.6e-3 at gain 6
 
 
 def test_launcher_refuses_inconsistent_self_attention_arguments():
