@@ -49,13 +49,13 @@ def load():
 
 
 def build_reference(sd, dn=3, seq_len=150, n_timestep=1000, latent=512, ff=1024, n_layers=8, n_head=8,
-                    cond_dim=438, nfeats=151, guidance_weight=2, activation=None):
+                    cond_dim=438, nfeats=151, guidance_weight=2, activation=None, use_rotary=True):
     """Reference model + diffusion with the production ctor arguments (TCDiff.py:76-102), eval mode."""
     import torch.nn.functional as F
     DanceDecoder, GaussianDiffusion = load()
     model = DanceDecoder(nfeats=nfeats, seq_len=seq_len, latent_dim=latent, ff_size=ff, num_layers=n_layers,
                          num_heads=n_head, dropout=0.1, cond_feature_dim=cond_dim,
-                         activation=F.gelu if activation is None else activation, required_dancer_num=dn)
+                         activation=F.gelu if activation is None else activation, required_dancer_num=dn, use_rotary=use_rotary)
     missing, unexpected = model.load_state_dict(sd, strict=True), None
     model.eval()
     diff = GaussianDiffusion(model, seq_len, nfeats, None, schedule="cosine", n_timestep=n_timestep,

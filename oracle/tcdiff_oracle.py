@@ -144,11 +144,24 @@ def make_tables(n_timestep: int = 1000, schedule: str = "cosine") -> Dict[str, t
 # ----------------------------------------------------------------------------------------------
 # building blocks
 # ----------------------------------------------------------------------------------------------
+def abs_pos(x: torch.Tensor, sd, drop=None) -> torch.Tensor:
+    """DanceDecoder.abs_pos_encoding (model/model.py:441-448,564,580): identity with rotary embeddings; with use_rotary=False
+    PositionalEncoding (model/utils.py:11-32, batch_first): x + pe[:len] (eval mode; its train-mode dropout is not restated)."""
+    pe = sd.get("abs_pos_encoding.pe")
+    if pe is None:
+        return x
+    if drop is not None and getattr(drop, "p", 0.0) > 0.0:
+        raise NotImplementedError("oracle: train-mode dropout of PositionalEncoding (use_rotary=False) is not restated")
+    return x + pe[: x.shape[-2], 0, :].to(x.dtype)
+
+
 def rotary(x: torch.Tensor, freqs: torch.Tensor) -> torch.Tensor:
     """RotaryEmbedding.rotate_queries_or_keys (model/rotary_embedding_torch.py:107-113,46-59,39-43).
 
     Position = index along dim -2; pair j=(2j,2j+1) rotates by angle pos*freqs[j]:
     (y0, y1) = (x0 cos - x1 sin, x1 cos + x0 sin)."""
+    if freqs is None:       # use_rotary=False (model/model.py:231,375,387-388): no rotation
+        return x
     n = x.shape[-2]
     ang = torch.arange(n, dtype=freqs.dtype)[:, None] * freqs[None, :]  # (n, D/2)
     ang = ang.repeat_interleave(2, dim=-1)  # (n, D): [a0,a0,a1,a1,...]
@@ -318,8 +331,9 @@ def music_branch(sd: SD, cond_embed: torch.Tensor, cfg: dict, drop=_nodrop):
         cond_embed = cond_embed[:, :-1, :]
     c = cond_embed.reshape(b, clen // 2, -1).float()
     tok = linear(F.relu(linear(c, sd, "cond_projection.0")), sd, "cond_projection.2")
+    tok = abs_pos(tok, sd, drop)           # :580
     for i in range(2):
-        tok = encoder_layer(tok, sd, f"cond_encoder.{i}", sd["rotary.freqs"], cfg["n_head"], drop, 4 * i)
+        tok = encoder_layer(tok, sd, f"cond_encoder.{i}", sd.get("rotary.freqs"), cfg["n_head"], drop, 4 * i)
     return tok
 
 
@@ -345,6 +359,7 @@ def decoder_forward(sd: SD, x, cond_embed, times, cond_drop_prob: float = 0.0,
     f = F.relu(linear(f, sd, "relative_projection_layer.0"))
     f = F.relu(linear(f, sd, "relative_projection_layer.2"))
     x = linear(f, sd, "relative_projection_layer.4").reshape(B, dn * S, D)
+    x = abs_pos(x, sd, drop)               # :564
     # :567-569 keep mask
     if keep_mask is None:
         p = 1 - cond_drop_prob
@@ -368,7 +383,7 @@ def decoder_forward(sd: SD, x, cond_embed, times, cond_drop_prob: float = 0.0,
     mem = layer_norm(torch.cat((tok, ttok), dim=-2), sd, "norm_cond", 1e-5)
     # :621 decoder stack, :623 final layer
     for i in range(cfg["n_layers"]):
-        x = decoder_layer(x, mem, t, sd, f"seqTransDecoder.stack.{i}", sd["rotary.freqs"], cfg["n_head"], drop, 16 + 8 * i)
+        x = decoder_layer(x, mem, t, sd, f"seqTransDecoder.stack.{i}", sd.get("rotary.freqs"), cfg["n_head"], drop, 16 + 8 * i)
     return linear(x, sd, "final_layer")
 
 
@@ -621,7 +636,7 @@ def q_sample(tab, x_start, t: torch.Tensor, noise: torch.Tensor):
 # module construction order.
 # ----------------------------------------------------------------------------------------------
 def reference_param_shapes(nfeats=151, seq_len=150, latent=512, ff=1024, n_layers=8, n_head=8,
-                           cond_dim=438, dn=3) -> Dict[str, tuple]:
+                           cond_dim=438, dn=3, use_rotary=True) -> Dict[str, tuple]:
     """Every state_dict entry of the reference DanceDecoder (attribute names model/model.py:440-540)."""
     D = latent
     s: Dict[str, tuple] = {}
@@ -637,11 +652,14 @@ def reference_param_shapes(nfeats=151, seq_len=150, latent=512, ff=1024, n_layer
 
     # the single RotaryEmbedding module is registered under every layer that holds it, so its
     # buffer appears once per holder in state_dict() (model/model.py:444,483,514)
-    s["rotary.freqs"] = (D // 2,)
-    for i in range(2):
-        s[f"cond_encoder.{i}.rotary.freqs"] = (D // 2,)
-    for i in range(n_layers):
-        s[f"seqTransDecoder.stack.{i}.rotary.freqs"] = (D // 2,)
+    if use_rotary:
+        s["rotary.freqs"] = (D // 2,)
+        for i in range(2):
+            s[f"cond_encoder.{i}.rotary.freqs"] = (D // 2,)
+        for i in range(n_layers):
+            s[f"seqTransDecoder.stack.{i}.rotary.freqs"] = (D // 2,)
+    else:
+        s["abs_pos_encoding.pe"] = (500, 1, D)      # PositionalEncoding's buffer (model/utils.py:12,18-25)
     lin("time_mlp.1", 4 * D, D)
     lin("to_time_cond.0", D, 4 * D)
     lin("to_time_tokens.0", 2 * D, 4 * D)
@@ -699,6 +717,14 @@ def synth_tensor(name: str, shape: tuple) -> torch.Tensor:
     if name.endswith("rotary.freqs"):
         d = shape[0] * 2
         return 1.0 / (10000 ** (torch.arange(0, d, 2)[: d // 2].float() / d))
+    if name == "abs_pos_encoding.pe":       # the buffer PositionalEncoding computes (model/utils.py:18-25), not a random tensor
+        n, _, d = shape
+        pe = torch.zeros(n, d)
+        pos = torch.arange(0, n).unsqueeze(1)
+        div = torch.exp(torch.arange(0, d, 2) * (-math.log(10000.0) / d))
+        pe[:, 0::2] = torch.sin(pos * div)
+        pe[:, 1::2] = torch.cos(pos * div)
+        return pe.unsqueeze(1)
     is_norm = ".norm" in name or "layer_norm" in name or name.startswith("norm_cond") \
         or name.startswith("non_attn_cond_projection.0")
     if is_norm and name.endswith(".weight"):

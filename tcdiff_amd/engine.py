@@ -58,8 +58,11 @@ class DenoiserEngine:
         self._sampler_state = None
         # row-block chain kernels (csrc/chain.hip): bf16 only; the f32 parity mode keeps the op-by-op kernels
         self.act = int(cfg.get("act", L.ACT_GELU))    # feed-forward activation (TC_ACT_*); the chain kernels are GELU only
+        # use_rotary=False (model/model.py:441-448,564,580): identity rotary table + PositionalEncoding rows added to the motion and
+        # music tokens -- on the op-by-op kernels (the chain launches fuse the last fusion linear with layer 0's norm1)
+        self.abs_pos = bool(cfg.get("abs_pos", False))
         self.use_chain = self.dt == L.DT_BF16 and os.environ.get("TCDIFF_CHAIN", "1") != "0" and self.ff == 1024 \
-            and self.H == 8 and self.act == L.ACT_GELU
+            and self.H == 8 and self.act == L.ACT_GELU and not self.abs_pos
         # TCDIFF_CHAIN=2 (default): cross-attention inside the chain too: per layer self-attention + ONE chain launch
         self.use_full = self.use_chain and os.environ.get("TCDIFF_CHAIN", "2") == "2"
         self.nkt = (self.S + 2 + 31) // 32          # 32-key tiles of the cross-attention memory
@@ -277,7 +280,14 @@ class DenoiserEngine:
         w["sin_freq"] = torch.exp(torch.arange(half) * -(math.log(10000) / (half - 1))).to(self.dev)  # model/utils.py:43-44
         n_pos = max(self.Lseq, self.S + 2)
         w["rope"] = torch.empty(n_pos, 512, device=self.dev, dtype=torch.float32)
-        K.rope_table(f(g("rotary.freqs")), w["rope"], n_pos)
+        if self.abs_pos:      # no rotation: angle 0 everywhere (cos 1, sin 0); the positional rows are added in network / encode_music
+            K.rope_table(torch.zeros(256, device=self.dev, dtype=torch.float32), w["rope"], n_pos)
+            w["pe"] = f(g("abs_pos_encoding.pe")[:, 0, :])
+            if max(self.Lseq, self.S) > w["pe"].shape[0]:
+                raise L.TcdiffError(f"PositionalEncoding holds {w['pe'].shape[0]} positions, the sequence has {self.Lseq} tokens "
+                                    "(model/utils.py:12,29)")
+        else:
+            K.rope_table(f(g("rotary.freqs")), w["rope"], n_pos)
         w["rope_cb"] = K.to_cb(w["rope"])                  # the chain kernels read it column-blocked [64][n_pos][8]
         self.w = w
         if self.use_chain:
@@ -334,6 +344,9 @@ class DenoiserEngine:
         b["pool"] = z(B, 512, dtype=torch.float32)
         b["pool_h"], b["pool_h2"] = z(B, 512), z(B, 512)
         b["hidden"] = z(B, 512, dtype=torch.float32)
+        if self.abs_pos:                              # the positional rows of every token of the batch (fp32, added with tcdiff_add_rows)
+            b["pe_x"] = self.w["pe"][:Lq].repeat(B, 1).contiguous()
+            b["pe_c"] = self.w["pe"][:S].repeat(B, 1).contiguous()
         self.b = b
         self.plan_B = B
         self.reset_graphs()
@@ -354,6 +367,8 @@ class DenoiserEngine:
         K.convert_pad(dt, cond, b["cin"], M, 2 * Cd, kc0, rows_per_batch=S, batch_stride=clen * Cd, row_stride=2 * Cd)
         K.gemm_tile(dt, b["cin"], w["c0.w"], M, Cd, kc0, bias=w["c0.b"], act=L.ACT_RELU, out=b["c1"], ldc=kc1)
         K.gemm_tile(dt, b["c1"], w["c2.w"], M, 512, kc1, bias=w["c2.b"], mode=L.EPI_STORE_F32, out=b["tok"], ldc=512)
+        if self.abs_pos:                              # cond_tokens = abs_pos_encoding(cond_tokens) (model/model.py:580)
+            K.add_rows(b["tok"], 512, b["pe_c"], 512, b["tok"], 512, M, 512)
         for i in range(2):
             e = f"e{i}."
             K.ln_rot(dt, b["tok"], M, w[e + "norm1.g"], w[e + "norm1.b"], 1e-5, h=b["mh"], rot=b["mrot"],
@@ -524,6 +539,12 @@ class DenoiserEngine:
             K.chain(L.CHAIN_FRONT, B * S, Lq, b["f2"], w["front"], b3=w["f3.b"], nn_g=w["l0.norm1.g"],
                     nn_b=w["l0.norm1.b"], nn_eps=1e-5, rope=w["rope_cb"], xout=b["xs"], q_out=b["Q"], k_out=b["K"],
                     v_out=b["V"], scale_q=0.125, Lp=self.Lp, H=H, dn=dn)
+        elif self.abs_pos:
+            # x = abs_pos_encoding(x) sits between the fusion projection and layer 0's norm1 (model/model.py:564): three launches
+            K.gemm_rowln(dt, b["f2"], w["f3.w"], B * S, 1024, bias=w["f3.b"], xout=b["xs"], Lseq=Lq,
+                         flags=L.ROW_BIAS | L.ROW_STORE_X, out_mul=dn, out_add=0, groups=dn)
+            K.add_rows(b["xs"], 512, b["pe_x"], 512, b["xs"], 512, Rs, 512)
+            K.ln_rot(dt, b["xs"], Rs, w["l0.norm1.g"], w["l0.norm1.b"], 1e-5, h=b["h"], rot=b["rot"], rope=rope, pos_mod=Lq)
         else:
             K.gemm_rowln(dt, b["f2"], w["f3.w"], B * S, 1024, bias=w["f3.b"], xout=b["xs"], Lseq=Lq,
                          flags=L.ROW_BIAS | L.ROW_STORE_X | L.ROW_NEXT_LN | L.ROW_STORE_H | L.ROW_STORE_ROT,

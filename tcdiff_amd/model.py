@@ -13,6 +13,7 @@ executed.
 """
 from __future__ import annotations
 
+import math
 from typing import Callable, Optional
 
 import torch
@@ -102,6 +103,20 @@ class DecoderLayerStack(nn.Module):
         self.stack = stack
 
 
+class PositionalEncoding(nn.Module):
+    """Holds the ``pe`` buffer of model/utils.py:11-32 ([max_len = 500, 1, d_model]: sin / cos of position x 10000^(-2i/d)); the
+    engine adds its rows to the tokens (eval mode: the module's dropout is the identity)."""
+
+    def __init__(self, d_model: int, max_len: int = 500):
+        super().__init__()
+        pe = torch.zeros(max_len, d_model)
+        position = torch.arange(0, max_len).unsqueeze(1)
+        div_term = torch.exp(torch.arange(0, d_model, 2) * (-math.log(10000.0) / d_model))
+        pe[:, 0::2] = torch.sin(position * div_term)
+        pe[:, 1::2] = torch.cos(position * div_term)
+        self.register_buffer("pe", pe.unsqueeze(1))
+
+
 class DanceDecoder(nn.Module):
     def __init__(
         self,
@@ -120,8 +135,9 @@ class DanceDecoder(nn.Module):
         **kwargs,
     ) -> None:
         super().__init__()
-        if not use_rotary:
-            raise L.TcdiffError("the MI355X path implements the rotary configuration only (TCDiff.py:76-87)")
+        # use_rotary=False (model/model.py:441-448; outside the production configuration, TCDiff.py:76-87): no rotation anywhere and
+        # PositionalEncoding added to the motion tokens and the music tokens instead -- inference on the op-by-op kernels
+        self.use_rotary = bool(use_rotary)
         # feed-forward activation of the encoder / decoder layers (model/model.py:244,400): the production configuration passes
         # F.gelu (TCDiff.py:85) and only that runs on the fused chain kernels; relu / silu / mish run on the op-by-op kernels
         acts = {F.gelu: L.ACT_GELU, F.relu: L.ACT_RELU, F.silu: L.ACT_SILU, F.mish: L.ACT_MISH}
@@ -140,8 +156,8 @@ class DanceDecoder(nn.Module):
         self.dropout_p = float(dropout)
         D = latent_dim
 
-        self.rotary = RotaryEmbedding(dim=D)
-        self.abs_pos_encoding = nn.Identity()
+        self.rotary = RotaryEmbedding(dim=D) if self.use_rotary else None
+        self.abs_pos_encoding = nn.Identity() if self.use_rotary else PositionalEncoding(D)
         self.time_mlp = nn.Sequential(_NoParam(), nn.Linear(D, D * 4), nn.Mish())
         self.to_time_cond = nn.Sequential(nn.Linear(D * 4, D))
         self.to_time_tokens = nn.Sequential(nn.Linear(D * 4, D * 2), _NoParam())
@@ -176,7 +192,7 @@ class DanceDecoder(nn.Module):
     def engine_config(self) -> dict:
         return dict(latent=self.latent_dim, nfeats=self.nfeats, dn=self.required_dancer_num, seq_len=self.seq_len,
                     n_layers=self.num_layers, n_head=self.num_heads, ff=self.ff_size, cond_dim=self.cond_feature_dim,
-                    act=self.act_id)
+                    act=self.act_id, abs_pos=not self.use_rotary)
 
     def _weights_version(self):
         return tuple(p._version for p in self.parameters()) + (str(next(self.parameters()).device),)
@@ -213,6 +229,9 @@ class DanceDecoder(nn.Module):
     def train_engine(self):
         """The (lazily built) training-step engine: operand packs, flat gradient buffer, forward / backward schedule."""
         from .train_engine import TrainEngine
+        if not self.use_rotary:
+            raise L.TcdiffError("use_rotary=False runs in inference only (torch.no_grad(): samplers, guided_forward, forward); the "
+                                "training step implements the rotary configuration (TCDiff.py:76-87)")
         eng = self._train_engine
         dev = next(self.parameters()).device
         # an opt-in gradient averager survives EVERY rebuild (new Parameter objects, another device, another arithmetic mode):

@@ -176,6 +176,21 @@ def test_guidance_clipping_and_ddim_schedule(small):
     assert float(ddpm[0, 1]) == float(tab["posterior_mean_coef1"][999])
 
 
+def test_use_rotary_false_surface_and_training_refusal(golden_dir):
+    """DanceDecoder(use_rotary=False): the reference's state_dict surface for that option (no rotary.freqs anywhere, the
+    PositionalEncoding buffer with the reference's values), and the training step refuses it with a clear error (inference only)."""
+    ref = np.load(os.path.join(golden_dir, "c1_abs_pos.npz"))
+    from oracle import tcdiff_oracle as O
+    m = DanceDecoder(nfeats=151, seq_len=60, latent_dim=512, ff_size=1024, num_layers=8, num_heads=8, dropout=0.1,
+                     cond_feature_dim=438, activation=F.gelu, required_dancer_num=2, use_rotary=False)
+    assert sorted(m.state_dict().keys()) == [str(k) for k in ref["state_dict_keys"]]
+    sd = O.synth_state_dict(dn=2, seq_len=60, use_rotary=False)
+    assert torch.equal(m.state_dict()["abs_pos_encoding.pe"], sd["abs_pos_encoding.pe"])      # (the oracle's = the real module's: generator script)
+    m.load_state_dict(sd, strict=True)
+    with pytest.raises(L.TcdiffError, match="inference only"):
+        m.train_engine()
+
+
 def test_no_cpu_fallback(small):
     model, diff = small
     with pytest.raises(L.TcdiffError):

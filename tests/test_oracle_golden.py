@@ -198,3 +198,20 @@ def test_c4_guided_forward_and_steps(golden_dir):
     for i in (999, 998):
         x, _ = O.p_sample(sd, tab, x, cond, i, T, 2, eps(i, x.shape))
         assert maxabs(x, ref[f"after_step_{i}"]) < 1e-4
+
+
+def test_use_rotary_false_option(golden_dir):
+    """DanceDecoder(use_rotary=False) (model/model.py:441-448,564,580; outside the production configuration): the oracle's
+    restatement -- no rotation, PositionalEncoding rows added to the motion and the music tokens -- against the REAL reference built
+    with that option (tests/golden/make_golden_abs_pos.py): state_dict surface, guided evaluation, conditional forward."""
+    ref = g(golden_dir, "c1_abs_pos")
+    shapes = O.reference_param_shapes(dn=2, seq_len=60, use_rotary=False)
+    assert sorted(shapes) == [str(k) for k in ref["state_dict_keys"]]
+    assert "abs_pos_encoding.pe" in shapes and not any(k.endswith("rotary.freqs") for k in shapes)
+    sd = O.synth_state_dict(dn=2, seq_len=60, use_rotary=False)
+    cond = torch.stack([O.synth_cond(0, 60)])
+    xT = torch.stack([O.synth_xT(0, 120)])
+    with torch.no_grad():
+        e1 = maxabs(O.guided_forward(sd, xT, cond, torch.tensor([50]), 2), ref["guided_w2_t50"])
+        e2 = maxabs(O.decoder_forward(sd, xT, cond, torch.tensor([3]), cond_drop_prob=0.0), ref["fwd_cond_t3"])
+    assert e1 < 2e-5 and e2 < 2e-5, (e1, e2)

@@ -168,6 +168,40 @@ def test_feed_forward_activation_option_vs_reference_golden(golden_dir, name):
         assert not model.engine(1).use_chain
 
 
+def test_use_rotary_false_option_vs_reference_golden(golden_dir):
+    """DanceDecoder(use_rotary=False) (model/model.py:441-448: no rotary embedding, PositionalEncoding added to the motion tokens :564
+    and the music tokens :580; rounds 1-4 refused it): a guided evaluation, a conditional forward and the full 100-step p_sample_loop
+    of config 1 against the REAL reference built with that option (tests/golden/make_golden_abs_pos.py).  Inference only, on the
+    op-by-op kernels (identity rotary table, positional rows added by tcdiff_add_rows); f32 mode to 1e-3, bf16 within its bound."""
+    from tcdiff_amd import _lib as L
+    ref = gold(golden_dir, "c1_abs_pos")
+    sd = O.synth_state_dict(dn=2, seq_len=60, use_rotary=False)
+    cond = torch.stack([O.synth_cond(0, 60)]).to(DEV)
+    xT = torch.stack([O.synth_xT(0, 120)]).to(DEV)
+    for compute, bound, lbound in (("f32", 1e-3, 1e-3), ("bf16x3", 1e-3, 1e-3), ("bf16", BF16_EVAL_BOUND, BF16_STEPS_BOUND)):
+        model = DanceDecoder(nfeats=151, seq_len=60, latent_dim=512, ff_size=1024, num_layers=8, num_heads=8, dropout=0.1,
+                             cond_feature_dim=438, activation=F.gelu, required_dancer_num=2, use_rotary=False,
+                             compute_dtype=compute).to(DEV).eval()
+        model.load_state_dict(sd, strict=True)
+        diff = GaussianDiffusion(model, 60, 151, None, schedule="cosine", n_timestep=100, predict_epsilon=False, loss_type="l2",
+                                 use_p2=False, cond_drop_prob=0.25, guidance_weight=2, seq_len=60)
+        diff.to(DEV).eval()
+        with torch.no_grad():
+            g = model.guided_forward(xT, cond, torch.full((1,), 50, dtype=torch.long, device=DEV), 2)
+            c = model(xT, cond, torch.full((1,), 3, dtype=torch.long, device=DEV), cond_drop_prob=0.0)
+        e1, e2 = maxabs(g, ref["guided_w2_t50"]), maxabs(c, ref["fwd_cond_t3"])
+        x, chain = diff.p_sample_loop((1, 120, 151), cond, noise=xT, step_noise=dev_noise([0], 120), return_diffusion=True)
+        errs = {k: maxabs(chain[i], ref[k]) for k, i in (("after_step_99", 1), ("after_step_50", 50), ("after_step_10", 90),
+                                                        ("after_step_1", 99))}
+        errs["final"] = maxabs(x, ref["final"])
+        print(f"use_rotary=False [{compute}]: guided t=50 {e1:.2e}, conditional t=3 {e2:.2e} (bound {bound}); loop",
+              {k: f"{v:.2e}" for k, v in errs.items()}, f"(bound {lbound})")
+        assert e1 < bound and e2 < bound and max(errs.values()) < lbound
+        assert not model.engine(1).use_chain and model.engine(1).abs_pos
+        with pytest.raises(L.TcdiffError, match="inference only"):
+            model(xT, cond, torch.full((1,), 3, dtype=torch.long, device=DEV), cond_drop_prob=0.0)      # (gradients enabled: the training path)
+
+
 def test_c1_graph_and_eager_agree(c1):
     _, _, diff, cond, xT = c1
     a = diff.p_sample_loop((1, 120, 151), cond, noise=xT, step_noise=dev_noise([0], 120), start_point=12, use_graph=True)
