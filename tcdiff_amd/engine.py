@@ -75,9 +75,8 @@ class DenoiserEngine:
         # ... and the last fusion linear + layer 0's norm1 / rotary / Q, K, V as one chain launch per (frame block, dancer)
         self.front = self.use_full and os.environ.get("TCDIFF_FRONT", "1") != "0" and self.S >= 8
         # the self-attention of layers 1.. inside the chain launch (row blocks cut per sequence, Q / K / V handed from launch to
-        # launch in MFMA-fragment order; csrc/chain.hip): large jobs only (64-row blocks), bf16, 8-wave form
+        # launch in MFMA-fragment order; csrc/chain.hip): every job size (16- / 32- / 64-row blocks), bf16, 8-wave form
         self.fuse_sa = self.use_full and self.dt == L.DT_BF16 and os.environ.get("TCDIFF_FUSE_SA", "1") == "1"
-        self.sa_min_rows = int(os.environ.get("TCDIFF_FUSE_SA_ROWS", "0"))        # (experiments: the old path below this many rows)
         self.chain_nw = int(os.environ.get("TCDIFF_CHAIN_NW", "8"))      # waves per workgroup of the chain launches (8 or 4)
         if self.chain_nw not in (4, 8):
             raise L.TcdiffError("TCDIFF_CHAIN_NW must be 8 or 4")
@@ -614,7 +613,7 @@ class DenoiserEngine:
                         out=b["Q"], out_k=b["K"], out_v=b["V"], scale_q=0.125, Lseq=Lq, Lp=self.Lp, H=H, n_q=512,
                         n_k=512)
         # fused: layers 1.. compute their self-attention inside the chain launch from the fragments the previous launch wrote
-        fused = self.fuse_sa and R >= self.sa_min_rows and self.chain_nw == 8
+        fused = self.fuse_sa and self.chain_nw == 8
         if not (fused and l > 0):
             K.attention(dt, b["Q"], b["K"], b["V"], b["O"], B if l == 0 else nseq, H, Lq, Lq, self.Lp, self.Lp, 512)
         last = l + 1 == NL
