@@ -56,6 +56,9 @@ def parse(argv=None):
     p.add_argument("--no-other-configs", action="store_true", help="skip the config-1 / config-4 sampling lines")
     p.add_argument("--train-batch", type=int, default=32, help="clips per GPU of the training step (BASELINE config 5: 32)")
     p.add_argument("--dump-samples", default=None, help="rank 0 saves the gathered samples of the last job here (tests)")
+    p.add_argument("--child-steps", type=int, default=0,
+                   help="(internal) profiling child of this script: prepare the sampler, run this many two-branch DDPM steps of the "
+                        "top of the schedule twice (warm, measured) and exit -- what the rocprofv3 passes of the parent wrap")
     p.add_argument("--stub", action="store_true",
                    help="rank plumbing only (process group, shard ranges, all-reduce, JSON relay); no GPU work: "
                         "what tests/test_launch_cpu.py runs over gloo")
@@ -178,16 +181,7 @@ def insampler_kernel_times(diff, shape, cond, xT, n_steps=40):
     return out, n_steps
 
 
-def kernel_source_sha() -> str:
-    """content hash of the sampler's kernel sources: a PMC file belongs to the build it was measured on"""
-    import hashlib
-    h = hashlib.sha256()
-    for f in ("chain.hip", "chain_core.h", "attention.hip", "attn_res.h", "gemm.hip", "ops.hip", "common.h"):
-        h.update(open(os.path.join(ROOT, "tcdiff_amd", "csrc", f), "rb").read())
-    return h.hexdigest()[:12]
-
-
-def kernel_roofline(times, n_steps, B_launch, streams, dn, S, dtype):
+def kernel_roofline(times, n_steps, B_launch, streams, dn, S, dtype, timing=None):
     """Fold profiler records into families; the dominant family's achieved rate = its algorithmic FLOPs per DDPM step /
     its device time per DDPM step."""
     peak = PEAK_BF16_TFLOPS if dtype == "bf16" else PEAK_F32_TFLOPS
@@ -221,8 +215,8 @@ def kernel_roofline(times, n_steps, B_launch, streams, dn, S, dtype):
     roof = dict(bound="mfma", kernel=dom, achieved=d["tflops"], peak=peak, unit="TFLOP/s", frac=d["mfma_frac"],
                 traffic=None, avg_launch_ms=d["avg_launch_ms"], launches_per_ddpm_step=d["launches_per_ddpm_step"],
                 share_of_gpu_time=d["share_of_gpu_time"],
-                timing=f"torch.profiler device durations inside the running sampler, {n_steps} two-branch DDPM steps, "
-                       f"{streams} free-running stream(s) of {B_launch} clips",
+                timing=timing or (f"torch.profiler device durations inside the running sampler, {n_steps} two-branch DDPM "
+                                  f"steps, {streams} free-running stream(s) of {B_launch} clips"),
                 algorithmic_gflop_per_ddpm_step=round(flops[dom] / 1e9, 2),
                 hbm=dict(algorithmic_gbps=d["algo_gbps"], peak=PEAK_HBM_GBPS, frac=d["hbm_frac"],
                          algorithmic_mb_per_ddpm_step=round(nbytes[dom] / 1e6, 1)))
@@ -242,89 +236,123 @@ def kernel_roofline(times, n_steps, B_launch, streams, dn, S, dtype):
             note="L2 -> CU weight bytes of the chain launches (row blocks x stream bytes) / their device time, epilogues included; "
                  "ceiling = tools/probe/l2_alias_probe.hip, pure loads of the same stream by 225 / 256 CUs at once "
                  "(profiles/r04_chain_experiments.txt)")
-    # HBM-side bytes from the committed rocprofv3 PMC passes of this command (never measured by this run: labelled), and only
-    # while that file was measured on THIS build of the dominant kernel's source (content hash recorded by make_pmc_json.py)
-    src_sha = kernel_source_sha()
-    for pm_name in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if re.fullmatch(r"r\d+_pmc\.json", f)), reverse=True):
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", pm_name)))
-            if pm.get("source_sha") != src_sha:
-                roof["traffic_from"] = (f"none: profiles/{pm_name} was measured on another build of the kernels "
-                                        f"(source hash {pm.get('source_sha')} != {src_sha}); re-run tools/gpu_measure.sh")
-                sys.stderr.write(f"bench.py: WARNING: {roof['traffic_from']}\n")
-                break
-            roof["traffic"] = pm[dom]["bytes_per_launch"]
-            roof["traffic_from"] = f"profiles/{pm_name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, committed)"
-            if "bytes_per_ddpm_step" in pm:
-                roof["traffic_per_ddpm_step"] = dict(bytes=pm["bytes_per_ddpm_step"],
-                                                     algorithmic_min_bytes=110e6, **{"from": f"profiles/{pm_name}"})
-            break
-        except Exception:
-            continue
     return roof, rows
 
 
 # ----------------------------------------------------------------------------------------------------------------
-# HBM-side traffic, measured by THIS run: two rocprofv3 PMC passes over a short child run of this script
+# launch durations and HBM-side traffic, measured by THIS run: three rocprofv3 passes over a short child run of this script
 # ----------------------------------------------------------------------------------------------------------------
 PMC_FAMILIES = {"chain": "chain_kernel", "gemm_rowln": "gemm_rowln_kernel", "gemm_tile": "gemm_tile_kernel", "attention": "attention"}
 
 
-def live_pmc_traffic(a, dom, steps=20, timeout=240.0):
-    """rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, as MI355X_MICROARCH.md prescribes: the two do
-    not fit one pass) around `python3 bench.py --ddpm-steps <steps>` with everything but the sampler switched off, started as a
-    CHILD of this process (never an exec: this process has the GPU open).  Returns {family: bytes per launch, ..., "per_step":
-    bytes per DDPM step} with the guide's gfx950 correction (FETCH_SIZE counts 128-byte requests as 64: doubled; both in KB), or
-    raises.  The child works on the same build, shapes and batch as the timed run, 20 DDPM steps (18 two-branch)."""
+def _run_profiler_child(cmd, env, timeout):
+    """One rocprofv3 pass in its OWN process group, output to temp files (no pipes a grandchild could keep open).  On a timeout
+    the whole group is killed and reaped before this returns: an orphaned sampler must not run beside the timings that follow."""
+    import signal
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryFile(mode="w+", dir="/tmp") as fo, tempfile.TemporaryFile(mode="w+", dir="/tmp") as fe:
+        p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=fo, stderr=fe, start_new_session=True)
+        try:
+            rc = p.wait(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(p.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+            p.wait()
+            raise RuntimeError(f"profiler pass timed out after {timeout:.0f} s (process group killed)")
+        fe.seek(0)
+        return rc, fe.read()[-300:]
+
+
+def _window(rows, n):
+    """The dispatches of the child's SECOND run of n DDPM steps: from the first step_prologue behind the n-th sampler_update
+    through the 2n-th sampler_update (rows = [(dispatch id, kernel name, value)] in dispatch order).  Setup kernels (weight
+    packing, the music encoder, the FiLM table) and the warm run lie outside."""
+    rows = sorted(rows, key=lambda r: r[0])
+    upd = [i for i, r in enumerate(rows) if "sampler_update_kernel" in r[1]]
+    if len(upd) < 2 * n:
+        raise RuntimeError(f"{len(upd)} sampler_update launches in the trace, expected {2 * n}")
+    lo = next(i for i in range(upd[n - 1] + 1, len(rows)) if "step_prologue_kernel" in rows[i][1])
+    return rows[lo:upd[2 * n - 1] + 1]
+
+
+def live_child_passes(a, n=40, timeout=300.0):
+    """Three rocprofv3 passes -- `--kernel-trace` alone (launch durations), `--kernel-trace --pmc FETCH_SIZE`, `--kernel-trace --pmc
+    WRITE_SIZE` (separate passes, as MI355X_MICROARCH.md prescribes: the two counters do not fit one pass, and counter collection
+    perturbs durations) -- around `python3 bench.py --child-steps n`, started as CHILDREN of this process (never an exec: this
+    process has the GPU open).  The child runs n two-branch DDPM steps of the top of the schedule twice on the same build, shapes
+    and batch as the timed run; only the second run's dispatches are counted.  Returns
+    {"times": {kernel name: (launches, total_us)}, "n": n, "bytes_per_launch": {family: bytes}, "bytes_per_step": bytes}; bytes
+    carry the guide's gfx950 correction (FETCH_SIZE counts 128-byte requests as 64: doubled; both are in KB)."""
     import csv
     import glob
     import shutil
-    import subprocess
     import tempfile
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         raise RuntimeError("rocprofv3 not found")
     child = [sys.executable if os.path.basename(sys.executable).startswith("python") else "python3", os.path.abspath(__file__),
-             "--steps", "1", "--warmup", "1", "--ddpm-steps", str(steps), "--batch", str(a.batch), "--dancers", str(a.dancers),
-             "--frames", str(a.frames), "--dtype", a.dtype, "--no-cpu-baseline", "--no-kernel-profile", "--no-parity-mode",
-             "--no-train-step", "--no-other-configs", "--no-pmc"]
+             "--child-steps", str(n), "--ddpm-steps", str(a.ddpm_steps), "--batch", str(a.batch), "--dancers", str(a.dancers),
+             "--frames", str(a.frames), "--dtype", a.dtype]
     env = dict(os.environ, TMPDIR="/tmp")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
-    tot, fam, n_update = {}, {}, 0
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-        d = tempfile.mkdtemp(prefix="tcdiff_pmc_", dir="/tmp")
+    out = {"n": n, "errors": {}}
+    for what in ("trace", "FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="tcdiff_prof_", dir="/tmp")
         try:
-            r = subprocess.run([exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + child,
-                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
-            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
-            if r.returncode != 0 or not files:
-                raise RuntimeError(f"rocprofv3 --pmc {counter}: rc {r.returncode}, {len(files)} counter files: {r.stderr[-300:]}")
-            kb_all, kb_fam, n_fam, n_upd = 0.0, {k: 0.0 for k in PMC_FAMILIES}, {k: 0 for k in PMC_FAMILIES}, 0
+            extra = [] if what == "trace" else ["--pmc", what]
+            rc, err = _run_profiler_child([exe, "--kernel-trace"] + extra + ["--output-format", "csv", "-d", d, "--"] + child, env, timeout)
+            pat = "*kernel_trace.csv" if what == "trace" else "*counter_collection.csv"
+            files = glob.glob(os.path.join(d, "**", pat), recursive=True)
+            if rc != 0 or not files:
+                raise RuntimeError(f"rocprofv3 {what}: rc {rc}, {len(files)} files: {err}")
+            rows = []
             for f in files:
                 for row in csv.DictReader(open(f)):
-                    if row.get("Counter_Name") != counter:
-                        continue
-                    v, name = float(row["Counter_Value"]), row.get("Kernel_Name", "")
-                    kb_all += v
-                    n_upd += "sampler_update_kernel" in name
+                    if what == "trace":
+                        rows.append((int(row["Dispatch_Id"]), row["Kernel_Name"],
+                                     (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3))
+                    elif row.get("Counter_Name") == what:
+                        rows.append((int(row["Dispatch_Id"]), row.get("Kernel_Name", ""), float(row["Counter_Value"])))
+            win = _window(rows, n)
+            if what == "trace":
+                times = {}
+                for _, name, us in win:
+                    c0, u0 = times.get(name, (0, 0.0))
+                    times[name] = (c0 + 1, u0 + us)
+                out["times"] = times
+            else:
+                fam = {k: [0.0, 0] for k in PMC_FAMILIES}
+                for _, name, v in win:
                     for k, sym in PMC_FAMILIES.items():
                         if sym in name.split("(")[0]:
-                            kb_fam[k] += v
-                            n_fam[k] += 1
-            tot[counter], fam[counter], n_update = kb_all, (kb_fam, n_fam), n_upd
+                            fam[k][0] += v
+                            fam[k][1] += 1
+                out[what] = (sum(v for _, _, v in win), fam)
+        except Exception as e:
+            out["errors"][what] = repr(e)[:300]
         finally:
             shutil.rmtree(d, ignore_errors=True)
-    if n_update <= 0:
-        raise RuntimeError("no sampler_update launches in the PMC trace")
-    out = {"per_step": int((2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024 / n_update), "ddpm_steps_profiled": n_update}
-    (fk, fn), (wk, wn) = fam["FETCH_SIZE"], fam["WRITE_SIZE"]
-    for k in PMC_FAMILIES:
-        if fn[k] and wn[k]:
-            out[k] = int((2 * fk[k] / fn[k] + wk[k] / wn[k]) * 1024)
-    if dom not in out:
-        raise RuntimeError(f"no launches of the dominant family {dom!r} in the PMC trace")
+    if "FETCH_SIZE" in out and "WRITE_SIZE" in out:
+        (ft, ff), (wt, wf) = out.pop("FETCH_SIZE"), out.pop("WRITE_SIZE")
+        out["bytes_per_step"] = int((2 * ft + wt) * 1024 / n)
+        out["bytes_per_launch"] = {k: int((2 * ff[k][0] / ff[k][1] + wf[k][0] / wf[k][1]) * 1024)
+                                   for k in PMC_FAMILIES if ff[k][1] and wf[k][1]}
     return out
+
+
+def profiling_child(a, diff, shape, cond, xT):
+    """`--child-steps n`: what the parent's rocprofv3 passes wrap."""
+    import torch
+    from tcdiff_amd import _lib as L
+    T = diff.n_timestep
+    tseq = list(range(T - 1, T - 1 - a.child_steps, -1))
+    for _ in range(2):
+        diff._run(L.SAMPLER_DDPM, tuple(shape), cond, xT.float(), tseq, diff._ddpm_params(tseq), seed=7)
+        torch.cuda.synchronize()
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -475,6 +503,9 @@ def rank_main(a):
         x = diff.p_sample_loop((hi - lo, Lq, 151), cond, noise=xT, seed=1234, clip_offset=lo)
         return D.gather_samples(x, n_total)
 
+    if a.child_steps > 0:
+        profiling_child(a, diff, (hi - lo, Lq, 151), cond, xT)
+        return
     for _ in range(a.warmup):
         one_job()
     D.barrier()
@@ -524,22 +555,37 @@ def rank_main(a):
                                  "executed_mfma_frac_per_gpu": round(clips_per_s / world * gf_exec * T / 1e3 / peak, 4)}
         roof, rows = None, {}
         if not a.no_kernel_profile and T >= 200:
+            # Launch durations and HBM-side bytes from rocprofv3 passes over a child run of this very command (the same files a
+            # `rocprofv3 --kernel-trace --stats` of it gives: profiles/rNN_kernel_stats_*): `frac` is reproducible from them and the
+            # family sum fits the wall time.  torch.profiler inside this process is the fallback (it inflates launches by 4-5 %).
+            prof = None
+            if world == 1 and not a.no_pmc and a.dtype == "bf16":
+                try:
+                    prof = live_child_passes(a)
+                except Exception as e:
+                    res["profiler_child_error"] = repr(e)[:300]
             try:
-                times, n_prof = insampler_kernel_times(diff, (nb, Lq, 151), cond, xT)
-                roof, rows = kernel_roofline(times, n_prof, nb // streams, streams, dn, S, a.dtype)
+                if prof and "times" in prof:
+                    roof, rows = kernel_roofline(
+                        prof["times"], prof["n"], nb // streams, streams, dn, S, a.dtype,
+                        timing=f"rocprofv3 --kernel-trace pass over a child run of this command: the second of two runs of "
+                               f"{prof['n']} two-branch DDPM steps, {nb} clips")
+                else:
+                    times, n_prof = insampler_kernel_times(diff, (nb, Lq, 151), cond, xT)
+                    roof, rows = kernel_roofline(times, n_prof, nb // streams, streams, dn, S, a.dtype)
             except Exception as e:   # the throughput line must not depend on the profiler
                 res["kernel_profile_error"] = repr(e)[:300]
-        if roof and world == 1 and not a.no_pmc and a.dtype == "bf16":
-            # roofline.traffic measured by THIS run: two PMC child passes over 20 DDPM steps of the same job
-            try:
-                pm = live_pmc_traffic(a, roof["kernel"] if roof["kernel"] in PMC_FAMILIES else "chain")
+            if roof and prof:
                 dom = roof["kernel"] if roof["kernel"] in PMC_FAMILIES else "chain"
-                roof["traffic"] = pm[dom]
-                roof["traffic_from"] = (f"this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE child passes over "
-                                        f"{pm['ddpm_steps_profiled']} DDPM steps of the same job (FETCH_SIZE doubled, KB -> bytes)")
-                roof["traffic_per_ddpm_step"] = {"bytes": pm["per_step"], "algorithmic_min_bytes": 110e6, "from": "this run"}
-            except Exception as e:   # the committed file's figure (if it belongs to this build) stays
-                roof["traffic_live_error"] = repr(e)[:300]
+                if "bytes_per_launch" in prof and dom in prof["bytes_per_launch"]:
+                    roof["traffic"] = prof["bytes_per_launch"][dom]
+                    roof["traffic_from"] = (f"this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE child passes, the same "
+                                            f"{prof['n']} DDPM steps (FETCH_SIZE doubled, KB -> bytes)")
+                    roof["traffic_per_ddpm_step"] = {"bytes": prof["bytes_per_step"], "algorithmic_min_bytes": 110e6,
+                                                     "from": f"this run: every dispatch of those {prof['n']} steps (prologue "
+                                                             f"through sampler update; setup and warm-up excluded)"}
+                if prof.get("errors"):
+                    roof["profiler_pass_errors"] = prof["errors"]
         res["roofline"] = roof
         res["kernels"] = rows
         if world == 1 and not a.no_parity_mode and a.dtype == "bf16" and T >= 200:

@@ -382,7 +382,15 @@ typedef struct tcdiff_step_prologue_args {
     const float* film_tab;
     float* film_out;
     int film_rows, nfilm, n_unc;
+    /* 0: everything in one launch.  Round 6: the step's first GEMM needs only x_t, the first decoder-layer launch ~110 us later
+     * needs the FiLM rows and the time-token rows -- so the captured step launches the prologue in two PARTS, the second on a
+     * forked stream beside the input / fusion GEMMs (which leave ~100 CUs idle):
+     * TC_PROLOGUE_X    = tidx, the model-dtype copy of x_t, counter[0] <- step;
+     * TC_PROLOGUE_COND = the FiLM generator input or the gathered FiLM rows, the time-token K / V rows (it only READS counter[3]). */
+    int parts;
 } tcdiff_step_prologue_args;
+#define TC_PROLOGUE_X 1
+#define TC_PROLOGUE_COND 2
 int tcdiff_step_prologue(int dtype, const tcdiff_step_prologue_args* a, hipStream_t stream);
 
 /* DDPM: params = {w, coef1, coef2, sigma}  (model/diffusion.py:217-252, model/model.py:546)

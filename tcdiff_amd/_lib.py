@@ -48,12 +48,15 @@ class ChainArgs(C.Structure):
                 ("sa_nkt", _i), ("qf_out", _vp), ("kf_out", _vp), ("vf_out", _vp), ("out_nkt", _i)]
 
 
+PROLOGUE_X, PROLOGUE_COND = 1, 2      # tcdiff_step_prologue_args.parts
+
+
 class StepPrologueArgs(C.Structure):
     _fields_ = [("counter", _vp), ("tseq", _vp), ("tidx", _vp), ("t_base", _vp), ("hidden", _vp), ("film_in", _vp),
                 ("n_seq", _i), ("tab", _vp), ("n_t", _i), ("Kc", _vp), ("Vc", _vp), ("Kf", _vp), ("Vf", _vp),
                 ("NL", _i), ("n_kv", _i), ("H", _i), ("Lp", _i), ("nkt", _i), ("tok0", _i), ("x", _vp), ("xin", _vp),
                 ("rows", _i), ("nfeat", _i), ("ld_xin", _i), ("film_tab", _vp), ("film_out", _vp), ("film_rows", _i),
-                ("nfilm", _i), ("n_unc", _i)]
+                ("nfilm", _i), ("n_unc", _i), ("parts", _i)]
 
 
 class RowArgs(C.Structure):

@@ -47,6 +47,11 @@
 #include "chain_core.h"
 
 #define CH_LOG2E 1.4426950408889634f
+#ifdef CH_ABLATE_ROWLAT      // timing experiment only (wrong values): the epilogues' residual / rotary rows 2, 3 are never fetched
+#define CH_RP_NEXT(rp, nt) do { } while (0)
+#else
+#define CH_RP_NEXT(rp, nt) rp_issue(rp, nt)
+#endif
 #ifndef CH_ATT_THR
 #define CH_ATT_THR 5.0f      // in-kernel attention: a tile moves the running maximum when a score exceeds it by more than this (log2 units)
 #endif
@@ -67,12 +72,17 @@
 // fragments are the ones this block's previous launch packed (store_qfrag), the keys are the block's own sequence (K / V in
 // fragment order from store_kfrag / store_vfrag of the previous launch, Lk = L, no slot mapping); blocks are cut per sequence.
 // Mv: first row past the block's valid rows (M, or the end of the block's sequence); lblk: the block's logical index.
-// (fmaxf canonicalises each operand first -- one more instruction per value -- and the loop below is bound by the number of
-// instructions a wave can issue: one per four cycles, whatever their kind)
-DEVINL float max3f(float a, float b, float c) {
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
+// The lane's maximum over its 8 scores of a 32-key tile, not below `floor`.  Four v_max3_f32: written as nested 3-input maxima of
+// fmaximum_num hipcc selects v_max3_f32 with no operand canonicalisation (fmaxf costs one more instruction per value, and the loops
+// below are bound by the number of instructions a wave can issue).  NOT inline assembly (rounds 4-5: `asm("v_max3_f32 ..")`): an MFMA's
+// result may only be read by a VALU instruction a number of wait states after the MFMA, the hardware does not interlock, and the
+// compiler's hazard pass counts them for instructions it knows -- it cannot for an asm statement (it emitted `s_nop 7` in front of a
+// builtin maximum of an accumulator and nothing in front of the asm one).  Round 5's loop read the scores a dozen MFMAs after they were
+// written; a software-pipelined form of the loop whose prologue reads them at once got stale registers -- rows of wrong maxima, NaNs
+// (profiles/r06_attention_pipeline.txt; the pipelined form itself is profiles/r06_attention_pipeline_experiment.patch).
+DEVINL float max3n(float a, float b, float c) { return __builtin_fmaximum_numf(__builtin_fmaximum_numf(a, b), c); }
+DEVINL float lane_max8(const f32x4_t& a, const f32x4_t& b, float floor) {
+    return max3n(max3n(max3n(max3n(a[0], a[1], a[2]), a[3], b[0]), b[1], b[2]), b[3], floor);
 }
 template <int HH, int MT, int NT, bool SELF = false>
 DEVINL void cross_attention(const f32x4_t (&qacc)[NT][MT], const tcdiff_chain_args& a, int m0, int Mv, int lblk, char* abuf,
@@ -213,8 +223,7 @@ DEVINL void cross_attention(const f32x4_t (&qacc)[NT][MT], const tcdiff_chain_ar
                 bool hot = kt == 0;
 #pragma unroll
                 for (int ml = 0; ml < NML; ++ml) {
-                    lm[ml] = max3f(max3f(s0[ml][0], s0[ml][1], s0[ml][2]), max3f(s0[ml][3], s1[ml][0], s1[ml][1]),
-                                   max3f(s1[ml][2], s1[ml][3], s1[ml][3]));
+                    lm[ml] = lane_max8(s0[ml], s1[ml], -INFINITY);
                     hot = hot || lm[ml] > CH_ATT_THR;
                 }
                 if (__builtin_amdgcn_ballot_w64(hot) != 0) {
@@ -324,16 +333,21 @@ DEVINL void store_kfrag(const f32x4_t (&acc)[4][MT], void* base, int seq, int fi
 // rows): the block owns one half of every lane's 16 bytes -- keys 16 (first_row / 16 & 1) .. + 15 of the tile; a half that lies past
 // the sequence is never written (the caller's image starts zeroed and only ever holds finite values; those keys are masked).
 template <int MT>
-DEVINL void store_vfrag(const f32x4_t (&accT)[4][MT], void* base, int seq, int first_row, int nkt, int wave, int lane) {
+DEVINL void store_vfrag(const f32x4_t (&accT)[4][MT], void* base, int seq, int first_row, int nkt, int Lseq, int wave, int lane) {
     u32x4* dst = reinterpret_cast<u32x4*>(base) + ((long)(seq * 8 + wave) * nkt) * 256 + lane;
     if constexpr (MT == 1) {
         const int kt = first_row >> 5, half = (first_row >> 4) & 1;
         if (kt < nkt) {
+            // the sequence's last row tile in the FIRST half of its 32-key tile: nobody owns the second half -- those keys are masked,
+            // but a masked P = 0 times a non-finite V is NaN, so the half is written (zeros) rather than left to the allocation
+            const bool tail = half == 0 && first_row + 16 >= Lseq;
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 const f32x4_t lo = accT[nt][0];
                 uint2 f = {pack_bf2(lo[0], lo[1]), pack_bf2(lo[2], lo[3])};
-                *reinterpret_cast<uint2*>(reinterpret_cast<char*>(dst + (kt * 4 + nt) * 64) + 8 * half) = f;
+                char* d8 = reinterpret_cast<char*>(dst + (kt * 4 + nt) * 64);
+                *reinterpret_cast<uint2*>(d8 + 8 * half) = f;
+                if (tail) *reinterpret_cast<uint2*>(d8 + 8) = uint2{0u, 0u};
             }
         }
         return;
@@ -562,7 +576,7 @@ DEVINL void chain_body(const tcdiff_chain_args& a) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
                 body(nt, mt, lds4b(cfilm + fb[mt], 64 * nt), lds4b(cfilm + fb[mt], 2048 + 64 * nt));
-            if (nt + 2 < NT) rp_issue(rp, nt + 2);
+            if (nt + 2 < NT) CH_RP_NEXT(rp, nt + 2);
             // one n-tile at a time: without a fence hipcc hoists the loads of ALL of them (row pipeline refills and LDS
             // constants) above the arithmetic, needs ~100 more registers and spills them
             CH_FENCE();
@@ -727,7 +741,7 @@ DEVINL void chain_body(const tcdiff_chain_args& a) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
                 body2(nt, mt, lds4b(cfilm + fb2[mt], 64 * nt), lds4b(cfilm + fb2[mt], 2048 + 64 * nt));
-            if (nt + 2 < NT) rp_issue(rp, nt + 2);
+            if (nt + 2 < NT) CH_RP_NEXT(rp, nt + 2);
             CH_FENCE();
         }
     }
@@ -820,7 +834,7 @@ DEVINL void chain_body(const tcdiff_chain_args& a) {
         if (frag_out) {
             phase_n512<16, true, MT, NT, true>(acc, smem + CH_ABUF2, ws, lane);
             CH_T(32);
-            store_vfrag<MT>(acc, a.vf_out, bseq, bis * BR, a.out_nkt, wave, lane);
+            store_vfrag<MT>(acc, a.vf_out, bseq, bis * BR, a.out_nkt, L, wave, lane);
             CH_T(33);
             CH_TC(61);
             return;

@@ -488,7 +488,9 @@ DEVINL void norm_to_lds(const f32x4_t (&acc)[NT][MT], const float (&nmr)[MT], co
             pk.y = pack_bf2(u[2], u[3]);
             *reinterpret_cast<uint2*>(abuf + wo + mt * 2048) = pk;
         }
+#ifndef CH_ABLATE_ROWLAT
         if (ROT && nt + 2 < NT) rp_issue(rp, nt + 2);
+#endif
         CH_FENCE();   // one n-tile at a time (see the fc epilogue)
     }
 }

@@ -323,10 +323,12 @@ __global__ __launch_bounds__(256) void step_prologue_kernel(tcdiff_step_prologue
     int* counter = a.counter;
     const int step = counter[3];
     const int t = a.tseq[step];
+    // index ranges of the launch's parts (tcdiff_step_prologue_args.parts): [FiLM input / tidx | time-token rows | x copy | FiLM gather]
+    const bool do_x = a.parts == 0 || (a.parts & TC_PROLOGUE_X), do_c = a.parts == 0 || (a.parts & TC_PROLOGUE_COND);
     const long n_film = (long)a.n_seq * 512;
-    const long n_kv = (long)a.NL * a.n_kv * 2 * 1024;
-    const long n_x = a.x ? (long)a.rows * a.ld_xin : 0;
-    const long q_tab = a.film_tab ? (long)a.n_seq * (a.nfilm / 4) : 0;       // float4 pieces of the gathered FiLM rows
+    const long n_kv = do_c ? (long)a.NL * a.n_kv * 2 * 1024 : 0;
+    const long n_x = (a.x && do_x) ? (long)a.rows * a.ld_xin : 0;
+    const long q_tab = (a.film_tab && do_c) ? (long)a.n_seq * (a.nfilm / 4) : 0;       // float4 pieces of the gathered FiLM rows
     const long total = n_film + n_kv + n_x + q_tab;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         if (i >= n_film + n_kv + n_x) {
@@ -338,8 +340,8 @@ __global__ __launch_bounds__(256) void step_prologue_kernel(tcdiff_step_prologue
                 reinterpret_cast<const f32x4_t*>(a.film_tab)[((long)t * a.film_rows + j) * q4 + c4];
         } else if (i < n_film) {
             const int c = (int)(i & 511);
-            if (c == 0) a.tidx[i >> 9] = t;
-            if (!a.film_tab) store_T<P>((E*)a.film_in, i, mish_f(a.t_base[(long)t * 512 + c] + a.hidden[i]));
+            if (c == 0 && do_x) a.tidx[i >> 9] = t;
+            if (!a.film_tab && do_c) store_T<P>((E*)a.film_in, i, mish_f(a.t_base[(long)t * 512 + c] + a.hidden[i]));
         } else if (i < n_film + n_kv) {
             const long k = i - n_film;
             const int c = (int)(k & 1023), rr = (int)((k >> 10) & 1);
@@ -360,7 +362,7 @@ __global__ __launch_bounds__(256) void step_prologue_kernel(tcdiff_step_prologue
             store_T<P>((E*)a.xin, k, c < a.nfeat ? a.x[(long)r * a.nfeat + c] : 0.0f);
         }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) counter[0] = step;
+    if (do_x && blockIdx.x == 0 && threadIdx.x == 0) counter[0] = step;
 }
 
 extern "C" int tcdiff_step_prologue(int dtype, const tcdiff_step_prologue_args* a, hipStream_t stream) {
@@ -374,8 +376,11 @@ extern "C" int tcdiff_step_prologue(int dtype, const tcdiff_step_prologue_args* 
                         a->n_seq - a->n_unc + 1 > a->film_rows ||
                         ((reinterpret_cast<uintptr_t>(a->film_tab) | reinterpret_cast<uintptr_t>(a->film_out)) & 15)))
         return TC_ERR_ARG;
-    const long total = (long)a->n_seq * 512 + (long)a->NL * a->n_kv * 2048 + (a->x ? (long)a->rows * a->ld_xin : 0) +
-                       (a->film_tab ? (long)a->n_seq * (a->nfilm / 4) : 0);
+    if (a->parts < 0 || a->parts > (TC_PROLOGUE_X | TC_PROLOGUE_COND)) return TC_ERR_ARG;
+    const bool do_x = a->parts == 0 || (a->parts & TC_PROLOGUE_X), do_c = a->parts == 0 || (a->parts & TC_PROLOGUE_COND);
+    const long total = (long)a->n_seq * 512 + (do_c ? (long)a->NL * a->n_kv * 2048 : 0) +
+                       ((a->x && do_x) ? (long)a->rows * a->ld_xin : 0) +
+                       ((a->film_tab && do_c) ? (long)a->n_seq * (a->nfilm / 4) : 0);
     const unsigned grid = (unsigned)std::min<long>((total + 255) / 256, 2048);
     if (dtype == TC_DTYPE_BF16)
         hipLaunchKernelGGL(step_prologue_kernel<MmaBF16>, dim3(grid), dim3(256), 0, stream, *a);

@@ -56,6 +56,7 @@ class DenoiserEngine:
         self.tables_key = None
         self.film_tab = None
         self._sampler_state = None
+        self._side, self._forked = None, False     # forked stream of the step prologue's conditioning part (step_prologue)
         # row-block chain kernels (csrc/chain.hip): bf16 only; the f32 parity mode keeps the op-by-op kernels
         self.act = int(cfg.get("act", L.ACT_GELU))    # feed-forward activation (TC_ACT_*); the chain kernels are GELU only
         # use_rotary=False (model/model.py:441-448,564,580): identity rotary table + PositionalEncoding rows added to the motion and
@@ -328,7 +329,10 @@ class DenoiserEngine:
             self.skt = (Lq + 31) // 32
             self.n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
             b["Qf"] = z(2 * B * ((Lq + 15) // 16), 8, 4, 2, 64, 8)       # (block, wave)-private; enough for 16-row blocks
-            # two of each: a launch reads layer l's keys in every block's prologue while its early blocks already write layer l + 1's
+            # two of each: a launch reads layer l's keys in every block's prologue while its early blocks already write layer l + 1's.
+            # INVARIANT the in-launch attention relies on: every V^T slot of a sequence's last 32-key tile is FINITE (keys >= L are
+            # masked, but P = 0 times NaN is NaN).  The chain launch writes every slot it owns (clamped copies of the last row) and
+            # zeros the one half-tile nobody owns (store_vfrag, MT = 1); the zero-fill here covers images no launch has written yet.
             b["sKf"], b["sVf"] = z(2, 2 * B, H, self.skt * 2048), z(2, 2 * B, H, self.skt * 2048)
         b["hidden_all"] = z(2 * B, 512, dtype=torch.float32)
         b["tidx"] = torch.zeros(2 * B, device=dev, dtype=torch.int32)
@@ -497,10 +501,25 @@ class DenoiserEngine:
             tab = None                                # a table of another batch plan: fall back to the per-step GEMM
         extra = {} if tab is None else dict(film_tab=tab, film_out=b["film"], film_rows=tab.shape[1], nfilm=nfilm,
                                             n_unc=n_rows_seq // 2)
-        K.step_prologue(dt, st["counter"], st["rows"], b["tidx"], self.t_base, b["hidden_all"], b["film_in"],
-                        n_rows_seq, self.kv_tab, self.n_t, None if full else b["Kc"], None if full else b["Vc"],
-                        b["Kf"] if full else None, b["Vf"] if full else None, self.NL, b["Kc"].shape[1], self.H,
-                        self.Lpc, self.nkt if full else 0, self.S, x, b["xin"], *self._xin_shape(rows), **extra)
+        args = (dt, st["counter"], st["rows"], b["tidx"], self.t_base, b["hidden_all"], b["film_in"],
+                n_rows_seq, self.kv_tab, self.n_t, None if full else b["Kc"], None if full else b["Vc"],
+                b["Kf"] if full else None, b["Vf"] if full else None, self.NL, b["Kc"].shape[1], self.H,
+                self.Lpc, self.nkt if full else 0, self.S, x, b["xin"], *self._xin_shape(rows))
+        if tab is not None and self.use_chain and self.front and os.environ.get("TCDIFF_FORK_PROLOGUE", "1") != "0":
+            # Two parts (tcdiff_step_prologue_args.parts): the x_t copy the first GEMM waits for, and -- on a forked stream, beside
+            # the input / fusion GEMMs and the front launch, which leave a third of the CUs idle -- the FiLM rows and time-token rows
+            # that nothing reads before layer 0's chain launch ~110 us later (network() joins there).  The fork is part of the
+            # captured step: a dependency edge of the graph, no host work per step.
+            K.step_prologue(*args, parts=L.PROLOGUE_X, **extra)
+            main = torch.cuda.current_stream()
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.dev)
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                K.step_prologue(*args, parts=L.PROLOGUE_COND, **extra)
+            self._forked = True
+            return
+        K.step_prologue(*args, **extra)
         if tab is None:
             K.gemm_tile(dt, b["film_in"], w["film.w"], n_rows_seq, nfilm, 512, bias=w["film.b"], mode=L.EPI_STORE_F32,
                         out=b["film"], ldc=nfilm)
@@ -551,6 +570,9 @@ class DenoiserEngine:
                          rope=rope, out_mul=dn, out_add=0, groups=dn)
         Kc0 = b["Kc"][:, kv_slot0:]
         Vc0 = b["Vc"][:, kv_slot0:]
+        if self._forked:                           # the conditioning part of the step prologue (step_prologue): first needed here
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._forked = False
         for l in range(NL):
             p = f"l{l}."
             rows_sa = Rs if l == 0 else R          # layer-0 self-attention is branch-independent

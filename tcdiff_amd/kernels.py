@@ -250,10 +250,10 @@ def step_end(counter):
 
 def step_prologue(dt, counter, tseq, tidx, t_base, hidden, film_in, n_seq, tab, n_t, Kc, Vc, Kf, Vf, NL, n_kv, H, Lp, nkt,
                   tok0, x=None, xin=None, rows=0, nfeat=0, ld_xin=0, film_tab=None, film_out=None, film_rows=0, nfilm=0,
-                  n_unc=0):
+                  n_unc=0, parts=0):
     a = L.StepPrologueArgs(_p(counter), _p(tseq), _p(tidx), _p(t_base), _p(hidden), _p(film_in), n_seq, _p(tab), n_t,
                            _p(Kc), _p(Vc), _p(Kf), _p(Vf), NL, n_kv, H, Lp, nkt, tok0, _p(x), _p(xin), rows, nfeat,
-                           ld_xin, _p(film_tab), _p(film_out), film_rows, nfilm, n_unc)
+                           ld_xin, _p(film_tab), _p(film_out), film_rows, nfilm, n_unc, parts)
     L.check(L.load().tcdiff_step_prologue(dt, C.byref(a), stream()), "tcdiff_step_prologue")
 
 

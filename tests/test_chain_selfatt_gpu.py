@@ -92,7 +92,10 @@ class Layer:
 # 450 = 7 x 64 + 2, 130 = 2 x 64 + 2, 100 = 3 x 32 + 4: a last block of <= 16 rows runs the one-row-tile body; 150 = 2 x 64 + 22: it does not
 @pytest.mark.parametrize("Lq,nseq,mt,qk_gain", [(150, 3, 4, 1.0), (150, 3, 2, 1.0), (150, 3, 1, 1.0), (450, 2, 4, 1.0), (450, 2, 1, 1.0),
                                                 (130, 3, 4, 1.0), (64, 5, 4, 1.0), (100, 4, 2, 1.0), (150, 3, 4, 3.0), (450, 2, 4, 4.0),
-                                                (150, 3, 2, 6.0)])
+                                                (150, 3, 2, 6.0),
+                                                # L % 32 in 1..15 and in 17..31 at every block size: the last key tile's first / second half
+                                                (137, 2, 4, 1.0), (137, 2, 2, 1.0), (137, 2, 1, 1.0), (185, 2, 4, 1.0), (185, 2, 2, 1.0),
+                                                (185, 2, 1, 1.0), (137, 2, 4, 4.0), (185, 2, 2, 4.0)])
 def test_self_attention_inside_the_chain_launch(Lq, nseq, mt, qk_gain):
     """Two consecutive decoder layers.  Path 1: fused launch -> head-major Q / K / V -> attention kernel -> fused launch.
     Path 2: sequence-cut fused launch -> fragment-order Q / K / V -> fused launch that computes the attention itself.
@@ -135,7 +138,10 @@ def test_self_attention_inside_the_chain_launch(Lq, nseq, mt, qk_gain):
     skt = (Lq + 31) // 32
     x2 = K.to_cb(xres)
     qf = z(nseq * nbs, 8, 4, 2, 64, 8)
-    skf, svf = z(nseq, H, skt * 2048), z(nseq, H, skt * 2048)
+    # (poisoned, not zeroed: every slot the next launch's attention reads must have been WRITTEN by this one -- keys >= L are masked,
+    # but a masked P = 0 times a NaN V would still be NaN)
+    skf = torch.full((nseq, H, skt * 2048), float("nan"), device=DEV, dtype=bf)
+    svf = torch.full((nseq, H, skt * 2048), float("nan"), device=DEV, dtype=bf)
     h2 = z(M, 512)
     K.chain(l0.mode, M, Lq, Oa, l0.ws, xres=x2, xout=x2, seq_blocks=True, qf_out=qf, kf_out=skf, vf_out=svf, out_nkt=skt,
             **l0.kw, **xatt)

@@ -16,6 +16,7 @@ from tcdiff_amd.engine import DenoiserEngine as E
 ap = argparse.ArgumentParser()
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--nseq", type=int, default=32)
+ap.add_argument("--only", default="", help="substring: time only the forms whose name contains it")
 a = ap.parse_args()
 dev, bf = "cuda", torch.bfloat16
 torch.manual_seed(0)
@@ -65,6 +66,8 @@ def launch(form):
 
 
 forms = ["plain", "seq-cut", "seq-cut + frag out", "seq-cut + frag out + self-attention", "attention kernel"]
+if a.only:
+    forms = [f for f in forms if a.only in f]
 times = {f: [] for f in forms}
 for rep in range(a.reps):
     for f in forms:

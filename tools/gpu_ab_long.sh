@@ -1,7 +1,7 @@
 #!/bin/bash
 # long same-box A/B: round-3 tree against the working tree, N alternating pairs of `bench.py --steps 4` (4 jobs of 16 clips x 1000 steps)
 mkdir -p gpurun_out
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?run under gpurun (or export GRAFT_REPO_ROOT=the repo root)}"
 B="--steps 4 --warmup 1 --no-kernel-profile --no-parity-mode --no-cpu-baseline --no-train-step --no-other-configs"
 for rep in $(seq 1 ${1:-8}); do
   (cd tools/probe/r3_tree && python bench.py $B 2>/dev/null | python ../../show_bench.py /dev/stdin | sed 's/^/r3:  /')

@@ -7,7 +7,7 @@
 #   bash tools/gpu_experiments.sh attn A B ..     -- self-attention launch for library variants
 #   bash tools/gpu_experiments.sh probe           -- the co-issue and MFMA-rate probes
 mkdir -p gpurun_out
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?run under gpurun (or export GRAFT_REPO_ROOT=the repo root)}"
 F="--steps 2 --warmup 1 --no-kernel-profile --no-parity-mode --no-cpu-baseline --no-train-step --no-other-configs"
 what=$1; shift
 case $what in

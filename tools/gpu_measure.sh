@@ -1,9 +1,9 @@
 #!/bin/bash
 # measurement pass of a round (one box visit; R=rNN names the outputs): full GPU suite, parity log at the benchmarked config, default bench, rocprofv3 kernel
 # stats (200 steps), FETCH/WRITE PMC passes (30 steps), SQ counters (20 steps), chain block-count scaling, training-step bench
-R=${R:-r05}
+R=${R:-r06}
 mkdir -p gpurun_out
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?run under gpurun (or export GRAFT_REPO_ROOT=the repo root)}"
 python -m pytest tests -q -m gpu 2>&1 | tail -3
 python -m pytest tests/test_parity_gpu.py -m gpu -s -q -k "c2 or bf16 or drift" > gpurun_out/${R}_parity_at_benchmarked_config.log 2>&1; tail -2 gpurun_out/${R}_parity_at_benchmarked_config.log
 if [ -z "$SKIP_TRAIN" ]; then
@@ -11,7 +11,7 @@ python -m pytest tests/test_train_step_gpu.py -m gpu -s -q 2>&1 | grep -E "\[f32
 fi
 python bench.py 2>gpurun_out/bench_default_err.log > gpurun_out/${R}_bench_full_1000steps.json; tail -c 2500 gpurun_out/${R}_bench_full_1000steps.json
 python tools/chain_full_bench.py --forms 8 --reps 3 2>/dev/null | grep "waves:" > gpurun_out/${R}_chain_block_scaling.txt; cat gpurun_out/${R}_chain_block_scaling.txt
-[ -z "$SKIP_TRAIN" ] && for b in 4 32; do python tools/train_bench.py --batch $b --iters 8 --kernels 2>/dev/null | tail -1; done > gpurun_out/${R}_train_step.jsonl; cut -c1-400 gpurun_out/${R}_train_step.jsonl
+if [ -z "$SKIP_TRAIN" ]; then for b in 4 32; do python tools/train_bench.py --batch $b --iters 8 --kernels 2>/dev/null | tail -1; done > gpurun_out/${R}_train_step.jsonl; cut -c1-400 gpurun_out/${R}_train_step.jsonl; fi
 ARGS="bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-profile --no-parity-mode --no-train-step --no-other-configs"
 rm -rf gpurun_out/prof_trace
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_trace -- python3 $ARGS --ddpm-steps 200 > gpurun_out/prof_trace.log 2>&1

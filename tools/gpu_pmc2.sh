@@ -1,7 +1,7 @@
 #!/bin/bash
 # SQ-level counters of a 20-step bench run, one rocprofv3 pass per counter set ($SETS: space-separated, commas inside a set)
 mkdir -p gpurun_out
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?run under gpurun (or export GRAFT_REPO_ROOT=the repo root)}"
 rocprofv3 --list-avail 2>/dev/null | grep -oE "\b(SQ|TCP|TA|TCC|GRBM)_[A-Z0-9_]+" | sort -u > gpurun_out/counters_avail.txt; wc -l gpurun_out/counters_avail.txt
 ARGS="bench.py --steps 1 --warmup 1 --ddpm-steps 20 --no-cpu-baseline --no-kernel-profile --no-parity-mode --no-train-step"
 i=0
