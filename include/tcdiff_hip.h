@@ -600,15 +600,21 @@ int tcdiff_row_param_reduce(const float* partials, int n_blocks, float* d_bias, 
 
 /* Train-mode attention: as tcdiff_attention (one K/V per sequence), plus dropout on the softmax weights
  * (model/model.py:98; nn.MultiheadAttention dropout) and lse[seq][H][Lp_q] = log2 sum_k 2^(s log2 e) for the backward. */
-int tcdiff_attention_train(int dtype, const void* Q, const void* K, const void* V, void* O, float* lse, int n_seq, int H,
-                           int Lq, int Lk, int Lp_q, int Lp_k, int ldo, const int* seed, int site, uint32_t drop_thr,
+/* O_lo (bf16 mode, optional): a second token-major image, bf16(o - float(bf16(o))) of the fp32 output o -- with it the backward's
+ * delta_i = sum_d dO_id O_id is taken from O + O_lo (16 bits of O instead of 8).  Round 6 found why it matters: delta enters
+ * dS = P (dP - delta), a cancellation, and 8-bit O alone put the decoder's self-attention w_qs / w_ks gradients at twice the error the
+ * operand rounding of the step explains (tests/test_train_step_gpu.py, oracle._AttnKernelDelta). */
+int tcdiff_attention_train(int dtype, const void* Q, const void* K, const void* V, void* O, void* O_lo, float* lse, int n_seq,
+                           int H, int Lq, int Lk, int Lp_q, int Lp_k, int ldo, const int* seed, int site, uint32_t drop_thr,
                            float drop_scale, hipStream_t stream);
 /* Backward of the above (P is recomputed from Q, K and lse; the dropout bits are regenerated).  dO: head-major image
  * T[n_seq][H][Lp_q][64] (zero pad rows); O: token-major T as written by the forward.  Outputs are token-major T:
  *   dQ[(seq Lq + q) ld_dq + head 64 + d] (times scale_q: the gradient with respect to the UNSCALED projection),
- *   dK[(seq Lk + k) ld_dkv + head 64 + d], dV likewise.   delta: fp32 workspace [n_seq][H][Lp_q].
+ *   dK[(seq Lk + k) ld_dkv + head 64 + d], dV likewise.   delta: fp32 workspace [n_seq][H][Lp_q].  O_lo: the forward's second
+ * image or NULL (delta from the 8-bit O alone).
  * Two launches (query-major for dQ, key-major for dK / dV): no atomics, bitwise reproducible. */
-int tcdiff_attention_bwd(int dtype, const void* Q, const void* K, const void* V, const void* O, const void* dO,
+int tcdiff_attention_bwd(int dtype, const void* Q, const void* K, const void* V, const void* O, const void* O_lo,
+                         const void* dO,
                          const float* lse, float* delta, void* dQ, int ld_dq, void* dK, void* dV, int ld_dkv, int n_seq,
                          int H, int Lq, int Lk, int Lp_q, int Lp_k, int ldo, float scale_q, const int* seed, int site,
                          uint32_t drop_thr, float drop_scale, hipStream_t stream);

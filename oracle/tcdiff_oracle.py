@@ -240,6 +240,34 @@ def _heads(x: torch.Tensor, n_head: int) -> torch.Tensor:
     return x.view(b, n, n_head, -1).transpose(1, 2)  # (b,h,n,dk)
 
 
+KERNEL_DELTA = False     # (experiment, eval mode only) the attention core with the backward the HIP kernels run: see _AttnKernelDelta
+
+
+class _AttnKernelDelta(torch.autograd.Function):
+    """softmax(q k^T) v with bf16 operands and the FLASH-style backward of csrc/attention_train.hip: the softmax Jacobian's row term
+    delta_i = sum_j P_ij dP_ij is taken as rowsum(dO * O) from the STORED (bf16) output -- equal in exact arithmetic, but O was
+    rounded to 8 bits and the term it enters, P (dP - delta), is a cancellation.  Autograd through torch.softmax (the plain
+    operand_rounding emulation) computes delta from the fp32 P and dP.  tests/golden/make_golden_bf16_draws.py --kernel-delta asks
+    whether this is what separates the kernels' w_qs / w_ks gradients from the emulated draws at the config-1 shape."""
+    @staticmethod
+    def forward(ctx, q, k, v):
+        qb, kb, vb = _bf(q), _bf(k), _bf(v)
+        p = torch.softmax(torch.matmul(qb, kb.transpose(2, 3)), dim=-1)
+        o = torch.matmul(_bf(p), vb)
+        ctx.save_for_backward(qb, kb, vb, p, _bf(o))
+        return o
+
+    @staticmethod
+    def backward(ctx, d_o):
+        qb, kb, vb, p, ob = ctx.saved_tensors
+        dob = _bf(d_o)
+        dv = torch.matmul(_bf(p).transpose(2, 3), dob)
+        dp = torch.matmul(dob, vb.transpose(2, 3))
+        delta = (dob * ob).sum(-1, keepdim=True)
+        ds = _bf(p * (dp - delta))
+        return _bf(torch.matmul(ds, kb)), _bf(torch.matmul(ds.transpose(2, 3), qb)), _bf(dv)
+
+
 def sbi_msa(q_in, k_in, v_in, sd: SD, prefix: str, n_head: int, drop=_nodrop, site0: int = 0) -> torch.Tensor:
     """SBI_MSA.forward with trj_dist=None (model/model.py:71-107); drop: train-mode dropout on the softmax weights (site0)
     and on the fc output (site0 + 1), :98,103.
@@ -249,8 +277,11 @@ def sbi_msa(q_in, k_in, v_in, sd: SD, prefix: str, n_head: int, drop=_nodrop, si
     q = _heads(F.linear(q_in, sd[prefix + ".w_qs.weight"]), n_head)
     k = _heads(F.linear(k_in, sd[prefix + ".w_ks.weight"]), n_head)
     v = _heads(F.linear(v_in, sd[prefix + ".w_vs.weight"]), n_head)
-    att = drop(torch.softmax(torch.matmul(q / (DK ** 0.5), k.transpose(2, 3)), dim=-1), site0)
-    o = torch.matmul(att, v).transpose(1, 2).reshape(q_in.shape[0], q_in.shape[1], -1)
+    if KERNEL_DELTA and (drop is _nodrop or getattr(drop, "p", 1.0) <= 0.0):
+        o = _AttnKernelDelta.apply(q / (DK ** 0.5), k, v).transpose(1, 2).reshape(q_in.shape[0], q_in.shape[1], -1)
+    else:
+        att = drop(torch.softmax(torch.matmul(q / (DK ** 0.5), k.transpose(2, 3)), dim=-1), site0)
+        o = torch.matmul(att, v).transpose(1, 2).reshape(q_in.shape[0], q_in.shape[1], -1)
     o = drop(F.linear(o, sd[prefix + ".fc.weight"]), site0 + 1)
     return layer_norm(o, sd, prefix + ".layer_norm", 1e-6)
 

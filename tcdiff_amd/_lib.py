@@ -140,8 +140,8 @@ _SIGS = {
     "tcdiff_row_fwd": [_i, C.POINTER(RowArgs), _vp],
     "tcdiff_row_bwd": [_i, C.POINTER(RowArgs), _vp],
     "tcdiff_row_param_reduce": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
-    "tcdiff_attention_train": [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, C.c_uint32, _f, _vp],
-    "tcdiff_attention_bwd": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i,
+    "tcdiff_attention_train": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, C.c_uint32, _f, _vp],
+    "tcdiff_attention_bwd": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i,
                              _f, _vp, _i, C.c_uint32, _f, _vp],
     "tcdiff_add_rows": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp],
     "tcdiff_select_rows": [_vp, _vp, _vp, _vp, _i, _l, _vp],

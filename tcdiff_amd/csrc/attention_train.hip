@@ -100,7 +100,8 @@ DEVINL void store_row4(void* base, long elem_off, float v0, float v1, float v2, 
 template <class P>
 __global__ __launch_bounds__(256) void attention_train_kernel(const char* __restrict__ Q, const char* __restrict__ K,
                                                               const char* __restrict__ V, char* __restrict__ O,
-                                                              float* __restrict__ lse, int H, int Lq, int Lk, int Lp_q,
+                                                              char* __restrict__ O_lo, float* __restrict__ lse, int H, int Lq,
+                                                              int Lk, int Lp_q,
                                                               int Lp_k, int ldo, const int* __restrict__ seed, int site,
                                                               uint32_t thr, float dscale) {
     typedef AttnCfg<P> C;
@@ -205,9 +206,18 @@ __global__ __launch_bounds__(256) void attention_train_kernel(const char* __rest
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                store_row4<P>(O, ((long)seq * Lq + qg) * ldo + head * 64 + dt * 32 + 8 * g + 4 * h, o[dt][4 * g + 0] * inv,
-                              o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+            for (int g = 0; g < 4; ++g) {
+                const long off = ((long)seq * Lq + qg) * ldo + head * 64 + dt * 32 + 8 * g + 4 * h;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = o[dt][4 * g + j] * inv;
+                store_row4<P>(O, off, v[0], v[1], v[2], v[3]);
+                if (P::IS_BF16 && O_lo) {      // what the 8-bit image dropped (tcdiff_attention_train: the backward's delta reads O + O_lo)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] -= bf2f((uint16_t)(pack_bf2(v[j], 0.0f) & 0xffffu));
+                    store_row4<P>(O_lo, off, v[0], v[1], v[2], v[3]);
+                }
+            }
     }
 }
 
@@ -216,7 +226,8 @@ __global__ __launch_bounds__(256) void attention_train_kernel(const char* __rest
 // =====================================================================================================================
 template <class P>
 __global__ __launch_bounds__(256) void attn_delta_kernel(const typename P::elem_t* __restrict__ dO,
-                                                         const typename P::elem_t* __restrict__ O, float* __restrict__ delta,
+                                                         const typename P::elem_t* __restrict__ O,
+                                                         const typename P::elem_t* __restrict__ O_lo, float* __restrict__ delta,
                                                          int n_bh, int H, int Lq, int Lp_q, int ldo) {
     // EPT = 16 bytes of a row per thread (bf16: 8 lanes per row, f32: 16): both rows are read as whole 128- / 256-byte lines
     // (a thread per row read 64 strided elements: 13 us per launch for 7 MB)
@@ -234,10 +245,12 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const typename P::elem_
         const u32x4 av = *reinterpret_cast<const u32x4*>(dO + ((long)bh * Lp_q + q) * 64 + part * EPT);
         const u32x4 bv = *reinterpret_cast<const u32x4*>(O + ((long)seq * Lq + q) * ldo + head * 64 + part * EPT);
         if (P::IS_BF16) {
+            u32x4 lv = {0u, 0u, 0u, 0u};
+            if (O_lo) lv = *reinterpret_cast<const u32x4*>(O_lo + ((long)seq * Lq + q) * ldo + head * 64 + part * EPT);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                s = fmaf(bf2f((uint16_t)(av[j] & 0xffffu)), bf2f((uint16_t)(bv[j] & 0xffffu)), s);
-                s = fmaf(bf2f((uint16_t)(av[j] >> 16)), bf2f((uint16_t)(bv[j] >> 16)), s);
+                s = fmaf(bf2f((uint16_t)(av[j] & 0xffffu)), bf2f((uint16_t)(bv[j] & 0xffffu)) + bf2f((uint16_t)(lv[j] & 0xffffu)), s);
+                s = fmaf(bf2f((uint16_t)(av[j] >> 16)), bf2f((uint16_t)(bv[j] >> 16)) + bf2f((uint16_t)(lv[j] >> 16)), s);
             }
         } else {
             const f32x4_t af = __builtin_bit_cast(f32x4_t, av), bf = __builtin_bit_cast(f32x4_t, bv);
@@ -735,10 +748,11 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_res_kernel(const char* __res
 // =====================================================================================================================
 static bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-extern "C" int tcdiff_attention_train(int dtype, const void* Q, const void* K, const void* V, void* O, float* lse,
+extern "C" int tcdiff_attention_train(int dtype, const void* Q, const void* K, const void* V, void* O, void* O_lo, float* lse,
                                       int n_seq, int H, int Lq, int Lk, int Lp_q, int Lp_k, int ldo, const int* seed,
                                       int site, uint32_t drop_thr, float drop_scale, hipStream_t stream) {
     if (!Q || !K || !V || !O || !lse || n_seq <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return TC_ERR_ARG;
+    if (O_lo && (dtype != TC_DTYPE_BF16 || !a16(O_lo))) return TC_ERR_ARG;
     if (dtype != TC_DTYPE_BF16 && dtype != TC_DTYPE_F32) return TC_ERR_ARG;
     if (Lp_q % 128 != 0 || Lp_k % 64 != 0 || Lp_q < Lq || Lp_k < Lk || ldo < H * 64 || ldo % 4 != 0) return TC_ERR_ARG;
     if (!a16(Q) || !a16(K) || !a16(V) || !a16(O)) return TC_ERR_ALIGN;
@@ -757,7 +771,7 @@ extern "C" int tcdiff_attention_train(int dtype, const void* Q, const void* K, c
         if (n_cu < 0) return n_cu;
         const int ng = ((Lq + 255) / 256) * H * n_seq <= n_cu ? 1 : 2;
         const int nqb = (Lq + 256 * ng - 1) / (256 * ng);
-        const AttnTrainArgs ta = {lse, seed, site, drop_thr, drop_scale};
+        const AttnTrainArgs ta = {lse, seed, site, drop_thr, drop_scale, (char*)O_lo};
         if (ng == 1)
             hipLaunchKernelGGL((attention_res_kernel<1, true>), dim3(nqb * H * n_seq), dim3(512), smem_bytes, stream,
                                (const char*)Q, (const char*)K, (const char*)V, (char*)O, H, Lq, Lk, Lp_q, Lp_k, ldo, 0, ta);
@@ -770,16 +784,16 @@ extern "C" int tcdiff_attention_train(int dtype, const void* Q, const void* K, c
     dim3 grid((Lp_q / 128) * H * n_seq);
     if (dtype == TC_DTYPE_BF16)
         hipLaunchKernelGGL(attention_train_kernel<MmaBF16>, grid, dim3(256), 0, stream, (const char*)Q, (const char*)K,
-                           (const char*)V, (char*)O, lse, H, Lq, Lk, Lp_q, Lp_k, ldo, seed, site, drop_thr, drop_scale);
+                           (const char*)V, (char*)O, (char*)O_lo, lse, H, Lq, Lk, Lp_q, Lp_k, ldo, seed, site, drop_thr, drop_scale);
     else
         hipLaunchKernelGGL(attention_train_kernel<MmaF32>, grid, dim3(256), 0, stream, (const char*)Q, (const char*)K,
-                           (const char*)V, (char*)O, lse, H, Lq, Lk, Lp_q, Lp_k, ldo, seed, site, drop_thr, drop_scale);
+                           (const char*)V, (char*)O, (char*)nullptr, lse, H, Lq, Lk, Lp_q, Lp_k, ldo, seed, site, drop_thr, drop_scale);
     TC_CHECK_LAUNCH();
     return TC_OK;
 }
 
 template <class P>
-static void launch_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* lse,
+static void launch_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* O_lo, const void* dO, const float* lse,
                             float* delta, void* dQ, int ld_dq, void* dK, void* dV, int ld_dkv, int n_seq, int H, int Lq,
                             int Lk, int Lp_q, int Lp_k, int ldo, float scale_q, const int* seed, int site, uint32_t thr,
                             float dscale, hipStream_t stream) {
@@ -787,7 +801,7 @@ static void launch_attn_bwd(const void* Q, const void* K, const void* V, const v
     const long nd = (long)n_seq * H * Lq;
     const long ndt = nd * (64 / (16 / (long)sizeof(T)));      // threads: 16 bytes of a row each
     hipLaunchKernelGGL(attn_delta_kernel<P>, dim3((unsigned)((ndt + 255) / 256)), dim3(256), 0, stream, (const T*)dO,
-                       (const T*)O, delta, n_seq * H, H, Lq, Lp_q, ldo);
+                       (const T*)O, (const T*)O_lo, delta, n_seq * H, H, Lq, Lp_q, ldo);
     hipLaunchKernelGGL(attn_bwd_dq_kernel<P>, dim3((Lp_q / 128) * H * n_seq), dim3(256), 0, stream, (const char*)Q,
                        (const char*)K, (const char*)V, (const char*)dO, lse, delta, dQ, ld_dq, H, Lq, Lk, Lp_q, Lp_k, scale_q,
                        seed, site, thr, dscale);
@@ -796,13 +810,15 @@ static void launch_attn_bwd(const void* Q, const void* K, const void* V, const v
                        site, thr, dscale);
 }
 
-extern "C" int tcdiff_attention_bwd(int dtype, const void* Q, const void* K, const void* V, const void* O, const void* dO,
+extern "C" int tcdiff_attention_bwd(int dtype, const void* Q, const void* K, const void* V, const void* O, const void* O_lo,
+                                    const void* dO,
                                     const float* lse, float* delta, void* dQ, int ld_dq, void* dK, void* dV, int ld_dkv,
                                     int n_seq, int H, int Lq, int Lk, int Lp_q, int Lp_k, int ldo, float scale_q,
                                     const int* seed, int site, uint32_t drop_thr, float drop_scale, hipStream_t stream) {
     if (!Q || !K || !V || !O || !dO || !lse || !delta || !dQ || !dK || !dV || n_seq <= 0 || H <= 0 || Lq <= 0 || Lk <= 0)
         return TC_ERR_ARG;
     if (dtype != TC_DTYPE_BF16 && dtype != TC_DTYPE_F32) return TC_ERR_ARG;
+    if (O_lo && (dtype != TC_DTYPE_BF16 || !a16(O_lo))) return TC_ERR_ARG;
     if (Lp_q % 128 != 0 || Lp_k % 128 != 0 || Lp_q < Lq || Lp_k < Lk || ldo < H * 64 || ld_dq < H * 64 || ld_dkv < H * 64 ||
         ld_dq % 4 != 0 || ld_dkv % 4 != 0)
         return TC_ERR_ARG;
@@ -827,7 +843,7 @@ extern "C" int tcdiff_attention_bwd(int dtype, const void* Q, const void* K, con
         if (n_cu < 0) return n_cu;
         const long nd = (long)n_seq * H * Lq;
         hipLaunchKernelGGL(attn_delta_kernel<MmaBF16>, dim3((unsigned)((nd * 8 + 255) / 256)), dim3(256), 0, stream,
-                           (const uint16_t*)dO, (const uint16_t*)O, delta, n_seq * H, H, Lq, Lp_q, ldo);
+                           (const uint16_t*)dO, (const uint16_t*)O, (const uint16_t*)O_lo, delta, n_seq * H, H, Lq, Lp_q, ldo);
         const int nqb = (Lq + 256 * DQ_NG - 1) / (256 * DQ_NG), nkb = (Lk + 256 * DKV_NG - 1) / (256 * DKV_NG);
         hipLaunchKernelGGL(attn_bwd_dq_res_kernel<DQ_NG>, dim3(nqb * H * n_seq), dim3(512), smem_dq, stream, (const char*)Q,
                            (const char*)K, (const char*)V, (const char*)dO, lse, delta, (uint16_t*)dQ, ld_dq, H, Lq, Lk, Lp_q,
@@ -836,10 +852,10 @@ extern "C" int tcdiff_attention_bwd(int dtype, const void* Q, const void* K, con
                            (const char*)K, (const char*)V, (const char*)dO, lse, delta, (uint16_t*)dK, (uint16_t*)dV, ld_dkv, H,
                            Lq, Lk, Lp_q, Lp_k, seed, site, drop_thr, drop_scale);
     } else if (dtype == TC_DTYPE_BF16)
-        launch_attn_bwd<MmaBF16>(Q, K, V, O, dO, lse, delta, dQ, ld_dq, dK, dV, ld_dkv, n_seq, H, Lq, Lk, Lp_q, Lp_k, ldo,
+        launch_attn_bwd<MmaBF16>(Q, K, V, O, O_lo, dO, lse, delta, dQ, ld_dq, dK, dV, ld_dkv, n_seq, H, Lq, Lk, Lp_q, Lp_k, ldo,
                                  scale_q, seed, site, drop_thr, drop_scale, stream);
     else
-        launch_attn_bwd<MmaF32>(Q, K, V, O, dO, lse, delta, dQ, ld_dq, dK, dV, ld_dkv, n_seq, H, Lq, Lk, Lp_q, Lp_k, ldo,
+        launch_attn_bwd<MmaF32>(Q, K, V, O, nullptr, dO, lse, delta, dQ, ld_dq, dK, dV, ld_dkv, n_seq, H, Lq, Lk, Lp_q, Lp_k, ldo,
                                 scale_q, seed, site, drop_thr, drop_scale, stream);
     TC_CHECK_LAUNCH();
     return TC_OK;

@@ -23,6 +23,7 @@ struct AttnTrainArgs {
     int site;
     uint32_t thr;
     float dscale;
+    char* o_lo;            // optional second output image: bf16(o - float(bf16(o))) (tcdiff_attention_train)
 };
 
 template <int NG, bool TRAIN>
@@ -327,15 +328,27 @@ __global__ __launch_bounds__(512) void attention_res_kernel(const char* __restri
             const int qg = qbase + g * 32 + r;
             if (h == 0 && qg < Lq) ta.lse[(long)(seq * H + head) * Lp_q + qg] = m_run[g] + log2f(l_run[g]);
         }
+        // (train mode: a second pass stores what the 8-bit image dropped, bf16(o - float(bf16(o))): AttnTrainArgs.o_lo)
+        bool lo_pass = false;
+        if constexpr (TRAIN) lo_pass = ta.o_lo != nullptr;
+        for (int pass = 0; pass < (lo_pass ? 2 : 1); ++pass) {
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[j] = o[g][dt][4 * q4 + j] * inv;
+                    if (pass == 1) v[j] -= __builtin_bit_cast(float, pack_bf2(v[j], 0.0f) << 16);
+                }
                 uint2 pk;
-                pk.x = pack_bf2(o[g][dt][4 * q4 + 0] * inv, o[g][dt][4 * q4 + 1] * inv);
-                pk.y = pack_bf2(o[g][dt][4 * q4 + 2] * inv, o[g][dt][4 * q4 + 3] * inv);
+                pk.x = pack_bf2(v[0], v[1]);
+                pk.y = pack_bf2(v[2], v[3]);
                 *reinterpret_cast<uint2*>(stg + r * 128 + (((4 * dt + q4) ^ ((r >> 1) & 7)) << 4) + 8 * h) = pk;
             }
+        char* dstO = O;
+        if constexpr (TRAIN) dstO = pass == 1 ? ta.o_lo : O;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int row = srow0 + 8 * k;
@@ -345,7 +358,8 @@ __global__ __launch_bounds__(512) void attention_res_kernel(const char* __restri
             if (v.x == 0x12345678u)
 #endif
             if (qg < Lq)
-                *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(O) + ((long)seq * Lq + qg) * ldo + head * 64 + sch * 8) = v;
+                *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(dstO) + ((long)seq * Lq + qg) * ldo + head * 64 + sch * 8) = v;
+        }
         }
     }
 }

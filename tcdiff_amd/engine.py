@@ -505,11 +505,14 @@ class DenoiserEngine:
                 n_rows_seq, self.kv_tab, self.n_t, None if full else b["Kc"], None if full else b["Vc"],
                 b["Kf"] if full else None, b["Vf"] if full else None, self.NL, b["Kc"].shape[1], self.H,
                 self.Lpc, self.nkt if full else 0, self.S, x, b["xin"], *self._xin_shape(rows))
-        if tab is not None and self.use_chain and self.front and os.environ.get("TCDIFF_FORK_PROLOGUE", "1") != "0":
+        if tab is not None and self.use_chain and self.front and os.environ.get("TCDIFF_FORK_PROLOGUE", "0") == "1":
             # Two parts (tcdiff_step_prologue_args.parts): the x_t copy the first GEMM waits for, and -- on a forked stream, beside
             # the input / fusion GEMMs and the front launch, which leave a third of the CUs idle -- the FiLM rows and time-token rows
             # that nothing reads before layer 0's chain launch ~110 us later (network() joins there).  The fork is part of the
             # captured step: a dependency edge of the graph, no host work per step.
+            # MEASURED AND OFF BY DEFAULT (round 6, profiles/r06_prologue_fork_ab.txt): four interleaved pairs of 12-job runs on one
+            # box, 14.74 clips/s in line against 14.48 forked (-1.8 %, every pair): the 10-us launch it hides costs more as a
+            # concurrent neighbour of the DMA-latency-bound fusion GEMMs and as a fork / join pair in every replayed graph.
             K.step_prologue(*args, parts=L.PROLOGUE_X, **extra)
             main = torch.cuda.current_stream()
             if self._side is None:

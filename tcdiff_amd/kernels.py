@@ -436,15 +436,16 @@ def row_param_reduce(partials, n_blocks, d_bias=None, d_ln_g=None, d_ln_b=None, 
                                              _p(d_nln_b), stream()), "tcdiff_row_param_reduce")
 
 
-def attention_train(dt, Q, K, V, O, lse, n_seq, H, Lq, Lk, Lp_q, Lp_k, ldo, seed, site, thr, scale):
-    L.check(L.load().tcdiff_attention_train(_sdt(dt), _p(Q), _p(K), _p(V), _p(O), _p(lse), n_seq, H, Lq, Lk, Lp_q, Lp_k, ldo,
-                                            _p(seed), site, thr, scale, stream()), "tcdiff_attention_train")
+def attention_train(dt, Q, K, V, O, lse, n_seq, H, Lq, Lk, Lp_q, Lp_k, ldo, seed, site, thr, scale, O_lo=None):
+    """O_lo (bf16 mode): a second image like O that receives what O's 8 bits dropped; hand it to attention_bwd"""
+    L.check(L.load().tcdiff_attention_train(_sdt(dt), _p(Q), _p(K), _p(V), _p(O), _p(O_lo), _p(lse), n_seq, H, Lq, Lk, Lp_q, Lp_k,
+                                            ldo, _p(seed), site, thr, scale, stream()), "tcdiff_attention_train")
 
 
 def attention_bwd(dt, Q, K, V, O, dO, lse, delta, dQ, ld_dq, dK, dV, ld_dkv, n_seq, H, Lq, Lk, Lp_q, Lp_k, ldo, scale_q,
-                  seed, site, thr, scale):
-    L.check(L.load().tcdiff_attention_bwd(_sdt(dt), _p(Q), _p(K), _p(V), _p(O), _p(dO), _p(lse), _p(delta), _p(dQ), ld_dq,
-                                          _p(dK), _p(dV), ld_dkv, n_seq, H, Lq, Lk, Lp_q, Lp_k, ldo, scale_q, _p(seed),
+                  seed, site, thr, scale, O_lo=None):
+    L.check(L.load().tcdiff_attention_bwd(_sdt(dt), _p(Q), _p(K), _p(V), _p(O), _p(O_lo), _p(dO), _p(lse), _p(delta), _p(dQ),
+                                          ld_dq, _p(dK), _p(dV), ld_dkv, n_seq, H, Lq, Lk, Lp_q, Lp_k, ldo, scale_q, _p(seed),
                                           site, thr, scale, stream()), "tcdiff_attention_bwd")
 
 

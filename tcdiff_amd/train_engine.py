@@ -590,6 +590,8 @@ class TrainEngine:
         their device time on a slow host)."""
         B = x.shape[0]
         self.thr, self.dscale = K.drop_params(p_drop)
+        # bf16: the attention forwards also keep what O's 8 bits dropped, for the backward's delta (tcdiff_attention_train; A/B: =0)
+        self.olo = self.dt == L.DT_BF16 and _os.environ.get("TCDIFF_TRAIN_OLO", "1") != "0"
         # two scalar fills, not a copy from a host tensor: a pageable host-to-device copy blocks the host until everything queued
         # before it has run -- one full device sync per step, after which the GPU idled while Python queued the next forward
         self.seed[0].fill_(seed[0] & 0x7FFFFFFF)
@@ -688,8 +690,9 @@ class TrainEngine:
             lins[f"e{i}.qkv"].fwd(mrot, Ms, A2=mh, heads=dict(out=Qi, out_k=Ki, out_v=Vi, scale_q=0.125, Lseq=S,
                                                                Lp=self.Lps, n_q=512, n_k=512))
             O, lse = e(Ms, 512), self.pz(f"e{i}.lse", B, H, self.Lps, dtype=f32)
+            Olo = e(Ms, 512) if self.olo else None      # what O's 8 bits dropped: the backward's delta reads O + O_lo (kernels.attention_train)
             K.attention_train(dt, Qi, Ki, Vi, O, lse, B, H, S, S, self.Lps, self.Lps, 512, self.seed, 4 * i + 0, self.thr,
-                              self.dscale)
+                              self.dscale, O_lo=Olo)
             zo = e(Ms, 512, dtype=f32)
             lins[f"e{i}.o"].fwd(O, Ms, out=zo, f32=True)
             x2, h2 = e(Ms, 512, dtype=f32), e(Ms, 512)
@@ -708,7 +711,7 @@ class TrainEngine:
                              nln_eps=1e-5, hout=mh, rout=mrot, rope=self.rope, pos_mod=S, site_pre=4 * i + 3)
             else:
                 self.row_fwd(flags=fl, M=Ms, L=S, z=zf, xres=x2, xout=x3, site_pre=4 * i + 3)
-            s.update(Q=Qi, K=Ki, V=Vi, O=O, lse=lse, zo=zo, x2=x2, h2=h2, a=a, f=f, zf=zf)
+            s.update(Q=Qi, K=Ki, V=Vi, O=O, Olo=Olo, lse=lse, zo=zo, x2=x2, h2=h2, a=a, f=f, zf=zf)
             enc.append(s)
             tok = x3
         sv["enc"] = enc
@@ -786,7 +789,8 @@ class TrainEngine:
             lins[f"l{l}.qkv"].fwd(r1, M, A2=h1, heads=dict(out=Q, out_k=Kk, out_v=V, scale_q=0.125, Lseq=Lq, Lp=Lp, n_q=512,
                                                             n_k=512))
             O, lse = e(M, 512), self.pz(f"l{l}.lse", B, H, Lp, dtype=f32)
-            K.attention_train(dt, Q, Kk, V, O, lse, B, H, Lq, Lq, Lp, Lp, 512, self.seed, sd + 0, self.thr, self.dscale)
+            Olo = e(M, 512) if self.olo else None
+            K.attention_train(dt, Q, Kk, V, O, lse, B, H, Lq, Lq, Lp, Lp, 512, self.seed, sd + 0, self.thr, self.dscale, O_lo=Olo)
             z1 = e(M, 512, dtype=f32)
             lins[f"l{l}.sfc"].fwd(O, M, out=z1, f32=True)
             x2, r2 = e(M, 512, dtype=f32), e(M, 512)
@@ -798,8 +802,9 @@ class TrainEngine:
             Qc = self.pz(f"l{l}.Qc", B, H, Lp, 64)
             lins[f"l{l}.cq"].fwd(r2, M, heads=dict(out=Qc, out_k=None, out_v=None, scale_q=0.125, Lseq=Lq, Lp=Lp, n_q=512, n_k=0))
             Oc, lsec = e(M, 512), self.pz(f"l{l}.lsec", B, H, Lp, dtype=f32)
+            Oclo = e(M, 512) if self.olo else None
             K.attention_train(dt, Qc, Kc[l], Vc[l], Oc, lsec, B, H, Lq, S + 2, Lp, Lpc, 512, self.seed, sd + 3, self.thr,
-                              self.dscale)
+                              self.dscale, O_lo=Oclo)
             z2 = e(M, 512, dtype=f32)
             lins[f"l{l}.cfc"].fwd(Oc, M, out=z2, f32=True)
             x3, h3 = e(M, 512, dtype=f32), e(M, 512)
@@ -817,7 +822,7 @@ class TrainEngine:
                          nln_b=P(q + "norm4.bias"), nln_eps=1e-5, hout=h4, site_pre=sd + 7)
             z4 = e(M, 512, dtype=f32)
             lins[f"l{l}.l3"].fwd(h4, M, out=z4, f32=True)
-            s.update(Q=Q, K=Kk, V=V, O=O, lse=lse, z1=z1, x2=x2, r2=r2, Qc=Qc, Oc=Oc, lsec=lsec, z2=z2, x3=x3, h3=h3, a=a, f=f,
+            s.update(Q=Q, K=Kk, V=V, O=O, Olo=Olo, Oclo=Oclo, lse=lse, z1=z1, x2=x2, r2=r2, Qc=Qc, Oc=Oc, lsec=lsec, z2=z2, x3=x3, h3=h3, a=a, f=f,
                      z3=z3, h4=h4, z4=z4)
             layers.append(s)
             if l + 1 < NL:
@@ -1044,7 +1049,7 @@ class TrainEngine:
             dQc, delta = e(M, 512), self.pz("delta", B, H, Lp, dtype=f32)
             K.attention_bwd(dt, s["Qc"], sv["Kc"][l], sv["Vc"][l], s["Oc"], dOc, s["lsec"], delta, dQc, 512,
                             dKV.view(-1)[512 * l:], dKV.view(-1)[nk + 512 * l:], 2 * nk, B, H, Lq, S + 2, Lp, Lpc, 512, 0.125,
-                            self.seed, sd + 3, self.thr, self.dscale)
+                            self.seed, sd + 3, self.thr, self.dscale, O_lo=s["Oclo"])
             dr2 = e(M, 512)
             lins[f"l{l}.cq"].bwd(dQc, 512, M, [s["r2"]], [("T", dr2, 512)])
             # self-attention block
@@ -1060,7 +1065,7 @@ class TrainEngine:
             dQKV, delta = e(M, 1536), self.pz("delta", B, H, Lp, dtype=f32)
             K.attention_bwd(dt, s["Q"], s["K"], s["V"], s["O"], dO, s["lse"], delta, dQKV, 1536, dQKV.view(-1)[512:],
                             dQKV.view(-1)[1024:], 1536, B, H, Lq, Lq, Lp, Lp, 512, 0.125, self.seed, sd + 0, self.thr,
-                            self.dscale)
+                            self.dscale, O_lo=s["Olo"])
             g_r, g_h = e(M, 512), e(M, 512)
             lins[f"l{l}.qkv"].bwd(dQKV, 1536, M, [s["r1"], s["h1"]], [("T", g_r, 512), ("T", g_h, 512)])
             g_x = gx1
@@ -1146,7 +1151,7 @@ class TrainEngine:
             dQKV, delta = e(Ms, 1536), self.pz("deltae", B, H, Lps, dtype=f32)
             K.attention_bwd(dt, s["Q"], s["K"], s["V"], s["O"], dO, s["lse"], delta, dQKV, 1536, dQKV.view(-1)[512:],
                             dQKV.view(-1)[1024:], 1536, B, H, S, S, Lps, Lps, 512, 0.125, self.seed, 4 * i + 0, self.thr,
-                            self.dscale)
+                            self.dscale, O_lo=s["Olo"])
             g_r, g_h = e(Ms, 512), e(Ms, 512)
             lins[f"e{i}.qkv"].bwd(dQKV, 1536, Ms, [s["rot"], s["h"]], [("T", g_r, 512), ("T", g_h, 512)])
             g_tok = gx1

@@ -50,9 +50,32 @@ def grads(sd, b, mode, k=0, seed=(2024, 1003)):
     return {n: v.grad.numpy().copy() for n, v in sd_now.items() if v.grad is not None}
 
 
+def c1_grads(sd, ref, k, mode, d=0):
+    """step k of tests/golden/c1_train_step.npz's two steps (config-1 shape, 3 clips of 2 x 60; step 0 eval, step 1 train mode with
+    the weights after Adan's first step, which only decays them: model/adan.py:71,96-107) -- test_train_step_gpu.step_inputs"""
+    DN, S, B = 2, 60, 3
+    noise0 = (10, 20)[k]
+    x_start = torch.stack([O.synth_motion(100 * k + c, DN * S).reshape(S, DN, 151).permute(1, 0, 2) for c in range(B)])
+    cond = torch.stack([O.synth_cond(100 * k + c, S) for c in range(B)])
+    noise = torch.stack([O.synth_xT(noise0 + c, DN * S).reshape(S, DN, 151) for c in range(B)])
+    t, keep = torch.from_numpy(ref[f"s{k}_t"]), torch.from_numpy(ref[f"s{k}_keep"])
+    seed = tuple(int(v) for v in ref[f"s{k}_seed"])
+    train = bool(ref[f"s{k}_train"])
+    x_start = x_start * (1.0 + d * 2.0 ** -18)
+    decay = 1.0 / (1.0 + float(ref["lr"]) * float(ref["wd"])) if k == 1 else 1.0
+    sd_now = {n: (p.detach().clone() * decay).requires_grad_(True) for n, p in sd.items() if p.is_floating_point()}
+    ctx = O.operand_rounding(**mode) if mode is not None else torch.enable_grad()
+    with ctx:
+        total, _ = O.p_losses(sd_now, O.make_tables(100), x_start, cond, t, noise, keep,
+                              drop=O.DropPlan(seed, float(ref["p_drop"]) if train else 0.0))
+        total.backward()
+    return {n: v.grad.numpy().copy() for n, v in sd_now.items() if v.grad is not None}
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--b", type=int, nargs="+", default=[3, 32])
+    ap.add_argument("--c1", action="store_true", help="also the two steps of c1_train_step.npz (3 clips of 2 x 60)")
+    ap.add_argument("--b", type=int, nargs="*", default=[3, 32])
     ap.add_argument("--draws", type=int, default=6)
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "c5_bf16_draws.npz"))
     a = ap.parse_args()
@@ -80,6 +103,22 @@ def main():
         out[f"b{b}_names"] = np.array(names)
         out[f"b{b}_err"] = np.stack(E)
         out[f"b{b}_draws"] = np.array(desc)
+        np.savez_compressed(a.out, **out)
+    if a.c1:
+        ref = np.load(os.path.join(ROOT, "tests", "golden", "c1_train_step.npz"))
+        sd1 = O.synth_state_dict(dn=2, seq_len=60)
+        for k in (0, 1):
+            g0 = c1_grads(sd1, ref, k, None)
+            names = sorted(g0)
+            E, desc = [], []
+            for d in range(a.draws):
+                m = "D" if d % 3 else "A"
+                ge = c1_grads(sd1, ref, k, MODES[m], d)
+                e = np.array([rel(ge[n], g0[n]) for n in names], np.float32)
+                E.append(e)
+                desc.append(f"{m}{d}")
+                print(f"c1 step {k} draw {desc[-1]}: median {np.median(e):.3e} worst {e.max():.3e} ({names[int(e.argmax())]})", flush=True)
+            out[f"c1s{k}_names"], out[f"c1s{k}_err"], out[f"c1s{k}_draws"] = np.array(names), np.stack(E), np.array(desc)
         np.savez_compressed(a.out, **out)
     print("saved", a.out)
 

@@ -387,6 +387,54 @@ def test_attention_train_forward_and_backward_vs_torch_autograd(compute, Lq, Lk,
     assert torch.equal(dQ, dQ2) and torch.equal(dKV, dKV2)
 
 
+@pytest.mark.parametrize("Lq,Lk", [(120, 120), (450, 450), (450, 152)])      # streaming / operand-resident kernels
+def test_attention_second_output_image_sharpens_the_backward_row_term(Lq, Lk):
+    """tcdiff_attention_train's O_lo (round 6): O + O_lo carries 16 bits of the fp32 output, and with it the backward's
+    delta_i = sum_d dO_id O_id -- the row term of dS = P (dP - delta), a cancellation -- is the exact one to ~2^-16 instead of 2^-9.
+    Checked on delta itself (against float64 on the same bf16 operands) and on dQ / dK, whose error against torch autograd must not
+    grow; the 8-bit image O is bit-identical with and without the second output."""
+    dt, T, _ = mode("bf16")
+    n, H, p = 2, 8, 0.0
+    Lpq, Lpk = K.round_up(Lq, 128), K.round_up(Lk, 128)
+    g = torch.Generator().manual_seed(9)
+    q, k, v = (torch.randn(n, H, Lx, 64, generator=g) for Lx in (Lq, Lk, Lk))
+    v = v + 1.5                                       # a common component in V: O's magnitude (and delta's) well above the row-to-row signal
+    do = torch.randn(n, H, Lq, 64, generator=g)
+    site = 16
+    thr, sc = K.drop_params(p)
+    Qi, Ki, Vi, dOi = _images(q * 0.125, Lpq, T), _images(k, Lpk, T), _images(v, Lpk, T), _images(do, Lpq, T)
+    O1, O2, Olo = (torch.zeros(n * Lq, 512, device=DEV, dtype=T) for _ in range(3))
+    lse = torch.zeros(n, H, Lpq, device=DEV)
+    K.attention_train(dt, Qi, Ki, Vi, O1, lse, n, H, Lq, Lk, Lpq, Lpk, 512, seed_dev(), site, thr, sc)
+    K.attention_train(dt, Qi, Ki, Vi, O2, lse, n, H, Lq, Lk, Lpq, Lpk, 512, seed_dev(), site, thr, sc, O_lo=Olo)
+    assert torch.equal(O1, O2)
+    D = torch.float64
+    qr = (Qi.cpu()[:, :, :Lq].to(D) * 8).requires_grad_(True)
+    kr, vr = Ki.cpu()[:, :, :Lk].to(D).requires_grad_(True), Vi.cpu()[:, :, :Lk].to(D).requires_grad_(True)
+    att = torch.softmax((qr * 0.125) @ kr.transpose(2, 3), -1)
+    o = att @ vr
+    dO64 = dOi.cpu()[:, :, :Lq].to(D)
+    o.backward(dO64)
+    o_tok = o.detach().transpose(1, 2).reshape(n * Lq, 512)
+    e_hi, e_both = rel(O2, o_tok), rel(O2.float() + Olo.float(), o_tok)
+    delta_ref = (dO64 * o.detach()).sum(-1)
+    out = {}
+    for name, lo in (("O alone", None), ("O + O_lo", Olo)):
+        delta = torch.zeros(n, H, Lpq, device=DEV)
+        dQ = torch.zeros(n * Lq, 1536, device=DEV, dtype=T)
+        dKV = torch.zeros(n * Lk, 1024, device=DEV, dtype=T)
+        K.attention_bwd(dt, Qi, Ki, Vi, O2, dOi, lse, delta, dQ, 1536, dKV, dKV.view(-1)[512:], 1024, n, H, Lq, Lk, Lpq, Lpk, 512,
+                        0.125, seed_dev(), site, thr, sc, O_lo=lo)
+        tok = lambda t, Lx: t.transpose(1, 2).reshape(n * Lx, 512)
+        out[name] = (rel(delta.cpu()[:, :, :Lq], delta_ref), rel(dQ[:, :512], tok(qr.grad, Lq)), rel(dKV[:, :512], tok(kr.grad, Lk)))
+    print(f"L={Lq}x{Lk}: O vs fp64 {e_hi:.2e}, O + O_lo {e_both:.2e}; (delta, dQ, dK) vs fp64: O alone " +
+          " ".join(f"{x:.2e}" for x in out["O alone"]) + " | O + O_lo " + " ".join(f"{x:.2e}" for x in out["O + O_lo"]))
+    # (the float64 reference does not round P to bf16 before P V as the kernels do: that, not O's rounding, is what is left)
+    assert e_both < 0.3 * e_hi
+    assert out["O + O_lo"][0] < 0.25 * out["O alone"][0]
+    assert out["O + O_lo"][1] <= 1.05 * out["O alone"][1] and out["O + O_lo"][2] <= 1.05 * out["O alone"][2]
+
+
 @pytest.mark.parametrize("loss_type", ["l2", "l1"])
 def test_loss_function_backward_vs_oracle_autograd(loss_type):
     """total(model_out) of model/diffusion.py:668-741, d total / d model_out, with contacts above 0.95 so that the

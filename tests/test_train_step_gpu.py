@@ -57,7 +57,31 @@ def rel(a, b):
 # bf16 observed (worst parameter): 1.1e-1 .. 1.5e-1 with the decoder linears through gemm_tile, 1.5e-1 .. 2.1e-1 through
 # gemm_rows (the default) -- two draws of the same forward rounding noise, see
 # test_row_block_gemm_path_and_tile_path_are_two_roundings_of_the_same_step
-TOL = {"f32": (1e-4, 2e-5), "bf16": (3e-1, 2e-2)}      # (per-parameter gradient, loss terms)
+TOL = {"f32": (1e-4, 2e-5), "bf16": (2.5e-1, 2e-2)}      # (per-parameter gradient, loss terms)
+# Round 6: the bf16 gradient bounds are DERIVED, not chosen: tests/golden/c5_bf16_draws.npz holds nine draws of the oracle evaluated with
+# the kernels' rounding points per configuration (make_golden_bf16_draws.py); a bf16 step's worst parameter may lie 1.35 x above the
+# worst draw's worst parameter (nine draws do not exhaust a distribution), and every parameter's error RELATIVE TO THE MEDIAN must follow
+# the draws' common profile (SHAPE_TOL; test_bf16_step_error_profile_is_a_draw_of_the_emulated_rounding_noise).  TOL["bf16"][0] remains
+# as the ceiling no derived bound may exceed.
+SHAPE_TOL = 1.3
+
+
+def bf16_bound(golden_dir, key):
+    """(worst-parameter bound, names, per-draw error matrix) of configuration `key` in c5_bf16_draws.npz"""
+    z = np.load(os.path.join(golden_dir, "c5_bf16_draws.npz"))
+    E = z[f"{key}_err"].astype(np.float64)
+    return min(TOL["bf16"][0] if key.startswith("c1") else 4e-1, 1.35 * float(E.max())), [str(n) for n in z[f"{key}_names"]], E
+
+
+def shape_ratio(err_by_name, names, E):
+    """max over the parameters of (error / median error) / (the draws' envelope of the same quantity)"""
+    idx = [i for i, n in enumerate(names) if n in err_by_name and E[:, i].max() > 0]
+    ek = np.array([err_by_name[names[i]] for i in idx])
+    Ed = E[:, idx]
+    hi = (Ed / np.median(Ed, axis=1)[:, None]).max(axis=0)
+    r = (ek / np.median(ek)) / hi
+    j = int(r.argmax())
+    return float(r[j]), names[idx[j]], float(np.median(ek)), np.median(Ed, axis=1)
 
 
 @pytest.mark.parametrize("compute", ["f32", "bf16"])
@@ -117,6 +141,18 @@ def test_two_training_steps_vs_reference_golden_and_oracle(golden_dir, compute):
         allr.sort(reverse=True)
         print(f"[{compute}] step {k}: ALL {len(allr)} parameter gradients vs the oracle's autograd, rel-L2: worst " +
               ", ".join(f"{n} {v:.2e}" for v, n in allr[:4]) + f"; median {np.median([v for v, _ in allr]):.2e}")
+        if compute == "bf16":
+            bound, dn_names, E = bf16_bound(golden_dir, f"c1s{k}")
+            sr, sn, med_k, med_d = shape_ratio({n: v for v, n in allr}, dn_names, E)
+            print(f"[bf16] step {k}: derived bound {bound:.2e} (1.35 x the nine draws' worst {E.max():.2e}); error shape against the draws' "
+                  f"envelope: max {sr:.2f} ({sn}); median {med_k:.2e} vs the draws' {med_d.min():.2e} .. {med_d.max():.2e}")
+            # What the pin found (round 6) and what became of it: at THIS shape, eval mode (the lowest noise floor of the file), the
+            # decoder's self-attention w_qs / w_ks gradients of layers 4-7 lay 1.4e-1 .. 1.5e-1 from the exact ones where the nine draws
+            # stay below 8.4e-2 -- 2.1 x the draws' profile, every other parameter within 1.3 x.  Owner: the backward's row term
+            # delta_i = sum_d dO_id O_id taken from the 8-bit O image; it enters dS = P (dP - delta), a cancellation.  The oracle with
+            # exactly that (oracle._AttnKernelDelta) reproduces the numbers, parameter by parameter.  Fix: the attention forward keeps
+            # what O's 8 bits dropped (tcdiff_attention_train's O_lo), delta reads O + O_lo: worst parameter 8.4e-2, shape 1.02.
+            assert allr[0][0] < bound and sr <= SHAPE_TOL and 0.5 * med_d.min() <= med_k <= 1.25 * med_d.max(), (allr[0], sr, sn, med_k)
         assert allr[0][0] < gtol, allr[0]
         assert n_dead == int(ref[f"s{k}_n_dead"]) == 125
         optim.step()
@@ -135,7 +171,7 @@ def test_two_training_steps_vs_reference_golden_and_oracle(golden_dir, compute):
 
 
 @pytest.mark.parametrize("compute,b", [("f32", 32), ("bf16", 32), ("f32", 3)])
-def test_training_step_at_the_benchmarked_config_vs_oracle_autograd(compute, b):
+def test_training_step_at_the_benchmarked_config_vs_oracle_autograd(golden_dir, compute, b):
     """BASELINE config 5's per-GPU work -- 32 clips of 3 dancers x 150 frames, dropout 0.1 -- is the shape at which the step
     takes its fast paths: 14 400 token rows (a multiple of the k-tile: weight gradients by tcdiff_gemm_tn straight from the
     token-major operands), 450-token sequences (K/V-resident attention forward, operand-resident attention backward), fused
@@ -189,8 +225,8 @@ def test_training_step_at_the_benchmarked_config_vs_oracle_autograd(compute, b):
     # rounding, not the backward kernels': the CPU oracle with rounding emulated in the forward only (exact fp32 backward) lands
     # the same parameters at 1.45e-1 .. 1.94e-1 (tools/grad_error_study.py, profiles/r04_grad_error_study.txt)
     # (through gemm_rows, the default since round 4: worst 3.0e-1, median 8e-2 -- another draw of the same noise)
-    bound = 3e-4 if compute == "f32" else 4e-1
-    assert len(allr) == 435 - 125 and allr[0][0] < bound, allr[0]
+    bound = 3e-4 if compute == "f32" else bf16_bound(golden_dir, f"b{b}")[0]      # bf16: 1.35 x the worst of the nine emulated draws, capped at 4e-1
+    assert len(allr) == 435 - 125 and allr[0][0] < bound, (allr[0], bound)
 
 
 @pytest.mark.parametrize("name", ["relu", "silu"])
@@ -272,7 +308,7 @@ def test_row_block_gemm_path_and_tile_path_are_two_roundings_of_the_same_step():
     assert tab[0][0] < 4e-1 and max(r[1] for r in tab) < 4e-1
 
 
-@pytest.mark.parametrize("b", [3, 32])
+@pytest.mark.parametrize("b", [3])        # (round 6: 32 clips are held by the per-parameter pin below, against nine draws instead of one)
 def test_bf16_step_against_the_oracle_that_rounds_where_the_kernels_round(b):
     """VERDICT r4 #3.  The bf16 step cannot be held to the EXACT fp32 gradient tightly: rounding the forward's GEMM / attention
     operands to bf16 alone moves the gradients by 5e-2 .. 1.4e-1 (median over the parameters) and up to 2.6e-1 (self- /
@@ -339,6 +375,76 @@ def test_bf16_step_against_the_oracle_that_rounds_where_the_kernels_round(b):
     # the two HIP paths 6.3e-2 / 1.6e-1 (b = 3) -- and the emulated draw itself moves with the CPU's thread count; observed here on
     # MI355X boxes: kernels / emulation = 0.66 (b = 3), 1.76 (b = 32, median and worst alike)
     assert med_k <= 2.5 * med_e and worst_k <= 2.5 * worst_e, (med_k, med_e, worst_k, worst_e)
+
+
+@pytest.mark.parametrize("b", [3, 32])
+def test_bf16_step_error_profile_is_a_draw_of_the_emulated_rounding_noise(golden_dir, b):
+    """the PIN.  tests/golden/c5_bf16_draws.npz (make_golden_bf16_draws.py, the CPU oracle alone) holds nine draws of the
+    oracle evaluated with the kernels' rounding points -- each perturbed immaterially (x_start x (1 + k 2^-18)) -- as per-parameter
+    relative L2 distances to the exact fp32 gradient.  What they show: (i) the SCALE of the error is a property of the draw (median over
+    the parameters 5.4e-2 .. 1.4e-1 at 3 clips, 4.3e-2 .. 8.3e-2 at 32 clips; worst parameter 1.5e-1 .. 2.7e-1 and 1.6e-1 .. 3.1e-1): round
+    5's "kernels / emulation = 1.76 at 32 clips" compared the kernels with ONE draw (4.6e-2) of a quantity whose own draws span 1.9 x;
+    (ii) the SHAPE of the error -- a parameter's error divided by the draw's median -- is the same in every draw: leave-one-out, no
+    parameter of any draw exceeds the envelope of the other eight by more than 1.15 x (which parameters suffer, and by how much relative
+    to the rest, is decided by the loss, not by the draw).
+    So the HIP step is held to both, per parameter: every one of the ~308 live parameters' (error / median error) within SHAPE x the
+    draws' envelope -- a defect in one backward kernel (attention dS, row_bwd's d_z, an input-gradient GEMM) raises ITS parameters
+    against the rest and fails here, where the old distribution envelope (median / worst <= 2.5 x one emulation) let 40 % through --
+    and the median / worst within the draws' range."""
+    z = np.load(os.path.join(golden_dir, "c5_bf16_draws.npz"))
+    names, E = [str(n) for n in z[f"b{b}_names"]], z[f"b{b}_err"].astype(np.float64)
+    gk, g0 = _c5_bf16_step(b)
+    idx = [i for i, n in enumerate(names) if n in gk and E[:, i].max() > 0]
+    assert len(idx) >= 300, len(idx)
+    names, E = [names[i] for i in idx], E[:, idx]
+    ek = np.array([rel(gk[n], g0[n]) for n in names])
+    med_d, worst_d = np.median(E, axis=1), E.max(axis=1)
+    med_k, worst_k = float(np.median(ek)), float(ek.max())
+    shape_hi = (E / med_d[:, None]).max(axis=0)
+    ratio = (ek / med_k) / shape_hi
+    order = np.argsort(-ratio)
+    print(f"[bf16, {b} x 3 x 150] kernels vs exact: median {med_k:.2e} worst {worst_k:.2e} ({names[int(ek.argmax())]}); the nine emulated "
+          f"draws: median {med_d.min():.2e} .. {med_d.max():.2e}, worst {worst_d.min():.2e} .. {worst_d.max():.2e}; error SHAPE against the draws' "
+          f"envelope: max {ratio[order[0]]:.2f} ({names[order[0]]}), then " + ", ".join(f"{ratio[i]:.2f} {names[i]}" for i in order[1:4]) +
+          f"; 95th percentile {np.percentile(ratio, 95):.2f}")
+    # scale: inside the draws' own range (a quarter above its top: nine draws do not exhaust a distribution)
+    assert 0.5 * med_d.min() <= med_k <= 1.25 * med_d.max(), (med_k, med_d)
+    assert worst_k <= 1.25 * worst_d.max(), (worst_k, worst_d)
+    # shape: leave-one-out the draws need 1.15; the kernels add their own summation orders (row-block GEMM streams, fp32 atomics)
+    assert ratio.max() <= SHAPE_TOL, (names[order[0]], float(ratio.max()))
+
+
+
+def _c5_bf16_step(b):
+    """One bf16 train-mode step of the HIP kernels at b x 3 x 150 and the oracle's exact fp32 gradients on the same inputs."""
+    if ("k", b) in _ORACLE_CACHE:
+        return _ORACLE_CACHE[("k", b)]
+    dn, S_ = 3, 150
+    sd, diff = build("bf16", dn=dn, S_=S_, T_=1000)
+    model = diff.model
+    diff.train()
+    x_start = torch.stack([O.synth_motion(300 + c, dn * S_).reshape(S_, dn, 151).permute(1, 0, 2) for c in range(b)])
+    cond = torch.stack([O.synth_cond(300 + c, S_) for c in range(b)])
+    noise = torch.stack([O.synth_xT(300 + c, dn * S_).reshape(S_, dn, 151) for c in range(b)])
+    g = torch.Generator().manual_seed(77)
+    t = torch.randint(0, 1000, (b,), generator=g)
+    keep = torch.rand(b, generator=g) > 0.25
+    seed = (2024, 1003)
+    model.train_seed = seed
+    total, _ = diff.p_losses(x_start.to(DEV), cond.to(DEV), t.to(DEV), noise=noise.to(DEV), keep_mask=keep.to(DEV))
+    for p in model.parameters():
+        p.grad = None
+    total.backward()
+    gk = {n: p.grad.cpu().numpy().copy() for n, p in model.named_parameters() if p.grad is not None}
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    if ("c5", b) not in _ORACLE_CACHE:
+        sd_now = {n: p.detach().cpu().clone().requires_grad_(True) for n, p in sd.items() if p.is_floating_point()}
+        o_total, o_losses = O.p_losses(sd_now, O.make_tables(1000), x_start, cond, t, noise, keep, drop=O.DropPlan(seed, 0.1))
+        o_total.backward()
+        _ORACLE_CACHE[("c5", b)] = (float(o_total), np.array([float(v) for v in o_losses]),
+                                   {n: (None if v.grad is None else v.grad.numpy().copy()) for n, v in sd_now.items()})
+    _ORACLE_CACHE[("k", b)] = (gk, _ORACLE_CACHE[("c5", b)][2])
+    return _ORACLE_CACHE[("k", b)]
 
 
 _ORACLE_CACHE = {}
