@@ -558,9 +558,9 @@ DEVINL void chain_body(const tcdiff_chain_args& a) {
                 acc[nt][mt][t] = v;
                 o[t] = v;
             }
-            // unguarded: rows past M rewrite row M - 1 with the SAME values (same inputs; every load of this column
-            // group, in place or not, was issued before this store)
+#ifdef CH_STORE_EARLY   // (rounds 2-5: the store beside the arithmetic; A/B build flag)
             cb_store<NT>(xo, Mtot, wv, nt, rw.mc[mt], gg, o);
+#endif
         };
         // (Measured in the listing and dropped: a second code path for blocks that lie in ONE sequence -- constants read once
         // per column quad instead of once per row tile.  The two paths raise the epilogue's register peak, hipcc spills ring
@@ -581,6 +581,18 @@ DEVINL void chain_body(const tcdiff_chain_args& a) {
             // constants) above the arithmetic, needs ~100 more registers and spills them
             CH_FENCE();
         }
+#ifndef CH_STORE_EARLY
+        // The new x leaves AFTER the loop, from the accumulators (they keep it for the next norm anyway).  gfx950 counts loads and
+        // stores in ONE in-order counter (vmcnt): a store issued in front of the next n-tile's row loads made the wait for those
+        // loads a wait for the store's acknowledgement too -- 1-2 us under load, twice per epilogue (round 6: the ISA showed
+        // `store, load, s_waitcnt vmcnt(2)` chains; the epilogue took 2.6 us per wave for 0.6 us of arithmetic).
+        // unguarded: rows past M rewrite row M - 1 with the SAME values (same inputs; every load of this column group, in place
+        // or not, was issued before these stores)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) cb_store<NT>(xo, Mtot, wv, nt, rw.mc[mt], gg, acc[nt][mt]);
+#endif
     };
     auto xres_start = [&]() {
         const Rows rw = rows();
@@ -768,6 +780,10 @@ DEVINL void chain_body(const tcdiff_chain_args& a) {
         phase_n512<16, false, MT, NT>(acc, abuf, ws, lane);
     CH_T(25);
     lds_barrier();
+#ifndef CH_STORE_EARLY
+    if (!LAST) rope_start();           // the next norm's rotary rows: issued BEFORE x' is stored (one in-order vmcnt: behind the stores,
+                                       // waiting for these loads would wait for the stores' acknowledgement too -- see fc_epilogue)
+#endif
     {
         const int g3 = fresh_v(g);
         const int cb3 = col_base_bytes<NT>(fresh_s(wave), g3);
@@ -804,7 +820,9 @@ DEVINL void chain_body(const tcdiff_chain_args& a) {
     if (LAST) return;
     // ================= next layer: norm1 + rotary -> Q, K ; norm1 -> V (model/model.py:326,374-383,78-80)
     CH_T(26);
+#ifdef CH_STORE_EARLY
     rope_start();
+#endif
     row_stats(acc, scr, wave, lane, a.nn_eps, nmr, rstd);
     CH_T(27);
     norm_to_lds<true, MT, NT>(acc, nmr, rstd, vecp(1), vecp(2), rp, abuf, wave, lane, smem + CH_ABUF2);

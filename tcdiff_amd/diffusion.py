@@ -273,35 +273,53 @@ class GaussianDiffusion(nn.Module):
         graphs = self.__dict__.setdefault("_graphs", {})
         gen = eng.generation
         q_noise = constrain.get("q_noise") if constrain is not None else None
-        for i, t in enumerate(tseq):
+        # Every per-step quantity lives in device memory (counter, step tables, seed), so one captured graph serves every step -- and
+        # SEVERAL consecutive steps of the same kind can be one graph: a replay boundary costs ~8 us of GPU idle time
+        # (profiles/r04_gap_analysis.txt), 0.8 % of a 1.05-ms step.  Runs of `unroll` steps with the same branch count and no host work
+        # between them (injected noise, callbacks, collected states) replay a graph of that many steps; the rest go one by one.
+        hostless = step_noise is None and q_noise is None and after_step is None and collect is None
+        unroll = max(1, int(os.environ.get("TCDIFF_GRAPH_STEPS", "20"))) if (use_graph and hostless) else 1
+        i = 0
+        while i < n:
+            t = tseq[i]
             branches = 1 if w_eff[i] == 1.0 else 2
+            u = 1
+            if unroll > 1:
+                while u < unroll and i + u < n and (1 if w_eff[i + u] == 1.0 else 2) == branches:
+                    u += 1
+                if u < unroll:
+                    u = 1                       # a run's tail: single steps (no graph per tail length)
             if step_noise is not None:
                 st["eps"].copy_(step_noise(int(t), (B, Lq, nf)).reshape(B * Lq, nf))
             if q_noise is not None:
                 st["qeps"].copy_(q_noise(int(t), (B, Lq, nf)).reshape(B * Lq, nf))
-            ckey = None if constrain is None else (constrain["kind"], q_noise is not None, mask_rows)
-            gkey = (mode, branches, step_noise is not None, traj is not None, clip_offset, B, gen, id(self.model), ckey, couple)
+            # (the constraint kernel is captured reading st["cparams"] or st["params"]: part of the key -- ADVICE r5)
+            ckey = None if constrain is None else (constrain["kind"], q_noise is not None, mask_rows, constrain.get("params") is not None)
+            gkey = (mode, branches, step_noise is not None, traj is not None, clip_offset, B, gen, id(self.model), ckey, couple, u)
             if not use_graph:
                 step(branches)
             elif gkey in graphs:
                 graphs[gkey].replay()
             elif ("warm", gkey) not in graphs:
-                step(branches)                  # first visit: eager (loads code objects, sets kernel attributes)
+                for _ in range(u):
+                    step(branches)              # first visit: eager (loads code objects, sets kernel attributes)
                 graphs[("warm", gkey)] = True
-            else:                               # second visit: capture the step once, replay from now on
-                for k in [k for k in graphs if isinstance(k, tuple) and len(k) == 10 and k[7] == id(self.model) and k[6] != gen]:
+            else:                               # second visit: capture once, replay from now on
+                for k in [k for k in graphs if isinstance(k, tuple) and len(k) == 11 and k[7] == id(self.model) and k[6] != gen]:
                     del graphs[k]               # graphs of engines whose buffers have moved
-                live = [k for k in graphs if isinstance(k, tuple) and len(k) == 10]
+                live = [k for k in graphs if isinstance(k, tuple) and len(k) == 11]
                 for k in live[:max(0, len(live) - 15)]:
                     del graphs[k]               # a bounded cache: at most 16 captured step graphs (oldest first) ...
                     graphs.pop(("warm", k), None)   # ... and their warm-up marks
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
-                    step(branches)
+                    for _ in range(u):
+                        step(branches)
                 graphs[gkey] = graph
                 graph.replay()
+            i += u
             if after_step is not None:
-                after_step(i, int(t), st["x"].view(B, Lq, nf))
+                after_step(i - 1, int(t), st["x"].view(B, Lq, nf))
             if collect is not None:
                 collect.append(st["x"].view(B, Lq, nf).clone())
         return st["x"].view(B, Lq, nf).clone()

@@ -589,6 +589,24 @@ def test_first_call_crossing_the_guidance_boundary_equals_the_replayed_call():
     assert torch.equal(first, eager)
 
 
+@pytest.mark.parametrize("steps", ["7", "20"])
+def test_several_steps_per_captured_graph_equal_one_step_per_graph(monkeypatch, steps):
+    """Round 6: runs of TCDIFF_GRAPH_STEPS consecutive steps of one kind replay ONE graph (every per-step quantity is in device
+    memory); run tails and the guidance boundary (t < 0.1 T: single-branch steps) fall back to single steps.  Bit-identical to
+    one step per graph, on the first call (eager warm-up, capture) and on the replayed one."""
+    cond = torch.stack([O.synth_cond(c, 150) for c in range(3)])
+    xT = torch.stack([O.synth_xT(c, 450) for c in range(3)])
+    outs = {}
+    for n in ("1", steps):
+        monkeypatch.setenv("TCDIFF_GRAPH_STEPS", n)
+        _, _, d = build(3, 150, 1000, "bf16")
+        first = d.p_sample_loop((3, 450, 151), cond, noise=xT, start_point=263, seed=5)       # 163 two-branch + 100 single-branch steps
+        again = d.p_sample_loop((3, 450, 151), cond, noise=xT, start_point=263, seed=5)
+        assert torch.equal(first, again)
+        outs[n] = first
+    assert torch.equal(outs["1"], outs[steps])
+
+
 def test_weights_written_by_fused_ema_and_adan_are_seen_by_the_next_forward():
     """The fused EMA / Adan kernels write parameters through raw pointers; the packed model-dtype weight copies,
     conditioning caches and captured graphs are keyed by Parameter._version, which those updates must bump

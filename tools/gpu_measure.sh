@@ -18,7 +18,11 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p
 echo "trace rc=$?"
 f=$(find gpurun_out/prof_trace -name "*kernel_stats.csv" | head -1); cp "$f" gpurun_out/${R}_kernel_stats_bench_200steps.csv; head -16 "$f" | cut -c1-160
 rm -rf gpurun_out/prof_trace
-# (roofline.traffic: bench.py runs the FETCH_SIZE / WRITE_SIZE passes itself since round 5; the default run above carries them)
+# config 4 (5 dancers x 300 frames, 4 clips: the 1 500-key two-chunk self-attention inside the launch) under the same trace
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_c4 -- python3 $ARGS --batch 4 --dancers 5 --frames 300 --ddpm-steps 60 > gpurun_out/prof_c4.log 2>&1
+f=$(find gpurun_out/prof_c4 -name "*kernel_stats.csv" | head -1); cp "$f" gpurun_out/${R}_kernel_stats_config4_5x300_b4_60steps.csv; head -8 "$f" | cut -c1-160
+rm -rf gpurun_out/prof_c4
+# (roofline: bench.py runs the kernel-trace / FETCH_SIZE / WRITE_SIZE child passes itself; the default run above carries them)
 SETS="SQ_LDS_BANK_CONFLICT,SQ_LDS_IDX_ACTIVE,SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES,SQ_INSTS_VALU,SQ_INSTS_MFMA,SQ_BUSY_CYCLES" bash tools/gpu_pmc2.sh > /dev/null 2>&1
 cp gpurun_out/pmc2_summary.txt gpurun_out/${R}_pmc_SQ_counters_20steps.txt; head -8 gpurun_out/${R}_pmc_SQ_counters_20steps.txt | cut -c1-250
 if [ -z "$SKIP_TRAIN" ]; then
@@ -39,13 +43,13 @@ for rep in 1 2 3; do for rows in 1 0; do
 done; done > gpurun_out/${R}_train_rows_ab.txt; cat gpurun_out/${R}_train_rows_ab.txt
 fi
 # round 4 additions: in-kernel stamps + shader clock of the fused layer, small-batch modes, pure-load ceiling of the weight stream
-bash tools/ab_build.sh STAMP "-DCH_STAMP" > /dev/null 2>&1
+[ -f tools/probe/libtc_STAMP.so ] || bash tools/ab_build.sh STAMP "-DCH_STAMP" > /dev/null 2>&1
 TCDIFF_LIB_PATH=tools/probe/libtc_STAMP.so timeout 300 python tools/chain_stamps.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_chain_stamps.txt; grep -E "fused layer|last wave|shader clock" gpurun_out/${R}_chain_stamps.txt
 # round 5: the launch with the self-attention inside (blocks cut per sequence: 8 / 256 blocks), its forms against each other, and the sampler with / without it
 SA=1 TCDIFF_LIB_PATH=tools/probe/libtc_STAMP.so timeout 300 python tools/chain_stamps.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_chain_stamps_self_attention.txt; grep -E "fused layer|last wave|shader clock|self-attention" gpurun_out/${R}_chain_stamps_self_attention.txt
 timeout 300 python tools/chain_sa_bench.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_chain_self_attention_forms.txt; cat gpurun_out/${R}_chain_self_attention_forms.txt
 for rep in 1 2; do for f in 0 1; do
-  echo "TCDIFF_FUSE_SA=$f: $(TCDIFF_FUSE_SA=$f timeout 900 python bench.py --steps 120 --warmup 10 --no-pmc --no-kernel-profile --no-parity-mode --no-cpu-baseline --no-train-step --no-other-configs 2>/dev/null | tail -1 | cut -c80-190)"
+  echo "TCDIFF_FUSE_SA=$f: $(TCDIFF_FUSE_SA=$f timeout 900 python bench.py --steps 30 --warmup 4 --no-pmc --no-kernel-profile --no-parity-mode --no-cpu-baseline --no-train-step --no-other-configs 2>/dev/null | tail -1 | cut -c80-190)"
 done; done > gpurun_out/${R}_sampler_self_attention_ab.txt; cat gpurun_out/${R}_sampler_self_attention_ab.txt
 timeout 1200 python tools/small_batch.py 2>&1 | tail -3 > gpurun_out/${R}_small_batch.txt; cat gpurun_out/${R}_small_batch.txt
 python -m pytest tests/test_parity_gpu.py -m gpu -s -q -k "attribution" 2>&1 | grep -E "guided evaluation|  bf16|  f32 parity|passed|failed" >> gpurun_out/${R}_parity_at_benchmarked_config.log
