@@ -169,3 +169,24 @@ def test_kv_fragment_images_compute_the_cross_attention_products():
         for l in range(64):
             c, g = l & 15, l >> 4
             assert np.array_equal(o[l], O[c, 16 * dt + 4 * g:16 * dt + 4 * g + 4])
+
+
+def test_no_inline_asm_vector_instruction_reads_kernel_registers():
+    """Round 6 (profiles/r06_attention_pipeline.txt, section 3): on gfx950 a VALU read of an MFMA result needs software wait states
+    that hipcc's hazard pass inserts for instructions it KNOWS -- an `asm("v_max3_f32 ..")` got none and read stale accumulators as
+    soon as it stood close to the MFMAs.  The kernels may contain scalar / wait / LDS-DMA asm statements (no VGPR results of matrix
+    instructions involved); a vector ALU instruction in an asm string is refused here."""
+    import glob
+    import os
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tcdiff_amd", "csrc")
+    bad = []
+    for f in sorted(glob.glob(os.path.join(root, "*.h")) + glob.glob(os.path.join(root, "*.hip"))):
+        src = open(f).read()
+        for m in re.finditer(r'\basm\s*(?:volatile)?\s*\(\s*((?:"[^"]*"\s*)+)', src):
+            text = "".join(re.findall(r'"([^"]*)"', m.group(1)))
+            if re.search(r"\bv_(?!readfirstlane)", text):           # any VALU / MFMA mnemonic
+                line = src.count("\n", 0, m.start()) + 1
+                if not src.splitlines()[line - 1].lstrip().startswith("//"):
+                    bad.append(f"{os.path.basename(f)}:{line}: {text[:60]}")
+    assert not bad, bad
