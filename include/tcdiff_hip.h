@@ -292,6 +292,19 @@ typedef struct {
 
 int tcdiff_chain(const tcdiff_chain_args* args, hipStream_t stream);
 
+/* The same decoder layer for SMALL jobs (tcdiff_amd/csrc/chain_split.hip; what TCDiff.py renders: a handful of clips,
+ * TCDiff.py:292-303, model/diffusion.py:386-442): FOUR workgroups per 16-row block, each streaming about a third of the layer's
+ * weights, as FOUR launches `part` = 1 .. 4 whose boundaries are the exchanges between the four --
+ *   1: self-attention of two heads per workgroup (sa_q / sa_kf / sa_vf; without sa_q: the rows of `A`), fc split over K -> p_out
+ *   2: sum of p_in; LN, FiLM, +xres -> xout; norm2, rotary; w_qs and cross-attention of two heads; fc split over K   -> p_out
+ *   3: sum of p_in; LN, FiLM, +xres -> xout; norm3; linear1 rows 256 c .., GELU, linear2 over those 256              -> p_out
+ *   4: sum of p_in; FiLM, +xres; norm4; linear3 (+ the folded final layer) -> xout / h_out; norm1, rotary; Q / K / V fragment images
+ * args: as for TC_CHAIN_FULL / TC_CHAIN_FULL_LAST with seq_blocks = 1, nw = 0 / 8, the same 176 / 128-stage `wstream`; the layer's
+ * fragment-order outputs (qf_out / kf_out / vf_out) are mandatory unless LAST.  `xres` -> `xout` is NOT in place (parts 2, 3, 4 read
+ * whole rows and store quarters: the caller alternates two buffers); p_in / p_out: fp32 [blocks][4][16][512] partial sums, two
+ * buffers alternating likewise.  grid = (M / L) * ceil(L / 16) * 4 workgroups: meant for jobs where that fits the chip. */
+int tcdiff_chain_split(const tcdiff_chain_args* args, int part, const float* p_in, float* p_out, hipStream_t stream);
+
 /* Fragment-ordered images of the cross-attention K / V caches for TC_CHAIN_FULL (bf16): for keys key_lo <= key < key_hi
  * of every (slot, head) of Kc / Vc (T[n_slots][H][Lp][64], natural [key][d] rows),
  *   Kf[slot][head][key / 32][(key % 32) / 16][d / 32][16 g + key % 16][jj]  with d % 32 = 16 (jj / 4) + 4 g + jj % 4

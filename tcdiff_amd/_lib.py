@@ -110,6 +110,7 @@ _SIGS = {
     "tcdiff_adan_step": [_vp, _i, C.POINTER(AdanScalars), _vp],
     "tcdiff_pack_kv_frags": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "tcdiff_chain": [C.POINTER(ChainArgs), _vp],
+    "tcdiff_chain_split": [C.POINTER(ChainArgs), _i, _vp, _vp, _vp],
     "tcdiff_ln_rot": [_i, _vp, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "tcdiff_rope_table": [_vp, _vp, _i, _vp],
     "tcdiff_convert_pad": [_i, _vp, _vp, _i, _i, _i, _i, _l, _l, _vp],

@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = [os.path.join(HERE, "csrc", f) for f in ("gemm.hip", "attention.hip", "ops.hip", "chain.hip", "train.hip", "train_ops.hip",
-                                               "attention_train.hip", "gemm_rows.hip")]
+                                               "attention_train.hip", "gemm_rows.hip", "chain_split.hip")]
 HDR = sorted(os.path.join(HERE, "csrc", h) for h in os.listdir(os.path.join(HERE, "csrc")) if h.endswith(".h")) + \
     [os.path.join(ROOT, "include", "tcdiff_hip.h")]
 LIB = os.path.join(HERE, "libtcdiff_gfx950.so")

@@ -567,3 +567,103 @@ DEVINL void store_heads(const f32x4_t (&acc)[NT][MT], void* base, float scale, i
     }
     }
 }
+
+// ---- shared by chain.hip and chain_split.hip: the in-kernel attention's constants and lane maxima, the fragment-order stores ----
+#define CH_LOG2E 1.4426950408889634f
+#ifndef CH_ATT_THR
+#define CH_ATT_THR 5.0f      // in-kernel attention: a tile moves the running maximum when a score exceeds it by more than this (log2 units)
+#endif
+
+// The lane's maximum over its 8 scores of a 32-key tile, not below `floor`.  Four v_max3_f32: written as nested 3-input maxima of
+// fmaximum_num hipcc selects v_max3_f32 with no operand canonicalisation (fmaxf costs one more instruction per value, and the loops
+// below are bound by the number of instructions a wave can issue).  NOT inline assembly (rounds 4-5: `asm("v_max3_f32 ..")`): an MFMA's
+// result may only be read by a VALU instruction a number of wait states after the MFMA, the hardware does not interlock, and the
+// compiler's hazard pass counts them for instructions it knows -- it cannot for an asm statement (it emitted `s_nop 7` in front of a
+// builtin maximum of an accumulator and nothing in front of the asm one).  Round 5's loop read the scores a dozen MFMAs after they were
+// written; a software-pipelined form of the loop whose prologue reads them at once got stale registers -- rows of wrong maxima, NaNs
+// (profiles/r06_attention_pipeline.txt; the pipelined form itself is profiles/r06_attention_pipeline_experiment.patch).
+DEVINL float max3n(float a, float b, float c) { return __builtin_fmaximum_numf(__builtin_fmaximum_numf(a, b), c); }
+DEVINL float lane_max8(const f32x4_t& a, const f32x4_t& b, float floor) {
+    return max3n(max3n(max3n(max3n(a[0], a[1], a[2]), a[3], b[0]), b[1], b[2]), b[3], floor);
+}
+
+// The next layer's Q^T / K / V^T in the order the in-kernel attention loads them, straight from the accumulators (NT = 4: wave =
+// head): every store is a 1-KB piece of one wave instruction.  The block is block `bis` of sequence `seq` (tcdiff_chain_args.seq_blocks).
+// Q: private to the (block, wave) that reads it back in the next launch -- [lblk][wave][mt < 4][d-step s][lane][8], scaled by
+// log2(e) / sqrt(d_k) (the attention works in the exp2 domain).
+template <int MT>
+DEVINL void store_qfrag(const f32x4_t (&acc)[4][MT], void* base, float scale, int lblk, int wave, int lane) {
+    u32x4* dst = reinterpret_cast<u32x4*>(base) + ((long)(lblk * 8 + wave) * 8) * 64 + lane;     // 8 pieces per (block, wave) whatever MT
+    scale *= CH_LOG2E;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const f32x4_t lo = acc[2 * s][mt], hi = acc[2 * s + 1][mt];
+            u32x4 f;
+            f[0] = pack_bf2(lo[0] * scale, lo[1] * scale);
+            f[1] = pack_bf2(lo[2] * scale, lo[3] * scale);
+            f[2] = pack_bf2(hi[0] * scale, hi[1] * scale);
+            f[3] = pack_bf2(hi[2] * scale, hi[3] * scale);
+            dst[(mt * 2 + s) * 64] = f;
+        }
+}
+// K: the 16 keys of row tile mt and d-step s are piece 2 (first_row / 16 + mt) + s of the (sequence, head) image [nkt][4][64 lanes][8]
+// (tcdiff_pack_kv_frags' K order: tile = 32 keys, piece = 2 (key half) + d-step); pieces of tiles >= nkt (rows past the last tile
+// of the sequence: clamped copies) are dropped.
+template <int MT>
+DEVINL void store_kfrag(const f32x4_t (&acc)[4][MT], void* base, int seq, int first_row, int nkt, int wave, int lane) {
+    u32x4* dst = reinterpret_cast<u32x4*>(base) + ((long)(seq * 8 + wave) * nkt) * 256 + lane;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int pc = 2 * ((first_row >> 4) + mt);
+        if ((pc >> 2) < nkt) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const f32x4_t lo = acc[2 * s][mt], hi = acc[2 * s + 1][mt];
+                u32x4 f = {pack_bf2(lo[0], lo[1]), pack_bf2(lo[2], lo[3]), pack_bf2(hi[0], hi[1]), pack_bf2(hi[2], hi[3])};
+                dst[(pc + s) * 64] = f;
+            }
+        }
+    }
+}
+// V: accT = the TRANSPOSED projection tiles (phase_n512<.., SWAP>): lane (c, g) holds keys 16 mt + 4 g + j of feature 16 nt + c,
+// and the pair of row tiles (2 t, 2 t + 1) IS the A operand of O^T += V^T P^T for the 32-key tile (MT / 2) bis + t and d tile nt.
+// first_row: the block's first row within its sequence.  MT = 1 (16-row blocks, or a sequence's last block when it holds <= 16
+// rows): the block owns one half of every lane's 16 bytes -- keys 16 (first_row / 16 & 1) .. + 15 of the tile; a half that lies past
+// the sequence is never written (the caller's image starts zeroed and only ever holds finite values; those keys are masked).
+template <int MT>
+DEVINL void store_vfrag(const f32x4_t (&accT)[4][MT], void* base, int seq, int first_row, int nkt, int Lseq, int wave, int lane) {
+    u32x4* dst = reinterpret_cast<u32x4*>(base) + ((long)(seq * 8 + wave) * nkt) * 256 + lane;
+    if constexpr (MT == 1) {
+        const int kt = first_row >> 5, half = (first_row >> 4) & 1;
+        if (kt < nkt) {
+            // the sequence's last row tile in the FIRST half of its 32-key tile: nobody owns the second half -- those keys are masked,
+            // but a masked P = 0 times a non-finite V is NaN, so the half is written (zeros) rather than left to the allocation
+            const bool tail = half == 0 && first_row + 16 >= Lseq;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const f32x4_t lo = accT[nt][0];
+                uint2 f = {pack_bf2(lo[0], lo[1]), pack_bf2(lo[2], lo[3])};
+                char* d8 = reinterpret_cast<char*>(dst + (kt * 4 + nt) * 64);
+                *reinterpret_cast<uint2*>(d8 + 8 * half) = f;
+                if (tail) *reinterpret_cast<uint2*>(d8 + 8) = uint2{0u, 0u};
+            }
+        }
+        return;
+    }
+    const int bis = first_row / (16 * MT);
+#pragma unroll
+    for (int t = 0; t < MT / 2; ++t) {
+        const int kt = (MT / 2) * bis + t;
+        if (kt < nkt) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const f32x4_t lo = accT[nt][2 * t], hi = accT[nt][2 * t + 1];
+                u32x4 f = {pack_bf2(lo[0], lo[1]), pack_bf2(lo[2], lo[3]), pack_bf2(hi[0], hi[1]), pack_bf2(hi[2], hi[3])};
+                dst[(kt * 4 + nt) * 64] = f;
+            }
+        }
+    }
+}
+

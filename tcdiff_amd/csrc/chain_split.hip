@@ -1,0 +1,494 @@
+// The decoder layer for SMALL jobs (bf16, gfx950): four workgroups per 16-row block, four launches per layer.
+//
+// A row block streams a layer's 5.5 MB of weights through ONE CU's vector-memory port whatever its rows (chain.hip: ~48 us at
+// 115 GB/s), so a job of a few hundred rows -- one clip, what TCDiff.py renders (TCDiff.py:292-303, model/diffusion.py:386-442) --
+// leaves 200 CUs idle while 58 sixteen-row blocks each take ~75 us per layer.  Here FOUR workgroups ("members" c = 0..3, one CU
+// each) share a block and each streams about a third of the weights; the partition ALTERNATES so that only three exchanges per
+// layer cross the CUs, and the exchanges are launch boundaries (no in-kernel hand-off, nothing to hang):
+//
+//   part 1  self-attention of heads 2c, 2c+1 (each head's key tiles over 4 waves, softmax partials merged through LDS)
+//           -> fc over the member's OWN 128 contraction columns (K split)                       -> partial sums P[block][c]
+//   part 2  z = sum_c P; LayerNorm(1e-6), FiLM, +x -> x; norm2, rotary; w_qs for heads 2c, 2c+1 (N split, K over 4 waves);
+//           cross-attention of those heads; fc over the member's 128 columns (K split)          -> P
+//   part 3  z = sum_c P; LN, FiLM, +x -> x; norm3; linear1 rows 256c.. (N split), GELU, linear2 over those 256 (K split)  -> P
+//   part 4  z = sum_c P; FiLM, +x; norm4; linear3 (every member, all of it: 0.5 MB, no exchange) -> x'; norm1', rotary;
+//           w_qs / w_ks / w_vs of heads 2c, 2c+1 -> the next layer's Q / K / V fragment images (chain.hip's formats)
+//
+// (model/model.py:97-107,323-344,374-401 as chain.hip.)  A member streams 0.13 + 0.26 + 0.5 + 0.9 MB instead of 5.5; every
+// member redoes the row-local LayerNorm / FiLM / residual of the 16 rows (nothing) and stores its quarter of x.  The weights are
+// chain.hip's per-wave streams, unchanged: a K split is a stage range of a wave's phase, an N split is the stream of the wave
+// that owns those columns.  Row blocks are cut per sequence as in the fused launch (tcdiff_chain_args.seq_blocks), MT = 1.
+// Results equal the fused launch's up to fp32 summation order (four partial sums instead of one chain of 16 k-steps).
+// The residual stream is NOT updated in place here: every member reads whole rows of x and stores a quarter, so a part reads `xres`
+// and writes `xout`, two different buffers (the caller alternates them: parts 2, 3, 4 each flip).
+#include "common.h"
+#include "tcdiff_hip.h"
+
+#include "chain_core.h"
+
+#define CS_NM 4                        // members per block
+// LDS (the fused kernel's map, 64-row geometry: a 16-row block uses rows 0..15 of every 8-KB k-tile)
+#define CS_RED(w) (CH_ABUF + (w) * 8192 + 2048)      // 4 KB per wave inside the UNUSED rows 16..47 of k-tile w: cross-wave reductions
+
+struct SplitGeo {
+    int lblk, member, bseq, bis, m0, Mend, L, Mtot;
+};
+DEVINL SplitGeo split_geo(const tcdiff_chain_args& a) {
+    SplitGeo g;
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);      // consecutive logical ids share an XCD: a block's four members do
+    g.lblk = logical / CS_NM;
+    g.member = logical % CS_NM;
+    const int nbs = (a.L + 15) / 16;
+    g.bseq = g.lblk / nbs;
+    g.bis = g.lblk - g.bseq * nbs;
+    g.L = a.L;
+    g.Mtot = a.M;
+    g.m0 = g.bseq * a.L + g.bis * 16;
+    g.Mend = (g.bseq + 1) * a.L;                                // first row past the block's sequence: rows beyond recompute row Mend - 1
+    return g;
+}
+DEVINL int my_row(const SplitGeo& g, int c) {
+    const int m = g.m0 + c;
+    return m < g.Mend ? m : g.Mend - 1;
+}
+// column-blocked fp32 [rows][512]: element (row, col) at ((col / 8) * rows + row) * 8 + col % 8
+DEVINL long cb_index(long rows, int row, int col) { return ((long)(col >> 3) * rows + row) * 8 + (col & 7); }
+
+// acc[nt] (columns 64 wave + 16 nt + 4 g .. of row c) <-> the member's partial-sum slab [16 rows][512] fp32
+DEVINL void partial_store(const f32x4_t (&acc)[4][1], float* P, const SplitGeo& g, int wave, int lane) {
+    const int c = lane & 15, gg = lane >> 4;
+    float* dst = P + ((long)(g.lblk * CS_NM + g.member) * 16 + c) * 512 + 64 * wave + 4 * gg;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) *reinterpret_cast<f32x4_t*>(dst + 16 * nt) = acc[nt][0];
+}
+DEVINL void partial_sum(f32x4_t (&acc)[4][1], const float* P, const SplitGeo& g, int wave, int lane) {
+    const int c = lane & 15, gg = lane >> 4;
+    const float* src = P + ((long)(g.lblk * CS_NM) * 16 + c) * 512 + 64 * wave + 4 * gg;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        f32x4_t s = ld4(src + 16 * nt);
+#pragma unroll
+        for (int m = 1; m < CS_NM; ++m) s += ld4(src + (long)m * 16 * 512 + 16 * nt);      // fixed order: deterministic
+        acc[nt][0] = s;
+    }
+}
+
+// a wave's stream positioned at `stage` with the next CH_D stages loaded
+DEVINL void stream_at(WStream& ws, const tcdiff_chain_args& a, int stream_wave, unsigned stage, int lane) {
+    ws.rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(a.wstream)) + (long)stream_wave * a.n_stages * CH_STAGE, 0,
+        a.n_stages * CH_STAGE, 0x00020000);
+    ws.voff = (unsigned)lane * 16u;
+    ws.pos = stage;
+    ws.last = (unsigned)a.n_stages - 1;
+#pragma unroll
+    for (int i = 0; i < CH_D; ++i) ws_load(ws, i, stage + (unsigned)i);
+}
+
+// z (accumulators) -> x_new = x + LN_eps(z) G + Bv (G, Bv: the sequence's pre-folded FiLM row; ln = false: x + z G + Bv), stored by the
+// member that owns the columns; returns with acc = x_new.  Constants come straight from global memory (L2): 16 rows, no staging.
+template <bool LN>
+DEVINL void block_epilogue(f32x4_t (&acc)[4][1], const tcdiff_chain_args& a, const SplitGeo& g, const float* film, float eps,
+                           const float* xin, long xin_rows, int xin_mod, bool xin_rowmajor, float* xout, float* scr, int wave, int lane,
+                           bool store) {
+    float nmr[1] = {0.0f}, rstd[1] = {1.0f};
+    if (LN) row_stats<1, 4>(acc, scr, wave, lane, eps, nmr, rstd);
+    const int c = lane & 15, gg = lane >> 4;
+    const int row = my_row(g, c);
+    const float* fr = film + (long)(row / g.L) * a.film_ld;
+    const int rin = xin_mod > 0 ? row % xin_mod : row;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int col = 64 * wave + 16 * nt + 4 * gg;
+        const f32x4_t G = ld4(fr + col), Bv = ld4(fr + 512 + col);
+        const f32x4_t x4 = xin_rowmajor ? ld4(xin + (long)rin * 512 + col) : ld4(xin + cb_index(xin_rows, rin, col));
+        f32x4_t o;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float u = LN ? fmaf(acc[nt][0][t], rstd[0], nmr[0]) : acc[nt][0][t];
+            o[t] = x4[t] + fmaf(u, G[t], Bv[t]);
+        }
+        acc[nt][0] = o;
+        if (store && xout) *reinterpret_cast<f32x4_t*>(xout + cb_index(g.Mtot, row, col)) = o;
+    }
+}
+
+// LayerNorm(acc) (optionally rotated) -> bf16 activation block in LDS (k-tile = wave); `plain`: the un-rotated image too
+template <bool ROT>
+DEVINL void norm_lds(const f32x4_t (&acc)[4][1], const tcdiff_chain_args& a, const SplitGeo& g, const float* ng, const float* nb,
+                     float eps, float* scr, char* abuf, char* plain, int wave, int lane) {
+    float nmr[1], rstd[1];
+    row_stats<1, 4>(acc, scr, wave, lane, eps, nmr, rstd);
+    const int c = lane & 15, gg = lane >> 4;
+    const int row = my_row(g, c);
+    const int pos = row - (row / g.L) * g.L;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int col = 64 * wave + 16 * nt + 4 * gg;
+        const f32x4_t g4 = ld4(ng + col), b4 = ld4(nb + col);
+        float u[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) u[t] = fmaf(fmaf(acc[nt][0][t], rstd[0], nmr[0]), g4[t], b4[t]);
+        const int wo = wave * 8192 + act_wr_off(lane, nt);
+        if (plain) {
+            uint2 pk = {pack_bf2(u[0], u[1]), pack_bf2(u[2], u[3])};
+            *reinterpret_cast<uint2*>(plain + wo) = pk;
+        }
+        if (ROT) {
+            const f32x4_t q = ld4(a.rope + cb_index(a.rope_rows, pos, col));       // cos0 sin0 cos1 sin1
+            const float y0 = u[0] * q[0] - u[1] * q[1], y1 = u[1] * q[0] + u[0] * q[1];
+            const float y2 = u[2] * q[2] - u[3] * q[3], y3 = u[3] * q[2] + u[2] * q[3];
+            u[0] = y0; u[1] = y1; u[2] = y2; u[3] = y3;
+        }
+        uint2 pk = {pack_bf2(u[0], u[1]), pack_bf2(u[2], u[3])};
+        *reinterpret_cast<uint2*>(abuf + wo) = pk;
+    }
+}
+
+// The 512 x 128 slice of a projection that belongs to head (2 member + wave / 4): the head's 64 output columns, its 16-stage phase
+// `phase0` cut in four k-quarters over the head's four waves (j = wave % 4: stages phase0 + 4 j ..), partial tiles summed through
+// LDS; afterwards EVERY wave of the head holds the full tile.  SWAP: transposed tiles (store_vfrag).  Two barriers.
+template <bool SWAP>
+DEVINL void head_projection(f32x4_t (&acc)[4][1], const tcdiff_chain_args& a, const SplitGeo& g, const char* act, unsigned phase0,
+                            char* smem, int wave, int lane) {
+    const int i = wave >> 2, j = wave & 3;
+    WStream ws;
+    stream_at(ws, a, 2 * g.member + i, phase0 + 4u * j, lane);
+    zero(acc);
+    phase_n512<4, true, 1, 4, SWAP>(acc, act + 2 * j * 8192, ws, lane);
+    f32x4_t* red = reinterpret_cast<f32x4_t*>(smem + CS_RED(wave));
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) red[nt * 64 + lane] = acc[nt][0];
+    lds_barrier();
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        f32x4_t s = reinterpret_cast<const f32x4_t*>(smem + CS_RED(4 * i))[nt * 64 + lane];
+#pragma unroll
+        for (int jj = 1; jj < 4; ++jj) s += reinterpret_cast<const f32x4_t*>(smem + CS_RED(4 * i + jj))[nt * 64 + lane];
+        acc[nt][0] = s;
+    }
+    lds_barrier();      // the reduction area is free again
+}
+
+// softmax(q k^T) v of the block's 16 rows for head (2 member + wave / 4), its 32-key tiles dealt to the head's four waves (tile kt
+// on wave kt % 4), each wave an online softmax as chain.hip's cross_attention (exp2 domain, lazy running maximum, row sums by an
+// all-ones MFMA), the four partial results merged through LDS (flash-decoding: rescale to the common maximum).  O (bf16) -> the
+// member's activation block, k-tile wave / 4.  qf: the head's Q^T fragments (scaled by log2 e / sqrt d_k).  Two barriers.
+DEVINL void head_attention(const u32x4 (&qf)[2], const void* kf, const void* vf, unsigned image_off, int nkt, int Lk, char* smem,
+                           int wave, int lane) {
+    const int i = wave >> 2, j = wave & 3, c = lane & 15, gg = lane >> 4;
+    u32x4 ones = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+    asm volatile("" : "+v"(ones));
+    const unsigned voff = (unsigned)lane * 16u;
+    const __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(kf), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(vf), 0, -1, 0x00020000);
+    auto ld_tile = [&](const __amdgpu_buffer_rsrc_t& r, int kt, u32x4 (&f)[4]) {
+        const unsigned so = image_off + (unsigned)(kt < nkt ? kt : nkt - 1) * 4096u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) f[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff + 1024u * q, so, 0));
+    };
+    f32x4_t o[4], lacc = {0, 0, 0, 0};
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4_t{0, 0, 0, 0};
+    float m_run = -INFINITY, nb = 0.0f;
+    u32x4 kn[4], vn[4];
+    ld_tile(kr, j, kn);
+    ld_tile(vr, j, vn);
+#pragma unroll 1
+    for (int kt = j; kt < nkt; kt += 4) {
+        u32x4 kc[4], vc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            kc[q] = kn[q];
+            vc[q] = vn[q];
+        }
+        ld_tile(kr, kt + 4, kn);            // (past the end: the last tile again, unused)
+        ld_tile(vr, kt + 4, vn);
+        f32x4_t s0 = {nb, nb, nb, nb}, s1 = s0;
+        mma16(s0, kc[0], qf[0]);
+        mma16(s1, kc[2], qf[0]);
+        mma16(s0, kc[1], qf[1]);
+        mma16(s1, kc[3], qf[1]);
+        if (kt * 32 + 32 > Lk) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (kt * 32 + 4 * gg + t >= Lk) s0[t] = -INFINITY;
+                if (kt * 32 + 16 + 4 * gg + t >= Lk) s1[t] = -INFINITY;
+            }
+        }
+        const float lm = lane_max8(s0, s1, -INFINITY);
+        const bool first = kt == j;
+        if (__builtin_amdgcn_ballot_w64(first || lm > CH_ATT_THR) != 0) {
+            const float mx = ar4_max(lm);                                   // relative to -nb
+            // (a wave's first tile may hold masked keys only for some row?  no: a tile has >= 1 valid key and every row sees every key)
+            const float m_new = (first || mx > CH_ATT_THR) ? fmaxf(m_run, mx - nb) : m_run;
+            const float shift = m_new + nb;
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);      // first tile: exp2(-inf) = 0, o and lacc are 0
+            m_run = m_new;
+            nb = -m_new;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                lacc[t] *= alpha;
+                s0[t] -= shift;
+                s1[t] -= shift;
+            }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) o[dt][t] *= alpha;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            s0[t] = __builtin_amdgcn_exp2f(s0[t]);
+            s1[t] = __builtin_amdgcn_exp2f(s1[t]);
+        }
+        const u32x4 pf = {pack_bf2(s0[0], s0[1]), pack_bf2(s0[2], s0[3]), pack_bf2(s1[0], s1[1]), pack_bf2(s1[2], s1[3])};
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) mma16(o[dt], vc[dt], pf);
+        mma16(lacc, ones, pf);
+    }
+    // ---- merge the head's four partial softmaxes: per query (lane c) the maximum m, the sum l, O^T[feature 16 dt + 4 g + t][query c]
+    float* red = reinterpret_cast<float*>(smem + CS_RED(wave));     // [64 features][16 queries] | m[16] at 1024 | l[16] at 1040 (floats)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) red[(16 * dt + 4 * gg + t) * 16 + c] = o[dt][t];
+    if (gg == 0) {
+        red[1024 + c] = m_run;
+        red[1040 + c] = lacc[0];
+    }
+    lds_barrier();
+    float mw[4], M = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        mw[w] = reinterpret_cast<const float*>(smem + CS_RED(4 * i + w))[1024 + c];
+        M = fmaxf(M, mw[w]);
+    }
+    float lsum = 0.0f, ov[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const float* rw = reinterpret_cast<const float*>(smem + CS_RED(4 * i + w));
+        const float sc = mw[w] == -INFINITY ? 0.0f : __builtin_amdgcn_exp2f(mw[w] - M);      // a wave without tiles: weight 0
+        lsum = fmaf(rw[1040 + c], sc, lsum);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) ov[t] = fmaf(rw[(16 * j + 4 * gg + t) * 16 + c], sc, ov[t]);     // this wave finishes d tile j
+    }
+    const float inv = __builtin_amdgcn_rcpf(lsum);
+    lds_barrier();      // every wave has read the partials: the area (and k-tile i's rows 0..15 below) may be rewritten
+    uint2 pk = {pack_bf2(ov[0] * inv, ov[1] * inv), pack_bf2(ov[2] * inv, ov[3] * inv)};
+    *reinterpret_cast<uint2*>(smem + CH_ABUF + i * 8192 + act_wr_off(lane, j)) = pk;
+}
+
+// accumulator tiles of a head's Q^T -> the score MFMA's B operands (chain.hip cross_attention)
+DEVINL void q_fragments(const f32x4_t (&qacc)[4][1], float qs, u32x4 (&qf)[2]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const f32x4_t lo = qacc[2 * s][0], hi = qacc[2 * s + 1][0];
+        qf[s][0] = pack_bf2(lo[0] * qs, lo[1] * qs);
+        qf[s][1] = pack_bf2(lo[2] * qs, lo[3] * qs);
+        qf[s][2] = pack_bf2(hi[0] * qs, hi[1] * qs);
+        qf[s][3] = pack_bf2(hi[2] * qs, hi[3] * qs);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// part 1: self-attention (or the attention output rows of layer 0) -> fc, K split
+// ------------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void chain_split1_kernel(tcdiff_chain_args a, float* p_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const SplitGeo g = split_geo(a);
+    char* abuf = smem + CH_ABUF;
+    WStream ws;
+    stream_at(ws, a, wave, 4u * g.member, lane);          // fc: the member's four k-steps of every wave's 16-stage phase
+    if (a.sa_q) {
+        const int head = 2 * g.member + (wave >> 2);
+        const u32x4* qsrc = reinterpret_cast<const u32x4*>(a.sa_q) + ((long)(g.lblk * 8 + head) * 8) * 64 + lane;
+        const u32x4 qf[2] = {qsrc[0], qsrc[64]};
+        head_attention(qf, a.sa_kf, a.sa_vf, (unsigned)((g.bseq * a.H + head) * a.sa_nkt) * 4096u, a.sa_nkt, a.L, smem, wave, lane);
+    } else if (wave < 2) {
+        // layer 0: O of the stand-alone attention launch, the member's two k-tiles (columns 128 member ..) of the 16 rows
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+            stage_glds<16, 2>(abuf + kt * 8192, reinterpret_cast<const char*>(a.A) + (2 * g.member + kt) * TC_ROWB, 1024, g.m0, g.Mend,
+                              a.a_mod, wave, lane);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    f32x4_t acc[4][1];
+    zero(acc);
+    phase_n512<4, true, 1>(acc, abuf, ws, lane);
+    partial_store(acc, p_out, g, wave, lane);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// part 2: self-attention block tail, cross-attention of the member's heads, fc K split
+// ------------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void chain_split2_kernel(tcdiff_chain_args a, const float* p_in, float* p_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const SplitGeo g = split_geo(a);
+    char* abuf = smem + CH_ABUF;
+    float* scr = reinterpret_cast<float*>(smem + CH_SCR);
+    const bool mine = (wave >> 1) == g.member;            // this member stores columns 128 member .. of x
+    f32x4_t acc[4][1];
+    partial_sum(acc, p_in, g, wave, lane);
+    block_epilogue<true>(acc, a, g, a.film, a.ln_eps, a.xres, a.xres_mod > 0 ? a.xres_mod : a.M, a.xres_mod, a.xres_rowmajor != 0,
+                         a.xout, scr, wave, lane, mine);
+    norm_lds<true>(acc, a, g, a.n2_g, a.n2_b, a.n2_eps, scr + 1024, abuf, nullptr, wave, lane);
+    lds_barrier();
+    // Q = rot(norm2 x) W_q^T of heads 2 member, 2 member + 1 (model/model.py:387,78): stages 16.. of those waves' streams
+    f32x4_t qacc[4][1];
+    head_projection<false>(qacc, a, g, abuf, 16u, smem, wave, lane);
+    u32x4 qf[2];
+    q_fragments(qacc, a.scale_q * CH_LOG2E, qf);
+    const int head = 2 * g.member + (wave >> 2);
+    const int kv = g.bseq < a.n_shared ? 0 : g.bseq - a.n_shared + (a.n_shared > 0 ? 1 : 0);
+    WStream ws;
+    stream_at(ws, a, wave, 32u + 4u * g.member, lane);    // the cross-attention block's fc, in flight under the attention
+    head_attention(qf, a.kf, a.vf, (unsigned)((kv * a.H + head) * a.nkt) * 4096u, a.nkt, a.Lk, smem, wave, lane);
+    lds_barrier();
+    zero(acc);
+    phase_n512<4, true, 1>(acc, abuf, ws, lane);
+    partial_store(acc, p_out, g, wave, lane);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// part 3: cross-attention block tail, feed-forward chunk `member`
+// ------------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void chain_split3_kernel(tcdiff_chain_args a, const float* p_in, float* p_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const SplitGeo g = split_geo(a);
+    char* abuf = smem + CH_ABUF;
+    char* hb = smem + CH_H1C;
+    float* scr = reinterpret_cast<float*>(smem + CH_SCR);
+    const bool mine = (wave >> 1) == g.member;
+    WStream ws;
+    stream_at(ws, a, wave, 48u + 16u * g.member, lane);   // {linear1 chunk, linear2 chunk} of this member: 16 contiguous stages
+    f32x4_t acc[4][1];
+    partial_sum(acc, p_in, g, wave, lane);
+    block_epilogue<true>(acc, a, g, a.filmb, a.ln_eps, a.xres, a.M, 0, false, a.xout, scr, wave, lane, mine);
+    norm_lds<false>(acc, a, g, a.n3_g, a.n3_b, a.n2_eps, scr + 1024, abuf, nullptr, wave, lane);
+    lds_barrier();
+    f32x4_t a1[2][1];
+    a1[0][0] = a1[1][0] = f32x4_t{0, 0, 0, 0};
+    phase_ff1<1>(a1, abuf, ws, lane);
+    {
+        const int gg = lane >> 4;
+        const float* b1 = a.b1 + 256 * g.member + 32 * wave + 4 * gg;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const f32x4_t b4 = ld4(b1 + 16 * nt);
+            const int cc = 32 * wave + 16 * nt;           // chunk column: k-tile cc / 64, 16-byte chunk (cc % 64) / 8 + (g >> 1)
+            float v[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[t] = a1[nt][0][t] + b4[t];
+            act4_ct<ACT_GELU>(v, ACT_GELU);
+            uint2 pk = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+            *reinterpret_cast<uint2*>(hb + (cc >> 6) * 8192 + act_wr_off(lane, 0, (cc & 63) >> 3)) = pk;
+        }
+    }
+    lds_barrier();
+    zero(acc);
+    phase_n512<8, true, 1>(acc, hb, ws, lane);
+    partial_store(acc, p_out, g, wave, lane);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// part 4: feed-forward block tail, linear3, the next layer's Q / K / V of the member's heads
+// ------------------------------------------------------------------------------------------------------------------------------
+template <bool LAST>
+__global__ __launch_bounds__(512) void chain_split4_kernel(tcdiff_chain_args a, const float* p_in) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const SplitGeo g = split_geo(a);
+    char* abuf = smem + CH_ABUF;
+    float* scr = reinterpret_cast<float*>(smem + CH_SCR);
+    const bool mine = (wave >> 1) == g.member;
+    WStream ws;
+    stream_at(ws, a, wave, 112u, lane);                   // linear3: every member computes all of it
+    f32x4_t acc[4][1];
+    partial_sum(acc, p_in, g, wave, lane);
+    block_epilogue<false>(acc, a, g, a.film3, 0.0f, a.xres, a.M, 0, false, nullptr, scr, wave, lane, false);
+    norm_lds<false>(acc, a, g, a.n4_g, a.n4_b, a.n4_eps, scr, abuf, nullptr, wave, lane);
+    lds_barrier();
+    zero(acc);
+    phase_n512<16, true, 1>(acc, abuf, ws, lane);
+    lds_barrier();                                         // every wave is out of linear3: the activation block is rewritten below
+    {
+        const int c = lane & 15, gg = lane >> 4;
+        const int row = my_row(g, c);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int col = 64 * wave + 16 * nt + 4 * gg;
+            acc[nt][0] += ld4(a.b3 + col);
+            if (!mine) continue;
+            if (LAST && a.out_ld > 0) {
+                if (col < a.out_ld) *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(a.h_out) + (long)row * a.out_ld + col) = acc[nt][0];
+            } else if (LAST) {
+                uint2 pk = {pack_bf2(acc[nt][0][0], acc[nt][0][1]), pack_bf2(acc[nt][0][2], acc[nt][0][3])};
+                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.h_out) + (long)row * 512 + col) = pk;
+            } else {
+                *reinterpret_cast<f32x4_t*>(a.xout + cb_index(g.Mtot, row, col)) = acc[nt][0];
+            }
+        }
+    }
+    if (LAST) return;
+    // next layer: norm1 + rotary -> Q, K ; norm1 -> V (model/model.py:326,374-383,78-80), heads 2 member, 2 member + 1
+    norm_lds<true>(acc, a, g, a.nn_g, a.nn_b, a.nn_eps, scr + 1024, abuf, smem + CH_ABUF2, wave, lane);
+    lds_barrier();
+    const int head = 2 * g.member + (wave >> 2);
+    const bool writer = (wave & 3) == 0;                   // one wave per head stores (all four hold the full tiles)
+    f32x4_t t[4][1];
+    head_projection<false>(t, a, g, abuf, 128u, smem, wave, lane);
+    if (writer) store_qfrag<1>(t, a.qf_out, a.scale_q, g.lblk, head, lane);
+    head_projection<false>(t, a, g, abuf, 144u, smem, wave, lane);
+    if (writer) store_kfrag<1>(t, a.kf_out, g.bseq, g.bis * 16, a.out_nkt, head, lane);
+    head_projection<true>(t, a, g, smem + CH_ABUF2, 160u, smem, wave, lane);
+    if (writer) store_vfrag<1>(t, a.vf_out, g.bseq, g.bis * 16, a.out_nkt, a.L, head, lane);
+}
+
+static bool cs_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+extern "C" int tcdiff_chain_split(const tcdiff_chain_args* a, int part, const float* p_in, float* p_out, hipStream_t stream) {
+    if (!a || a->M <= 0 || a->L < 16 || a->M % a->L || !a->wstream || part < 1 || part > 4) return TC_ERR_ARG;
+    if (part > 1 && a->xres == a->xout) return TC_ERR_ARG;          // not in place (see the file header)
+    const bool last = a->mode == TC_CHAIN_FULL_LAST;
+    if (a->mode != TC_CHAIN_FULL && !last) return TC_ERR_UNSUPPORTED;
+    if (a->n_stages != (last ? 128 : 176) || a->H != 8 || a->nw == 4 || !a->seq_blocks) return TC_ERR_ARG;
+    if (!a->film || !a->filmb || !a->film3 || a->film_ld % 4 || !a->xres || !a->xout || !a->n2_g || !a->n2_b || !a->n3_g || !a->n3_b ||
+        !a->n4_g || !a->n4_b || !a->b1 || !a->b3 || !a->rope || a->rope_rows < a->L || !a->kf || !a->vf || a->nkt <= 0 || a->Lk <= 0 ||
+        a->Lk > 32 * a->nkt || a->n_shared < 0)
+        return TC_ERR_ARG;
+    if (a->sa_q ? (!a->sa_kf || !a->sa_vf || a->sa_nkt <= 0 || a->L > 32 * a->sa_nkt) : !a->A) return TC_ERR_ARG;
+    if (last ? !a->h_out || a->out_ld < 0 || a->out_ld % 4 || a->out_ld > 512
+             : (!a->qf_out || !a->kf_out || !a->vf_out || !a->nn_g || !a->nn_b || a->out_nkt <= 0 || a->L > 32 * a->out_nkt))
+        return TC_ERR_ARG;
+    if ((part > 1 && !p_in) || (part < 4 && !p_out)) return TC_ERR_ARG;
+    const void* ptrs[] = {a->A, a->wstream, a->film, a->filmb, a->film3, a->xres, a->xout, a->n2_g, a->n2_b, a->n3_g, a->n3_b, a->n4_g,
+                          a->n4_b, a->b1, a->b3, a->nn_g, a->nn_b, a->rope, a->kf, a->vf, a->sa_q, a->sa_kf, a->sa_vf, a->qf_out,
+                          a->kf_out, a->vf_out, a->h_out, p_in, p_out};
+    for (const void* p : ptrs)
+        if (p && !cs_al16(p)) return TC_ERR_ALIGN;
+    static tc_dev_state dev_state;
+    const int n_cu = tc_device_once(dev_state, [](int) {
+        const void* fns[5] = {reinterpret_cast<const void*>(chain_split1_kernel), reinterpret_cast<const void*>(chain_split2_kernel),
+                              reinterpret_cast<const void*>(chain_split3_kernel), reinterpret_cast<const void*>(chain_split4_kernel<false>),
+                              reinterpret_cast<const void*>(chain_split4_kernel<true>)};
+        for (const void* f : fns) {
+            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, CH_SMEM);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    });
+    if (n_cu < 0) return n_cu;
+    const dim3 grid((unsigned)((a->M / a->L) * ((a->L + 15) / 16) * CS_NM)), blk(512);
+    if (part == 1) hipLaunchKernelGGL(chain_split1_kernel, grid, blk, CH_SMEM, stream, *a, p_out);
+    else if (part == 2) hipLaunchKernelGGL(chain_split2_kernel, grid, blk, CH_SMEM, stream, *a, p_in, p_out);
+    else if (part == 3) hipLaunchKernelGGL(chain_split3_kernel, grid, blk, CH_SMEM, stream, *a, p_in, p_out);
+    else if (last) hipLaunchKernelGGL(chain_split4_kernel<true>, grid, blk, CH_SMEM, stream, *a, p_in);
+    else hipLaunchKernelGGL(chain_split4_kernel<false>, grid, blk, CH_SMEM, stream, *a, p_in);
+    TC_CHECK_LAUNCH();
+    return TC_OK;
+}

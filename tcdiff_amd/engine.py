@@ -57,6 +57,7 @@ class DenoiserEngine:
         self.film_tab = None
         self._sampler_state = None
         self._side, self._forked = None, False     # forked stream of the step prologue's conditioning part (step_prologue)
+        self._xcur = 0                             # small-job layers (chain_split): which of b["xa"], b["xb"] holds the residual stream
         # row-block chain kernels (csrc/chain.hip): bf16 only; the f32 parity mode keeps the op-by-op kernels
         self.act = int(cfg.get("act", L.ACT_GELU))    # feed-forward activation (TC_ACT_*); the chain kernels are GELU only
         # use_rotary=False (model/model.py:441-448,564,580): identity rotary table + PositionalEncoding rows added to the motion and
@@ -334,6 +335,10 @@ class DenoiserEngine:
             # masked, but P = 0 times NaN is NaN).  The chain launch writes every slot it owns (clamped copies of the last row) and
             # zeros the one half-tile nobody owns (store_vfrag, MT = 1); the zero-fill here covers images no launch has written yet.
             b["sKf"], b["sVf"] = z(2, 2 * B, H, self.skt * 2048), z(2, 2 * B, H, self.skt * 2048)
+            if self._split_rows(2 * B, Lq):          # small jobs: second residual buffer, two partial-sum slabs (chain_split.hip)
+                nblk = 2 * B * ((Lq + 15) // 16)
+                b["xb"] = z(R, 512, dtype=torch.float32)
+                b["P0"], b["P1"] = z(nblk, 4, 16, 512, dtype=torch.float32), z(nblk, 4, 16, 512, dtype=torch.float32)
         b["hidden_all"] = z(2 * B, 512, dtype=torch.float32)
         b["tidx"] = torch.zeros(2 * B, device=dev, dtype=torch.int32)
         # music encoder (setup only)
@@ -624,6 +629,12 @@ class DenoiserEngine:
         K.gemm_tile(dt, b["h"], w["fin.w"], R, self.nf, 512, bias=w["fin.b"], mode=L.EPI_STORE_F32, out=b["out"], ldc=152)
         return b["out"]
 
+    def _split_rows(self, nseq: int, Lq: int) -> bool:
+        """the small-job form of the layer (four workgroups per 16-row block): when all of them fit the chip at once"""
+        if os.environ.get("TCDIFF_SPLIT", "1") == "0" or self.chain_nw != 8 or Lq < 16:
+            return False
+        return 4 * nseq * ((Lq + 15) // 16) <= self.n_cu
+
     def _layer_chained(self, l: int, B: int, branches: int, Kc0, Vc0, film0, fld: int, n_shared: int, kv_slot0: int):
         """One decoder layer as attention / chain A / attention / chain B (csrc/chain.hip): the Q, K, V images of
         this layer's self-attention were written by the previous layer's chain B (layer 0: by the QKV GEMM below)."""
@@ -661,6 +672,28 @@ class DenoiserEngine:
                     film=film0[:, (l * 3 + 0) * 1024:], film_ld=fld, xres=b["xs"] if l == 0 else b["xa"],
                     xres_mod=Rs if l == 0 else 0, xres_rowmajor=l == 0 and not self.front, xout=b["xa"], n2_g=w[p + "norm2.g"],
                     n2_b=w[p + "norm2.b"], n2_eps=1e-5, rope=rope)     # b["xa"] is COLUMN-BLOCKED on this path
+        if self.use_full and fused and "xb" in b and self._split_rows(nseq, Lq):
+            # SMALL jobs (csrc/chain_split.hip): four workgroups per 16-row block, four launches per layer; the residual stream
+            # alternates between b["xa"] and b["xb"] (a part reads whole rows and stores quarters), the partial sums between two slabs
+            full = dict(filmb=film0[:, (l * 3 + 1) * 1024:], n3_g=w[p + "norm3.g"], n3_b=w[p + "norm3.b"], kf=b["Kf"][l, kv_slot0:],
+                        vf=b["Vf"][l, kv_slot0:], n_shared=n_shared, nkt=self.nkt, Lk=S + 2)
+            args = {**head, **tail, **full}
+            args["mt"] = 1
+            mode = L.CHAIN_FULL_LAST if last else L.CHAIN_FULL
+            X, P = (b["xa"], b["xb"]), (b["P0"], b["P1"])
+            cur = self._xcur                           # X[cur] holds this layer's input x (layer 0 reads b["xs"] instead)
+            o1 = 0 if l == 0 else cur ^ 1
+            launch = lambda part, **kw: K.chain(mode, R, Lq, b["O"], w[p + "chainF"], split_part=part, **{**args, **kw})
+            launch(1, p_out=P[0])
+            if l == 0:
+                launch(2, p_in=P[0], p_out=P[1], xout=X[o1])                                   # xres = b["xs"] (head)
+            else:
+                launch(2, p_in=P[0], p_out=P[1], xres=X[cur], xout=X[o1])
+            flat = dict(xres_mod=0, xres_rowmajor=False)
+            launch(3, p_in=P[1], p_out=P[0], xres=X[o1], xout=X[o1 ^ 1], **flat)
+            launch(4, p_in=P[0], xres=X[o1 ^ 1], xout=X[o1], **flat)
+            self._xcur = o1
+            return
         if self.use_full:
             # self-attention tail, cross-attention (K / V from the fragment-ordered caches) and feed-forward in ONE launch
             K.chain(L.CHAIN_FULL_LAST if last else L.CHAIN_FULL, R, Lq, b["O"], w[p + "chainF"],

@@ -1,0 +1,103 @@
+"""The small-job form of the decoder layer (csrc/chain_split.hip, tcdiff_chain_split): four workgroups per 16-row block, four
+launches per layer -- self-attention of two heads per workgroup with the keys dealt to four waves, fc / linear2 split over the
+contraction, w_qs / linear1 / Q, K, V split over the output columns -- against the ONE fused launch it replaces on small jobs
+(TC_CHAIN_FULL at 16-row blocks, which tests/test_chain_gpu.py, test_chain_selfatt_gpu.py and the parity goldens hold to the
+reference).  Same weights stream, same fragment images in and out; the arithmetic differs in fp32 summation order only (four
+partial sums per product, four partial softmaxes per head)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tcdiff_amd import _lib as L  # noqa: E402
+from tcdiff_amd import kernels as K  # noqa: E402
+from test_chain_selfatt_gpu import DEV, Layer, bf, rnd  # noqa: E402
+
+
+def run_layers(Lq, nseq, split, qk_gain=1.0, Lk=62):
+    H = 8
+    M = nseq * Lq
+    Lp = K.round_up(Lq, 128)
+    Lpc, nkt = K.round_up(Lk, 128), (Lk + 31) // 32
+    n_kv = nseq
+    l0, l1, l2 = Layer(100, nseq, False, qk_gain), Layer(200, nseq, False), Layer(300, nseq, True)
+    Oa = rnd(M, 512, seed=51, scale=0.5).to(bf)
+    xres = rnd(M, 512, seed=94)
+    rope = torch.empty(Lq, 512, device=DEV)
+    K.rope_table((1.0 / (10000 ** (torch.arange(0, 512, 2).float() / 512))).to(DEV), rope, Lq)
+    rope = K.to_cb(rope)
+    z = lambda *s, dtype=bf: torch.zeros(*s, device=DEV, dtype=dtype)
+    Kc, Vc = z(n_kv, H, Lpc, 64), z(n_kv, H, Lpc, 64)
+    Kc[:, :, :Lk] = rnd(n_kv, H, Lk, 64, seed=95).to(bf)
+    Vc[:, :, :Lk] = rnd(n_kv, H, Lk, 64, seed=96).to(bf)
+    Kf, Vf = z(n_kv, H, nkt * 2048), z(n_kv, H, nkt * 2048)
+    K.pack_kv_frags(Kc, Vc, Kf, Vf, n_kv, H, Lpc, nkt, 0, Lk)
+    xatt = dict(kf=Kf, vf=Vf, n_shared=1, nkt=nkt, Lk=Lk, rope=rope, Lp=Lp, mt=1, seq_blocks=True)
+    nbs, skt = (Lq + 15) // 16, (Lq + 31) // 32
+    X = [K.to_cb(xres), torch.zeros(64, M, 8, device=DEV)]
+    P = [torch.zeros(nseq * nbs, 4, 16, 512, device=DEV) for _ in range(2)]
+    qf = [z(nseq * nbs, 8, 4, 2, 64, 8) for _ in range(2)]
+    skf = [torch.full((nseq, H, skt * 2048), float("nan"), device=DEV, dtype=bf) for _ in range(2)]
+    svf = [torch.full((nseq, H, skt * 2048), float("nan"), device=DEV, dtype=bf) for _ in range(2)]
+    h = torch.zeros(M, 512, device=DEV, dtype=bf)
+    outs = {}
+    cur = 0
+    for li, lay in enumerate((l0, l1, l2)):
+        last = li == 2
+        kw = dict(lay.kw, **xatt)
+        if li > 0:
+            kw.update(sa_q=qf[(li - 1) & 1], sa_kf=skf[(li - 1) & 1], sa_vf=svf[(li - 1) & 1], sa_nkt=skt)
+        if last:
+            kw.update(h_out=h)
+        else:
+            kw.update(qf_out=qf[li & 1], kf_out=skf[li & 1], vf_out=svf[li & 1], out_nkt=skt)
+        if not split:
+            K.chain(lay.mode, M, Lq, Oa, lay.ws, xres=X[cur], xout=X[cur], **kw)
+        else:
+            o1 = cur ^ 1
+            K.chain(lay.mode, M, Lq, Oa, lay.ws, split_part=1, p_out=P[0], xres=X[cur], xout=X[o1], **kw)
+            K.chain(lay.mode, M, Lq, Oa, lay.ws, split_part=2, p_in=P[0], p_out=P[1], xres=X[cur], xout=X[o1], **kw)
+            K.chain(lay.mode, M, Lq, Oa, lay.ws, split_part=3, p_in=P[1], p_out=P[0], xres=X[o1], xout=X[cur], **kw)
+            K.chain(lay.mode, M, Lq, Oa, lay.ws, split_part=4, p_in=P[0], xres=X[cur], xout=X[o1], **kw)
+            cur = o1
+        if not last:
+            outs[f"x{li}"] = K.from_cb(X[cur], M).clone()
+            outs[f"q{li}"], outs[f"k{li}"], outs[f"v{li}"] = qf[li & 1].clone(), skf[li & 1].clone(), svf[li & 1].clone()
+    torch.cuda.synchronize()
+    outs["h"] = h.float().clone()
+    return outs
+
+
+# 450 = 28 x 16 + 2 (a last block of 2 rows), 120 / 150: the small configurations (C1: 2 x 60; 3 x 150 = 450 per clip); 62 / 152 keys:
+# the cross-attention memories of those configurations (2 / 5 key tiles: heads whose four waves do not all get a tile)
+@pytest.mark.parametrize("Lq,nseq,Lk,gain", [(120, 2, 62, 1.0), (450, 2, 152, 1.0), (150, 3, 62, 1.0), (137, 2, 152, 1.0), (450, 1, 152, 4.0)])
+def test_split_layers_equal_the_fused_launch(Lq, nseq, Lk, gain):
+    """Three consecutive layers (the first reads attention-output rows, the others compute their self-attention from the fragments
+    the layer before left; the last is the folded *_LAST form) through tcdiff_chain_split's four parts and through the fused
+    launch: residual stream, Q / K / V fragment images and the final rows."""
+    a, b = run_layers(Lq, nseq, False, gain, Lk), run_layers(Lq, nseq, True, gain, Lk)
+    for k in a:
+        x, y = a[k].float(), b[k].float()
+        ok = ~(x.isnan() & y.isnan())            # fragment slots nobody owns stay as the poison they were allocated with in both
+        assert bool((x.isnan() == y.isnan()).all()), k
+        d = (x[ok] - y[ok]).abs()
+        print(f"L={Lq} n={nseq} Lk={Lk} gain={gain} {k}: max diff {float(d.max()):.2e} mean {float(d.mean()):.2e} (max |.| {float(x[ok].abs().max()):.2f})")
+        assert torch.isfinite(y[ok]).all(), k
+        # the two forms round the same fp32 values to bf16 operands at every stage: isolated one-ulp flips, amplified by the layers behind
+        big = gain > 1.0
+        assert float(d.mean()) < (6e-3 if big else 2.5e-3) and float(d.max()) < (0.5 if big else 0.12), (k, float(d.max()), float(d.mean()))
+
+
+def test_launcher_refuses_in_place_and_missing_buffers():
+    lay = Layer(7, 1, False)
+    z = lambda *s, dtype=bf: torch.zeros(*s, device=DEV, dtype=dtype)
+    x = torch.zeros(64, 64, 8, device=DEV)
+    rope = torch.zeros(64, 64, 8, device=DEV)
+    P = torch.zeros(4, 4, 16, 512, device=DEV)
+    kf = z(1, 8, 2 * 2048)
+    kw = dict(lay.kw, kf=kf, vf=kf, n_shared=1, nkt=2, Lk=62, rope=rope, Lp=128, mt=1, seq_blocks=True, qf_out=z(4, 8, 4, 2, 64, 8),
+              kf_out=z(1, 8, 2 * 2048), vf_out=z(1, 8, 2 * 2048), out_nkt=2)
+    with pytest.raises(L.TcdiffError):            # parts 2-4 are not in place
+        K.chain(lay.mode, 64, 64, z(64, 512), lay.ws, split_part=2, p_in=P, p_out=P, xres=x, xout=x, **kw)
+    with pytest.raises(L.TcdiffError):            # a part that reads partial sums needs them
+        K.chain(lay.mode, 64, 64, z(64, 512), lay.ws, split_part=3, p_out=P, xres=x, xout=torch.zeros_like(x), **kw)

@@ -13,8 +13,9 @@ a = types.SimpleNamespace(dtype="bf16")
 out = bench.other_configs(a, torch.device("cuda", 0))
 print("RESULT " + json.dumps({k: [v["value"], v["ms_per_step"]] for k, v in out.items() if "config4" not in k}))
 '''
-for mode in sys.argv[1:] or ["2", "1", "0"]:
-    env = dict(os.environ, TC_ROOT=ROOT, TCDIFF_CHAIN=mode)
+# "2s": the fused mode with the small-job form of the layer switched off (TCDIFF_SPLIT=0: one workgroup per 16-row block, round 5)
+for mode in sys.argv[1:] or ["2", "2s", "1", "0"]:
+    env = dict(os.environ, TC_ROOT=ROOT, TCDIFF_CHAIN=mode[0], TCDIFF_SPLIT="0" if mode.endswith("s") else "1")
     r = subprocess.run([sys.executable, "-c", CODE], env=env, capture_output=True, text=True, timeout=1200)
     line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
-    print(f"TCDIFF_CHAIN={mode}:", line[-1][7:] if line else r.stderr[-800:])
+    print(f"TCDIFF_CHAIN={mode[0]} TCDIFF_SPLIT={env['TCDIFF_SPLIT']}:", line[-1][7:] if line else r.stderr[-800:])
