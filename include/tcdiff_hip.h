@@ -302,7 +302,14 @@ int tcdiff_chain(const tcdiff_chain_args* args, hipStream_t stream);
  * args: as for TC_CHAIN_FULL / TC_CHAIN_FULL_LAST with seq_blocks = 1, nw = 0 / 8, the same 176 / 128-stage `wstream`; the layer's
  * fragment-order outputs (qf_out / kf_out / vf_out) are mandatory unless LAST.  `xres` -> `xout` is NOT in place (parts 2, 3, 4 read
  * whole rows and store quarters: the caller alternates two buffers); p_in / p_out: fp32 [blocks][4][16][512] partial sums, two
- * buffers alternating likewise.  grid = (M / L) * ceil(L / 16) * 4 workgroups: meant for jobs where that fits the chip. */
+ * buffers alternating likewise.  grid = (M / L) * ceil(L / 16) * 4 workgroups: meant for jobs where that fits the chip.
+ * part 1 with sa_q and a_mod > 0: sequence s reads the fragment images of sequence s % (a_mod / L) (layer 0 under classifier-free
+ * guidance: the stacked branches share x).
+ * part = 0 (mode TC_CHAIN_FRONT, the 80-stage front stream of any dancer): layer 0's Q / K / V fragment images from the token
+ * rows the fusion projection left -- xres: ROW-MAJOR fp32 [M][512] (model/model.py:561 as one [frames][512 dn] product, which is
+ * the same memory); nn_g / nn_b / nn_eps: layer 0's norm1; rope; qf_out / kf_out / vf_out / out_nkt; scale_q.  With it a small job
+ * runs the fusion projection as plain small products (tcdiff_gemm_tile picks its small-M kernel) and layer 0's self-attention
+ * inside part 1, instead of the TC_CHAIN_FRONT launch (9 workgroups for one 3 x 150 clip) and a stand-alone attention. */
 int tcdiff_chain_split(const tcdiff_chain_args* args, int part, const float* p_in, float* p_out, hipStream_t stream);
 
 /* Fragment-ordered images of the cross-attention K / V caches for TC_CHAIN_FULL (bf16): for keys key_lo <= key < key_hi

@@ -30,6 +30,16 @@
 // LDS (the fused kernel's map, 64-row geometry: a 16-row block uses rows 0..15 of every 8-KB k-tile)
 #define CS_RED(w) (CH_ABUF + (w) * 8192 + 2048)      // 4 KB per wave inside the UNUSED rows 16..47 of k-tile w: cross-wave reductions
 
+#ifdef CS_STAMP   // diagnostic build: s_memrealtime (100 MHz) of every wave of block 0 / member CS_STAMP_MEMBER at the marked points, into h_out
+#ifndef CS_STAMP_MEMBER
+#define CS_STAMP_MEMBER 0
+#endif
+#define CS_T(part, i) do { if (g.lblk == 0 && g.member == CS_STAMP_MEMBER && (threadIdx.x & 63) == 0 && a.h_out) \
+        reinterpret_cast<unsigned long long*>(a.h_out)[((part) - 1) * 128 + (threadIdx.x >> 6) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define CS_T(part, i) do { } while (0)
+#endif
+
 struct SplitGeo {
     int lblk, member, bseq, bis, m0, Mend, L, Mtot;
 };
@@ -85,28 +95,77 @@ DEVINL void stream_at(WStream& ws, const tcdiff_chain_args& a, int stream_wave, 
     for (int i = 0; i < CH_D; ++i) ws_load(ws, i, stage + (unsigned)i);
 }
 
-// z (accumulators) -> x_new = x + LN_eps(z) G + Bv (G, Bv: the sequence's pre-folded FiLM row; ln = false: x + z G + Bv), stored by the
-// member that owns the columns; returns with acc = x_new.  Constants come straight from global memory (L2): 16 rows, no staging.
-template <bool LN>
-DEVINL void block_epilogue(f32x4_t (&acc)[4][1], const tcdiff_chain_args& a, const SplitGeo& g, const float* film, float eps,
-                           const float* xin, long xin_rows, int xin_mod, bool xin_rowmajor, float* xout, float* scr, int wave, int lane,
-                           bool store) {
-    float nmr[1] = {0.0f}, rstd[1] = {1.0f};
-    if (LN) row_stats<1, 4>(acc, scr, wave, lane, eps, nmr, rstd);
+// These kernels are chains of short dependent steps, so every global load whose address does not depend on an earlier step is ISSUED
+// AT THE TOP of the kernel (FiLM rows, residual rows, norm weights, rotary rows, biases, the weight-stream rings of the later phases)
+// and used where it is needed: a 16-row block has the registers for it, and one exposed L2 round trip is ~1.5 us of a ~10-us kernel.
+// Vectors indexed by the column only (FiLM rows -- a block lies in one sequence --, LayerNorm weights, biases) would cost a full
+// 1-KB wave load per 16 bytes a lane needs (lanes that differ in the row ask for the same address, and the address unit is paid per
+// lane): lanes 0..15 of a wave fetch the wave's 64 columns once (256 B), park them in the wave's own LDS slot and every lane reads
+// its chunk back.  No barrier: a wave reads what it wrote.  Slots: the FiLM / vector area the fused launch stages to (CH_FILM, CH_VEC).
+DEVINL f32x4_t col_fetch(const float* vec, int wave, int lane) {
+    f32x4_t v = {0, 0, 0, 0};
+    if (lane < 16) v = ld4(vec + 64 * wave + 4 * lane);
+    return v;
+}
+DEVINL void col_park(char* smem, int slot, f32x4_t v, int wave, int lane) {
+    if (lane < 16) *reinterpret_cast<f32x4_t*>(smem + slot * 2048 + wave * 256 + lane * 16) = v;
+}
+DEVINL f32x4_t col_get(const char* smem, int slot, int wave, int nt, int gg) {
+    return *reinterpret_cast<const f32x4_t*>(smem + slot * 2048 + wave * 256 + (4 * nt + gg) * 16);
+}
+
+struct RowC { f32x4_t G, Bv, x[4]; };             // the block's FiLM row (pre-folded; column chunks) and the residual rows
+DEVINL RowC row_consts(const tcdiff_chain_args& a, const SplitGeo& g, const float* film, const float* xin, long xin_rows, int xin_mod,
+                       bool xin_rowmajor, int wave, int lane) {
+    RowC r;
     const int c = lane & 15, gg = lane >> 4;
     const int row = my_row(g, c);
-    const float* fr = film + (long)(row / g.L) * a.film_ld;
+    const float* fr = film + (long)g.bseq * a.film_ld;
     const int rin = xin_mod > 0 ? row % xin_mod : row;
+    r.G = col_fetch(fr, wave, lane);
+    r.Bv = col_fetch(fr + 512, wave, lane);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
         const int col = 64 * wave + 16 * nt + 4 * gg;
-        const f32x4_t G = ld4(fr + col), Bv = ld4(fr + 512 + col);
-        const f32x4_t x4 = xin_rowmajor ? ld4(xin + (long)rin * 512 + col) : ld4(xin + cb_index(xin_rows, rin, col));
+        r.x[nt] = xin_rowmajor ? ld4(xin + (long)rin * 512 + col) : ld4(xin + cb_index(xin_rows, rin, col));
+    }
+    return r;
+}
+struct NormC { f32x4_t g, b, r[4]; };             // a LayerNorm's weights (column chunks) and (ROT) the rows' rotary table entries
+template <bool ROT>
+DEVINL NormC norm_consts(const tcdiff_chain_args& a, const SplitGeo& g, const float* ng, const float* nb, int wave, int lane) {
+    NormC n;
+    const int c = lane & 15, gg = lane >> 4;
+    const int row = my_row(g, c);
+    const int pos = row - (row / g.L) * g.L;
+    n.g = col_fetch(ng, wave, lane);
+    n.b = col_fetch(nb, wave, lane);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+        n.r[nt] = ROT ? ld4(a.rope + cb_index(a.rope_rows, pos, 64 * wave + 16 * nt + 4 * gg)) : f32x4_t{1, 0, 1, 0};       // cos0 sin0 cos1 sin1
+    return n;
+}
+
+// z (accumulators) -> x_new = x + LN_eps(z) G + Bv (LN = false: x + z G + Bv), stored by the member that owns the columns;
+// returns with acc = x_new
+template <bool LN>
+DEVINL void block_epilogue(f32x4_t (&acc)[4][1], const RowC& rc, const SplitGeo& g, float eps, float* xout, float* scr, char* smem,
+                           int wave, int lane, bool store) {
+    float nmr[1] = {0.0f}, rstd[1] = {1.0f};
+    col_park(smem, 0, rc.G, wave, lane);
+    col_park(smem, 1, rc.Bv, wave, lane);
+    if (LN) row_stats<1, 4>(acc, scr, wave, lane, eps, nmr, rstd);
+    const int c = lane & 15, gg = lane >> 4;
+    const int row = my_row(g, c);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int col = 64 * wave + 16 * nt + 4 * gg;
+        const f32x4_t G = col_get(smem, 0, wave, nt, gg), Bv = col_get(smem, 1, wave, nt, gg);
         f32x4_t o;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const float u = LN ? fmaf(acc[nt][0][t], rstd[0], nmr[0]) : acc[nt][0][t];
-            o[t] = x4[t] + fmaf(u, G[t], Bv[t]);
+            o[t] = rc.x[nt][t] + fmaf(u, G[t], Bv[t]);
         }
         acc[nt][0] = o;
         if (store && xout) *reinterpret_cast<f32x4_t*>(xout + cb_index(g.Mtot, row, col)) = o;
@@ -115,27 +174,26 @@ DEVINL void block_epilogue(f32x4_t (&acc)[4][1], const tcdiff_chain_args& a, con
 
 // LayerNorm(acc) (optionally rotated) -> bf16 activation block in LDS (k-tile = wave); `plain`: the un-rotated image too
 template <bool ROT>
-DEVINL void norm_lds(const f32x4_t (&acc)[4][1], const tcdiff_chain_args& a, const SplitGeo& g, const float* ng, const float* nb,
-                     float eps, float* scr, char* abuf, char* plain, int wave, int lane) {
+DEVINL void norm_lds(const f32x4_t (&acc)[4][1], const NormC& nc, float eps, float* scr, char* smem, char* abuf, char* plain, int wave,
+                     int lane) {
     float nmr[1], rstd[1];
+    col_park(smem, 2, nc.g, wave, lane);
+    col_park(smem, 3, nc.b, wave, lane);
     row_stats<1, 4>(acc, scr, wave, lane, eps, nmr, rstd);
-    const int c = lane & 15, gg = lane >> 4;
-    const int row = my_row(g, c);
-    const int pos = row - (row / g.L) * g.L;
+    const int gg = lane >> 4;
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
-        const int col = 64 * wave + 16 * nt + 4 * gg;
-        const f32x4_t g4 = ld4(ng + col), b4 = ld4(nb + col);
+        const f32x4_t wg = col_get(smem, 2, wave, nt, gg), wb = col_get(smem, 3, wave, nt, gg);
         float u[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) u[t] = fmaf(fmaf(acc[nt][0][t], rstd[0], nmr[0]), g4[t], b4[t]);
+        for (int t = 0; t < 4; ++t) u[t] = fmaf(fmaf(acc[nt][0][t], rstd[0], nmr[0]), wg[t], wb[t]);
         const int wo = wave * 8192 + act_wr_off(lane, nt);
         if (plain) {
             uint2 pk = {pack_bf2(u[0], u[1]), pack_bf2(u[2], u[3])};
             *reinterpret_cast<uint2*>(plain + wo) = pk;
         }
         if (ROT) {
-            const f32x4_t q = ld4(a.rope + cb_index(a.rope_rows, pos, col));       // cos0 sin0 cos1 sin1
+            const f32x4_t q = nc.r[nt];
             const float y0 = u[0] * q[0] - u[1] * q[1], y1 = u[1] * q[0] + u[0] * q[1];
             const float y2 = u[2] * q[2] - u[3] * q[3], y3 = u[3] * q[2] + u[2] * q[3];
             u[0] = y0; u[1] = y1; u[2] = y2; u[3] = y3;
@@ -146,14 +204,15 @@ DEVINL void norm_lds(const f32x4_t (&acc)[4][1], const tcdiff_chain_args& a, con
 }
 
 // The 512 x 128 slice of a projection that belongs to head (2 member + wave / 4): the head's 64 output columns, its 16-stage phase
-// `phase0` cut in four k-quarters over the head's four waves (j = wave % 4: stages phase0 + 4 j ..), partial tiles summed through
-// LDS; afterwards EVERY wave of the head holds the full tile.  SWAP: transposed tiles (store_vfrag).  Two barriers.
+// `phase0` cut in four k-quarters over the head's four waves (j = wave % 4: stages phase0 + 4 j .., issued by head_stream -- early),
+// partial tiles summed through LDS; afterwards EVERY wave of the head holds the full tile.  SWAP: transposed tiles (store_vfrag).
+// Two barriers.
+DEVINL void head_stream(WStream& ws, const tcdiff_chain_args& a, const SplitGeo& g, unsigned phase0, int wave, int lane) {
+    stream_at(ws, a, 2 * g.member + (wave >> 2), phase0 + 4u * (wave & 3), lane);
+}
 template <bool SWAP>
-DEVINL void head_projection(f32x4_t (&acc)[4][1], const tcdiff_chain_args& a, const SplitGeo& g, const char* act, unsigned phase0,
-                            char* smem, int wave, int lane) {
+DEVINL void head_projection(f32x4_t (&acc)[4][1], WStream& ws, const char* act, char* smem, int wave, int lane) {
     const int i = wave >> 2, j = wave & 3;
-    WStream ws;
-    stream_at(ws, a, 2 * g.member + i, phase0 + 4u * j, lane);
     zero(acc);
     phase_n512<4, true, 1, 4, SWAP>(acc, act + 2 * j * 8192, ws, lane);
     f32x4_t* red = reinterpret_cast<f32x4_t*>(smem + CS_RED(wave));
@@ -170,30 +229,72 @@ DEVINL void head_projection(f32x4_t (&acc)[4][1], const tcdiff_chain_args& a, co
     lds_barrier();      // the reduction area is free again
 }
 
+// Two projections of the same activation block (the next layer's Q and K) with ONE exchange: the second reduction area sits in the
+// unused rows of the other activation buffer's k-tiles.
+#define CS_RED2(w) (CH_ABUF2 + (w) * 8192 + 2048)
+DEVINL void head_projection2(f32x4_t (&a0)[4][1], f32x4_t (&a1)[4][1], WStream& w0, WStream& w1, const char* act, char* smem, int wave,
+                             int lane) {
+    const int i = wave >> 2, j = wave & 3;
+    zero(a0);
+    zero(a1);
+    phase_n512<4, true, 1, 4, false>(a0, act + 2 * j * 8192, w0, lane);
+    phase_n512<4, true, 1, 4, false>(a1, act + 2 * j * 8192, w1, lane);
+    f32x4_t* r0 = reinterpret_cast<f32x4_t*>(smem + CS_RED(wave));
+    f32x4_t* r1 = reinterpret_cast<f32x4_t*>(smem + CS_RED2(wave));
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        r0[nt * 64 + lane] = a0[nt][0];
+        r1[nt * 64 + lane] = a1[nt][0];
+    }
+    lds_barrier();
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        f32x4_t s0 = reinterpret_cast<const f32x4_t*>(smem + CS_RED(4 * i))[nt * 64 + lane];
+        f32x4_t s1 = reinterpret_cast<const f32x4_t*>(smem + CS_RED2(4 * i))[nt * 64 + lane];
+#pragma unroll
+        for (int jj = 1; jj < 4; ++jj) {
+            s0 += reinterpret_cast<const f32x4_t*>(smem + CS_RED(4 * i + jj))[nt * 64 + lane];
+            s1 += reinterpret_cast<const f32x4_t*>(smem + CS_RED2(4 * i + jj))[nt * 64 + lane];
+        }
+        a0[nt][0] = s0;
+        a1[nt][0] = s1;
+    }
+    lds_barrier();      // the reduction areas are free again
+}
+
 // softmax(q k^T) v of the block's 16 rows for head (2 member + wave / 4), its 32-key tiles dealt to the head's four waves (tile kt
 // on wave kt % 4), each wave an online softmax as chain.hip's cross_attention (exp2 domain, lazy running maximum, row sums by an
 // all-ones MFMA), the four partial results merged through LDS (flash-decoding: rescale to the common maximum).  O (bf16) -> the
 // member's activation block, k-tile wave / 4.  qf: the head's Q^T fragments (scaled by log2 e / sqrt d_k).  Two barriers.
-DEVINL void head_attention(const u32x4 (&qf)[2], const void* kf, const void* vf, unsigned image_off, int nkt, int Lk, char* smem,
-                           int wave, int lane) {
+struct KVTiles { u32x4 k0[4], v0[4], k1[4], v1[4]; };      // a wave's first two key tiles (j, j + 4), issued ahead of the attention
+DEVINL void kv_tile(const __amdgpu_buffer_rsrc_t& r, unsigned image_off, int kt, int nkt, int lane, u32x4 (&f)[4]) {
+    const unsigned so = image_off + (unsigned)(kt < nkt ? kt : nkt - 1) * 4096u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) f[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (unsigned)lane * 16u + 1024u * q, so, 0));
+}
+DEVINL void kv_issue(KVTiles& t, const void* kf, const void* vf, unsigned image_off, int nkt, int wave, int lane) {
+    const __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(kf), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(vf), 0, -1, 0x00020000);
+    const int j = wave & 3;
+    kv_tile(kr, image_off, j, nkt, lane, t.k0);
+    kv_tile(vr, image_off, j, nkt, lane, t.v0);
+    kv_tile(kr, image_off, j + 4, nkt, lane, t.k1);
+    kv_tile(vr, image_off, j + 4, nkt, lane, t.v1);
+}
+DEVINL void head_attention(const u32x4 (&qf)[2], KVTiles& pre, const void* kf, const void* vf, unsigned image_off, int nkt, int Lk,
+                           char* smem, int wave, int lane) {
     const int i = wave >> 2, j = wave & 3, c = lane & 15, gg = lane >> 4;
     u32x4 ones = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
     asm volatile("" : "+v"(ones));
-    const unsigned voff = (unsigned)lane * 16u;
     const __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(kf), 0, -1, 0x00020000);
     const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(vf), 0, -1, 0x00020000);
-    auto ld_tile = [&](const __amdgpu_buffer_rsrc_t& r, int kt, u32x4 (&f)[4]) {
-        const unsigned so = image_off + (unsigned)(kt < nkt ? kt : nkt - 1) * 4096u;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) f[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff + 1024u * q, so, 0));
-    };
+    auto ld_tile = [&](const __amdgpu_buffer_rsrc_t& r, int kt, u32x4 (&f)[4]) { kv_tile(r, image_off, kt, nkt, lane, f); };
     f32x4_t o[4], lacc = {0, 0, 0, 0};
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4_t{0, 0, 0, 0};
     float m_run = -INFINITY, nb = 0.0f;
-    u32x4 kn[4], vn[4];
-    ld_tile(kr, j, kn);
-    ld_tile(vr, j, vn);
+    u32x4 (&kn)[4] = pre.k0, (&vn)[4] = pre.v0, (&kn2)[4] = pre.k1, (&vn2)[4] = pre.v1;      // the wave's tiles run TWO ahead (1-4 tiles of a
+                                                                                               // 450-key sequence per wave: latency, not rate)
 #pragma unroll 1
     for (int kt = j; kt < nkt; kt += 4) {
         u32x4 kc[4], vc[4];
@@ -201,9 +302,11 @@ DEVINL void head_attention(const u32x4 (&qf)[2], const void* kf, const void* vf,
         for (int q = 0; q < 4; ++q) {
             kc[q] = kn[q];
             vc[q] = vn[q];
+            kn[q] = kn2[q];
+            vn[q] = vn2[q];
         }
-        ld_tile(kr, kt + 4, kn);            // (past the end: the last tile again, unused)
-        ld_tile(vr, kt + 4, vn);
+        ld_tile(kr, kt + 8, kn2);           // (past the end: the last tile again, unused)
+        ld_tile(vr, kt + 8, vn2);
         f32x4_t s0 = {nb, nb, nb, nb}, s1 = s0;
         mma16(s0, kc[0], qf[0]);
         mma16(s1, kc[2], qf[0]);
@@ -292,6 +395,42 @@ DEVINL void q_fragments(const f32x4_t (&qacc)[4][1], float qs, u32x4 (&qf)[2]) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
+// part 0 (TC_CHAIN_FRONT): layer 0's norm1 + rotary -> Q, K ; norm1 -> V of the token rows the fusion projection left (row-major fp32:
+// model/model.py:561 seen per token), heads 2 member, 2 member + 1, as the fragment images part 1 of layer 0 reads.  The weights: the
+// w_qs / w_ks / w_vs phases at the end of the TC_CHAIN_FRONT stream (stages 32 / 48 / 64 of its 80; any dancer's copy).
+// ------------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void chain_split0_kernel(tcdiff_chain_args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const SplitGeo g = split_geo(a);
+    char* abuf = smem + CH_ABUF;
+    float* scr = reinterpret_cast<float*>(smem + CH_SCR);
+    f32x4_t acc[4][1];
+    {
+        const int c = lane & 15, gg = lane >> 4;
+        const float* src = a.xres + (long)my_row(g, c) * 512 + 64 * wave + 4 * gg;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[nt][0] = ld4(src + 16 * nt);
+    }
+    const NormC nn = norm_consts<true>(a, g, a.nn_g, a.nn_b, wave, lane);
+    WStream wq, wk;
+    head_stream(wq, a, g, 32u, wave, lane);
+    head_stream(wk, a, g, 48u, wave, lane);
+    norm_lds<true>(acc, nn, a.nn_eps, scr, smem, abuf, smem + CH_ABUF2, wave, lane);
+    lds_barrier();
+    const int head = 2 * g.member + (wave >> 2);
+    const bool writer = (wave & 3) == 0;
+    f32x4_t t[4][1], tk[4][1];
+    head_projection2(t, tk, wq, wk, abuf, smem, wave, lane);
+    WStream wv;
+    head_stream(wv, a, g, 64u, wave, lane);
+    if (writer) store_qfrag<1>(t, a.qf_out, a.scale_q, g.lblk, head, lane);
+    if (writer) store_kfrag<1>(tk, a.kf_out, g.bseq, g.bis * 16, a.out_nkt, head, lane);
+    head_projection<true>(t, wv, smem + CH_ABUF2, smem, wave, lane);
+    if (writer) store_vfrag<1>(t, a.vf_out, g.bseq, g.bis * 16, a.out_nkt, a.L, head, lane);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
 // part 1: self-attention (or the attention output rows of layer 0) -> fc, K split
 // ------------------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512) void chain_split1_kernel(tcdiff_chain_args a, float* p_out) {
@@ -300,12 +439,19 @@ __global__ __launch_bounds__(512) void chain_split1_kernel(tcdiff_chain_args a, 
     const SplitGeo g = split_geo(a);
     char* abuf = smem + CH_ABUF;
     WStream ws;
+    CS_T(1, 0);
     stream_at(ws, a, wave, 4u * g.member, lane);          // fc: the member's four k-steps of every wave's 16-stage phase
     if (a.sa_q) {
         const int head = 2 * g.member + (wave >> 2);
-        const u32x4* qsrc = reinterpret_cast<const u32x4*>(a.sa_q) + ((long)(g.lblk * 8 + head) * 8) * 64 + lane;
+        // layer 0 under classifier-free guidance: the stacked branches share x, hence Q / K / V (a_mod rows of them exist)
+        const int sseq = a.a_mod > 0 ? g.bseq % (a.a_mod / a.L) : g.bseq;
+        const int qblk = sseq * ((a.L + 15) / 16) + g.bis;
+        const u32x4* qsrc = reinterpret_cast<const u32x4*>(a.sa_q) + ((long)(qblk * 8 + head) * 8) * 64 + lane;
         const u32x4 qf[2] = {qsrc[0], qsrc[64]};
-        head_attention(qf, a.sa_kf, a.sa_vf, (unsigned)((g.bseq * a.H + head) * a.sa_nkt) * 4096u, a.sa_nkt, a.L, smem, wave, lane);
+        const unsigned img = (unsigned)((sseq * a.H + head) * a.sa_nkt) * 4096u;
+        KVTiles pre;
+        kv_issue(pre, a.sa_kf, a.sa_vf, img, a.sa_nkt, wave, lane);
+        head_attention(qf, pre, a.sa_kf, a.sa_vf, img, a.sa_nkt, a.L, smem, wave, lane);
     } else if (wave < 2) {
         // layer 0: O of the stand-alone attention launch, the member's two k-tiles (columns 128 member ..) of the 16 rows
 #pragma unroll
@@ -313,12 +459,16 @@ __global__ __launch_bounds__(512) void chain_split1_kernel(tcdiff_chain_args a, 
             stage_glds<16, 2>(abuf + kt * 8192, reinterpret_cast<const char*>(a.A) + (2 * g.member + kt) * TC_ROWB, 1024, g.m0, g.Mend,
                               a.a_mod, wave, lane);
     }
+    CS_T(1, 1);
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
+    CS_T(1, 2);
     f32x4_t acc[4][1];
     zero(acc);
     phase_n512<4, true, 1>(acc, abuf, ws, lane);
+    CS_T(1, 3);
     partial_store(acc, p_out, g, wave, lane);
+    CS_T(1, 4);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -332,25 +482,40 @@ __global__ __launch_bounds__(512) void chain_split2_kernel(tcdiff_chain_args a, 
     float* scr = reinterpret_cast<float*>(smem + CH_SCR);
     const bool mine = (wave >> 1) == g.member;            // this member stores columns 128 member .. of x
     f32x4_t acc[4][1];
+    CS_T(2, 0);
     partial_sum(acc, p_in, g, wave, lane);
-    block_epilogue<true>(acc, a, g, a.film, a.ln_eps, a.xres, a.xres_mod > 0 ? a.xres_mod : a.M, a.xres_mod, a.xres_rowmajor != 0,
-                         a.xout, scr, wave, lane, mine);
-    norm_lds<true>(acc, a, g, a.n2_g, a.n2_b, a.n2_eps, scr + 1024, abuf, nullptr, wave, lane);
+    const RowC rc = row_consts(a, g, a.film, a.xres, a.xres_mod > 0 ? a.xres_mod : a.M, a.xres_mod, a.xres_rowmajor != 0, wave, lane);
+    const NormC nc = norm_consts<true>(a, g, a.n2_g, a.n2_b, wave, lane);
+    WStream wq;
+    head_stream(wq, a, g, 16u, wave, lane);               // w_qs (cross) of heads 2 member, 2 member + 1: stages 16.. of those waves' streams
+    CS_T(2, 1);
+    block_epilogue<true>(acc, rc, g, a.ln_eps, a.xout, scr, smem, wave, lane, mine);
+    CS_T(2, 2);
+    norm_lds<true>(acc, nc, a.n2_eps, scr + 1024, smem, abuf, nullptr, wave, lane);
     lds_barrier();
-    // Q = rot(norm2 x) W_q^T of heads 2 member, 2 member + 1 (model/model.py:387,78): stages 16.. of those waves' streams
+    CS_T(2, 3);
+    // Q = rot(norm2 x) W_q^T (model/model.py:387,78)
     f32x4_t qacc[4][1];
-    head_projection<false>(qacc, a, g, abuf, 16u, smem, wave, lane);
-    u32x4 qf[2];
-    q_fragments(qacc, a.scale_q * CH_LOG2E, qf);
+    WStream ws;
     const int head = 2 * g.member + (wave >> 2);
     const int kv = g.bseq < a.n_shared ? 0 : g.bseq - a.n_shared + (a.n_shared > 0 ? 1 : 0);
-    WStream ws;
-    stream_at(ws, a, wave, 32u + 4u * g.member, lane);    // the cross-attention block's fc, in flight under the attention
-    head_attention(qf, a.kf, a.vf, (unsigned)((kv * a.H + head) * a.nkt) * 4096u, a.nkt, a.Lk, smem, wave, lane);
+    const unsigned img = (unsigned)((kv * a.H + head) * a.nkt) * 4096u;
+    KVTiles pre;
+    kv_issue(pre, a.kf, a.vf, img, a.nkt, wave, lane);    // the wave's first key tiles and ...
+    stream_at(ws, a, wave, 32u + 4u * g.member, lane);    // ... the cross-attention block's fc: in flight under the projection
+    head_projection<false>(qacc, wq, abuf, smem, wave, lane);
+    CS_T(2, 4);
+    u32x4 qf[2];
+    q_fragments(qacc, a.scale_q * CH_LOG2E, qf);
+    head_attention(qf, pre, a.kf, a.vf, img, a.nkt, a.Lk, smem, wave, lane);
+    CS_T(2, 5);
     lds_barrier();
+    CS_T(2, 6);
     zero(acc);
     phase_n512<4, true, 1>(acc, abuf, ws, lane);
+    CS_T(2, 7);
     partial_store(acc, p_out, g, wave, lane);
+    CS_T(2, 8);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -364,35 +529,42 @@ __global__ __launch_bounds__(512) void chain_split3_kernel(tcdiff_chain_args a, 
     char* hb = smem + CH_H1C;
     float* scr = reinterpret_cast<float*>(smem + CH_SCR);
     const bool mine = (wave >> 1) == g.member;
+    f32x4_t acc[4][1];
+    CS_T(3, 0);
+    partial_sum(acc, p_in, g, wave, lane);
+    const RowC rc = row_consts(a, g, a.filmb, a.xres, a.M, 0, false, wave, lane);
+    const NormC nc = norm_consts<false>(a, g, a.n3_g, a.n3_b, wave, lane);
+    const float* b1 = a.b1 + 256 * g.member + 32 * wave + 4 * (lane >> 4);
+    const f32x4_t b1v[2] = {ld4(b1), ld4(b1 + 16)};
     WStream ws;
     stream_at(ws, a, wave, 48u + 16u * g.member, lane);   // {linear1 chunk, linear2 chunk} of this member: 16 contiguous stages
-    f32x4_t acc[4][1];
-    partial_sum(acc, p_in, g, wave, lane);
-    block_epilogue<true>(acc, a, g, a.filmb, a.ln_eps, a.xres, a.M, 0, false, a.xout, scr, wave, lane, mine);
-    norm_lds<false>(acc, a, g, a.n3_g, a.n3_b, a.n2_eps, scr + 1024, abuf, nullptr, wave, lane);
+    CS_T(3, 1);
+    block_epilogue<true>(acc, rc, g, a.ln_eps, a.xout, scr, smem, wave, lane, mine);
+    CS_T(3, 2);
+    norm_lds<false>(acc, nc, a.n2_eps, scr + 1024, smem, abuf, nullptr, wave, lane);
     lds_barrier();
+    CS_T(3, 3);
     f32x4_t a1[2][1];
     a1[0][0] = a1[1][0] = f32x4_t{0, 0, 0, 0};
     phase_ff1<1>(a1, abuf, ws, lane);
-    {
-        const int gg = lane >> 4;
-        const float* b1 = a.b1 + 256 * g.member + 32 * wave + 4 * gg;
+    CS_T(3, 4);
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const f32x4_t b4 = ld4(b1 + 16 * nt);
-            const int cc = 32 * wave + 16 * nt;           // chunk column: k-tile cc / 64, 16-byte chunk (cc % 64) / 8 + (g >> 1)
-            float v[4];
+    for (int nt = 0; nt < 2; ++nt) {
+        const int cc = 32 * wave + 16 * nt;               // chunk column: k-tile cc / 64, 16-byte chunk (cc % 64) / 8 + (g >> 1)
+        float v[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) v[t] = a1[nt][0][t] + b4[t];
-            act4_ct<ACT_GELU>(v, ACT_GELU);
-            uint2 pk = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-            *reinterpret_cast<uint2*>(hb + (cc >> 6) * 8192 + act_wr_off(lane, 0, (cc & 63) >> 3)) = pk;
-        }
+        for (int t = 0; t < 4; ++t) v[t] = a1[nt][0][t] + b1v[nt][t];
+        act4_ct<ACT_GELU>(v, ACT_GELU);
+        uint2 pk = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+        *reinterpret_cast<uint2*>(hb + (cc >> 6) * 8192 + act_wr_off(lane, 0, (cc & 63) >> 3)) = pk;
     }
     lds_barrier();
+    CS_T(3, 5);
     zero(acc);
     phase_n512<8, true, 1>(acc, hb, ws, lane);
+    CS_T(3, 6);
     partial_store(acc, p_out, g, wave, lane);
+    CS_T(3, 7);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -406,23 +578,39 @@ __global__ __launch_bounds__(512) void chain_split4_kernel(tcdiff_chain_args a, 
     char* abuf = smem + CH_ABUF;
     float* scr = reinterpret_cast<float*>(smem + CH_SCR);
     const bool mine = (wave >> 1) == g.member;
+    f32x4_t acc[4][1];
+    CS_T(4, 0);
+    partial_sum(acc, p_in, g, wave, lane);
+    const RowC rc = row_consts(a, g, a.film3, a.xres, a.M, 0, false, wave, lane);
+    const NormC n4 = norm_consts<false>(a, g, a.n4_g, a.n4_b, wave, lane);
     WStream ws;
     stream_at(ws, a, wave, 112u, lane);                   // linear3: every member computes all of it
-    f32x4_t acc[4][1];
-    partial_sum(acc, p_in, g, wave, lane);
-    block_epilogue<false>(acc, a, g, a.film3, 0.0f, a.xres, a.M, 0, false, nullptr, scr, wave, lane, false);
-    norm_lds<false>(acc, a, g, a.n4_g, a.n4_b, a.n4_eps, scr, abuf, nullptr, wave, lane);
+    const f32x4_t b3c = col_fetch(a.b3, wave, lane);
+    CS_T(4, 1);
+    block_epilogue<false>(acc, rc, g, 0.0f, nullptr, scr, smem, wave, lane, false);
+    CS_T(4, 2);
+    norm_lds<false>(acc, n4, a.n4_eps, scr, smem, abuf, nullptr, wave, lane);
     lds_barrier();
+    CS_T(4, 3);
+    NormC nn;
+    WStream wq, wk;
+    if (!LAST) {                                           // the next phases' constants and streams: in flight under linear3
+        nn = norm_consts<true>(a, g, a.nn_g, a.nn_b, wave, lane);
+        head_stream(wq, a, g, 128u, wave, lane);
+    }
     zero(acc);
     phase_n512<16, true, 1>(acc, abuf, ws, lane);
+    if (!LAST) CS_T(4, 4);
+    if (!LAST) head_stream(wk, a, g, 144u, wave, lane);    // (linear3's ring is free): lands under the stores and the norm
     lds_barrier();                                         // every wave is out of linear3: the activation block is rewritten below
     {
         const int c = lane & 15, gg = lane >> 4;
         const int row = my_row(g, c);
+        col_park(smem, 4, b3c, wave, lane);
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             const int col = 64 * wave + 16 * nt + 4 * gg;
-            acc[nt][0] += ld4(a.b3 + col);
+            acc[nt][0] += col_get(smem, 4, wave, nt, gg);
             if (!mine) continue;
             if (LAST && a.out_ld > 0) {
                 if (col < a.out_ld) *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(a.h_out) + (long)row * a.out_ld + col) = acc[nt][0];
@@ -435,46 +623,35 @@ __global__ __launch_bounds__(512) void chain_split4_kernel(tcdiff_chain_args a, 
         }
     }
     if (LAST) return;
+    CS_T(4, 5);
     // next layer: norm1 + rotary -> Q, K ; norm1 -> V (model/model.py:326,374-383,78-80), heads 2 member, 2 member + 1
-    norm_lds<true>(acc, a, g, a.nn_g, a.nn_b, a.nn_eps, scr + 1024, abuf, smem + CH_ABUF2, wave, lane);
+    norm_lds<true>(acc, nn, a.nn_eps, scr + 1024, smem, abuf, smem + CH_ABUF2, wave, lane);
     lds_barrier();
+    CS_T(4, 6);
     const int head = 2 * g.member + (wave >> 2);
     const bool writer = (wave & 3) == 0;                   // one wave per head stores (all four hold the full tiles)
-    f32x4_t t[4][1];
-    head_projection<false>(t, a, g, abuf, 128u, smem, wave, lane);
+    f32x4_t t[4][1], tk[4][1];
+    head_projection2(t, tk, wq, wk, abuf, smem, wave, lane);
+    WStream wv;
+    head_stream(wv, a, g, 160u, wave, lane);              // (the Q stream's registers are free again)
     if (writer) store_qfrag<1>(t, a.qf_out, a.scale_q, g.lblk, head, lane);
-    head_projection<false>(t, a, g, abuf, 144u, smem, wave, lane);
-    if (writer) store_kfrag<1>(t, a.kf_out, g.bseq, g.bis * 16, a.out_nkt, head, lane);
-    head_projection<true>(t, a, g, smem + CH_ABUF2, 160u, smem, wave, lane);
+    CS_T(4, 7);
+    if (writer) store_kfrag<1>(tk, a.kf_out, g.bseq, g.bis * 16, a.out_nkt, head, lane);
+    CS_T(4, 8);
+    head_projection<true>(t, wv, smem + CH_ABUF2, smem, wave, lane);
     if (writer) store_vfrag<1>(t, a.vf_out, g.bseq, g.bis * 16, a.out_nkt, a.L, head, lane);
+    CS_T(4, 9);
 }
 
 static bool cs_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 extern "C" int tcdiff_chain_split(const tcdiff_chain_args* a, int part, const float* p_in, float* p_out, hipStream_t stream) {
-    if (!a || a->M <= 0 || a->L < 16 || a->M % a->L || !a->wstream || part < 1 || part > 4) return TC_ERR_ARG;
-    if (part > 1 && a->xres == a->xout) return TC_ERR_ARG;          // not in place (see the file header)
-    const bool last = a->mode == TC_CHAIN_FULL_LAST;
-    if (a->mode != TC_CHAIN_FULL && !last) return TC_ERR_UNSUPPORTED;
-    if (a->n_stages != (last ? 128 : 176) || a->H != 8 || a->nw == 4 || !a->seq_blocks) return TC_ERR_ARG;
-    if (!a->film || !a->filmb || !a->film3 || a->film_ld % 4 || !a->xres || !a->xout || !a->n2_g || !a->n2_b || !a->n3_g || !a->n3_b ||
-        !a->n4_g || !a->n4_b || !a->b1 || !a->b3 || !a->rope || a->rope_rows < a->L || !a->kf || !a->vf || a->nkt <= 0 || a->Lk <= 0 ||
-        a->Lk > 32 * a->nkt || a->n_shared < 0)
-        return TC_ERR_ARG;
-    if (a->sa_q ? (!a->sa_kf || !a->sa_vf || a->sa_nkt <= 0 || a->L > 32 * a->sa_nkt) : !a->A) return TC_ERR_ARG;
-    if (last ? !a->h_out || a->out_ld < 0 || a->out_ld % 4 || a->out_ld > 512
-             : (!a->qf_out || !a->kf_out || !a->vf_out || !a->nn_g || !a->nn_b || a->out_nkt <= 0 || a->L > 32 * a->out_nkt))
-        return TC_ERR_ARG;
-    if ((part > 1 && !p_in) || (part < 4 && !p_out)) return TC_ERR_ARG;
-    const void* ptrs[] = {a->A, a->wstream, a->film, a->filmb, a->film3, a->xres, a->xout, a->n2_g, a->n2_b, a->n3_g, a->n3_b, a->n4_g,
-                          a->n4_b, a->b1, a->b3, a->nn_g, a->nn_b, a->rope, a->kf, a->vf, a->sa_q, a->sa_kf, a->sa_vf, a->qf_out,
-                          a->kf_out, a->vf_out, a->h_out, p_in, p_out};
-    for (const void* p : ptrs)
-        if (p && !cs_al16(p)) return TC_ERR_ALIGN;
+    if (!a || a->M <= 0 || a->L < 16 || a->M % a->L || !a->wstream || part < 0 || part > 4) return TC_ERR_ARG;
     static tc_dev_state dev_state;
     const int n_cu = tc_device_once(dev_state, [](int) {
-        const void* fns[5] = {reinterpret_cast<const void*>(chain_split1_kernel), reinterpret_cast<const void*>(chain_split2_kernel),
-                              reinterpret_cast<const void*>(chain_split3_kernel), reinterpret_cast<const void*>(chain_split4_kernel<false>),
+        const void* fns[6] = {reinterpret_cast<const void*>(chain_split0_kernel), reinterpret_cast<const void*>(chain_split1_kernel),
+                              reinterpret_cast<const void*>(chain_split2_kernel), reinterpret_cast<const void*>(chain_split3_kernel),
+                              reinterpret_cast<const void*>(chain_split4_kernel<false>),
                               reinterpret_cast<const void*>(chain_split4_kernel<true>)};
         for (const void* f : fns) {
             hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, CH_SMEM);
@@ -484,6 +661,36 @@ extern "C" int tcdiff_chain_split(const tcdiff_chain_args* a, int part, const fl
     });
     if (n_cu < 0) return n_cu;
     const dim3 grid((unsigned)((a->M / a->L) * ((a->L + 15) / 16) * CS_NM)), blk(512);
+    if (part == 0) {
+        if (a->mode != TC_CHAIN_FRONT) return TC_ERR_UNSUPPORTED;
+        if (a->n_stages != 80 || a->H != 8 || a->nw == 4 || !a->xres || !a->nn_g || !a->nn_b || !a->rope || a->rope_rows < a->L ||
+            !a->qf_out || !a->kf_out || !a->vf_out || a->out_nkt <= 0 || a->L > 32 * a->out_nkt)
+            return TC_ERR_ARG;
+        const void* ptrs0[] = {a->wstream, a->xres, a->nn_g, a->nn_b, a->rope, a->qf_out, a->kf_out, a->vf_out};
+        for (const void* p : ptrs0)
+            if (!cs_al16(p)) return TC_ERR_ALIGN;
+        hipLaunchKernelGGL(chain_split0_kernel, grid, blk, CH_SMEM, stream, *a);
+        TC_CHECK_LAUNCH();
+        return TC_OK;
+    }
+    if (part > 1 && a->xres == a->xout) return TC_ERR_ARG;          // not in place (see the file header)
+    const bool last = a->mode == TC_CHAIN_FULL_LAST;
+    if (a->mode != TC_CHAIN_FULL && !last) return TC_ERR_UNSUPPORTED;
+    if (a->n_stages != (last ? 128 : 176) || a->H != 8 || a->nw == 4 || !a->seq_blocks) return TC_ERR_ARG;
+    if (!a->film || !a->filmb || !a->film3 || a->film_ld % 4 || !a->xres || !a->xout || !a->n2_g || !a->n2_b || !a->n3_g || !a->n3_b ||
+        !a->n4_g || !a->n4_b || !a->b1 || !a->b3 || !a->rope || a->rope_rows < a->L || !a->kf || !a->vf || a->nkt <= 0 || a->Lk <= 0 ||
+        a->Lk > 32 * a->nkt || a->n_shared < 0)
+        return TC_ERR_ARG;
+    if (a->sa_q ? (!a->sa_kf || !a->sa_vf || a->sa_nkt <= 0 || a->L > 32 * a->sa_nkt || a->a_mod % a->L) : !a->A) return TC_ERR_ARG;
+    if (last ? !a->h_out || a->out_ld < 0 || a->out_ld % 4 || a->out_ld > 512
+             : (!a->qf_out || !a->kf_out || !a->vf_out || !a->nn_g || !a->nn_b || a->out_nkt <= 0 || a->L > 32 * a->out_nkt))
+        return TC_ERR_ARG;
+    if ((part > 1 && !p_in) || (part < 4 && !p_out)) return TC_ERR_ARG;
+    const void* ptrs[] = {a->A, a->wstream, a->film, a->filmb, a->film3, a->xres, a->xout, a->n2_g, a->n2_b, a->n3_g, a->n3_b, a->n4_g,
+                          a->n4_b, a->b1, a->b3, a->nn_g, a->nn_b, a->rope, a->kf, a->vf, a->sa_q, a->sa_kf, a->sa_vf, a->qf_out,
+                          a->kf_out, a->vf_out, a->h_out, p_in, p_out};
+    for (const void* p : ptrs)
+        if (p && !cs_al16(p)) return TC_ERR_ALIGN;
     if (part == 1) hipLaunchKernelGGL(chain_split1_kernel, grid, blk, CH_SMEM, stream, *a, p_out);
     else if (part == 2) hipLaunchKernelGGL(chain_split2_kernel, grid, blk, CH_SMEM, stream, *a, p_in, p_out);
     else if (part == 3) hipLaunchKernelGGL(chain_split3_kernel, grid, blk, CH_SMEM, stream, *a, p_in, p_out);

@@ -774,6 +774,81 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(const char* __restrict_
 // =================================================================================================
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// ---- small-M products: K dealt to the waves of a workgroup ---------------------------------------------------------------------
+// The sampler's input / fusion projections on a small job (model/model.py:560-561: M = frames of a few clips, 150 for one 3-dancer
+// clip; N = 1024, K = 576 / 1024) are 16 tiles of gemm_tile_kernel: 16 of 256 CUs, each walking 16 k-tiles between barriers --
+// 17 us for 0.3 GFLOP (profiles/r06_kernel_stats_small_job_ddim50_1clip.csv).  Here one workgroup owns a 32 x 32 output tile and
+// its 8 waves SPLIT K (k-step ks on wave ks % 8): a wave loads its operand fragments global -> registers in the MFMA layout (lane
+// (c, g): row c, 16 bytes at k = 32 ks + 8 g; no LDS staging, no barrier inside the k loop), all of them in flight at once for
+// K <= 1024, and the eight partial tiles meet once in LDS.  160 workgroups for 150 x 1024; the launch is one memory round trip,
+// 4 k-steps of MFMA and one exchange.  Transposed product (weights on the MFMA's row operand): a lane ends up with four consecutive
+// columns of one output row.  bf16 operands, TC_EPI_STORE_T / TC_EPI_STORE_F32 epilogues without the training extras.
+template <bool F32OUT>
+__global__ __launch_bounds__(512) void gemm_small_kernel(const char* A, const char* W, int M, int N, int K, long lda_b, long ldw_b,
+                                                         int a_mod, tcdiff_tile_epi e) {
+    __shared__ f32x4_t red[8][4][64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nct = N >> 5;
+    const int ct = blockIdx.x % nct, rt = blockIdx.x / nct;       // the column tiles of a row tile are neighbours: its A rows stay in L2
+    const int c = lane & 15, g = lane >> 4;
+    const char *ap[2], *wp[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int m = rt * 32 + 16 * i + c;
+        m = m < M ? m : M - 1;
+        if (a_mod > 0) m %= a_mod;
+        ap[i] = A + (long)m * lda_b + g * 16;
+        wp[i] = W + (long)(ct * 32 + 16 * i + c) * ldw_b + g * 16;
+    }
+    f32x4_t acc[2][2];                                            // [n tile][m tile]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i >> 1][i & 1] = f32x4_t{0, 0, 0, 0};
+    const int nk = K >> 5;
+#pragma unroll 4
+    for (int ks = wave; ks < nk; ks += 8) {
+        const u32x4 a0 = *reinterpret_cast<const u32x4*>(ap[0] + ks * 64), a1 = *reinterpret_cast<const u32x4*>(ap[1] + ks * 64);
+        const u32x4 w0 = *reinterpret_cast<const u32x4*>(wp[0] + ks * 64), w1 = *reinterpret_cast<const u32x4*>(wp[1] + ks * 64);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w0), __builtin_bit_cast(bf16x8_t, a0), acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w0), __builtin_bit_cast(bf16x8_t, a1), acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w1), __builtin_bit_cast(bf16x8_t, a0), acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w1), __builtin_bit_cast(bf16x8_t, a1), acc[1][1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red[wave][i][lane] = acc[i >> 1][i & 1];
+    __syncthreads();
+    if (wave >= 4) return;
+    f32x4_t s = red[0][wave][lane];                               // wave w (< 4) finishes tile w: fixed summation order
+#pragma unroll
+    for (int w = 1; w < 8; ++w) s += red[w][wave][lane];
+    const int m = rt * 32 + 16 * (wave & 1) + c, n = ct * 32 + 16 * (wave >> 1) + 4 * g;
+    if (m >= M) return;
+    float v[4] = {s[0], s[1], s[2], s[3]};
+    if (e.bias) {
+        const f32x4_t b = *reinterpret_cast<const f32x4_t*>(e.bias + n);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] += b[t];
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) v[t] = apply_act(v[t], e.act);
+    if (F32OUT) {
+        *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(e.out) + (long)m * e.ldc + n) = f32x4_t{v[0], v[1], v[2], v[3]};
+    } else {
+        uint2 pk = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(e.out) + (long)m * e.ldc + n) = pk;
+    }
+}
+
+// whether launch_tile hands a product to gemm_small_kernel: bf16, plain epilogue, and a 128 x 128 tiling that would leave at least
+// three quarters of the CUs idle while the 32 x 32 tiling still fits the machine once or twice (TCDIFF_GEMM_SMALL=0: never)
+static bool small_product(int dtype, const void* A2, int M, int N, int K, const tcdiff_tile_epi& e, int n_cu) {
+    static const bool off = [] { const char* v = getenv("TCDIFF_GEMM_SMALL"); return v && v[0] == '0'; }();
+    if (off || dtype != TC_DTYPE_BF16 || A2 || (e.mode != TC_EPI_STORE_T && e.mode != TC_EPI_STORE_F32) || e.out2 || e.act_src)
+        return false;
+    if (N % 32 || K % 32 || K > 2048 || e.ldc % 4 || (e.bias && !aligned16(e.bias))) return false;
+    const long big = (long)((N + 127) / 128) * ((M + 127) / 128), small = (long)(N / 32) * ((M + 31) / 32);
+    return big * 4 <= n_cu && small <= 2L * n_cu;
+}
+
 static int launch_tile(int dtype, const void* A, const void* A2, int split_n, const void* W, int M, int N, int K,
                        int lda, int ldw, int a_mod, const tcdiff_tile_epi* epi, hipStream_t stream) {
     if (!A || !W || !epi || M <= 0 || N <= 0 || K <= 0) return TC_ERR_ARG;
@@ -832,6 +907,17 @@ static int launch_tile(int dtype, const void* A, const void* A2, int split_n, co
         return err;
     });
     if (n_cu < 0) return n_cu;
+    if (small_product(dtype, A2, M, N, K, e, n_cu)) {
+        const dim3 sgrid((unsigned)((N / 32) * ((M + 31) / 32)));
+        if (e.mode == TC_EPI_STORE_F32)
+            hipLaunchKernelGGL(gemm_small_kernel<true>, sgrid, dim3(512), 0, stream, (const char*)A, (const char*)W, M, N, K,
+                               (long)lda * es, (long)ldw * es, a_mod, e);
+        else
+            hipLaunchKernelGGL(gemm_small_kernel<false>, sgrid, dim3(512), 0, stream, (const char*)A, (const char*)W, M, N, K,
+                               (long)lda * es, (long)ldw * es, a_mod, e);
+        TC_CHECK_LAUNCH();
+        return TC_OK;
+    }
     // about one tile per CU and a k-loop long enough to matter: four stages, one workgroup per CU
     const bool deep = (long)grid.x * 4 <= (long)n_cu * 5 && K / kt / e.k_splits >= 3;
 #define TC_LAUNCH_TILE(POL, ACTK)                                                                                       \

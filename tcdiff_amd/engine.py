@@ -559,7 +559,17 @@ class DenoiserEngine:
         K.gemm_tile(dt, b["f1"], w["f2.w"], B * S, 1024, 1024, bias=w["f2.b"], act=L.ACT_RELU, out=b["f2"], ldc=1024)
         # last fusion linear, one group per dancer in ONE launch: group d writes token rows m*dn + d (de-interleave:
         # frame row m, dancer d -> token m*dn + d); fused with layer-0 norm1 + rotary
-        if self.front:
+        self._frag_front = self.front and self._split_job(nseq) and os.environ.get("TCDIFF_SPLIT_FRONT", "1") != "0"
+        if self._frag_front:
+            # SMALL jobs: the last fusion linear as one plain product -- [frames][512 dn] fp32 IS the token rows [frames dn][512] --
+            # then layer 0's norm1 / rotary / Q, K, V as fragment images (tcdiff_chain_split part 0): layer 0's self-attention runs
+            # inside its first launch like every other layer's.  (TC_CHAIN_FRONT has 9 workgroups for one 3 x 150 clip.)
+            K.gemm_tile(dt, b["f2"], w["f3.w"], B * S, 512 * dn, 1024, bias=w["f3.b"], mode=L.EPI_STORE_F32, out=b["xs"],
+                        ldc=512 * dn)
+            K.chain(L.CHAIN_FRONT, Rs, Lq, None, w["front"][0], split_part=0, xres=b["xs"], nn_g=w["l0.norm1.g"],
+                    nn_b=w["l0.norm1.b"], nn_eps=1e-5, rope=w["rope_cb"], qf_out=b["Qf"], kf_out=b["sKf"][0], vf_out=b["sVf"][0],
+                    out_nkt=self.skt, scale_q=0.125, H=H)
+        elif self.front:
             # ... as ONE chain launch per (64-frame block, dancer) that also runs layer 0's norm1, rotary and Q / K / V
             # projections; b["xs"] (layer 0's residual input) is then column-blocked like the rest of the stream
             K.chain(L.CHAIN_FRONT, B * S, Lq, b["f2"], w["front"], b3=w["f3.b"], nn_g=w["l0.norm1.g"],
@@ -629,6 +639,10 @@ class DenoiserEngine:
         K.gemm_tile(dt, b["h"], w["fin.w"], R, self.nf, 512, bias=w["fin.b"], mode=L.EPI_STORE_F32, out=b["out"], ldc=152)
         return b["out"]
 
+    def _split_job(self, nseq: int) -> bool:
+        """whether this forward runs the decoder layers in their small-job form (csrc/chain_split.hip)"""
+        return bool(self.use_full and self.fuse_sa and self.chain_nw == 8 and "xb" in self.b and self._split_rows(nseq, self.Lseq))
+
     def _split_rows(self, nseq: int, Lq: int) -> bool:
         """the small-job form of the layer (four workgroups per 16-row block): when all of them fit the chip at once"""
         if os.environ.get("TCDIFF_SPLIT", "1") == "0" or self.chain_nw != 8 or Lq < 16:
@@ -650,7 +664,8 @@ class DenoiserEngine:
                         n_k=512)
         # fused: layers 1.. compute their self-attention inside the chain launch from the fragments the previous launch wrote
         fused = self.fuse_sa and self.chain_nw == 8
-        if not (fused and l > 0):
+        frag0 = l == 0 and getattr(self, "_frag_front", False)      # layer 0's Q / K / V came as fragment images (network())
+        if not (fused and l > 0) and not frag0:
             K.attention(dt, b["Q"], b["K"], b["V"], b["O"], B if l == 0 else nseq, H, Lq, Lq, self.Lp, self.Lp, 512)
         last = l + 1 == NL
         nn = f"l{l + 1}.norm1." if not last else None
@@ -663,16 +678,17 @@ class DenoiserEngine:
         if fused:
             # the smallest row blocks that still give every block its own CU (a block streams the layer's weights whatever its rows)
             tail.update(seq_blocks=True, mt=next((m for m in (1, 2) if nseq * ((Lq + 16 * m - 1) // (16 * m)) <= self.n_cu), 4))
-            if l > 0:
+            if l > 0 or frag0:
                 tail.update(sa_q=b["Qf"], sa_kf=b["sKf"][l & 1], sa_vf=b["sVf"][l & 1], sa_nkt=self.skt)
             if not last:
                 tail.update(q_out=None, k_out=None, v_out=None, qf_out=b["Qf"], kf_out=b["sKf"][(l + 1) & 1],
                             vf_out=b["sVf"][(l + 1) & 1], out_nkt=self.skt)
         head = dict(a_mod=Rs if l == 0 else 0, ln_eps=1e-6,     # (film rows: pre-folded with sln / cln / ff2.b, load_weights)
                     film=film0[:, (l * 3 + 0) * 1024:], film_ld=fld, xres=b["xs"] if l == 0 else b["xa"],
-                    xres_mod=Rs if l == 0 else 0, xres_rowmajor=l == 0 and not self.front, xout=b["xa"], n2_g=w[p + "norm2.g"],
+                    xres_mod=Rs if l == 0 else 0, xres_rowmajor=l == 0 and (not self.front or frag0), xout=b["xa"],
+                    n2_g=w[p + "norm2.g"],
                     n2_b=w[p + "norm2.b"], n2_eps=1e-5, rope=rope)     # b["xa"] is COLUMN-BLOCKED on this path
-        if self.use_full and fused and "xb" in b and self._split_rows(nseq, Lq):
+        if self._split_job(nseq):
             # SMALL jobs (csrc/chain_split.hip): four workgroups per 16-row block, four launches per layer; the residual stream
             # alternates between b["xa"] and b["xb"] (a part reads whole rows and stores quarters), the partial sums between two slabs
             full = dict(filmb=film0[:, (l * 3 + 1) * 1024:], n3_g=w[p + "norm3.g"], n3_b=w[p + "norm3.b"], kf=b["Kf"][l, kv_slot0:],

@@ -160,14 +160,15 @@ def chain(mode, M, Lseq, A, wstream, *, ln_eps=1e-6, film=None, film_ld=0, xres=
           n4_b=None, n4_eps=1e-5, b3=None, nn_g=None, nn_b=None, nn_eps=1e-5, k_out=None, v_out=None, h_out=None,
           filmb=None, n3_g=None, n3_b=None, kf=None, vf=None, n_shared=0, nkt=0, Lk=0,
           xres_rowmajor=False, out_ld=0, dn=1, mt=0, seq_blocks=False, sa_q=None, sa_kf=None, sa_vf=None, sa_nkt=0,
-          qf_out=None, kf_out=None, vf_out=None, out_nkt=0, split_part=0, p_in=None, p_out=None):
+          qf_out=None, kf_out=None, vf_out=None, out_nkt=0, split_part=None, p_in=None, p_out=None):
     """rope: the COLUMN-BLOCKED rotary table (to_cb(rope_table)); xres / xout: column-blocked fp32 residual stream
     (xres_rowmajor: xres is a plain [*, 512] matrix); wstream: [(dn,) 8 waves, n_stages, 2048] bf16 (or the 4-wave form
     [(dn,) 4, n_stages, 4096]: tcdiff_chain_args.nw), the stage and wave counts are read from it.  film / filmb / film3 rows are PRE-FOLDED with the LayerNorm weights / linear2 bias around them
     (fold_film below; engine.load_weights folds them into the FiLM generator).  seq_blocks / sa_* / *f_out: row blocks cut per
     sequence, the layer's self-attention inside the launch and the fragment-order Q / K / V outputs that feed it.
     split_part = 1 .. 4: the small-job form of the layer, four workgroups per 16-row block and four launches per layer
-    (tcdiff_chain_split: xres -> xout not in place, p_in / p_out the partial-sum buffers).
+    (tcdiff_chain_split: xres -> xout not in place, p_in / p_out the partial-sum buffers); split_part = 0 with CHAIN_FRONT: layer 0's
+    Q / K / V fragment images from row-major token rows.
     See include/tcdiff_hip.h tcdiff_chain_args."""
     nw = wstream.shape[-3]
     if (nw, wstream.shape[-1]) not in ((8, 2048), (4, 4096)) or not wstream.is_contiguous():
@@ -180,7 +181,7 @@ def chain(mode, M, Lseq, A, wstream, *, ln_eps=1e-6, film=None, film_ld=0, xres=
                     n4_eps, nn_eps, scale_q, _p(filmb), _p(n3_g), _p(n3_b), _p(kf), _p(vf), n_shared,
                     nkt, Lk, int(bool(xres_rowmajor)), 0 if rope is None else rope.shape[1], dn, mt, out_ld, nw,
                     int(bool(seq_blocks)), _p(sa_q), _p(sa_kf), _p(sa_vf), sa_nkt, _p(qf_out), _p(kf_out), _p(vf_out), out_nkt)
-    if split_part:
+    if split_part is not None:
         L.check(L.load().tcdiff_chain_split(C.byref(a), split_part, _p(p_in), _p(p_out), stream()), "tcdiff_chain_split")
         return
     L.check(L.load().tcdiff_chain(C.byref(a), stream()), "tcdiff_chain")

@@ -4,17 +4,22 @@ contraction, w_qs / linear1 / Q, K, V split over the output columns -- against t
 (TC_CHAIN_FULL at 16-row blocks, which tests/test_chain_gpu.py, test_chain_selfatt_gpu.py and the parity goldens hold to the
 reference).  Same weights stream, same fragment images in and out; the arithmetic differs in fp32 summation order only (four
 partial sums per product, four partial softmaxes per head)."""
+import os
+
 import pytest
 import torch
+import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
 from tcdiff_amd import _lib as L  # noqa: E402
 from tcdiff_amd import kernels as K  # noqa: E402
+from tcdiff_amd.model import DanceDecoder  # noqa: E402
+from oracle import tcdiff_oracle as O  # noqa: E402
 from test_chain_selfatt_gpu import DEV, Layer, bf, rnd  # noqa: E402
 
 
-def run_layers(Lq, nseq, split, qk_gain=1.0, Lk=62):
+def run_layers(Lq, nseq, split, qk_gain=1.0, Lk=62, stamps=None):
     H = 8
     M = nseq * Lq
     Lp = K.round_up(Lq, 128)
@@ -51,6 +56,8 @@ def run_layers(Lq, nseq, split, qk_gain=1.0, Lk=62):
             kw.update(h_out=h)
         else:
             kw.update(qf_out=qf[li & 1], kf_out=skf[li & 1], vf_out=svf[li & 1], out_nkt=skt)
+            if stamps is not None:            # (tools/split_stamps.py, -DCS_STAMP builds: the buffer the rows of a last layer would go to)
+                kw.update(h_out=stamps)
         if not split:
             K.chain(lay.mode, M, Lq, Oa, lay.ws, xres=X[cur], xout=X[cur], **kw)
         else:
@@ -76,16 +83,24 @@ def test_split_layers_equal_the_fused_launch(Lq, nseq, Lk, gain):
     the layer before left; the last is the folded *_LAST form) through tcdiff_chain_split's four parts and through the fused
     launch: residual stream, Q / K / V fragment images and the final rows."""
     a, b = run_layers(Lq, nseq, False, gain, Lk), run_layers(Lq, nseq, True, gain, Lk)
+    bad = []
     for k in a:
         x, y = a[k].float(), b[k].float()
         ok = ~(x.isnan() & y.isnan())            # fragment slots nobody owns stay as the poison they were allocated with in both
         assert bool((x.isnan() == y.isnan()).all()), k
-        d = (x[ok] - y[ok]).abs()
-        print(f"L={Lq} n={nseq} Lk={Lk} gain={gain} {k}: max diff {float(d.max()):.2e} mean {float(d.mean()):.2e} (max |.| {float(x[ok].abs().max()):.2f})")
         assert torch.isfinite(y[ok]).all(), k
-        # the two forms round the same fp32 values to bf16 operands at every stage: isolated one-ulp flips, amplified by the layers behind
-        big = gain > 1.0
-        assert float(d.mean()) < (6e-3 if big else 2.5e-3) and float(d.max()) < (0.5 if big else 0.12), (k, float(d.max()), float(d.mean()))
+        d = (x[ok] - y[ok]).abs()
+        top = float(x[ok].abs().max())
+        rel_mean, rel_max = float(d.mean()) / top, float(d.max()) / top
+        print(f"L={Lq} n={nseq} Lk={Lk} gain={gain} {k}: max diff {float(d.max()):.2e} mean {float(d.mean()):.2e} of max |.| {top:.2f}"
+              f" -> {rel_max:.1e} / {rel_mean:.1e}")
+        # The two forms round the same fp32 values to bf16 operands at every stage, in a different summation order: isolated one-ulp
+        # flips (2^-8 of the value), carried and amplified by the layers behind.  Measured against the largest magnitude of the output:
+        # the first layer's outputs sit at 3e-3..7e-3 (max) / 1.5e-4..6e-4 (mean) -- one bf16 ulp of the top binade is 7.8e-3.
+        first = k.endswith("0")
+        if rel_mean > (1.5e-3 if first else 4e-3) or rel_max > (2e-2 if first else 6e-2):
+            bad.append((k, rel_max, rel_mean))
+    assert not bad, bad
 
 
 def test_launcher_refuses_in_place_and_missing_buffers():
@@ -101,3 +116,40 @@ def test_launcher_refuses_in_place_and_missing_buffers():
         K.chain(lay.mode, 64, 64, z(64, 512), lay.ws, split_part=2, p_in=P, p_out=P, xres=x, xout=x, **kw)
     with pytest.raises(L.TcdiffError):            # a part that reads partial sums needs them
         K.chain(lay.mode, 64, 64, z(64, 512), lay.ws, split_part=3, p_out=P, xres=x, xout=torch.zeros_like(x), **kw)
+
+
+@pytest.mark.parametrize("dn,S,B", [(2, 60, 1), (3, 150, 1), (2, 60, 3)])
+def test_small_job_network_matches_the_fused_layers(dn, S, B, monkeypatch):
+    """The whole denoiser on a job small enough for the four-workgroups-per-block layers (both CFG branches stacked -- layer 0's
+    Q / K / V shared by the branches -- and a plain forward): TCDIFF_SPLIT=0 (one fused launch per layer, TC_CHAIN_FRONT, the
+    stand-alone layer-0 attention; held to the reference by the parity goldens) against the small-job form with the TC_CHAIN_FRONT
+    launch (TCDIFF_SPLIT_FRONT=0) and with the fragment front (the default: fusion projection as small products, part 0, layer 0's
+    self-attention in part 1).  Same bound as the in-launch-attention network test: independent bf16 rounding draws behind layer 2."""
+    Lq = dn * S
+    cond = torch.stack([O.synth_cond(c, S) for c in range(B)]).to(DEV)
+    x = torch.stack([O.synth_xT(c, Lq) for c in range(B)]).to(DEV)
+    m = DanceDecoder(nfeats=151, seq_len=S, latent_dim=512, ff_size=1024, num_layers=8, num_heads=8, dropout=0.1,
+                     cond_feature_dim=438, activation=F.gelu, required_dancer_num=dn, compute_dtype="bf16")
+    m.load_state_dict(O.synth_state_dict(dn=dn, seq_len=S))
+    m.to(DEV).eval()
+    outs = {}
+    # (the small-job workspaces are planned with the engine: the default form first, the switches afterwards)
+    for name, env in (("split+front", {}), ("split", dict(TCDIFF_SPLIT_FRONT="0")), ("fused", dict(TCDIFF_SPLIT="0"))):
+        for k in ("TCDIFF_SPLIT", "TCDIFF_SPLIT_FRONT"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        tt = torch.full((B,), 640, dtype=torch.long, device=DEV)
+        g = m.guided_forward(x, cond, tt, 2.0)
+        with torch.no_grad():
+            f = m(x, cond, torch.arange(B, device=DEV) * 37 + 5, cond_drop_prob=0.0)
+        eng = list(m._engines.values())
+        assert all(e._split_job(2 * B) == (name != "fused") for e in eng if "xb" in e.b), name
+        assert any(getattr(e, "_frag_front", False) for e in eng) == (name == "split+front"), name
+        outs[name] = (g.clone(), f.clone())
+    for name in ("split", "split+front"):
+        for nm, a, b in zip(("guided", "forward"), outs["fused"], outs[name]):
+            d, mean = float((a - b).abs().max()), float((a - b).abs().mean())
+            print(f"{name} vs fused ({dn}x{S}, B={B}, {nm}): max-abs {d:.2e}, mean-abs {mean:.2e}, |out| max {float(a.abs().max()):.2f}")
+            assert torch.isfinite(b).all()
+            assert d < 3e-2 and mean < 4e-3, (name, nm, d, mean)

@@ -55,6 +55,29 @@ def test_gemm_tile_store(dt, M, N, Kd, act):
         assert bool((out[:, N:] == 7.0).all()), "wrote outside the N columns"
 
 
+@pytest.mark.parametrize("M,N,Kd,act,a_mod", [(150, 1024, 576, L.ACT_RELU, 0), (150, 1536, 1024, L.ACT_NONE, 0), (60, 1024, 1024, L.ACT_RELU, 0),
+                                              (7, 64, 64, L.ACT_GELU, 0), (33, 96, 2048, L.ACT_SILU, 0), (150, 512, 320, L.ACT_NONE, 50),
+                                              (450, 1024, 1024, L.ACT_RELU, 0)])
+def test_gemm_tile_small_products(M, N, Kd, act, a_mod):
+    """The shapes tcdiff_gemm_tile hands to its small-M kernel (csrc/gemm.hip gemm_small_kernel: bf16, plain epilogue, a 128 x 128
+    tiling that would leave the chip idle -- the sampler's input / fusion projections on a one-clip job, model/model.py:560-561):
+    32 x 32 output tiles, K dealt to the eight waves, one exchange.  Row tails (M % 32), k-steps that do not divide by the waves
+    (K = 576: 18 steps; K = 64: two waves work), a_mod, both output types, an output wider than N."""
+    dt = L.DT_BF16
+    A = rnd(a_mod if a_mod else M, Kd, seed=1).to(T(dt))
+    W = (rnd(N, Kd, seed=2) / math.sqrt(Kd)).to(T(dt))
+    bias = rnd(N, seed=3)
+    rows = torch.arange(M, device=DEV) % a_mod if a_mod else torch.arange(M, device=DEV)
+    ref = act_ref(A.double()[rows] @ W.double().T + bias.double(), act)
+    for mode, odt in ((L.EPI_STORE_F32, torch.float32), (L.EPI_STORE_T, T(dt))):
+        ldc = N + 4
+        out = torch.full((M + 1, ldc), 7.0, device=DEV, dtype=odt)
+        K.gemm_tile(dt, A, W, M, N, Kd, bias=bias, act=act, mode=mode, out=out, ldc=ldc, a_mod=a_mod)
+        torch.cuda.synchronize()
+        assert relerr(out[:M, :N], ref) < (1e-5 if mode == L.EPI_STORE_F32 else tol(dt)), (mode, relerr(out[:M, :N], ref))
+        assert bool((out[:M, N:] == 7.0).all()) and bool((out[M] == 7.0).all()), "wrote outside the M x N block"
+
+
 @pytest.mark.parametrize("dt", DTS)
 def test_gemm_tile_split_and_amod(dt):
     M, Kd, N = 260, 128, 512
