@@ -614,7 +614,8 @@ class GaussianDiffusion(nn.Module):
         Keyword-only extras inject the random draws (parity tests): ``noise`` in the permuted (b, S, dn, C) layout the
         reference draws it in, ``keep_mask`` (b,) bool; the dropout seed through ``self.model.train_seed``."""
         if trj_dist is not None:
-            raise L.TcdiffError("trj_dist is not supported (never passed by the reference's callers, TCDiff.py:227-229)")
+            raise L.TcdiffError("trj_dist: the reference raises for any trj_dist (model/model.py:97,394: an [L, L] score bias added "
+                                "to [L, S + 2] cross-attention scores); so does this build")
         dev = self._device()
         if dev.type != "cuda":
             raise L.TcdiffError("p_losses runs on MI355X only (no CPU fallback)")

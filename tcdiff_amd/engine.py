@@ -43,7 +43,9 @@ class DenoiserEngine:
         self.kt = K.k_tile(self.dt)
         c = self.cfg
         if c["latent"] != 512 or c["n_head"] * 64 != 512:
-            raise L.TcdiffError("gfx950 kernels are built for latent_dim=512, 8 heads x 64 (TCDiff.py:76-87)")
+            raise L.TcdiffError(f"latent_dim={c['latent']}, num_heads={c['n_head']}: the gfx950 kernels are built for the width the "
+                                "reference instantiates, latent_dim=512 as 8 heads x 64 (TCDiff.py:76-87); the constructor's own "
+                                "defaults (256 / 4, model/model.py:417-431) and any other width are not built")
         self.D, self.H, self.NL = 512, c["n_head"], c["n_layers"]
         self.S, self.dn, self.nf, self.ff = c["seq_len"], c["dn"], c["nfeats"], c["ff"]
         self.Lseq = self.S * self.dn

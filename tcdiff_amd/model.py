@@ -304,9 +304,12 @@ class DanceDecoder(nn.Module):
         schedule of tcdiff_amd/train_engine.py: in ``.train()`` mode with the reference's dropout (probability
         ``dropout`` of the constructor, counter-hash masks keyed by a seed drawn from torch's generator or injected through
         ``self.train_seed``), in ``.eval()`` mode with dropout off.  Under ``torch.no_grad()`` it is the inference engine.
-        ``trj_dist`` is accepted for signature parity; the reference never passes it (TCDiff.py:227-229)."""
+        ``trj_dist`` is accepted for signature parity and raises, as the reference does: its gathered bias [B, H, L, L]
+        (model/model.py:90-97) is added to the cross-attention scores [B, H, L, S + 2] too (model/model.py:332,394), a size
+        mismatch RuntimeError for every dancer count; its callers never pass it (TCDiff.py:227-229)."""
         if trj_dist is not None:
-            raise L.TcdiffError("trj_dist is not supported (never used by the reference's callers)")
+            raise L.TcdiffError("trj_dist: the reference raises for any trj_dist (its [B, H, L, L] score bias is added to the "
+                                "cross-attention scores [B, H, L, S + 2] as well, model/model.py:97,394); so does this build")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             from .train_engine import denoiser_train
             B = x.shape[0]

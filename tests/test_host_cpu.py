@@ -191,6 +191,28 @@ def test_use_rotary_false_surface_and_training_refusal(golden_dir):
         m.train_engine()
 
 
+def test_trj_dist_raises_as_the_reference_does(small):
+    """`trj_dist` (model/model.py:71-97): the reference gathers a [B, H, L, L] bias and adds it to the scores of BOTH attention
+    blocks of a layer (model/model.py:326,332) -- the cross-attention's are [B, H, L, S + 2], so the reference raises a RuntimeError
+    for any trj_dist at any dancer count (checked against the real module where /root/reference exists).  The drop-in raises a
+    RuntimeError as well (before touching a device)."""
+    model, diff = small
+    trj = torch.randint(0, 10, (1, 450, 450))
+    with pytest.raises(RuntimeError, match="trj_dist"):
+        model(torch.zeros(1, 450, 151), torch.zeros(1, 301, 438), torch.zeros(1, dtype=torch.long), trj_dist=trj)
+    with pytest.raises(RuntimeError, match="trj_dist"):
+        diff(torch.zeros(1, 3, 150, 151), torch.zeros(1, 301, 438), trj_dist=trj)
+    if not os.path.isdir("/root/reference"):
+        return
+    from oracle import refload
+    from oracle import tcdiff_oracle as O
+    ref, _ = refload.build_reference(O.synth_state_dict(dn=2, seq_len=60), dn=2, seq_len=60, n_timestep=100)
+    ref.eval()
+    with pytest.raises(RuntimeError, match="must match the size"), torch.no_grad():
+        ref(torch.stack([O.synth_xT(0, 120)]), torch.stack([O.synth_cond(0, 60)]), torch.tensor([50]), cond_drop_prob=0.0,
+            trj_dist=torch.randint(0, 10, (1, 120, 120)))
+
+
 def test_no_cpu_fallback(small):
     model, diff = small
     with pytest.raises(L.TcdiffError):
