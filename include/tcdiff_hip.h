@@ -82,6 +82,11 @@ typedef struct {
      * decoder layers' cross-attention K, or V: model/model.py:394-396 evaluated for every layer in one GEMM); image g starts
      * hgroup_stride elements after image g - 1. */
     int hgroup; long hgroup_stride;
+    /* small_m != 0: the caller's whole job is small -- tcdiff_gemm_tile may run the product as 32 x 32 tiles with K dealt to the
+     * waves (gemm_small_kernel: bf16, TC_EPI_STORE_T / _F32 without out2 / act_src, N % 32 == 0, K % 32 == 0 <= 2048, when the
+     * 128 x 128 tiling would leave three quarters of the chip idle).  Another summation order than the 128 x 128 tiling, hence opt-in:
+     * with 0 an output element does not depend on how many rows share the launch. */
+    int small_m;
 } tcdiff_tile_epi;
 
 /* C[M,N] = A[M,K] * W[N,K]^T with epilogue.  If A2 != NULL, output columns >= split_n (a multiple of 128)
@@ -556,6 +561,12 @@ typedef struct {
     tcdiff_tn_problem p[TC_TN_MAX_PROB];
 } tcdiff_tn_group;
 int tcdiff_gemm_tn_grouped(int dtype, const tcdiff_tn_problem* probs, int n_prob, hipStream_t stream);
+
+/* x[m][c] = dropout(x[m][c] + pe[m % pos_mod][c]) in place on fp32 rows [rows][cols] (cols % 4 == 0); pe == NULL: dropout only;
+ * drop_thr == 0: the addition only.  Hash index = m * cols + c (the index tcdiff_act_drop_bwd uses, which carries the backward).
+ * Replaces PositionalEncoding.forward in train mode, model/utils.py:27-32 as called at model/model.py:564,580 (use_rotary=False). */
+int tcdiff_pos_drop(float* x, int rows, int cols, const float* pe, int pos_mod, const int* seed, int site, uint32_t drop_thr,
+                    float drop_scale, hipStream_t stream);
 
 /* y = T(dropout(act(a)))  /  da = dy * mask / (1 - p) * act'(a).  a, da: fp32 (a_f32 != 0) or T [rows][ld_a]; y, dy:
  * T [rows][ld_y]; columns >= cols of y / da are written as zeros up to the leading dimension.  Hash index = r * cols + c.

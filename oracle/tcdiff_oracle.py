@@ -144,15 +144,15 @@ def make_tables(n_timestep: int = 1000, schedule: str = "cosine") -> Dict[str, t
 # ----------------------------------------------------------------------------------------------
 # building blocks
 # ----------------------------------------------------------------------------------------------
-def abs_pos(x: torch.Tensor, sd, drop=None) -> torch.Tensor:
+def abs_pos(x: torch.Tensor, sd, drop=None, site: int = 8) -> torch.Tensor:
     """DanceDecoder.abs_pos_encoding (model/model.py:441-448,564,580): identity with rotary embeddings; with use_rotary=False
-    PositionalEncoding (model/utils.py:11-32, batch_first): x + pe[:len] (eval mode; its train-mode dropout is not restated)."""
+    PositionalEncoding (model/utils.py:11-32, batch_first): dropout(x + pe[:len]) -- the module's own nn.Dropout (same p as the
+    model's, model/model.py:446-448), sites 8 (motion tokens, :564) and 9 (music tokens, :580) of the DropPlan."""
     pe = sd.get("abs_pos_encoding.pe")
     if pe is None:
         return x
-    if drop is not None and getattr(drop, "p", 0.0) > 0.0:
-        raise NotImplementedError("oracle: train-mode dropout of PositionalEncoding (use_rotary=False) is not restated")
-    return x + pe[: x.shape[-2], 0, :].to(x.dtype)
+    y = x + pe[: x.shape[-2], 0, :].to(x.dtype)
+    return y if drop is None else drop(y, site)
 
 
 def rotary(x: torch.Tensor, freqs: torch.Tensor) -> torch.Tensor:
@@ -209,7 +209,8 @@ def dropout_keep(seed, site: int, shape, p: float) -> torch.Tensor:
 
 class DropPlan:
     """Train-mode dropout with the product's masks: plan(x, site) = x * keep / (1 - p)  (nn.Dropout, F.dropout).
-    Sites: encoder layer i -> 4 i + {0 attention weights, 1 dropout1, 2 feed-forward inner, 3 dropout2}; decoder layer l
+    Sites: PositionalEncoding (use_rotary=False) 8 motion tokens, 9 music tokens (model/utils.py:32 at model/model.py:564,580);
+    encoder layer i -> 4 i + {0 attention weights, 1 dropout1, 2 feed-forward inner, 3 dropout2}; decoder layer l
     -> 16 + 8 l + {0 self weights, 1 self fc out, 2 dropout1, 3 cross weights, 4 cross fc out, 5 dropout2, 6 inner,
     7 dropout3}  (model/model.py:98,103,240,244-245,383,396,400-401)."""
 
@@ -362,7 +363,7 @@ def music_branch(sd: SD, cond_embed: torch.Tensor, cfg: dict, drop=_nodrop):
         cond_embed = cond_embed[:, :-1, :]
     c = cond_embed.reshape(b, clen // 2, -1).float()
     tok = linear(F.relu(linear(c, sd, "cond_projection.0")), sd, "cond_projection.2")
-    tok = abs_pos(tok, sd, drop)           # :580
+    tok = abs_pos(tok, sd, drop, 9)        # :580
     for i in range(2):
         tok = encoder_layer(tok, sd, f"cond_encoder.{i}", sd.get("rotary.freqs"), cfg["n_head"], drop, 4 * i)
     return tok
@@ -390,7 +391,7 @@ def decoder_forward(sd: SD, x, cond_embed, times, cond_drop_prob: float = 0.0,
     f = F.relu(linear(f, sd, "relative_projection_layer.0"))
     f = F.relu(linear(f, sd, "relative_projection_layer.2"))
     x = linear(f, sd, "relative_projection_layer.4").reshape(B, dn * S, D)
-    x = abs_pos(x, sd, drop)               # :564
+    x = abs_pos(x, sd, drop, 8)            # :564
     # :567-569 keep mask
     if keep_mask is None:
         p = 1 - cond_drop_prob

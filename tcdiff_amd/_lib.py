@@ -26,7 +26,7 @@ class TileEpi(C.Structure):
                 ("out_v", _vp), ("ldc", _i), ("L", _i), ("Lp", _i), ("H", _i), ("n_q", _i), ("n_k", _i),
                 ("tok_off", _i), ("seq_off", _i), ("k_splits", _i), ("out2", _vp), ("ldc2", _i), ("act_src", _vp),
                 ("ld_src", _i), ("act2", _i), ("drop_seed", _vp), ("drop_site", _i), ("drop_thr", C.c_uint32),
-                ("drop_scale", _f), ("hgroup", _i), ("hgroup_stride", _l)]
+                ("drop_scale", _f), ("hgroup", _i), ("hgroup_stride", _l), ("small_m", _i)]
 
 
 class RowEpi(C.Structure):
@@ -136,6 +136,7 @@ _SIGS = {
     "tcdiff_cast_transpose_multi": [_i, _vp, _i, _i, _vp],
     "tcdiff_pack_row_streams": [_vp, _i, _i, _vp],
     "tcdiff_gemm_rows": [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp],
+    "tcdiff_pos_drop": [_vp, _i, _i, _vp, _i, _vp, _i, C.c_uint32, _f, _vp],
     "tcdiff_act_drop": [_i, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, C.c_uint32, _f, _vp],
     "tcdiff_act_drop_bwd": [_i, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i, C.c_uint32, _f, _vp],
     "tcdiff_row_fwd": [_i, C.POINTER(RowArgs), _vp],

@@ -838,11 +838,11 @@ __global__ __launch_bounds__(512) void gemm_small_kernel(const char* A, const ch
     }
 }
 
-// whether launch_tile hands a product to gemm_small_kernel: bf16, plain epilogue, and a 128 x 128 tiling that would leave at least
+// whether launch_tile hands a product to gemm_small_kernel: asked for (tcdiff_tile_epi.small_m), bf16, plain epilogue, and a 128 x 128 tiling that would leave at least
 // three quarters of the CUs idle while the 32 x 32 tiling still fits the machine once or twice (TCDIFF_GEMM_SMALL=0: never)
 static bool small_product(int dtype, const void* A2, int M, int N, int K, const tcdiff_tile_epi& e, int n_cu) {
     static const bool off = [] { const char* v = getenv("TCDIFF_GEMM_SMALL"); return v && v[0] == '0'; }();
-    if (off || dtype != TC_DTYPE_BF16 || A2 || (e.mode != TC_EPI_STORE_T && e.mode != TC_EPI_STORE_F32) || e.out2 || e.act_src)
+    if (off || !e.small_m || dtype != TC_DTYPE_BF16 || A2 || (e.mode != TC_EPI_STORE_T && e.mode != TC_EPI_STORE_F32) || e.out2 || e.act_src)
         return false;
     if (N % 32 || K % 32 || K > 2048 || e.ldc % 4 || (e.bias && !aligned16(e.bias))) return false;
     const long big = (long)((N + 127) / 128) * ((M + 127) / 128), small = (long)(N / 32) * ((M + 31) / 32);

@@ -291,6 +291,37 @@ extern "C" int tcdiff_act_drop_bwd(int dtype, int a_f32, const void* a, int ld_a
 }
 
 // =====================================================================================================================
+// PositionalEncoding in train mode (use_rotary=False): x = dropout(x + pe[position]) on fp32 rows, in place
+// (model/utils.py:27-32 at model/model.py:564,580; batch_first: row m of a [B, L, D] tensor is position m % L)
+// =====================================================================================================================
+__global__ __launch_bounds__(256) void pos_drop_kernel(float* __restrict__ x, const float* __restrict__ pe, int rows, int cols,
+                                                       int pos_mod, const int* __restrict__ seed, int site, uint32_t thr,
+                                                       float dscale) {
+    const int quads = cols >> 2;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)rows * quads) return;
+    const int row = (int)(i / quads), c4 = (int)(i % quads) * 4;
+    const DropCtx dc = drop_ctx(seed, site, thr, dscale);
+    f32x4_t v = *reinterpret_cast<const f32x4_t*>(x + (long)row * cols + c4);
+    if (pe) v += *reinterpret_cast<const f32x4_t*>(pe + (long)(row % pos_mod) * cols + c4);
+    if (thr) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = drop_keep(dc, (uint32_t)row * (uint32_t)cols + (uint32_t)(c4 + j)) ? v[j] * dscale : 0.0f;
+    }
+    *reinterpret_cast<f32x4_t*>(x + (long)row * cols + c4) = v;
+}
+extern "C" int tcdiff_pos_drop(float* x, int rows, int cols, const float* pe, int pos_mod, const int* seed, int site,
+                               uint32_t drop_thr, float drop_scale, hipStream_t stream) {
+    if (!x || rows <= 0 || cols <= 0 || cols % 4 || (pe && pos_mod <= 0) || (drop_thr && !seed)) return TC_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(x) & 15) || (pe && (reinterpret_cast<uintptr_t>(pe) & 15))) return TC_ERR_ALIGN;
+    const long n = (long)rows * (cols / 4);
+    hipLaunchKernelGGL(pos_drop_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, pe, rows, cols, pe ? pos_mod : 1,
+                       seed, site, drop_thr, drop_scale);
+    TC_CHECK_LAUNCH();
+    return TC_OK;
+}
+
+// =====================================================================================================================
 // row-local block glue: one wave per 512-wide row; lane l owns columns [4l, 4l+4) and [256+4l, 256+4l+4)
 // =====================================================================================================================
 struct Row8 { f32x4_t a, b; };      // the lane's eight columns

@@ -551,14 +551,17 @@ class DenoiserEngine:
         # input projection + fusion projection over per-frame concatenated dancers (model/model.py:560-561)
         if not x_ready:                      # the sampler's step_prologue already wrote b["xin"]
             K.convert_pad(dt, x, b["xin"], *self._xin_shape(Rs))
+        # small jobs (the layers in their four-workgroups-per-block form): these products through the launcher's small-M kernel too
+        # -- another summation order, so only together with that kernel family (tcdiff_tile_epi.small_m)
+        sm = self._split_job(nseq)
         if self.fold_in:
             K.gemm_tile(dt, b["xin"], w["f1in.w"], B * S, 1024, self.kin, bias=w["f1in.b"], act=L.ACT_RELU, out=b["f1"],
-                        ldc=1024)
+                        ldc=1024, small_m=sm)
         else:
-            K.gemm_tile(dt, b["xin"], w["in.w"], Rs, 512, 192, bias=w["in.b"], out=b["xp"], ldc=512)
+            K.gemm_tile(dt, b["xin"], w["in.w"], Rs, 512, 192, bias=w["in.b"], out=b["xp"], ldc=512, small_m=sm)
             K.gemm_tile(dt, b["xp"], w["f1.w"], B * S, 1024, 512 * dn, bias=w["f1.b"], act=L.ACT_RELU, out=b["f1"],
-                        ldc=1024)
-        K.gemm_tile(dt, b["f1"], w["f2.w"], B * S, 1024, 1024, bias=w["f2.b"], act=L.ACT_RELU, out=b["f2"], ldc=1024)
+                        ldc=1024, small_m=sm)
+        K.gemm_tile(dt, b["f1"], w["f2.w"], B * S, 1024, 1024, bias=w["f2.b"], act=L.ACT_RELU, out=b["f2"], ldc=1024, small_m=sm)
         # last fusion linear, one group per dancer in ONE launch: group d writes token rows m*dn + d (de-interleave:
         # frame row m, dancer d -> token m*dn + d); fused with layer-0 norm1 + rotary
         self._frag_front = self.front and self._split_job(nseq) and os.environ.get("TCDIFF_SPLIT_FRONT", "1") != "0"
@@ -567,7 +570,7 @@ class DenoiserEngine:
             # then layer 0's norm1 / rotary / Q, K, V as fragment images (tcdiff_chain_split part 0): layer 0's self-attention runs
             # inside its first launch like every other layer's.  (TC_CHAIN_FRONT has 9 workgroups for one 3 x 150 clip.)
             K.gemm_tile(dt, b["f2"], w["f3.w"], B * S, 512 * dn, 1024, bias=w["f3.b"], mode=L.EPI_STORE_F32, out=b["xs"],
-                        ldc=512 * dn)
+                        ldc=512 * dn, small_m=True)
             K.chain(L.CHAIN_FRONT, Rs, Lq, None, w["front"][0], split_part=0, xres=b["xs"], nn_g=w["l0.norm1.g"],
                     nn_b=w["l0.norm1.b"], nn_eps=1e-5, rope=w["rope_cb"], qf_out=b["Qf"], kf_out=b["sKf"][0], vf_out=b["sVf"][0],
                     out_nkt=self.skt, scale_q=0.125, H=H)

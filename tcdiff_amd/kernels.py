@@ -69,11 +69,13 @@ def _p(t):
 def gemm_tile(dt, A, W, M, N, K, *, lda=None, ldw=None, A2=None, split_n=0, a_mod=0, mode=L.EPI_STORE_T,
               act=L.ACT_NONE, bias=None, out=None, ldc=0, out_k=None, out_v=None, scale_q=1.0, Lseq=0, Lp=0, H=0,
               n_q=0, n_k=0, tok_off=0, seq_off=0, out2=None, ldc2=0, act_src=None, ld_src=0, act2=L.ACT_NONE, seed=None,
-              site=0, thr=0, drop_scale=1.0, hgroup=0, hgroup_stride=0):
-    """out2 / act_src: the training step's fused activation epilogues (include/tcdiff_hip.h tcdiff_tile_epi)."""
+              site=0, thr=0, drop_scale=1.0, hgroup=0, hgroup_stride=0, small_m=False):
+    """out2 / act_src: the training step's fused activation epilogues; small_m: the launcher may take its small-M kernel
+    (include/tcdiff_hip.h tcdiff_tile_epi)."""
     lib = L.load()
     e = L.TileEpi(mode, act, scale_q, _p(bias), _p(out), _p(out_k), _p(out_v), ldc, Lseq, Lp, H, n_q, n_k, tok_off,
-                  seq_off, 0, _p(out2), ldc2, _p(act_src), ld_src, act2, _p(seed), site, thr, drop_scale, hgroup, hgroup_stride)
+                  seq_off, 0, _p(out2), ldc2, _p(act_src), ld_src, act2, _p(seed), site, thr, drop_scale, hgroup, hgroup_stride,
+                  int(bool(small_m)))
     rc = lib.tcdiff_gemm_tile(dt, _p(A), _p(A2), split_n, _p(W), M, N, K, lda if lda else K, ldw if ldw else K,
                               a_mod, C.byref(e), stream())
     L.check(rc, "tcdiff_gemm_tile")
@@ -411,6 +413,11 @@ def ct_table(dt, entries, device):
 def cast_transpose_multi(dt, table):
     tab, n, tiles = table
     L.check(L.load().tcdiff_cast_transpose_multi(_sdt(dt), _p(tab), n, tiles, stream()), "tcdiff_cast_transpose_multi")
+
+
+def pos_drop(x, rows, cols, pe=None, pos_mod=1, seed=None, site=0, thr=0, scale=1.0):
+    """x = dropout(x + pe[row % pos_mod]) in place, fp32 rows (PositionalEncoding in train mode, model/utils.py:27-32)"""
+    L.check(L.load().tcdiff_pos_drop(_p(x), rows, cols, _p(pe), pos_mod, _p(seed), site, thr, scale, stream()), "tcdiff_pos_drop")
 
 
 def act_drop(dt, a, ld_a, y, ld_y, rows, cols, act, seed=None, site=0, thr=0, scale=1.0):

@@ -229,9 +229,6 @@ class DanceDecoder(nn.Module):
     def train_engine(self):
         """The (lazily built) training-step engine: operand packs, flat gradient buffer, forward / backward schedule."""
         from .train_engine import TrainEngine
-        if not self.use_rotary:
-            raise L.TcdiffError("use_rotary=False runs in inference only (torch.no_grad(): samplers, guided_forward, forward); the "
-                                "training step implements the rotary configuration (TCDiff.py:76-87)")
         eng = self._train_engine
         dev = next(self.parameters()).device
         # an opt-in gradient averager survives EVERY rebuild (new Parameter objects, another device, another arithmetic mode):

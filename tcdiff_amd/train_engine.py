@@ -51,6 +51,9 @@ def _is_dead(name: str) -> bool:
     return any(d in name for d in DEAD)
 
 
+# dropout sites of PositionalEncoding (use_rotary=False); 0-7: the music encoder's, 16 + 8 l ..: decoder layer l's (oracle DropPlan)
+SITE_PE_X, SITE_PE_COND = 8, 9
+
 class _Lin:
     """One nn.Linear, or several stacked along the output dimension and evaluated as one GEMM."""
 
@@ -306,7 +309,17 @@ class TrainEngine:
         self.sin_freq = torch.exp(torch.arange(half) * -(math.log(10000) / (half - 1))).to(self.dev)   # model/utils.py:43-44
         n_pos = max(self.Lq, self.S + 2)
         self.rope = torch.empty(n_pos, 512, device=self.dev, dtype=torch.float32)
-        K.rope_table(model.rotary.freqs.detach().float().contiguous(), self.rope, n_pos)
+        # use_rotary=False (model/model.py:441-448): no rotation anywhere (angle 0: cos 1, sin 0 -- the same launches) and
+        # PositionalEncoding, with its own nn.Dropout, on the motion tokens and the music tokens (model/model.py:564,580)
+        self.abs_pos = not getattr(model, "use_rotary", True)
+        if self.abs_pos:
+            K.rope_table(torch.zeros(256, device=self.dev, dtype=torch.float32), self.rope, n_pos)
+            self.pe = model.abs_pos_encoding.pe.detach()[:, 0, :].to(device=self.dev, dtype=torch.float32).contiguous()
+            if max(self.Lq, self.S) > self.pe.shape[0]:
+                raise L.TcdiffError(f"PositionalEncoding holds {self.pe.shape[0]} positions, the sequence has {self.Lq} tokens "
+                                    "(model/utils.py:12,29)")
+        else:
+            K.rope_table(model.rotary.freqs.detach().float().contiguous(), self.rope, n_pos)
 
     # ------------------------------------------------------------------------------------------------------------------
     # parameter groups and the flat gradient buffer
@@ -679,6 +692,8 @@ class TrainEngine:
         c1 = self.act_fwd(c0a, Ms, Cd, L.ACT_RELU)
         tok = e(Ms, 512, dtype=f32)
         lins["c2"].fwd(c1, Ms, out=tok, f32=True)
+        if self.abs_pos:                      # cond_tokens = abs_pos_encoding(cond_tokens) (model/model.py:580): dropout site 9
+            K.pos_drop(tok, Ms, 512, self.pe, S, self.seed, SITE_PE_COND, self.thr, self.dscale)
         sv.update(cin=cin, c0a=c0a, c1=c1, tok0=tok)
         mh, mrot = e(Ms, 512), e(Ms, 512)
         self.row_fwd(flags=L.ROWF_NEXT_LN | L.ROWF_STORE_H | L.ROWF_STORE_ROT, M=Ms, L=S, z=tok,
@@ -774,6 +789,8 @@ class TrainEngine:
         xs = e(Ms, 512 * dn, dtype=f32)
         lins["f3"].fwd(f2, Ms, out=xs, f32=True)
         xs = xs.view(M, 512)
+        if self.abs_pos:                      # x = abs_pos_encoding(x) (model/model.py:564): dropout site 8
+            K.pos_drop(xs, M, 512, self.pe, Lq, self.seed, SITE_PE_X, self.thr, self.dscale)
         st = "seqTransDecoder.stack."
         h1, r1 = e(M, 512), e(M, 512)
         self.row_fwd(flags=L.ROWF_NEXT_LN | L.ROWF_STORE_H | L.ROWF_STORE_ROT, M=M, L=Lq, z=xs, nln_g=P(st + "0.norm1.weight"),
@@ -1079,6 +1096,8 @@ class TrainEngine:
         self.row_bwd(M=M, L_=Lq, nln=st + "0.norm1", flags=L.ROWF_NEXT_LN | L.ROWF_STORE_H | L.ROWF_STORE_ROT, z=sv["xs"],
                      nln_g=P(st + "0.norm1.weight"), nln_b=P(st + "0.norm1.bias"), nln_eps=1e-5, rope=self.rope, pos_mod=Lq,
                      d_xn=g_x, d_h=g_h, d_rot=g_r, d_z=dxs)
+        if self.abs_pos and self.thr:         # through PositionalEncoding's dropout (the mask of site 8 again)
+            dxs = self.act_bwd(dxs, dxs, M, 512, L.ACT_NONE, site=SITE_PE_X)
         df2a, df1a = e(Ms, 1024), e(Ms, 1024)
         lins["f3"].bwd(dxs.view(Ms, 512 * dn), 512 * dn, Ms, [sv["f2"]], [("ACT", df2a, 1024, sv["f2a"], L.ACT_RELU, None)])
         lins["f2"].bwd(df2a, 1024, Ms, [sv["f1"]], [("ACT", df1a, 1024, sv["f1a"], L.ACT_RELU, None)])
@@ -1158,12 +1177,15 @@ class TrainEngine:
             lins[f"e{i}.qkv"].bwd(dQKV, 1536, Ms, [s["rot"], s["h"]], [("T", g_r, 512), ("T", g_h, 512)])
             g_tok = gx1
         dtok0 = e(Ms, 512)
-        self.row_bwd(M=Ms, L_=S, nln="cond_encoder.0.norm1", lin="c2", flags=L.ROWF_NEXT_LN | L.ROWF_STORE_H | L.ROWF_STORE_ROT,
-                     z=sv["tok0"],
+        pe_drop = self.abs_pos and self.thr     # (then c2's bias gradient is taken behind the mask, by the linear's own backward)
+        self.row_bwd(M=Ms, L_=S, nln="cond_encoder.0.norm1", lin=None if pe_drop else "c2",
+                     flags=L.ROWF_NEXT_LN | L.ROWF_STORE_H | L.ROWF_STORE_ROT, z=sv["tok0"],
                      nln_g=P("cond_encoder.0.norm1.weight"), nln_b=P("cond_encoder.0.norm1.bias"), nln_eps=1e-5, rope=self.rope,
                      pos_mod=S, d_xn=g_tok, d_h=g_h, d_rot=g_r, d_z=dtok0)
         dc1 = self.pz("dc1", Ms, sv["c1"].shape[1])
-        lins["c2"].bwd(dtok0, 512, Ms, [sv["c1"]], [("T", dc1, dc1.shape[1])], bias_done=True)
+        if pe_drop:
+            dtok0 = self.act_bwd(dtok0, dtok0, Ms, 512, L.ACT_NONE, site=SITE_PE_COND)
+        lins["c2"].bwd(dtok0, 512, Ms, [sv["c1"]], [("T", dc1, dc1.shape[1])], bias_done=not pe_drop)
         dc0a = self.act_bwd(sv["c0a"], dc1, Ms, self.Cd, L.ACT_RELU)
         lins["c0"].bwd(dc0a, dc0a.shape[1], Ms, [sv["cin"]], [None])
         self.flush_wgrad()

@@ -72,9 +72,26 @@ def c1_grads(sd, ref, k, mode, d=0):
     return {n: v.grad.numpy().copy() for n, v in sd_now.items() if v.grad is not None}
 
 
+def norot_grads(sd, mode, d=0):
+    """the train-mode step of test_training_step_without_rotary_embedding_vs_oracle_autograd (config-1 shape, use_rotary=False)"""
+    DN, S, B = 2, 60, 3
+    x_start = torch.stack([O.synth_motion(c, DN * S).reshape(S, DN, 151).permute(1, 0, 2) for c in range(B)]) * (1.0 + d * 2.0 ** -18)
+    cond = torch.stack([O.synth_cond(c, S) for c in range(B)])
+    noise = torch.stack([O.synth_xT(10 + c, DN * S).reshape(S, DN, 151) for c in range(B)])
+    t, keep, seed = torch.tensor([17, 80, 3]), torch.tensor([True, False, True]), (11, 5)
+    sd_now = {n: p.detach().clone().requires_grad_(True) if p.is_floating_point() and n != "abs_pos_encoding.pe" else p
+              for n, p in sd.items()}
+    ctx = O.operand_rounding(**mode) if mode is not None else torch.enable_grad()
+    with ctx:
+        total, _ = O.p_losses(sd_now, O.make_tables(100), x_start, cond, t, noise, keep, drop=O.DropPlan(seed, 0.1))
+        total.backward()
+    return {n: v.grad.detach().numpy().copy() for n, v in sd_now.items() if v.requires_grad and v.grad is not None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--c1", action="store_true", help="also the two steps of c1_train_step.npz (3 clips of 2 x 60)")
+    ap.add_argument("--norot", action="store_true", help="also the use_rotary=False step (3 clips of 2 x 60, train mode)")
     ap.add_argument("--b", type=int, nargs="*", default=[3, 32])
     ap.add_argument("--draws", type=int, default=6)
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "c5_bf16_draws.npz"))
@@ -119,6 +136,20 @@ def main():
                 desc.append(f"{m}{d}")
                 print(f"c1 step {k} draw {desc[-1]}: median {np.median(e):.3e} worst {e.max():.3e} ({names[int(e.argmax())]})", flush=True)
             out[f"c1s{k}_names"], out[f"c1s{k}_err"], out[f"c1s{k}_draws"] = np.array(names), np.stack(E), np.array(desc)
+        np.savez_compressed(a.out, **out)
+    if a.norot:
+        sdn = O.synth_state_dict(dn=2, seq_len=60, use_rotary=False)
+        g0 = norot_grads(sdn, None)
+        names = sorted(g0)
+        E, desc = [], []
+        for d in range(a.draws):
+            m = "D" if d % 3 else "A"
+            ge = norot_grads(sdn, MODES[m], d)
+            e = np.array([rel(ge[n], g0[n]) for n in names], np.float32)
+            E.append(e)
+            desc.append(f"{m}{d}")
+            print(f"use_rotary=False draw {desc[-1]}: median {np.median(e):.3e} worst {e.max():.3e} ({names[int(e.argmax())]})", flush=True)
+        out["norot_names"], out["norot_err"], out["norot_draws"] = np.array(names), np.stack(E), np.array(desc)
         np.savez_compressed(a.out, **out)
     print("saved", a.out)
 

@@ -16,7 +16,8 @@ from tcdiff_amd import _lib as L  # noqa: E402
 from tcdiff_amd import kernels as K  # noqa: E402
 from tcdiff_amd.model import DanceDecoder  # noqa: E402
 from oracle import tcdiff_oracle as O  # noqa: E402
-from test_chain_selfatt_gpu import DEV, Layer, bf, rnd  # noqa: E402
+from tcdiff_amd.engine import DenoiserEngine as E  # noqa: E402
+from test_chain_selfatt_gpu import DEV, Layer, bf, kf_index, rnd, unpack_kv, unpack_q, vf_index  # noqa: E402
 
 
 def run_layers(Lq, nseq, split, qk_gain=1.0, Lk=62, stamps=None):
@@ -101,6 +102,49 @@ def test_split_layers_equal_the_fused_launch(Lq, nseq, Lk, gain):
         if rel_mean > (1.5e-3 if first else 4e-3) or rel_max > (2e-2 if first else 6e-2):
             bad.append((k, rel_max, rel_mean))
     assert not bad, bad
+
+
+@pytest.mark.parametrize("Lq,nseq", [(120, 2), (450, 1), (137, 3)])
+def test_front_part_writes_the_fragment_images_of_layer_0(Lq, nseq):
+    """tcdiff_chain_split part 0 (TC_CHAIN_FRONT stream, stages 32 / 48 / 64): norm1 + rotary of row-major fp32 token rows -> Q, K;
+    norm1 -> V (model/model.py:326,374-383,78-80 for layer 0), as the fragment images part 1 reads, against a float64 torch evaluation
+    with the kernel's rounding points (bf16 activations into the products, bf16 images out).  Rows of a last partial block (450 = 28 x
+    16 + 2, 137 = 8 x 16 + 9) and the slots nobody owns (NaN-poisoned images: a key slot past the sequence must come out finite)."""
+    H, M = 8, nseq * Lq
+    Wf3 = rnd(512, 1024, seed=1, scale=1024 ** -0.5).to(bf)                    # (the front stream's first 32 stages: unused by part 0)
+    Wqkv = rnd(1536, 512, seed=2, scale=512 ** -0.5).to(bf)
+    ws = torch.cat([E._stages_n512(Wf3)] + [E._stages_n512(Wqkv[i * 512:(i + 1) * 512]) for i in range(3)], 1).contiguous()
+    assert ws.shape[1] == 80
+    x = rnd(M, 512, seed=3)
+    g, b = 1.0 + 0.1 * rnd(512, seed=4), 0.1 * rnd(512, seed=5)
+    rope = torch.empty(Lq, 512, device=DEV)
+    K.rope_table((1.0 / (10000 ** (torch.arange(0, 512, 2).float() / 512))).to(DEV), rope, Lq)
+    nbs, skt = (Lq + 15) // 16, (Lq + 31) // 32
+    qf = torch.zeros(nseq * nbs, 8, 4, 2, 64, 8, device=DEV, dtype=bf)
+    kf = torch.full((nseq, H, skt * 2048), float("nan"), device=DEV, dtype=bf)
+    vf = torch.full((nseq, H, skt * 2048), float("nan"), device=DEV, dtype=bf)
+    K.chain(L.CHAIN_FRONT, M, Lq, None, ws, split_part=0, xres=x, nn_g=g, nn_b=b, nn_eps=1e-5, rope=K.to_cb(rope), qf_out=qf, kf_out=kf,
+            vf_out=vf, out_nkt=skt, scale_q=0.125, H=H)
+    torch.cuda.synchronize()
+    # reference: LayerNorm in float64, rotation by the same table, bf16 operands
+    xd = x.double()
+    h = (xd - xd.mean(1, keepdim=True)) / torch.sqrt(xd.var(1, unbiased=False, keepdim=True) + 1e-5) * g.double() + b.double()
+    rp = rope.double().repeat(nseq, 1).reshape(M, 256, 2)                    # (cos, sin) per pair
+    hp = h.reshape(M, 256, 2)
+    rot = torch.stack([hp[..., 0] * rp[..., 0] - hp[..., 1] * rp[..., 1], hp[..., 1] * rp[..., 0] + hp[..., 0] * rp[..., 1]], -1).reshape(M, 512)
+    hb, rb = h.float().to(bf).double(), rot.float().to(bf).double()
+    W = Wqkv.double()
+    heads = lambda t: t.reshape(nseq, Lq, H, 64).permute(0, 2, 1, 3)
+    q_ref = heads(rb @ W[:512].T) * (0.125 * 1.4426950408889634)              # the in-launch softmax works in the exp2 domain
+    k_ref, v_ref = heads(rb @ W[512:1024].T), heads(hb @ W[1024:].T)
+    q = unpack_q(qf, nseq, Lq, 16).double()
+    k, v = unpack_kv(kf, kf_index, Lq).double(), unpack_kv(vf, vf_index, Lq).double()
+    for nm, got, ref in (("q", q, q_ref), ("k", k, k_ref), ("v", v, v_ref)):
+        d = (got - ref).abs()
+        print(f"part 0, {nseq} x {Lq}: {nm} max-abs {float(d.max()):.2e} mean {float(d.mean()):.2e} (max |.| {float(ref.abs().max()):.2f})")
+        assert torch.isfinite(got).all() and float(d.max()) < 2.5e-2 * max(1.0, float(ref.abs().max())) and float(d.mean()) < 2.5e-3, nm
+    # every V^T slot of the last key tile is finite (P = 0 times NaN would poison the in-launch attention)
+    assert torch.isfinite(vf.float()).all()
 
 
 def test_launcher_refuses_in_place_and_missing_buffers():

@@ -176,9 +176,9 @@ def test_guidance_clipping_and_ddim_schedule(small):
     assert float(ddpm[0, 1]) == float(tab["posterior_mean_coef1"][999])
 
 
-def test_use_rotary_false_surface_and_training_refusal(golden_dir):
+def test_use_rotary_false_surface(golden_dir):
     """DanceDecoder(use_rotary=False): the reference's state_dict surface for that option (no rotary.freqs anywhere, the
-    PositionalEncoding buffer with the reference's values), and the training step refuses it with a clear error (inference only)."""
+    PositionalEncoding buffer with the reference's values); the training engine -- like every engine -- needs the HIP device."""
     ref = np.load(os.path.join(golden_dir, "c1_abs_pos.npz"))
     from oracle import tcdiff_oracle as O
     m = DanceDecoder(nfeats=151, seq_len=60, latent_dim=512, ff_size=1024, num_layers=8, num_heads=8, dropout=0.1,
@@ -187,7 +187,7 @@ def test_use_rotary_false_surface_and_training_refusal(golden_dir):
     sd = O.synth_state_dict(dn=2, seq_len=60, use_rotary=False)
     assert torch.equal(m.state_dict()["abs_pos_encoding.pe"], sd["abs_pos_encoding.pe"])      # (the oracle's = the real module's: generator script)
     m.load_state_dict(sd, strict=True)
-    with pytest.raises(L.TcdiffError, match="inference only"):
+    with pytest.raises(L.TcdiffError):            # (no CPU fallback; on the GPU the option trains: test_train_step_gpu.py)
         m.train_engine()
 
 

@@ -59,8 +59,9 @@ def test_gemm_tile_store(dt, M, N, Kd, act):
                                               (7, 64, 64, L.ACT_GELU, 0), (33, 96, 2048, L.ACT_SILU, 0), (150, 512, 320, L.ACT_NONE, 50),
                                               (450, 1024, 1024, L.ACT_RELU, 0)])
 def test_gemm_tile_small_products(M, N, Kd, act, a_mod):
-    """The shapes tcdiff_gemm_tile hands to its small-M kernel (csrc/gemm.hip gemm_small_kernel: bf16, plain epilogue, a 128 x 128
-    tiling that would leave the chip idle -- the sampler's input / fusion projections on a one-clip job, model/model.py:560-561):
+    """The shapes tcdiff_gemm_tile hands to its small-M kernel when the caller allows it (tcdiff_tile_epi.small_m; csrc/gemm.hip
+    gemm_small_kernel: bf16, plain epilogue, a 128 x 128 tiling that would leave the chip idle -- the sampler's input / fusion
+    projections on a one-clip job, model/model.py:560-561; the last case is too large and stays on the 128 x 128 tiling):
     32 x 32 output tiles, K dealt to the eight waves, one exchange.  Row tails (M % 32), k-steps that do not divide by the waves
     (K = 576: 18 steps; K = 64: two waves work), a_mod, both output types, an output wider than N."""
     dt = L.DT_BF16
@@ -72,7 +73,7 @@ def test_gemm_tile_small_products(M, N, Kd, act, a_mod):
     for mode, odt in ((L.EPI_STORE_F32, torch.float32), (L.EPI_STORE_T, T(dt))):
         ldc = N + 4
         out = torch.full((M + 1, ldc), 7.0, device=DEV, dtype=odt)
-        K.gemm_tile(dt, A, W, M, N, Kd, bias=bias, act=act, mode=mode, out=out, ldc=ldc, a_mod=a_mod)
+        K.gemm_tile(dt, A, W, M, N, Kd, bias=bias, act=act, mode=mode, out=out, ldc=ldc, a_mod=a_mod, small_m=True)
         torch.cuda.synchronize()
         assert relerr(out[:M, :N], ref) < (1e-5 if mode == L.EPI_STORE_F32 else tol(dt)), (mode, relerr(out[:M, :N], ref))
         assert bool((out[:M, N:] == 7.0).all()) and bool((out[M] == 7.0).all()), "wrote outside the M x N block"

@@ -260,6 +260,55 @@ def test_training_step_with_another_feed_forward_activation_vs_oracle_autograd(n
     assert abs(float(total) - float(o_total)) <= 2e-5 * abs(float(o_total)) and allr[0][0] < 1e-4
 
 
+@pytest.mark.parametrize("compute,train", [("f32", True), ("f32", False), ("bf16", True)])
+def test_training_step_without_rotary_embedding_vs_oracle_autograd(golden_dir, compute, train):
+    """DanceDecoder(use_rotary=False) (model/model.py:441-448): no rotation anywhere and PositionalEncoding -- with its own nn.Dropout,
+    model/utils.py:27-32 -- on the motion tokens (:564) and the music tokens (:580).  One step at the C1 shape, dropout live (the two
+    extra sites 8 / 9 of the DropPlan: same counter-hash masks on both sides) and in eval mode, every live parameter's gradient
+    against the oracle's autograd; the oracle's use_rotary=False forward is pinned to the real reference by c1_abs_pos.npz
+    (test_parity_gpu.py).  f32 <= 1e-4 relative L2 -- in eval mode the self-attention of the last layers saturates with these weights
+    and its w_qs / w_ks gradients vanish (|g| 3e-8 against a median of 7e-3): those are held to an absolute floor of 1e-10 per element,
+    fp32 summation noise.  bf16: this configuration amplifies rounding noise more than the rotary one (nine emulated draws,
+    tests/golden/c5_bf16_draws.npz `norot`: median error 0.11 .. 0.76) -- the step is held to the draws' per-parameter profile and range."""
+    sd = O.synth_state_dict(dn=DN, seq_len=S, use_rotary=False)
+    model = DanceDecoder(nfeats=151, seq_len=S, latent_dim=512, ff_size=1024, num_layers=8, num_heads=8, dropout=0.1,
+                         cond_feature_dim=438, activation=F.gelu, required_dancer_num=DN, use_rotary=False, compute_dtype=compute)
+    model.load_state_dict(sd)
+    diff = GaussianDiffusion(model, S, 151, None, schedule="cosine", n_timestep=T, predict_epsilon=False, loss_type="l2",
+                             use_p2=False, cond_drop_prob=0.25, guidance_weight=2, seq_len=S).to(DEV)
+    diff.train(train)
+    x_start, cond, noise = step_inputs(0, 10)
+    t, keep, seed = torch.tensor([17, 80, 3]), torch.tensor([True, False, True]), (11, 5)
+    model.train_seed = seed
+    total, _ = diff.p_losses(x_start.to(DEV), cond.to(DEV), t.to(DEV), noise=noise.to(DEV), keep_mask=keep.to(DEV))
+    total.backward()
+    assert model.train_engine().abs_pos
+    sd_now = {n: p.detach().clone().requires_grad_(True) if p.is_floating_point() and n != "abs_pos_encoding.pe" else p
+              for n, p in sd.items()}
+    o_total, _ = O.p_losses(sd_now, O.make_tables(T), x_start, cond, t, noise, keep, drop=O.DropPlan(seed, 0.1 if train else 0.0))
+    o_total.backward()
+    def rel_floor(a, b):          # relative L2 with an absolute floor of 1e-10 per element under the reference's norm
+        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-10 * np.sqrt(b.size) / TOL["f32"][0]))
+    allr = sorted(((rel_floor(p.grad.cpu().numpy(), sd_now[n].grad.numpy()), n) for n, p in model.named_parameters() if p.grad is not None),
+                  reverse=True)
+    gn = {n: float(sd_now[n].grad.norm()) for _, n in allr}
+    print(f"[{compute}, use_rotary=False, {'train' if train else 'eval'}] total {float(total):.6f} (oracle {float(o_total):.6f}); "
+          f"{len(allr)} gradients vs the oracle's autograd: worst " + ", ".join(f"{n} {v:.2e} (|g| {gn[n]:.1e})" for v, n in allr[:6]) +
+          f"; median {np.median([v for v, _ in allr]):.2e}, median |g| {np.median(list(gn.values())):.1e}")
+    gtol, ltol = TOL[compute]
+    assert abs(float(total) - float(o_total)) <= ltol * abs(float(o_total)) and len(allr) > 300
+    if compute == "f32":
+        assert allr[0][0] < gtol, allr[0]
+        return
+    z = np.load(os.path.join(golden_dir, "c5_bf16_draws.npz"))
+    names, E = [str(n) for n in z["norot_names"]], z["norot_err"].astype(np.float64)
+    sr, sn, med_k, med_d = shape_ratio({n: v for v, n in allr}, names, E)
+    print(f"[bf16, use_rotary=False] error profile vs nine emulated draws: shape {sr:.2f} ({sn}), median {med_k:.2e} (draws {med_d.min():.2e} .. "
+          f"{med_d.max():.2e}), worst {allr[0][0]:.2e} (draws' worst {E.max():.2e})")
+    assert sr <= SHAPE_TOL and 0.5 * med_d.min() <= med_k <= 1.25 * med_d.max() and allr[0][0] < 1.35 * float(E.max()), (sr, sn, med_k, allr[0])
+
+
 def test_row_block_gemm_path_and_tile_path_are_two_roundings_of_the_same_step():
     """The decoder layers' linears run through tcdiff_gemm_rows (default) or tcdiff_gemm_tile (TCDIFF_TRAIN_ROWS=0): the same
     bf16 operands and fp32 accumulation, another summation order.  One train-mode step (3 clips of 3 x 150) both ways against
