@@ -17,3 +17,8 @@ SA=1 TCDIFF_LIB_PATH=tools/probe/libtc_STAMP.so timeout 300 python tools/chain_s
 timeout 300 python tools/chain_sa_bench.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r06_chain_self_attention_forms.txt; cat gpurun_out/r06_chain_self_attention_forms.txt
 timeout 1200 python tools/small_batch.py 2>&1 | tail -3 > gpurun_out/r06_small_batch.txt; cat gpurun_out/r06_small_batch.txt
 for b in 4 32; do python tools/train_bench.py --batch $b --iters 8 --kernels 2>/dev/null | tail -1; done > gpurun_out/r06_train_step.jsonl; cut -c1-200 gpurun_out/r06_train_step.jsonl
+TCDIFF_LIB_PATH=tools/probe/libtc_STAMPS.so timeout 300 python tools/split_stamps.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r06_split_stamps.txt; grep -E "part|partial stored|V  " gpurun_out/r06_split_stamps.txt | head -12
+rm -rf gpurun_out/prof_small
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_small -- python3 tools/small_job.py > gpurun_out/prof_small.log 2>&1
+f=$(find gpurun_out/prof_small -name "*kernel_stats.csv" | head -1); cp "$f" gpurun_out/r06_kernel_stats_small_job_ddim50_1clip.csv; head -12 "$f" | cut -c1-140
+rm -rf gpurun_out/prof_small
