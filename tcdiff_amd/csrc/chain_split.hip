@@ -14,6 +14,13 @@
 //   part 4  z = sum_c P; FiLM, +x; norm4; linear3 (every member, all of it: 0.5 MB, no exchange) -> x'; norm1', rotary;
 //           w_qs / w_ks / w_vs of heads 2c, 2c+1 -> the next layer's Q / K / V fragment images (chain.hip's formats)
 //
+//   part 0  (once per forward, TC_CHAIN_FRONT stream) layer 0's norm1, rotary, w_qs / w_ks / w_vs of heads 2c, 2c+1 from the token
+//           rows the fusion projection left -> layer 0's fragment images: its self-attention then runs in part 1 like every layer's
+//
+// Measured (profiles/r06_split_stamps.txt, r06_flag_sync_probe.txt): parts 1-4 = 9 / 16 / 14 / 19 us against 75
+// for the fused 16-row launch; in parts 2-4 the first ~6 us are the exchange itself (kernel arguments, then partial slabs and residual
+// rows from memory), the rest runs at the CU's ingest rate -- and an exchange through flags inside one launch costs MORE than a
+// launch boundary on this machine (7-9 us with scope bits on the accesses, 33 us with fences, against 5.9).
 // (model/model.py:97-107,323-344,374-401 as chain.hip.)  A member streams 0.13 + 0.26 + 0.5 + 0.9 MB instead of 5.5; every
 // member redoes the row-local LayerNorm / FiLM / residual of the 16 rows (nothing) and stores its quarter of x.  The weights are
 // chain.hip's per-wave streams, unchanged: a K split is a stage range of a wave's phase, an N split is the stream of the wave

@@ -171,7 +171,7 @@ def test_feed_forward_activation_option_vs_reference_golden(golden_dir, name):
 def test_use_rotary_false_option_vs_reference_golden(golden_dir):
     """DanceDecoder(use_rotary=False) (model/model.py:441-448: no rotary embedding, PositionalEncoding added to the motion tokens :564
     and the music tokens :580; rounds 1-4 refused it): a guided evaluation, a conditional forward and the full 100-step p_sample_loop
-    of config 1 against the REAL reference built with that option (tests/golden/make_golden_abs_pos.py).  Inference only, on the
+    of config 1 against the REAL reference built with that option (tests/golden/make_golden_abs_pos.py), on the
     op-by-op kernels (identity rotary table, positional rows added by tcdiff_add_rows); f32 mode to 1e-3, bf16 within its bound."""
     from tcdiff_amd import _lib as L
     ref = gold(golden_dir, "c1_abs_pos")
@@ -198,8 +198,11 @@ def test_use_rotary_false_option_vs_reference_golden(golden_dir):
               {k: f"{v:.2e}" for k, v in errs.items()}, f"(bound {lbound})")
         assert e1 < bound and e2 < bound and max(errs.values()) < lbound
         assert not model.engine(1).use_chain and model.engine(1).abs_pos
-        with pytest.raises(L.TcdiffError, match="inference only"):
-            model(xT, cond, torch.full((1,), 3, dtype=torch.long, device=DEV), cond_drop_prob=0.0)      # (gradients enabled: the training path)
+        # with gradients enabled the same call is the training path (eval mode: dropout off): the same values, now with a graph
+        # (its gradients: tests/test_train_step_gpu.py::test_training_step_without_rotary_embedding_vs_oracle_autograd)
+        model.eval()
+        y = model(xT, cond, torch.full((1,), 3, dtype=torch.long, device=DEV), cond_drop_prob=0.0)
+        assert y.requires_grad and maxabs(y.detach(), ref["fwd_cond_t3"]) < bound
 
 
 def test_c1_graph_and_eager_agree(c1):
