@@ -310,6 +310,8 @@ int tcdiff_chain(const tcdiff_chain_args* args, hipStream_t stream);
  * buffers alternating likewise.  grid = (M / L) * ceil(L / 16) * 4 workgroups: meant for jobs where that fits the chip.
  * part 1 with sa_q and a_mod > 0: sequence s reads the fragment images of sequence s % (a_mod / L) (layer 0 under classifier-free
  * guidance: the stacked branches share x).
+ * part = 12: parts 1 and 2 as one launch (no p_in): every member computes the self-attention of all eight heads and the whole fc
+ * (more K / V and weight bytes per member, one exchange less: for short sequences).
  * part = 0 (mode TC_CHAIN_FRONT, the 80-stage front stream of any dancer): layer 0's Q / K / V fragment images from the token
  * rows the fusion projection left -- xres: ROW-MAJOR fp32 [M][512] (model/model.py:561 as one [frames][512 dn] product, which is
  * the same memory); nn_g / nn_b / nn_eps: layer 0's norm1; rope; qf_out / kf_out / vf_out / out_nkt; scale_q.  With it a small job

@@ -279,18 +279,22 @@ DEVINL void kv_tile(const __amdgpu_buffer_rsrc_t& r, unsigned image_off, int kt,
 #pragma unroll
     for (int q = 0; q < 4; ++q) f[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (unsigned)lane * 16u + 1024u * q, so, 0));
 }
+// WPH: waves per head -- 4 (a workgroup runs two heads: wave w is head w / 4, key tiles w % 4, w % 4 + 4, ..) or 1 (eight heads, a
+// wave runs all key tiles of head w: no merge)
+template <int WPH = 4>
 DEVINL void kv_issue(KVTiles& t, const void* kf, const void* vf, unsigned image_off, int nkt, int wave, int lane) {
     const __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(kf), 0, -1, 0x00020000);
     const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(vf), 0, -1, 0x00020000);
-    const int j = wave & 3;
+    const int j = WPH == 4 ? wave & 3 : 0;
     kv_tile(kr, image_off, j, nkt, lane, t.k0);
     kv_tile(vr, image_off, j, nkt, lane, t.v0);
-    kv_tile(kr, image_off, j + 4, nkt, lane, t.k1);
-    kv_tile(vr, image_off, j + 4, nkt, lane, t.v1);
+    kv_tile(kr, image_off, j + WPH, nkt, lane, t.k1);
+    kv_tile(vr, image_off, j + WPH, nkt, lane, t.v1);
 }
+template <int WPH = 4>
 DEVINL void head_attention(const u32x4 (&qf)[2], KVTiles& pre, const void* kf, const void* vf, unsigned image_off, int nkt, int Lk,
                            char* smem, int wave, int lane) {
-    const int i = wave >> 2, j = wave & 3, c = lane & 15, gg = lane >> 4;
+    const int i = WPH == 4 ? wave >> 2 : wave, j = WPH == 4 ? wave & 3 : 0, c = lane & 15, gg = lane >> 4;
     u32x4 ones = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
     asm volatile("" : "+v"(ones));
     const __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(kf), 0, -1, 0x00020000);
@@ -303,7 +307,7 @@ DEVINL void head_attention(const u32x4 (&qf)[2], KVTiles& pre, const void* kf, c
     u32x4 (&kn)[4] = pre.k0, (&vn)[4] = pre.v0, (&kn2)[4] = pre.k1, (&vn2)[4] = pre.v1;      // the wave's tiles run TWO ahead (1-4 tiles of a
                                                                                                // 450-key sequence per wave: latency, not rate)
 #pragma unroll 1
-    for (int kt = j; kt < nkt; kt += 4) {
+    for (int kt = j; kt < nkt; kt += WPH) {
         u32x4 kc[4], vc[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -312,8 +316,8 @@ DEVINL void head_attention(const u32x4 (&qf)[2], KVTiles& pre, const void* kf, c
             kn[q] = kn2[q];
             vn[q] = vn2[q];
         }
-        ld_tile(kr, kt + 8, kn2);           // (past the end: the last tile again, unused)
-        ld_tile(vr, kt + 8, vn2);
+        ld_tile(kr, kt + 2 * WPH, kn2);     // (past the end: the last tile again, unused)
+        ld_tile(vr, kt + 2 * WPH, vn2);
         f32x4_t s0 = {nb, nb, nb, nb}, s1 = s0;
         mma16(s0, kc[0], qf[0]);
         mma16(s1, kc[2], qf[0]);
@@ -356,6 +360,15 @@ DEVINL void head_attention(const u32x4 (&qf)[2], KVTiles& pre, const void* kf, c
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) mma16(o[dt], vc[dt], pf);
         mma16(lacc, ones, pf);
+    }
+    if (WPH == 1) {      // the wave has seen every key: normalise and write the head's 64 columns (k-tile `wave`) of the activation block
+        const float inv1 = __builtin_amdgcn_rcpf(lacc[0]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            uint2 pk = {pack_bf2(o[dt][0] * inv1, o[dt][1] * inv1), pack_bf2(o[dt][2] * inv1, o[dt][3] * inv1)};
+            *reinterpret_cast<uint2*>(smem + CH_ABUF + i * 8192 + act_wr_off(lane, dt)) = pk;
+        }
+        return;
     }
     // ---- merge the head's four partial softmaxes: per query (lane c) the maximum m, the sum l, O^T[feature 16 dt + 4 g + t][query c]
     float* red = reinterpret_cast<float*>(smem + CS_RED(wave));     // [64 features][16 queries] | m[16] at 1024 | l[16] at 1040 (floats)
@@ -476,6 +489,64 @@ __global__ __launch_bounds__(512) void chain_split1_kernel(tcdiff_chain_args a, 
     CS_T(1, 3);
     partial_store(acc, p_out, g, wave, lane);
     CS_T(1, 4);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// parts 1 + 2 in ONE launch (part = 12): every member runs the self-attention of ALL eight heads of its 16 rows (one wave per head)
+// and the whole fc -- 0.7 MB more K / V and 0.4 MB more weights per member than the split form -- and saves the exchange between them
+// (a launch boundary: ~6 us of exchange + ~2.5 us of ramp + the gap).  Pays for short sequences (config 1: 120 keys) and about breaks
+// even at 450; then as part 2.
+// ------------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void chain_split12_kernel(tcdiff_chain_args a, float* p_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const SplitGeo g = split_geo(a);
+    char* abuf = smem + CH_ABUF;
+    float* scr = reinterpret_cast<float*>(smem + CH_SCR);
+    const bool mine = (wave >> 1) == g.member;
+    WStream ws;
+    stream_at(ws, a, wave, 0u, lane);                      // fc of the self-attention block: all 16 stages of every wave's phase
+    if (a.sa_q) {
+        const int sseq = a.a_mod > 0 ? g.bseq % (a.a_mod / a.L) : g.bseq;      // (layer 0 under guidance: see part 1)
+        const int qblk = sseq * ((a.L + 15) / 16) + g.bis;
+        const u32x4* qsrc = reinterpret_cast<const u32x4*>(a.sa_q) + ((long)(qblk * 8 + wave) * 8) * 64 + lane;
+        const u32x4 qf[2] = {qsrc[0], qsrc[64]};
+        const unsigned img = (unsigned)((sseq * a.H + wave) * a.sa_nkt) * 4096u;
+        KVTiles pre;
+        kv_issue<1>(pre, a.sa_kf, a.sa_vf, img, a.sa_nkt, wave, lane);
+        head_attention<1>(qf, pre, a.sa_kf, a.sa_vf, img, a.sa_nkt, a.L, smem, wave, lane);
+    } else {
+        // layer 0 without the fragment front: O of the stand-alone attention launch, all eight k-tiles of the 16 rows
+        stage_glds<16, 1>(abuf + wave * 8192, reinterpret_cast<const char*>(a.A) + wave * TC_ROWB, 1024, g.m0, g.Mend, a.a_mod, 0, lane);
+    }
+    const RowC rc = row_consts(a, g, a.film, a.xres, a.xres_mod > 0 ? a.xres_mod : a.M, a.xres_mod, a.xres_rowmajor != 0, wave, lane);
+    const NormC nc = norm_consts<true>(a, g, a.n2_g, a.n2_b, wave, lane);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    f32x4_t acc[4][1];
+    zero(acc);
+    phase_n512<16, true, 1>(acc, abuf, ws, lane);
+    WStream wq;
+    head_stream(wq, a, g, 16u, wave, lane);
+    lds_barrier();                                         // every wave is out of fc: the activation block is rewritten below
+    block_epilogue<true>(acc, rc, g, a.ln_eps, a.xout, scr, smem, wave, lane, mine);
+    norm_lds<true>(acc, nc, a.n2_eps, scr + 1024, smem, abuf, nullptr, wave, lane);
+    lds_barrier();
+    f32x4_t qacc[4][1];
+    const int head = 2 * g.member + (wave >> 2);
+    const int kv = g.bseq < a.n_shared ? 0 : g.bseq - a.n_shared + (a.n_shared > 0 ? 1 : 0);
+    const unsigned img = (unsigned)((kv * a.H + head) * a.nkt) * 4096u;
+    KVTiles pre;
+    kv_issue(pre, a.kf, a.vf, img, a.nkt, wave, lane);
+    stream_at(ws, a, wave, 32u + 4u * g.member, lane);
+    head_projection<false>(qacc, wq, abuf, smem, wave, lane);
+    u32x4 qf[2];
+    q_fragments(qacc, a.scale_q * CH_LOG2E, qf);
+    head_attention(qf, pre, a.kf, a.vf, img, a.nkt, a.Lk, smem, wave, lane);
+    lds_barrier();
+    zero(acc);
+    phase_n512<4, true, 1>(acc, abuf, ws, lane);
+    partial_store(acc, p_out, g, wave, lane);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -653,10 +724,11 @@ __global__ __launch_bounds__(512) void chain_split4_kernel(tcdiff_chain_args a, 
 static bool cs_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 extern "C" int tcdiff_chain_split(const tcdiff_chain_args* a, int part, const float* p_in, float* p_out, hipStream_t stream) {
-    if (!a || a->M <= 0 || a->L < 16 || a->M % a->L || !a->wstream || part < 0 || part > 4) return TC_ERR_ARG;
+    if (!a || a->M <= 0 || a->L < 16 || a->M % a->L || !a->wstream || part < 0 || (part > 4 && part != 12)) return TC_ERR_ARG;
     static tc_dev_state dev_state;
     const int n_cu = tc_device_once(dev_state, [](int) {
-        const void* fns[6] = {reinterpret_cast<const void*>(chain_split0_kernel), reinterpret_cast<const void*>(chain_split1_kernel),
+        const void* fns[7] = {reinterpret_cast<const void*>(chain_split12_kernel),
+                              reinterpret_cast<const void*>(chain_split0_kernel), reinterpret_cast<const void*>(chain_split1_kernel),
                               reinterpret_cast<const void*>(chain_split2_kernel), reinterpret_cast<const void*>(chain_split3_kernel),
                               reinterpret_cast<const void*>(chain_split4_kernel<false>),
                               reinterpret_cast<const void*>(chain_split4_kernel<true>)};
@@ -692,13 +764,14 @@ extern "C" int tcdiff_chain_split(const tcdiff_chain_args* a, int part, const fl
     if (last ? !a->h_out || a->out_ld < 0 || a->out_ld % 4 || a->out_ld > 512
              : (!a->qf_out || !a->kf_out || !a->vf_out || !a->nn_g || !a->nn_b || a->out_nkt <= 0 || a->L > 32 * a->out_nkt))
         return TC_ERR_ARG;
-    if ((part > 1 && !p_in) || (part < 4 && !p_out)) return TC_ERR_ARG;
+    if ((part > 1 && part != 12 && !p_in) || (part != 4 && !p_out)) return TC_ERR_ARG;
     const void* ptrs[] = {a->A, a->wstream, a->film, a->filmb, a->film3, a->xres, a->xout, a->n2_g, a->n2_b, a->n3_g, a->n3_b, a->n4_g,
                           a->n4_b, a->b1, a->b3, a->nn_g, a->nn_b, a->rope, a->kf, a->vf, a->sa_q, a->sa_kf, a->sa_vf, a->qf_out,
                           a->kf_out, a->vf_out, a->h_out, p_in, p_out};
     for (const void* p : ptrs)
         if (p && !cs_al16(p)) return TC_ERR_ALIGN;
-    if (part == 1) hipLaunchKernelGGL(chain_split1_kernel, grid, blk, CH_SMEM, stream, *a, p_out);
+    if (part == 12) hipLaunchKernelGGL(chain_split12_kernel, grid, blk, CH_SMEM, stream, *a, p_out);
+    else if (part == 1) hipLaunchKernelGGL(chain_split1_kernel, grid, blk, CH_SMEM, stream, *a, p_out);
     else if (part == 2) hipLaunchKernelGGL(chain_split2_kernel, grid, blk, CH_SMEM, stream, *a, p_in, p_out);
     else if (part == 3) hipLaunchKernelGGL(chain_split3_kernel, grid, blk, CH_SMEM, stream, *a, p_in, p_out);
     else if (last) hipLaunchKernelGGL(chain_split4_kernel<true>, grid, blk, CH_SMEM, stream, *a, p_in);

@@ -28,6 +28,7 @@ import torch
 from . import _lib as L
 from . import kernels as K
 
+MERGE12_MAX_L = 512      # measured: profiles/r06_small_batch_split.txt
 NL_FILM = 3
 
 
@@ -648,6 +649,13 @@ class DenoiserEngine:
         """whether this forward runs the decoder layers in their small-job form (csrc/chain_split.hip)"""
         return bool(self.use_full and self.fuse_sa and self.chain_nw == 8 and "xb" in self.b and self._split_rows(nseq, self.Lseq))
 
+    @staticmethod
+    def _merge12(Lq: int) -> bool:
+        """parts 1 + 2 of the small-job layer as one launch (tcdiff_chain_split part 12): TCDIFF_SPLIT_MERGE=0 never, =1 always,
+        default: sequences of at most MERGE12_MAX_L tokens (every member then streams the sequence's K / V for all eight heads)"""
+        v = os.environ.get("TCDIFF_SPLIT_MERGE", "")
+        return v == "1" or (v != "0" and Lq <= MERGE12_MAX_L)
+
     def _split_rows(self, nseq: int, Lq: int) -> bool:
         """the small-job form of the layer (four workgroups per 16-row block): when all of them fit the chip at once"""
         if os.environ.get("TCDIFF_SPLIT", "1") == "0" or self.chain_nw != 8 or Lq < 16:
@@ -705,11 +713,13 @@ class DenoiserEngine:
             cur = self._xcur                           # X[cur] holds this layer's input x (layer 0 reads b["xs"] instead)
             o1 = 0 if l == 0 else cur ^ 1
             launch = lambda part, **kw: K.chain(mode, R, Lq, b["O"], w[p + "chainF"], split_part=part, **{**args, **kw})
-            launch(1, p_out=P[0])
-            if l == 0:
-                launch(2, p_in=P[0], p_out=P[1], xout=X[o1])                                   # xres = b["xs"] (head)
+            x_in = {} if l == 0 else dict(xres=X[cur])                                         # layer 0: xres = b["xs"] (head)
+            if self._merge12(Lq):
+                # short sequences: self-attention of all eight heads and the whole fc in every member, one exchange less
+                launch(12, p_out=P[1], xout=X[o1], **x_in)
             else:
-                launch(2, p_in=P[0], p_out=P[1], xres=X[cur], xout=X[o1])
+                launch(1, p_out=P[0])
+                launch(2, p_in=P[0], p_out=P[1], xout=X[o1], **x_in)
             flat = dict(xres_mod=0, xres_rowmajor=False)
             launch(3, p_in=P[1], p_out=P[0], xres=X[o1], xout=X[o1 ^ 1], **flat)
             launch(4, p_in=P[0], xres=X[o1 ^ 1], xout=X[o1], **flat)

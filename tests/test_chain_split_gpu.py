@@ -63,8 +63,11 @@ def run_layers(Lq, nseq, split, qk_gain=1.0, Lk=62, stamps=None):
             K.chain(lay.mode, M, Lq, Oa, lay.ws, xres=X[cur], xout=X[cur], **kw)
         else:
             o1 = cur ^ 1
-            K.chain(lay.mode, M, Lq, Oa, lay.ws, split_part=1, p_out=P[0], xres=X[cur], xout=X[o1], **kw)
-            K.chain(lay.mode, M, Lq, Oa, lay.ws, split_part=2, p_in=P[0], p_out=P[1], xres=X[cur], xout=X[o1], **kw)
+            if split == "merged":         # parts 1 + 2 as one launch
+                K.chain(lay.mode, M, Lq, Oa, lay.ws, split_part=12, p_out=P[1], xres=X[cur], xout=X[o1], **kw)
+            else:
+                K.chain(lay.mode, M, Lq, Oa, lay.ws, split_part=1, p_out=P[0], xres=X[cur], xout=X[o1], **kw)
+                K.chain(lay.mode, M, Lq, Oa, lay.ws, split_part=2, p_in=P[0], p_out=P[1], xres=X[cur], xout=X[o1], **kw)
             K.chain(lay.mode, M, Lq, Oa, lay.ws, split_part=3, p_in=P[1], p_out=P[0], xres=X[o1], xout=X[cur], **kw)
             K.chain(lay.mode, M, Lq, Oa, lay.ws, split_part=4, p_in=P[0], xres=X[cur], xout=X[o1], **kw)
             cur = o1
@@ -78,12 +81,14 @@ def run_layers(Lq, nseq, split, qk_gain=1.0, Lk=62, stamps=None):
 
 # 450 = 28 x 16 + 2 (a last block of 2 rows), 120 / 150: the small configurations (C1: 2 x 60; 3 x 150 = 450 per clip); 62 / 152 keys:
 # the cross-attention memories of those configurations (2 / 5 key tiles: heads whose four waves do not all get a tile)
+@pytest.mark.parametrize("form", [True, "merged"])
 @pytest.mark.parametrize("Lq,nseq,Lk,gain", [(120, 2, 62, 1.0), (450, 2, 152, 1.0), (150, 3, 62, 1.0), (137, 2, 152, 1.0), (450, 1, 152, 4.0)])
-def test_split_layers_equal_the_fused_launch(Lq, nseq, Lk, gain):
+def test_split_layers_equal_the_fused_launch(Lq, nseq, Lk, gain, form):
     """Three consecutive layers (the first reads attention-output rows, the others compute their self-attention from the fragments
     the layer before left; the last is the folded *_LAST form) through tcdiff_chain_split's four parts and through the fused
-    launch: residual stream, Q / K / V fragment images and the final rows."""
-    a, b = run_layers(Lq, nseq, False, gain, Lk), run_layers(Lq, nseq, True, gain, Lk)
+    launch: residual stream, Q / K / V fragment images and the final rows.  form "merged": parts 1 and 2 as one launch (part 12:
+    self-attention of all eight heads and the whole fc in every member)."""
+    a, b = run_layers(Lq, nseq, False, gain, Lk), run_layers(Lq, nseq, form, gain, Lk)
     bad = []
     for k in a:
         x, y = a[k].float(), b[k].float()
@@ -178,8 +183,10 @@ def test_small_job_network_matches_the_fused_layers(dn, S, B, monkeypatch):
     m.to(DEV).eval()
     outs = {}
     # (the small-job workspaces are planned with the engine: the default form first, the switches afterwards)
-    for name, env in (("split+front", {}), ("split", dict(TCDIFF_SPLIT_FRONT="0")), ("fused", dict(TCDIFF_SPLIT="0"))):
-        for k in ("TCDIFF_SPLIT", "TCDIFF_SPLIT_FRONT"):
+    for name, env in (("split+front", dict(TCDIFF_SPLIT_MERGE="0")), ("merged+front", dict(TCDIFF_SPLIT_MERGE="1")),
+                      ("split", dict(TCDIFF_SPLIT_FRONT="0", TCDIFF_SPLIT_MERGE="0")), ("merged", dict(TCDIFF_SPLIT_FRONT="0", TCDIFF_SPLIT_MERGE="1")),
+                      ("fused", dict(TCDIFF_SPLIT="0"))):
+        for k in ("TCDIFF_SPLIT", "TCDIFF_SPLIT_FRONT", "TCDIFF_SPLIT_MERGE"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -189,9 +196,9 @@ def test_small_job_network_matches_the_fused_layers(dn, S, B, monkeypatch):
             f = m(x, cond, torch.arange(B, device=DEV) * 37 + 5, cond_drop_prob=0.0)
         eng = list(m._engines.values())
         assert all(e._split_job(2 * B) == (name != "fused") for e in eng if "xb" in e.b), name
-        assert any(getattr(e, "_frag_front", False) for e in eng) == (name == "split+front"), name
+        assert any(getattr(e, "_frag_front", False) for e in eng) == name.endswith("+front"), name
         outs[name] = (g.clone(), f.clone())
-    for name in ("split", "split+front"):
+    for name in ("split", "split+front", "merged", "merged+front"):
         for nm, a, b in zip(("guided", "forward"), outs["fused"], outs[name]):
             d, mean = float((a - b).abs().max()), float((a - b).abs().mean())
             print(f"{name} vs fused ({dn}x{S}, B={B}, {nm}): max-abs {d:.2e}, mean-abs {mean:.2e}, |out| max {float(a.abs().max()):.2f}")
