@@ -210,6 +210,33 @@ def test_act_drop_forward_and_backward(compute, act):
     assert rel(da[:, :cols], ar.grad) < max(tol, 1e-6) and float(da[:, cols:].float().abs().max()) == 0.0
 
 
+def test_pos_drop_is_positional_encoding_in_train_mode():
+    """tcdiff_pos_drop: x = dropout(x + pe[row % L]) in place on fp32 rows (PositionalEncoding.forward in train mode, model/utils.py:27-32
+    at model/model.py:564,580) with the oracle's counter-hash mask of the site; without a table: dropout only; with threshold 0: the
+    addition only.  Its backward is tcdiff_act_drop_bwd of TC_ACT_NONE at the same site (same flat index m * cols + c)."""
+    rows, Lm, cols, site = 3 * 37, 37, 512, 9
+    g = torch.Generator().manual_seed(5)
+    x0, pe = torch.randn(rows, cols, generator=g), torch.randn(50, cols, generator=g)
+    thr, sc = K.drop_params(0.1)
+    keep = O.dropout_keep(SEED, site, (rows, cols), 0.1)
+    want = (x0 + pe[:Lm].repeat(3, 1)) * keep * np.float32(1.0 / 0.9)
+    x = x0.to(DEV).clone()
+    K.pos_drop(x, rows, cols, pe.to(DEV), Lm, seed_dev(), site, thr, sc)
+    assert torch.equal((x.cpu() != 0) | (want == 0), torch.ones(rows, cols, dtype=torch.bool)) and rel(x, want) < 1e-6
+    x = x0.to(DEV).clone()
+    K.pos_drop(x, rows, cols, None, 1, seed_dev(), site, thr, sc)
+    assert rel(x, x0 * keep * np.float32(1.0 / 0.9)) < 1e-6
+    x = x0.to(DEV).clone()
+    K.pos_drop(x, rows, cols, pe.to(DEV), Lm)
+    assert torch.equal(x.cpu(), x0 + pe[:Lm].repeat(3, 1))
+    dy = torch.randn(rows, cols, generator=g).to(DEV)
+    da = torch.empty_like(dy)
+    K.act_drop_bwd(L.DT_F32, dy, cols, dy, cols, da, rows, cols, L.ACT_NONE, seed_dev(), site, thr, sc)
+    assert rel(da, dy.cpu() * keep * np.float32(1.0 / 0.9)) < 1e-6
+    with pytest.raises(L.TcdiffError):
+        K.pos_drop(x, rows, 510, pe.to(DEV), Lm)            # whole 16-byte quads only
+
+
 def _rope(n_pos):
     freqs = (1.0 / (10000 ** (torch.arange(0, 512, 2).float() / 512))).to(DEV)
     rope = torch.empty(n_pos, 512, device=DEV)
