@@ -167,7 +167,8 @@ def test_launcher_refuses_in_place_and_missing_buffers():
         K.chain(lay.mode, 64, 64, z(64, 512), lay.ws, split_part=3, p_out=P, xres=x, xout=torch.zeros_like(x), **kw)
 
 
-@pytest.mark.parametrize("dn,S,B", [(2, 60, 1), (3, 150, 1), (2, 60, 3)])
+# (1 x 150: one dancer; 5 x 40: 200-token sequences, 12.5 blocks; 2 x 37: 74 tokens, a 10-row last block, 37 frames in the front products)
+@pytest.mark.parametrize("dn,S,B", [(2, 60, 1), (3, 150, 1), (2, 60, 3), (1, 150, 1), (5, 40, 1), (2, 37, 2)])
 def test_small_job_network_matches_the_fused_layers(dn, S, B, monkeypatch):
     """The whole denoiser on a job small enough for the four-workgroups-per-block layers (both CFG branches stacked -- layer 0's
     Q / K / V shared by the branches -- and a plain forward): TCDIFF_SPLIT=0 (one fused launch per layer, TC_CHAIN_FRONT, the
