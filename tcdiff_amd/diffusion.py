@@ -194,7 +194,7 @@ class GaussianDiffusion(nn.Module):
         eng.fill_kv_slots(tok, B, 1)
         b["hidden_all"][:B] = eng.w["null_hidden"]
         b["hidden_all"][B:2 * B] = hid
-        uniq = sorted(set(int(t) for t in tseq))
+        uniq, rows = self._time_rows(tseq)
         key = (eng.weights_version, tuple(uniq))
         if eng.tables_key != key:
             eng.build_time_tables(torch.tensor(uniq, dtype=torch.int32, device=dev))
@@ -208,8 +208,14 @@ class GaussianDiffusion(nn.Module):
             eng.film_tab = tab = None
         if (tab.data_ptr() if tab is not None else None) != old:
             eng.reset_graphs()
+        return eng, rows
+
+    @staticmethod
+    def _time_rows(tseq):
+        """(sorted distinct timesteps of a job, the row of every step in the per-job time tables)"""
+        uniq = sorted(set(int(t) for t in tseq))
         row_of = {t: i for i, t in enumerate(uniq)}
-        return eng, [row_of[int(t)] for t in tseq]
+        return uniq, [row_of[int(t)] for t in tseq]
 
     def _run(self, mode: int, shape, cond, x: torch.Tensor, tseq, params: torch.Tensor, *, traj=None,
              step_noise: Optional[Callable] = None, seed: Optional[int] = None, clip_offset: int = 0,
@@ -228,7 +234,11 @@ class GaussianDiffusion(nn.Module):
         x = x.reshape(B, Lq, nf)
         # one stream, one launch chain: with one resident-block kernel per layer the chip is full, and two half-batch chains on
         # two streams measured 3 % slower (rounds 1-3 kept that as a default-off option; removed in round 4)
-        eng, rows = self._prepare(B, cond, tseq, slot=0)
+        # Host-to-device copies of the job's step tables FIRST, the job's device work (music branch, caches, tables) after them: a copy
+        # from pageable host memory blocks the host until everything queued before it has run, and behind _prepare's ~40 launches that
+        # was 0.6 ms of host wait per job plus the launches that could not be queued meanwhile (a one-clip ddim_sample is 27 ms).
+        eng = self.model.engine(B, 0)
+        rows = self._time_rows(tseq)[1]
         st = eng.sampler_state(n, B * Lq, nf)
         st["x"].copy_(x.reshape(B * Lq, nf))
         st["counter"].zero_()
@@ -251,6 +261,8 @@ class GaussianDiffusion(nn.Module):
             st["cmask"][:mask_rows].copy_(m)
         # the seed lives in device memory (counter[1..2]) so that a captured graph can be re-seeded
         st["counter"][1:3] = torch.tensor([seed & 0x7FFFFFFF, (seed >> 31) & 0x7FFFFFFF], dtype=torch.int32)
+        eng2, rows2 = self._prepare(B, cond, tseq, slot=0)
+        assert eng2 is eng and rows2 == rows
 
         def step(branches: int):
             eng.step_prologue(st, 2 * B, st["x"], B * Lq)
@@ -362,7 +374,24 @@ class GaussianDiffusion(nn.Module):
         mean, var, logvar = self.q_posterior(x_start=x_recon, x_t=x, t=t)
         return mean, var, logvar, x_recon
 
+    def _cached_params(self, key, make) -> torch.Tensor:
+        """Step tables are functions of the (constant) schedule buffers and the options in `key`: computed once per process and key on the
+        host (three device-to-host copies and, for DDIM, ~20 tensor ops per step -- a millisecond of host time in front of a 27-ms
+        one-clip job), handed out as copies (callers edit theirs)."""
+        cache = self.__dict__.setdefault("_param_cache", {})
+        key = key + (self.n_timestep, bool(self.predict_epsilon), bool(self.clip_denoised))      # (the schedule of an instance never changes)
+        if key not in cache:
+            if len(cache) >= 32:
+                cache.clear()
+            cache[key] = make()
+        return cache[key].clone()
+
     def _ddpm_params(self, tseq, weight=None) -> torch.Tensor:
+        tk = tuple(int(i) for i in tseq)
+        return self._cached_params(("ddpm", tk, None if weight is None else float(weight), float(self.guidance_weight)),
+                                   lambda: self._make_ddpm_params(tk, weight))
+
+    def _make_ddpm_params(self, tseq, weight=None) -> torch.Tensor:
         t = torch.tensor([int(i) for i in tseq], dtype=torch.long)
         c1 = self.posterior_mean_coef1.cpu()[t]
         c2 = self.posterior_mean_coef2.cpu()[t]
@@ -417,6 +446,10 @@ class GaussianDiffusion(nn.Module):
         return list(zip(times[:-1], times[1:]))
 
     def _ddim_params(self, pairs, weights) -> torch.Tensor:
+        pk, wk = tuple((int(a), int(b)) for a, b in pairs), tuple(float(w) for w in weights)
+        return self._cached_params(("ddim", pk, wk), lambda: self._make_ddim_params(pk, wk))
+
+    def _make_ddim_params(self, pairs, weights) -> torch.Tensor:
         ac = self.alphas_cumprod.cpu()
         sr, srm1 = self.sqrt_recip_alphas_cumprod.cpu(), self.sqrt_recipm1_alphas_cumprod.cpu()
         p = torch.zeros(len(pairs), 8)
