@@ -211,6 +211,18 @@ class GaussianDiffusion(nn.Module):
         return eng, rows
 
     @staticmethod
+    def _steps_per_graph(run_len: int, unroll: int) -> int:
+        """steps per captured graph for a run of `run_len` equal steps: `unroll`, or -- when that leaves a tail of single-step replays
+        (50 DDIM steps = 20 + 20 + 10 x 1) -- the divisor of the run length nearest above / below it (50 -> 25)"""
+        if run_len < unroll or run_len % unroll == 0:
+            return unroll                       # (a run shorter than that goes step by step: a graph is captured on its SECOND visit,
+                                                # and a whole-run graph would be visited once per job)
+        for u in range(unroll + unroll // 2, unroll // 2, -1):
+            if run_len % u == 0:
+                return u
+        return unroll
+
+    @staticmethod
     def _time_rows(tseq):
         """(sorted distinct timesteps of a job, the row of every step in the per-job time tables)"""
         uniq = sorted(set(int(t) for t in tseq))
@@ -292,15 +304,17 @@ class GaussianDiffusion(nn.Module):
         hostless = step_noise is None and q_noise is None and after_step is None and collect is None
         unroll = max(1, int(os.environ.get("TCDIFF_GRAPH_STEPS", "20"))) if (use_graph and hostless) else 1
         i = 0
+        run_until, run_u = 0, 1
         while i < n:
             t = tseq[i]
             branches = 1 if w_eff[i] == 1.0 else 2
-            u = 1
-            if unroll > 1:
-                while u < unroll and i + u < n and (1 if w_eff[i + u] == 1.0 else 2) == branches:
-                    u += 1
-                if u < unroll:
-                    u = 1                       # a run's tail: single steps (no graph per tail length)
+            if unroll > 1 and i >= run_until:   # a new run of steps with the same branch count: its length picks the steps per graph
+                j = i
+                while j < n and (1 if w_eff[j] == 1.0 else 2) == branches:
+                    j += 1
+                run_until, run_u = j, self._steps_per_graph(j - i, unroll)
+            # (what is left of a run after its whole graphs goes one step at a time: no graph per tail length)
+            u = run_u if (unroll > 1 and i + run_u <= run_until) else 1
             if step_noise is not None:
                 st["eps"].copy_(step_noise(int(t), (B, Lq, nf)).reshape(B * Lq, nf))
             if q_noise is not None:

@@ -191,6 +191,17 @@ def test_use_rotary_false_surface(golden_dir):
         m.train_engine()
 
 
+def test_steps_per_captured_graph_divide_the_run():
+    """GaussianDiffusion._steps_per_graph: a run of equal sampler steps is replayed as whole graphs of u steps; u is the configured
+    count when that divides the run, else the nearest divisor (50 DDIM steps: 2 x 25, not 20 + 20 + 10 single steps), and the
+    configured count when the run is shorter or has no divisor nearby (what does not fill a graph goes step by step)."""
+    f = GaussianDiffusion._steps_per_graph
+    assert [f(r, 20) for r in (1000, 900, 100, 90, 50, 45, 20, 10, 1, 37)] == [20, 20, 20, 30, 25, 15, 20, 20, 20, 20]
+    for r in range(1, 300):
+        u = f(r, 20)
+        assert 10 < u <= 30 and (r % u == 0 or u == 20)
+
+
 def test_trj_dist_raises_as_the_reference_does(small):
     """`trj_dist` (model/model.py:71-97): the reference gathers a [B, H, L, L] bias and adds it to the scores of BOTH attention
     blocks of a layer (model/model.py:326,332) -- the cross-attention's are [B, H, L, S + 2], so the reference raises a RuntimeError
