@@ -649,7 +649,15 @@ class GaussianDiffusion(nn.Module):
         smpl = self.smpl
         if smpl is None or not hasattr(smpl, "_parents"):
             smpl = self.__dict__.setdefault("_smpl_hip", SMPLSkeleton(dev))
-        return [int(p) for p in smpl._parents], smpl._offsets.detach().cpu().tolist()
+        # the kernels take the skeleton as host lists: fetched ONCE per skeleton object, not with a device-to-host copy (a host wait for
+        # the whole denoiser forward) in every training step.  Measured neutral at batch 32 -- the step is device-bound and the host
+        # catches up during the backward (profiles/r06_train_skeleton_sync_ab.txt) -- kept because it is one sync less
+        key = (id(smpl), smpl._offsets.data_ptr(), smpl._offsets._version)
+        hit = self.__dict__.get("_skeleton_lists")
+        if hit is None or hit[0] != key:
+            hit = (key, [int(p) for p in smpl._parents], smpl._offsets.detach().cpu().tolist())
+            self.__dict__["_skeleton_lists"] = hit
+        return hit[1], hit[2]
 
     def p_losses(self, x_start, cond, t, trj_dist=None, *, noise=None, keep_mask=None):
         """The four-term training loss (reference model/diffusion.py:636-741): q_sample with the trajectory channels
