@@ -236,6 +236,26 @@ DEVINL void head_projection(f32x4_t (&acc)[4][1], WStream& ws, const char* act, 
     lds_barrier();      // the reduction area is free again
 }
 
+// A 16-stage product that EVERY member (and every block) computes in full -- linear3, the merged form's fc -- is the same 512 KB read
+// by all workgroups of the launch at the same time: 88 GB/s per CU against 116 for the member-private streams of part 3
+// (profiles/r06_split_stamps.txt).  The four k-quarters commute, so a workgroup starts at quarter (block + member) % 4: four
+// phases of readers instead of one.  Two rings alternate (a quarter's ring is refilled with the quarter after next while the other is
+// consumed); `first` holds quarter q(0) already (issued at the top of the launch).  fp32 summation order differs between members by
+// the rotation (each member uses its own copy of the result: ~1e-7, far below the bf16 operands that follow).
+DEVINL unsigned quarter_of(int i, int rot) { return (unsigned)((i + rot) & 3); }
+template <class AfterThird, class AfterFourth>
+DEVINL void rotated_product16(f32x4_t (&acc)[4][1], const char* act, const tcdiff_chain_args& a, int stream_wave, unsigned stage0, int rot,
+                              WStream& first, WStream& second, int lane, AfterThird&& after_third, AfterFourth&& after_fourth) {
+    phase_n512<4, true, 1>(acc, act + quarter_of(0, rot) * 16384u, first, lane);
+    stream_at(first, a, stream_wave, stage0 + 4u * quarter_of(2, rot), lane);
+    phase_n512<4, true, 1>(acc, act + quarter_of(1, rot) * 16384u, second, lane);
+    stream_at(second, a, stream_wave, stage0 + 4u * quarter_of(3, rot), lane);
+    phase_n512<4, true, 1>(acc, act + quarter_of(2, rot) * 16384u, first, lane);
+    after_third();                                          // `first` is free
+    phase_n512<4, true, 1>(acc, act + quarter_of(3, rot) * 16384u, second, lane);
+    after_fourth();                                         // `second` is free
+}
+
 // Two projections of the same activation block (the next layer's Q and K) with ONE exchange: the second reduction area sits in the
 // unused rows of the other activation buffer's k-tiles.
 #define CS_RED2(w) (CH_ABUF2 + (w) * 8192 + 2048)
@@ -504,8 +524,9 @@ __global__ __launch_bounds__(512) void chain_split12_kernel(tcdiff_chain_args a,
     char* abuf = smem + CH_ABUF;
     float* scr = reinterpret_cast<float*>(smem + CH_SCR);
     const bool mine = (wave >> 1) == g.member;
-    WStream ws;
-    stream_at(ws, a, wave, 0u, lane);                      // fc of the self-attention block: all 16 stages of every wave's phase
+    const int rot = (g.lblk + g.member) & 3;               // fc of the self-attention block: all 16 stages, k-quarters rotated
+    WStream ws, wq;
+    stream_at(ws, a, wave, 4u * quarter_of(0, rot), lane);
     if (a.sa_q) {
         const int sseq = a.a_mod > 0 ? g.bseq % (a.a_mod / a.L) : g.bseq;      // (layer 0 under guidance: see part 1)
         const int qblk = sseq * ((a.L + 15) / 16) + g.bis;
@@ -523,11 +544,10 @@ __global__ __launch_bounds__(512) void chain_split12_kernel(tcdiff_chain_args a,
     const NormC nc = norm_consts<true>(a, g, a.n2_g, a.n2_b, wave, lane);
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
+    stream_at(wq, a, wave, 4u * quarter_of(1, rot), lane);
     f32x4_t acc[4][1];
     zero(acc);
-    phase_n512<16, true, 1>(acc, abuf, ws, lane);
-    WStream wq;
-    head_stream(wq, a, g, 16u, wave, lane);
+    rotated_product16(acc, abuf, a, wave, 0u, rot, ws, wq, lane, [] {}, [&] { head_stream(wq, a, g, 16u, wave, lane); });
     lds_barrier();                                         // every wave is out of fc: the activation block is rewritten below
     block_epilogue<true>(acc, rc, g, a.ln_eps, a.xout, scr, smem, wave, lane, mine);
     norm_lds<true>(acc, nc, a.n2_eps, scr + 1024, smem, abuf, nullptr, wave, lane);
@@ -661,8 +681,9 @@ __global__ __launch_bounds__(512) void chain_split4_kernel(tcdiff_chain_args a, 
     partial_sum(acc, p_in, g, wave, lane);
     const RowC rc = row_consts(a, g, a.film3, a.xres, a.M, 0, false, wave, lane);
     const NormC n4 = norm_consts<false>(a, g, a.n4_g, a.n4_b, wave, lane);
-    WStream ws;
-    stream_at(ws, a, wave, 112u, lane);                   // linear3: every member computes all of it
+    const int rot = (g.lblk + g.member) & 3;               // linear3: every member computes all of it, k-quarters rotated (rotated_product16)
+    WStream wa, wb;
+    stream_at(wa, a, wave, 112u + 4u * quarter_of(0, rot), lane);
     const f32x4_t b3c = col_fetch(a.b3, wave, lane);
     CS_T(4, 1);
     block_epilogue<false>(acc, rc, g, 0.0f, nullptr, scr, smem, wave, lane, false);
@@ -670,16 +691,14 @@ __global__ __launch_bounds__(512) void chain_split4_kernel(tcdiff_chain_args a, 
     norm_lds<false>(acc, n4, a.n4_eps, scr, smem, abuf, nullptr, wave, lane);
     lds_barrier();
     CS_T(4, 3);
+    stream_at(wb, a, wave, 112u + 4u * quarter_of(1, rot), lane);
     NormC nn;
-    WStream wq, wk;
-    if (!LAST) {                                           // the next phases' constants and streams: in flight under linear3
-        nn = norm_consts<true>(a, g, a.nn_g, a.nn_b, wave, lane);
-        head_stream(wq, a, g, 128u, wave, lane);
-    }
+    if (!LAST) nn = norm_consts<true>(a, g, a.nn_g, a.nn_b, wave, lane);      // the next phase's constants: in flight under linear3
     zero(acc);
-    phase_n512<16, true, 1>(acc, abuf, ws, lane);
+    rotated_product16(acc, abuf, a, wave, 112u, rot, wa, wb, lane,
+                      [&] { if (!LAST) head_stream(wa, a, g, 128u, wave, lane); },       // the next layer's w_qs slice, then its w_ks slice:
+                      [&] { if (!LAST) head_stream(wb, a, g, 144u, wave, lane); });      // land under the stores and the norm
     if (!LAST) CS_T(4, 4);
-    if (!LAST) head_stream(wk, a, g, 144u, wave, lane);    // (linear3's ring is free): lands under the stores and the norm
     lds_barrier();                                         // every wave is out of linear3: the activation block is rewritten below
     {
         const int c = lane & 15, gg = lane >> 4;
@@ -709,14 +728,13 @@ __global__ __launch_bounds__(512) void chain_split4_kernel(tcdiff_chain_args a, 
     const int head = 2 * g.member + (wave >> 2);
     const bool writer = (wave & 3) == 0;                   // one wave per head stores (all four hold the full tiles)
     f32x4_t t[4][1], tk[4][1];
-    head_projection2(t, tk, wq, wk, abuf, smem, wave, lane);
-    WStream wv;
-    head_stream(wv, a, g, 160u, wave, lane);              // (the Q stream's registers are free again)
+    head_projection2(t, tk, wa, wb, abuf, smem, wave, lane);
+    head_stream(wa, a, g, 160u, wave, lane);              // w_vs slice
     if (writer) store_qfrag<1>(t, a.qf_out, a.scale_q, g.lblk, head, lane);
     CS_T(4, 7);
     if (writer) store_kfrag<1>(tk, a.kf_out, g.bseq, g.bis * 16, a.out_nkt, head, lane);
     CS_T(4, 8);
-    head_projection<true>(t, wv, smem + CH_ABUF2, smem, wave, lane);
+    head_projection<true>(t, wa, smem + CH_ABUF2, smem, wave, lane);
     if (writer) store_vfrag<1>(t, a.vf_out, g.bseq, g.bis * 16, a.out_nkt, a.L, head, lane);
     CS_T(4, 9);
 }
