@@ -301,19 +301,23 @@ DEVINL void kv_tile(const __amdgpu_buffer_rsrc_t& r, unsigned image_off, int kt,
 }
 // WPH: waves per head -- 4 (a workgroup runs two heads: wave w is head w / 4, key tiles w % 4, w % 4 + 4, ..) or 1 (eight heads, a
 // wave runs all key tiles of head w: no merge)
+// WPH = 1 walks the tiles in a ROTATED order, start tile `rot0` % nkt (the online softmax does not care): the workgroups of a
+// sequence -- all of which read the same K / V -- then do not all ask for the same lines at the same time.
+DEVINL int kt_wrap(int kt, int nkt) { return kt >= nkt ? kt - nkt : kt; }
 template <int WPH = 4>
-DEVINL void kv_issue(KVTiles& t, const void* kf, const void* vf, unsigned image_off, int nkt, int wave, int lane) {
+DEVINL void kv_issue(KVTiles& t, const void* kf, const void* vf, unsigned image_off, int nkt, int wave, int lane, int rot0 = 0) {
     const __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(kf), 0, -1, 0x00020000);
     const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(vf), 0, -1, 0x00020000);
-    const int j = WPH == 4 ? wave & 3 : 0;
+    const int j = WPH == 4 ? wave & 3 : rot0 % nkt;
+    const int j1 = WPH == 4 ? j + 4 : kt_wrap(j + 1, nkt);
     kv_tile(kr, image_off, j, nkt, lane, t.k0);
     kv_tile(vr, image_off, j, nkt, lane, t.v0);
-    kv_tile(kr, image_off, j + WPH, nkt, lane, t.k1);
-    kv_tile(vr, image_off, j + WPH, nkt, lane, t.v1);
+    kv_tile(kr, image_off, j1, nkt, lane, t.k1);
+    kv_tile(vr, image_off, j1, nkt, lane, t.v1);
 }
 template <int WPH = 4>
 DEVINL void head_attention(const u32x4 (&qf)[2], KVTiles& pre, const void* kf, const void* vf, unsigned image_off, int nkt, int Lk,
-                           char* smem, int wave, int lane) {
+                           char* smem, int wave, int lane, int rot0 = 0) {
     const int i = WPH == 4 ? wave >> 2 : wave, j = WPH == 4 ? wave & 3 : 0, c = lane & 15, gg = lane >> 4;
     u32x4 ones = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
     asm volatile("" : "+v"(ones));
@@ -326,8 +330,10 @@ DEVINL void head_attention(const u32x4 (&qf)[2], KVTiles& pre, const void* kf, c
     float m_run = -INFINITY, nb = 0.0f;
     u32x4 (&kn)[4] = pre.k0, (&vn)[4] = pre.v0, (&kn2)[4] = pre.k1, (&vn2)[4] = pre.v1;      // the wave's tiles run TWO ahead (1-4 tiles of a
                                                                                                // 450-key sequence per wave: latency, not rate)
+    const int count = WPH == 4 ? (nkt - j + 3) / 4 : nkt;       // tiles of this wave (none: j >= nkt)
+    int kt = WPH == 4 ? j : rot0 % nkt;
 #pragma unroll 1
-    for (int kt = j; kt < nkt; kt += WPH) {
+    for (int it = 0; it < count; ++it, kt = WPH == 4 ? kt + 4 : kt_wrap(kt + 1, nkt)) {
         u32x4 kc[4], vc[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -336,8 +342,9 @@ DEVINL void head_attention(const u32x4 (&qf)[2], KVTiles& pre, const void* kf, c
             kn[q] = kn2[q];
             vn[q] = vn2[q];
         }
-        ld_tile(kr, kt + 2 * WPH, kn2);     // (past the end: the last tile again, unused)
-        ld_tile(vr, kt + 2 * WPH, vn2);
+        const int k2 = WPH == 4 ? kt + 8 : kt_wrap(kt_wrap(kt + 1, nkt) + 1, nkt);     // (WPH = 4 past the end: the last tile again, unused)
+        ld_tile(kr, k2, kn2);
+        ld_tile(vr, k2, vn2);
         f32x4_t s0 = {nb, nb, nb, nb}, s1 = s0;
         mma16(s0, kc[0], qf[0]);
         mma16(s1, kc[2], qf[0]);
@@ -351,7 +358,7 @@ DEVINL void head_attention(const u32x4 (&qf)[2], KVTiles& pre, const void* kf, c
             }
         }
         const float lm = lane_max8(s0, s1, -INFINITY);
-        const bool first = kt == j;
+        const bool first = it == 0;
         if (__builtin_amdgcn_ballot_w64(first || lm > CH_ATT_THR) != 0) {
             const float mx = ar4_max(lm);                                   // relative to -nb
             // (a wave's first tile may hold masked keys only for some row?  no: a tile has >= 1 valid key and every row sees every key)
@@ -534,8 +541,9 @@ __global__ __launch_bounds__(512) void chain_split12_kernel(tcdiff_chain_args a,
         const u32x4 qf[2] = {qsrc[0], qsrc[64]};
         const unsigned img = (unsigned)((sseq * a.H + wave) * a.sa_nkt) * 4096u;
         KVTiles pre;
-        kv_issue<1>(pre, a.sa_kf, a.sa_vf, img, a.sa_nkt, wave, lane);
-        head_attention<1>(qf, pre, a.sa_kf, a.sa_vf, img, a.sa_nkt, a.L, smem, wave, lane);
+        const int rk = 5 * g.bis + 3 * g.member;           // start tile: spread over the sequence's blocks and members
+        kv_issue<1>(pre, a.sa_kf, a.sa_vf, img, a.sa_nkt, wave, lane, rk);
+        head_attention<1>(qf, pre, a.sa_kf, a.sa_vf, img, a.sa_nkt, a.L, smem, wave, lane, rk);
     } else {
         // layer 0 without the fragment front: O of the stand-alone attention launch, all eight k-tiles of the 16 rows
         stage_glds<16, 1>(abuf + wave * 8192, reinterpret_cast<const char*>(a.A) + wave * TC_ROWB, 1024, g.m0, g.Mend, a.a_mod, 0, lane);
