@@ -25,6 +25,18 @@ from . import _lib as L
 from . import kernels as K
 from .engine import DenoiserEngine
 
+# Bumped by torch whenever a Parameter or a submodule is registered on ANY nn.Module of the process (global registration hooks): the
+# cheap signal DanceDecoder._weights_version uses to know that its cached parameter list may be stale.
+_REGISTRATIONS = [0]
+
+
+def _count_registration(*_args):
+    _REGISTRATIONS[0] += 1
+
+
+torch.nn.modules.module.register_module_parameter_registration_hook(_count_registration)
+torch.nn.modules.module.register_module_module_registration_hook(_count_registration)
+
 
 class RotaryEmbedding(nn.Module):
     """Holds the ``freqs`` buffer (model/rotary_embedding_torch.py:75-105, freqs_for='lang', theta=1e4)."""
@@ -195,7 +207,16 @@ class DanceDecoder(nn.Module):
                     act=self.act_id, abs_pos=not self.use_rotary)
 
     def _weights_version(self):
-        return tuple(p._version for p in self.parameters()) + (str(next(self.parameters()).device),)
+        """What the packed weights of an engine were made from: the identity and in-place version of every Parameter, and the device.
+        Walking the module tree for the 435 Parameters costs 0.3-0.8 ms of host time -- in front of every sampler call, i.e. of a 25-ms
+        one-clip job -- so the LIST is kept and refreshed only when torch reports a (sub)module or Parameter registration somewhere in the
+        process (_REGISTRATIONS below: `module.weight = nn.Parameter(...)`, `module.sub = ...`, `load_state_dict` does not register)."""
+        if self.__dict__.get("_plist_epoch") != _REGISTRATIONS[0]:
+            self.__dict__["_plist"] = list(self.parameters())
+            self.__dict__["_plist_ids"] = tuple(map(id, self._plist))
+            self.__dict__["_plist_epoch"] = _REGISTRATIONS[0]
+        pl = self.__dict__["_plist"]
+        return tuple(p._version for p in pl) + (self.__dict__["_plist_ids"], str(pl[0].device))
 
     def engine(self, batch: int, slot: int = 0) -> DenoiserEngine:
         """The (lazily built) kernel engine, with weights re-packed whenever a parameter changed in place.

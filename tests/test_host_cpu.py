@@ -191,6 +191,33 @@ def test_use_rotary_false_surface(golden_dir):
         m.train_engine()
 
 
+def test_weights_version_sees_in_place_changes_and_replaced_parameters():
+    """DanceDecoder._weights_version -- what decides whether an engine's packed weights are current -- walks a CACHED parameter list
+    (the module-tree walk is 0.3-0.8 ms in front of every sampler call).  It must still change for an in-place update (optimizer step,
+    load_state_dict), for a Parameter object replaced by another one with the same in-place version, and must not change when
+    something unrelated is registered elsewhere in the process."""
+    import torch.nn as nn
+    m = DanceDecoder(nfeats=151, seq_len=60, latent_dim=512, ff_size=1024, num_layers=8, num_heads=8, dropout=0.1, cond_feature_dim=438,
+                     activation=F.gelu, required_dancer_num=2)
+    v0 = m._weights_version()
+    assert m._weights_version() == v0
+    with torch.no_grad():
+        next(m.parameters()).add_(1.0)
+    v1 = m._weights_version()
+    assert v1 != v0
+    m.load_state_dict(m.state_dict())                         # copies in place: every version moves
+    v2 = m._weights_version()
+    assert v2 != v1
+    m.final_layer.weight = nn.Parameter(torch.zeros_like(m.final_layer.weight))      # a NEW object
+    v3 = m._weights_version()
+    assert v3 != v2 and len(v3) == len(v2)
+    m.final_layer = nn.Linear(512, 151)                       # a replaced submodule
+    v4 = m._weights_version()
+    assert v4 != v3
+    nn.Linear(3, 3)                                           # unrelated registrations: the list is re-walked, the version is not new
+    assert m._weights_version() == v4
+
+
 def test_steps_per_captured_graph_divide_the_run():
     """GaussianDiffusion._steps_per_graph: a run of equal sampler steps is replayed as whole graphs of u steps; u is the configured
     count when that divides the run, else the nearest divisor (50 DDIM steps: 2 x 25, not 20 + 20 + 10 single steps), and the
